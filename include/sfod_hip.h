@@ -1,0 +1,242 @@
+/* libsfod_hip.so -- C ABI of the MI355X (gfx950) teacher-student Faster R-CNN hot path.
+ *
+ * The reference (EPFL-IMOS/simple-SFOD) has no FFI: its hot path is Python calling
+ * Detectron2 / torchvision / torch device ops.  Each entry point below replaces the device op
+ * the reference reaches at the cited site (paths relative to /root/reference; "d2:" / "tv:" =
+ * upstream Detectron2 / torchvision semantics restated in SURVEY.md Appendix A).
+ *
+ * Conventions
+ *   - every pointer is a BORROWED device pointer (tensor.data_ptr()); the caller keeps the
+ *     memory alive until the stream is synchronised.  The library never allocates.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); all work is enqueued on it,
+ *     nothing synchronises.
+ *   - return value: 0 on success, negative hipError_t otherwise, -1000 for bad arguments.
+ *   - activations are NHWC ("pixel-major rows, channels contiguous"); `dt` selects the storage /
+ *     MFMA input type: SFOD_F32 (parity mode, v_mfma_f32_32x32x2_f32) or SFOD_BF16 (throughput
+ *     mode, v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+ *   - per-image variable-length results live in fixed-capacity arrays plus an int32 count per
+ *     image, so that no entry point needs a host round trip.
+ */
+#ifndef SFOD_HIP_H
+#define SFOD_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SFOD_F32 0
+#define SFOD_BF16 1
+
+int sfod_version(void);
+/* last error text of the calling thread ("" if none) */
+const char* sfod_last_error(void);
+
+/* ---- K1: preprocess.  d2 GeneralizedRCNN.preprocess_image (normalise, pad) as called at
+ * daod/modeling/meta_arch/source_free_adaptive_teacher_rcnn.py:212 ; uint8 CHW BGR -> NHWC.
+ * img_ptrs: device array of B pointers to uint8 [3,h_i,w_i]; sizes: int32 [B,2] (h,w);
+ * out: [B,Hp,Wp,Cpad] (channels >= 3 are zero, padding pixels are zero). */
+int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes, int B, int Hp, int Wp,
+                    int Cpad, const float* mean3, const float* std3, void* out, int dt,
+                    void* stream);
+
+/* ---- K2/K5/K14/K18: implicit-GEMM convolution / linear layer on MFMA.
+ * y[m, n] = act( sum_{tap, c} x[pix(m) + tap][c] * w[n][tap][c] + bias[n] ),  m = (b, oy, ox)
+ * x: [B,H,W,Cin] NHWC, w: packed [Cout][KH*KW][Cin] (K contiguous), y: [B,H,W,ldy] with ldy >=
+ * Cout.  KH=KW=3 pad 1 (vgg.py:18 conv3x3; d2 StandardRPNHead.conv; dann.py:14-17) or KH=KW=1
+ * (1x1 convs and nn.Linear: x [R,K] -> y [R,N]).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).
+ * stats (optional, fp32 [gridM][2][Cout]): per-row-block (sum, M2) of the pre-activation output
+ * for the train-mode BatchNorm that follows (vgg.py:20).  out_dt may differ from dt (e.g. fp32
+ * logits out of a bf16 head).  Also used for data-gradient (dgrad) with rotated weights. */
+int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
+                  int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
+                  void* stream);
+/* number of row blocks (gridM) sfod_conv_fwd uses for M = B*H*W rows (size of `stats`) */
+int sfod_conv_stats_blocks(int M);
+
+/* weight gradient: dw[n][tap][c] (+)= sum_m dy[m][n] * x[pix(m)+tap][c]  (fp32, packed layout,
+ * accumulated with float atomics into a zero-initialised buffer; split over row chunks). */
+int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
+                    int Cout, int ksize, int lddy, int dt, void* stream);
+
+/* weight (re)packing between the reference's state-dict layouts and the kernel layouts.
+ * OIHW fp32 [Cout][Cin][KH][KW] -> packed [Cout][KH*KW][CinPad] (dt); rot180=1 additionally
+ * swaps in/out channels and flips the taps: the dgrad weight [Cin][KH*KW][Cout]. */
+int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Cout, int Cin, int ksize,
+                          int CinPad, int rot180, int dt, void* stream);
+/* packed fp32 grad [Cout][taps][CinPad] -> OIHW fp32 grad (accumulate=0: overwrite) */
+int sfod_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int Cout, int Cin, int ksize,
+                           int CinPad, int accumulate, void* stream);
+/* nn.Linear weight [N][K] fp32 -> [N][Kperm] (dt) where, if chw_c > 0, the K axis is permuted
+ * from (c, p) (flatten of [C,7,7], d2 FastRCNNConvFCHead) to (p, c) (our ROIAlign layout);
+ * transpose=1 writes [K][N] instead (the dgrad operand). */
+int sfod_pack_fc_weight(const float* w, void* out, int N, int K, int chw_c, int transpose, int dt,
+                        void* stream);
+int sfod_unpack_fc_wgrad(const float* dw_packed, float* dw, int N, int K, int chw_c,
+                         int accumulate, void* stream);
+/* same with an explicit leading dimension `ld` of the packed matrix (zero-padded inner axis, so
+ * that every row is a whole number of 16-byte chunks, e.g. the 41 predictor outputs -> 48) */
+int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose, int ld,
+                           int dt, void* stream);
+int sfod_unpack_fc_wgrad_ld(const float* dw_packed, float* dw, int N, int K, int chw_c, int ld,
+                            int accumulate, void* stream);
+/* column sums of a [M, ld] matrix's first N columns: bias gradients.  db[n] (+)= sum_m dy[m][n] */
+int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, int accumulate, int dt,
+                   void* stream);
+
+/* ---- K3/K4: train-mode BatchNorm2d + ReLU (+ 2x2 max-pool), NHWC.  vgg.py:15,20; torch
+ * BatchNorm2d semantics of SURVEY.md A.14 (biased var to normalise, unbiased var into
+ * running_var, momentum 0.1, eps 1e-5).  This is also the AdaBN running-stat refresh
+ * (daod/engine/trainers/base.py:270-337): it runs identically under no_grad. */
+int sfod_bn_finalize(const float* stats, int nblocks, int rows_per_block, int M, int C,
+                     float* mean, float* invstd, float* running_mean, float* running_var,
+                     float momentum, float eps, int update_running, void* stream);
+/* z = relu(gamma*(y-mean)*invstd+beta); pool=1 additionally 2x2/2 max-pools z (floor) */
+int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, void* z, int B, int H, int W,
+                          int C, int pool, int dt, void* stream);
+/* backward of the block above.  dz: grad w.r.t. block output; y: saved conv output; returns dy
+ * (grad w.r.t. conv output), dgamma, dbeta.  ws: fp32 workspace [nblk*2*C] (see ws query). */
+int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
+                          const float* gamma, const float* beta, void* dy, float* dgamma,
+                          float* dbeta, float* ws, int B, int H, int W, int C, int pool, int dt,
+                          void* stream);
+int sfod_bn_bwd_ws_floats(int M, int C);
+/* elementwise: dx = dy * (y > 0) (ReLU) or dy * (y > 0 ? 1 : 0.2) (LeakyReLU) in place on dy */
+int sfod_act_bwd(void* dy, const void* y, int64_t n, int act, int dt, void* stream);
+/* a += b  (fp32 or bf16 elementwise) */
+int sfod_add_inplace(void* a, const void* b, int64_t n, int dt, void* stream);
+
+/* ---- K6/K7: anchors + proposal decode.  d2 DefaultAnchorGenerator / Box2BoxTransform /
+ * find_top_rpn_proposals reached from daod/modeling/proposal_generator/rpn.py:25,54-56.
+ * rpn_out: fp32 [B*Hf*Wf, ld]: cols [0,A) objectness, cols [A, 5A) deltas (a*4+j).
+ * props: [B,NA,4] decoded+clipped boxes (order y,x,a); scores: [B,NA]; flags[0] |= 1 if any
+ * non-finite prediction (d2 raises FloatingPointError). */
+int sfod_rpn_decode(const float* rpn_out, int ld, const float* cell_anchors, int A, int B, int Hf,
+                    int Wf, int stride, const int32_t* image_sizes, float* props, float* scores,
+                    int32_t* flags, void* stream);
+/* stable descending segmented sort of B segments of n floats; out_idx int32 [B,n].
+ * ws: workspace of sfod_sort_ws_bytes(B,n) bytes. */
+int64_t sfod_sort_ws_bytes(int B, int n);
+int sfod_segmented_sort_desc(const float* keys, int B, int n, float* out_keys, int32_t* out_idx,
+                             void* ws, int64_t ws_bytes, void* stream);
+/* gather the first k sorted candidates: boxes[b][j] = props[b][idx[b][j]], valid = nonempty */
+int sfod_rpn_gather_topk(const float* props, const float* sorted_scores, const int32_t* sorted_idx,
+                         int B, int NA, int k, float* cand_boxes, float* cand_scores,
+                         uint8_t* cand_valid, void* stream);
+
+/* ---- K8/K16: greedy NMS.  tv nms / batched_nms via d2 batched_nms (Appendix A.6):
+ * boxes already sorted by descending score; suppress j>i when IoU > thr (strict, fp32, no +1).
+ * classes (optional int32): pairs of different class never suppress each other ("vanilla"
+ * batched_nms); alt_boxes/mode (optional): per image mode[b]!=0 selects alt_boxes (the
+ * coordinate-offset boxes) and disables the class test -- torchvision's strategy switch.
+ * n_per_image (optional int32 [B]) bounds the live prefix, else n.  mask: u64 [B,n,ceil(n/64)].
+ * keep_idx int32 [B,max_keep] (positions in the sorted order), keep_count int32 [B]. */
+int64_t sfod_nms_mask_bytes(int B, int n);
+int sfod_nms(const float* boxes, const float* alt_boxes, const int32_t* classes,
+             const int32_t* mode, const uint8_t* valid, const int32_t* n_per_image, int B, int n,
+             float thr, int max_keep, uint64_t* mask, int32_t* keep_idx, int32_t* keep_count,
+             void* stream);
+/* proposals[b][j] = cand_boxes[b][keep_idx[b][j]] for j < keep_count[b], zero-filled above */
+int sfod_gather_kept(const float* cand_boxes, const float* cand_scores, const int32_t* keep_idx,
+                     const int32_t* keep_count, int B, int n, int max_keep, float* out_boxes,
+                     float* out_scores, void* stream);
+
+/* ---- K9/K12: pairwise IoU + Matcher.  d2 pairwise_iou + Matcher (Appendix A.8) as reached
+ * from rpn.py:45 (anchors, thresholds [0.3,0.7], labels [0,-1,1], low-quality on) and
+ * source_free_adaptive_teacher_roi_heads.py:179-183 (proposals, [0.5], [0,1]).
+ * anchors are generated in-kernel from (Hf,Wf,stride,cell_anchors).  gt: [B,Gcap,4] + count.
+ * out: matched int32 [B,NA], labels int8 [B,NA]; gtmax fp32 [B,Gcap] scratch. */
+int sfod_anchor_match(const float* cell_anchors, int A, int B, int Hf, int Wf, int stride,
+                      const float* gt_boxes, const int32_t* gt_count, int Gcap, float lo, float hi,
+                      int32_t* matched, int8_t* labels, float* gtmax, void* stream);
+/* ROI version: boxes [B,P,4] with count; one threshold; writes the class target:
+ * cls[b][p] = gt_classes[matched] if IoU>=thr else num_classes; -2 for p >= count. */
+int sfod_roi_match(const float* boxes, const int32_t* box_count, int B, int P,
+                   const float* gt_boxes, const int32_t* gt_classes, const int32_t* gt_count,
+                   int Gcap, float thr, int num_classes, int32_t* matched, int32_t* cls,
+                   void* stream);
+/* ---- K10: subsample_labels (Appendix A.9).  The random choice is an INPUT: one uint32 key per
+ * element; the sample is the n candidates with the smallest (key, index).
+ * mode 0 (RPN, _subsample_labels): labels int8 in/out [B,n]: positives = 1, negatives = 0,
+ *   everything not sampled becomes -1.
+ * mode 1 (ROI, _sample_proposals): cls int32 [B,n] in; out_idx int32 [B,num] = sampled fg indices
+ *   ascending then bg ascending, out_count [B]. */
+int sfod_subsample(void* labels_or_cls, const uint32_t* keys, int B, int n, int num, float pos_frac,
+                   int bg_label, int mode, int32_t* out_idx, int32_t* out_count, void* stream);
+
+/* ---- K11: RPN losses (Appendix A.10; rpn.py:46-49).  loss[0]=loss_rpn_cls, loss[1]=
+ * loss_rpn_loc, both / (batch_per_image*B).  With grad_scale != NULL (device fp32 [2], the
+ * upstream d(total)/d(loss_k)) also writes d_rpn_out (same layout as rpn_out, dense). */
+int sfod_rpn_loss(const float* rpn_out, int ld, const float* cell_anchors, int A, int B, int Hf,
+                  int Wf, int stride, const int8_t* labels, const int32_t* matched,
+                  const float* gt_boxes, const int32_t* gt_count, int Gcap, int batch_per_image,
+                  float* loss, const float* grad_scale, float* d_rpn_out, float* ws, void* stream);
+
+/* concat proposals and GT boxes: d2 add_ground_truth_to_proposals (roi_heads.py:170) */
+int sfod_append_gt(const float* props, const int32_t* prop_count, int B, int P,
+                   const float* gt_boxes, const int32_t* gt_count, int Gcap, float* out_boxes,
+                   int32_t* out_count, void* stream);
+/* build the sampled ROI batch: rois [B*S,5], gt_cls int32 [B*S] (-1 on padding rows),
+ * gt_box [B*S,4]; n_valid int32[1] = number of real rows in the whole batch. */
+int sfod_roi_build_samples(const float* boxes, const int32_t* cls, const int32_t* matched,
+                           const int32_t* samp_idx, const int32_t* samp_count, int B, int P, int S,
+                           const float* gt_boxes, const int32_t* gt_count, int Gcap, float* rois,
+                           int32_t* gt_cls, float* gt_box, int32_t* n_valid, void* stream);
+/* rois [B*P,5] from per-image proposal arrays (padding rows get batch index -1) */
+int sfod_make_rois(const float* props, const int32_t* prop_count, int B, int P, float* rois,
+                   void* stream);
+
+/* ---- K13: ROIAlign (tv roi_align aligned=True, adaptive sampling; Appendix A.11) on NHWC
+ * features.  out: [R, PH*PW, C] (dt).  rois with batch index < 0 produce zeros. */
+int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, const float* rois, int R,
+                       int pooled, float scale, void* out, int dt, void* stream);
+/* dfeat fp32 [B,H,W,C], accumulated with float atomics (zero-init by the caller) */
+int sfod_roi_align_bwd(const void* dout, int B, int H, int W, int C, const float* rois, int R,
+                       int pooled, float scale, float* dfeat, int dt, void* stream);
+
+/* ---- K15: Fast R-CNN losses (Appendix A.12; roi_heads.py:124).  pred: fp32 [R, ld]: cols
+ * [0,K] class scores, cols [K+1, K+1+4K) deltas.  loss[0]=loss_cls, loss[1]=loss_box_reg. */
+int sfod_frcnn_loss(const float* pred, int ld, int R, int K, const float* rois,
+                    const int32_t* gt_cls, const float* gt_box, const int32_t* n_valid,
+                    float* loss, const float* grad_scale, float* d_pred, float* ws, void* stream);
+
+/* ---- K16: teacher inference post-processing (Appendix A.13; roi_heads.py:161) ----
+ * step 1: softmax + per-class decode + clip + score filter -> candidates [B, P*K]
+ *         (cand_scores = -1 for filtered entries), cand_count[b] = number passing. */
+int sfod_frcnn_candidates(const float* pred, int ld, int B, int P, int K, const float* props,
+                          const int32_t* prop_count, const int32_t* image_sizes,
+                          float score_thresh, float* cand_boxes, float* cand_scores,
+                          int32_t* cand_count, void* stream);
+/* step 2 (after sorting scores): gather sorted candidates, classes, coordinate-offset boxes
+ * and the torchvision strategy flag (mode[b]=1: coordinate trick, 0: per-class). */
+int sfod_frcnn_prepare_nms(const float* cand_boxes, const float* sorted_scores,
+                           const int32_t* sorted_idx, const int32_t* cand_count, int B, int n,
+                           int K, int numel_limit, float* s_boxes, float* s_alt_boxes,
+                           int32_t* s_classes, int32_t* mode, float* maxcoord_ws, void* stream);
+/* step 3 (after NMS): top-`max_det` detections + the pseudo-label filter score > thr
+ * (daod/engine/trainers/source_free_adaptive_teacher.py:167-181, strict '>'). */
+int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_scores, const int32_t* s_classes,
+                        const int32_t* keep_idx, const int32_t* keep_count, int B, int n,
+                        int max_det, float pseudo_thr, float* det_boxes, float* det_scores,
+                        int32_t* det_classes, int32_t* det_count, float* gt_boxes,
+                        int32_t* gt_classes, int32_t* gt_count, void* stream);
+
+/* ---- K20/K21: fused SGD(momentum, weight decay) + EMA teacher update over flat fp32 arrays.
+ * d2 build_optimizer + torch SGD (Appendix A.15) and _update_teacher_model
+ * (source_free_adaptive_teacher.py:583-603).  lr is a device scalar (no host sync on schedule).
+ * first_step: momentum buffer is initialised to the gradient (torch SGD semantics).
+ * teacher may be NULL (no EMA). */
+int sfod_sgd_ema(float* param, const float* grad, float* mom, float* teacher, int64_t n,
+                 const float* lr, float momentum, float weight_decay, float grad_scale,
+                 float ema_keep, int first_step, void* stream);
+/* t = s*(1-k) + t*k  on fp32 buffers (BN running stats) */
+int sfod_ema(float* teacher, const float* student, int64_t n, float keep, void* stream);
+
+/* utilities */
+int sfod_fill_f32(float* p, int64_t n, float v, void* stream);
+int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int dst_dt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,393 @@
+"""Config contract of the hot path: a minimal yacs-style ``CfgNode`` on PyYAML, the Detectron2
+default keys the three named yamls rely on, and the project keys of the reference.
+
+Mirrors (same key names, defaults and merge order ``defaults <- add_config <- yaml <- CLI opts``):
+  * ``/root/reference/daod/config.py:8-142``  (``add_config`` / ``add_trainer_config``)
+  * ``/root/reference/train_net_mt.py:34-42``  (``setup``)
+  * Detectron2 ``get_cfg()`` defaults for the keys the path reads.
+Keys the reference declares but never reads on this path are still declared so its yamls merge.
+"""
+import ast
+import copy
+
+import yaml
+
+
+class CfgNode(dict):
+    """dict with attribute access, yacs-like merge/type-check/freeze semantics."""
+
+    _FROZEN = "__frozen__"
+
+    def __init__(self, init=None):
+        super().__init__()
+        object.__setattr__(self, CfgNode._FROZEN, False)
+        for k, v in (init or {}).items():
+            self[k] = CfgNode(v) if isinstance(v, dict) and not isinstance(v, CfgNode) else v
+
+    def __getattr__(self, name):
+        if name in self:
+            return self[name]
+        raise AttributeError(name)
+
+    def __setattr__(self, name, value):
+        if self.is_frozen():
+            raise AttributeError(f"Attempted to set {name} to {value}, but CfgNode is immutable")
+        self[name] = value
+
+    def is_frozen(self):
+        return object.__getattribute__(self, CfgNode._FROZEN)
+
+    def _set_frozen(self, flag):
+        object.__setattr__(self, CfgNode._FROZEN, flag)
+        for v in self.values():
+            if isinstance(v, CfgNode):
+                v._set_frozen(flag)
+
+    def freeze(self):
+        self._set_frozen(True)
+
+    def defrost(self):
+        self._set_frozen(False)
+
+    def clone(self):
+        return copy.deepcopy(self)
+
+    def __deepcopy__(self, memo):
+        out = CfgNode()
+        for k, v in self.items():
+            dict.__setitem__(out, k, copy.deepcopy(v, memo))
+        return out
+
+    # -- merging ------------------------------------------------------------------------------
+    @staticmethod
+    def _coerce(new, old, key):
+        if old is None or new is None:
+            return new
+        if type(new) is type(old):
+            return new
+        if isinstance(old, tuple) and isinstance(new, list):
+            return tuple(new)
+        if isinstance(old, list) and isinstance(new, tuple):
+            return list(new)
+        if isinstance(old, float) and isinstance(new, int) and not isinstance(new, bool):
+            return float(new)
+        raise ValueError(
+            f"Type mismatch ({type(old)} vs. {type(new)}) with values ({old} vs. {new}) "
+            f"for config key: {key}")
+
+    def _merge(self, other, path):
+        for k, v in other.items():
+            full = ".".join(path + [k])
+            if k not in self:
+                raise KeyError(f"Non-existent config key: {full}")
+            if isinstance(self[k], CfgNode):
+                if not isinstance(v, dict):
+                    raise ValueError(f"Type mismatch for config key: {full}")
+                self[k]._merge(v, path + [k])
+            else:
+                if isinstance(v, dict):
+                    v = CfgNode(v)
+                dict.__setitem__(self, k, self._coerce(v, self[k], full))
+
+    def merge_from_other_cfg(self, other):
+        self._merge(other, [])
+
+    def merge_from_file(self, path):
+        with open(path, "r") as f:
+            loaded = yaml.safe_load(f) or {}
+        loaded = _literal_tuples(loaded)
+        self._merge(loaded, [])
+
+    def merge_from_list(self, opts):
+        if len(opts) % 2 != 0:
+            raise ValueError(f"Override list has odd length: {opts}; it must be a list of pairs")
+        for full, raw in zip(opts[0::2], opts[1::2]):
+            node = self
+            parts = full.split(".")
+            for p in parts[:-1]:
+                if p not in node:
+                    raise KeyError(f"Non-existent config key: {full}")
+                node = node[p]
+            if parts[-1] not in node:
+                raise KeyError(f"Non-existent config key: {full}")
+            val = raw
+            if isinstance(raw, str):
+                try:
+                    val = ast.literal_eval(raw)
+                except (ValueError, SyntaxError):
+                    val = raw
+            dict.__setitem__(node, parts[-1], self._coerce(val, node[parts[-1]], full))
+
+    def dump(self):
+        def plain(n):
+            return {k: plain(v) if isinstance(v, CfgNode) else (list(v) if isinstance(v, tuple) else v)
+                    for k, v in n.items()}
+        return yaml.safe_dump(plain(self), default_flow_style=None)
+
+
+def _literal_tuples(d):
+    """yaml reads ``(60000, 80000)`` as a string; yacs literal_evals it.  Same here."""
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out[k] = _literal_tuples(v)
+        elif isinstance(v, str) and v.strip().startswith("(") and v.strip().endswith(")"):
+            try:
+                out[k] = ast.literal_eval(v)
+            except (ValueError, SyntaxError):
+                out[k] = v
+        else:
+            out[k] = v
+    return out
+
+
+CN = CfgNode
+
+
+def get_cfg():
+    """Detectron2 defaults restricted to the keys this path (and its yamls) touch."""
+    _C = CN()
+    _C.VERSION = 2
+    _C.MODEL = CN()
+    _C.MODEL.LOAD_PROPOSALS = False
+    _C.MODEL.MASK_ON = False
+    _C.MODEL.KEYPOINT_ON = False
+    _C.MODEL.DEVICE = "cuda"
+    _C.MODEL.META_ARCHITECTURE = "GeneralizedRCNN"
+    _C.MODEL.WEIGHTS = ""
+    _C.MODEL.PIXEL_MEAN = [103.530, 116.280, 123.675]
+    _C.MODEL.PIXEL_STD = [1.0, 1.0, 1.0]
+    _C.MODEL.BACKBONE = CN()
+    _C.MODEL.BACKBONE.NAME = "build_resnet_backbone"
+    _C.MODEL.BACKBONE.FREEZE_AT = 2
+    _C.MODEL.FPN = CN()
+    _C.MODEL.FPN.IN_FEATURES = []
+    _C.MODEL.FPN.OUT_CHANNELS = 256
+    _C.MODEL.FPN.NORM = ""
+    _C.MODEL.FPN.FUSE_TYPE = "sum"
+    _C.MODEL.PROPOSAL_GENERATOR = CN()
+    _C.MODEL.PROPOSAL_GENERATOR.NAME = "RPN"
+    _C.MODEL.PROPOSAL_GENERATOR.MIN_SIZE = 0
+    _C.MODEL.ANCHOR_GENERATOR = CN()
+    _C.MODEL.ANCHOR_GENERATOR.NAME = "DefaultAnchorGenerator"
+    _C.MODEL.ANCHOR_GENERATOR.SIZES = [[32, 64, 128, 256, 512]]
+    _C.MODEL.ANCHOR_GENERATOR.ASPECT_RATIOS = [[0.5, 1.0, 2.0]]
+    _C.MODEL.ANCHOR_GENERATOR.ANGLES = [[-90, 0, 90]]
+    _C.MODEL.ANCHOR_GENERATOR.OFFSET = 0.0
+    _C.MODEL.RPN = CN()
+    _C.MODEL.RPN.HEAD_NAME = "StandardRPNHead"
+    _C.MODEL.RPN.IN_FEATURES = ["res4"]
+    _C.MODEL.RPN.BOUNDARY_THRESH = -1
+    _C.MODEL.RPN.IOU_THRESHOLDS = [0.3, 0.7]
+    _C.MODEL.RPN.IOU_LABELS = [0, -1, 1]
+    _C.MODEL.RPN.BATCH_SIZE_PER_IMAGE = 256
+    _C.MODEL.RPN.POSITIVE_FRACTION = 0.5
+    _C.MODEL.RPN.BBOX_REG_LOSS_TYPE = "smooth_l1"
+    _C.MODEL.RPN.BBOX_REG_LOSS_WEIGHT = 1.0
+    _C.MODEL.RPN.BBOX_REG_WEIGHTS = (1.0, 1.0, 1.0, 1.0)
+    _C.MODEL.RPN.SMOOTH_L1_BETA = 0.0
+    _C.MODEL.RPN.LOSS_WEIGHT = 1.0
+    _C.MODEL.RPN.PRE_NMS_TOPK_TRAIN = 12000
+    _C.MODEL.RPN.PRE_NMS_TOPK_TEST = 6000
+    _C.MODEL.RPN.POST_NMS_TOPK_TRAIN = 2000
+    _C.MODEL.RPN.POST_NMS_TOPK_TEST = 1000
+    _C.MODEL.RPN.NMS_THRESH = 0.7
+    _C.MODEL.RPN.CONV_DIMS = [-1]
+    _C.MODEL.ROI_HEADS = CN()
+    _C.MODEL.ROI_HEADS.NAME = "Res5ROIHeads"
+    _C.MODEL.ROI_HEADS.NUM_CLASSES = 80
+    _C.MODEL.ROI_HEADS.IN_FEATURES = ["res4"]
+    _C.MODEL.ROI_HEADS.IOU_THRESHOLDS = [0.5]
+    _C.MODEL.ROI_HEADS.IOU_LABELS = [0, 1]
+    _C.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE = 512
+    _C.MODEL.ROI_HEADS.POSITIVE_FRACTION = 0.25
+    _C.MODEL.ROI_HEADS.SCORE_THRESH_TEST = 0.05
+    _C.MODEL.ROI_HEADS.NMS_THRESH_TEST = 0.5
+    _C.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT = True
+    _C.MODEL.ROI_BOX_HEAD = CN()
+    _C.MODEL.ROI_BOX_HEAD.NAME = ""
+    _C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE = "smooth_l1"
+    _C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT = 1.0
+    _C.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
+    _C.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA = 0.0
+    _C.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 14
+    _C.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = 0
+    _C.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignV2"
+    _C.MODEL.ROI_BOX_HEAD.NUM_FC = 0
+    _C.MODEL.ROI_BOX_HEAD.FC_DIM = 1024
+    _C.MODEL.ROI_BOX_HEAD.NUM_CONV = 0
+    _C.MODEL.ROI_BOX_HEAD.CONV_DIM = 256
+    _C.MODEL.ROI_BOX_HEAD.NORM = ""
+    _C.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG = False
+    _C.MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES = False
+    _C.MODEL.RESNETS = CN()
+    _C.MODEL.RESNETS.DEPTH = 50
+    _C.MODEL.RESNETS.OUT_FEATURES = ["res4"]
+    _C.MODEL.RESNETS.NUM_GROUPS = 1
+    _C.MODEL.RESNETS.NORM = "FrozenBN"
+    _C.MODEL.RESNETS.WIDTH_PER_GROUP = 64
+    _C.MODEL.RESNETS.STRIDE_IN_1X1 = True
+    _C.MODEL.RESNETS.RES5_DILATION = 1
+    _C.MODEL.RESNETS.RES2_OUT_CHANNELS = 256
+    _C.MODEL.RESNETS.STEM_OUT_CHANNELS = 64
+
+    _C.INPUT = CN()
+    _C.INPUT.MIN_SIZE_TRAIN = (800,)
+    _C.INPUT.MIN_SIZE_TRAIN_SAMPLING = "choice"
+    _C.INPUT.MAX_SIZE_TRAIN = 1333
+    _C.INPUT.MIN_SIZE_TEST = 800
+    _C.INPUT.MAX_SIZE_TEST = 1333
+    _C.INPUT.RANDOM_FLIP = "horizontal"
+    _C.INPUT.FORMAT = "BGR"
+    _C.INPUT.MASK_FORMAT = "polygon"
+
+    _C.DATASETS = CN()
+    _C.DATASETS.TRAIN = ()
+    _C.DATASETS.TEST = ()
+    _C.DATALOADER = CN()
+    _C.DATALOADER.NUM_WORKERS = 4
+    _C.DATALOADER.ASPECT_RATIO_GROUPING = True
+    _C.DATALOADER.SAMPLER_TRAIN = "TrainingSampler"
+    _C.DATALOADER.FILTER_EMPTY_ANNOTATIONS = True
+
+    _C.SOLVER = CN()
+    _C.SOLVER.LR_SCHEDULER_NAME = "WarmupMultiStepLR"
+    _C.SOLVER.MAX_ITER = 40000
+    _C.SOLVER.BASE_LR = 0.001
+    _C.SOLVER.MOMENTUM = 0.9
+    _C.SOLVER.NESTEROV = False
+    _C.SOLVER.WEIGHT_DECAY = 0.0001
+    _C.SOLVER.WEIGHT_DECAY_NORM = 0.0
+    _C.SOLVER.GAMMA = 0.1
+    _C.SOLVER.STEPS = (30000,)
+    _C.SOLVER.WARMUP_FACTOR = 1.0 / 1000
+    _C.SOLVER.WARMUP_ITERS = 1000
+    _C.SOLVER.WARMUP_METHOD = "linear"
+    _C.SOLVER.CHECKPOINT_PERIOD = 5000
+    _C.SOLVER.IMS_PER_BATCH = 16
+    _C.SOLVER.REFERENCE_WORLD_SIZE = 0
+    _C.SOLVER.BIAS_LR_FACTOR = 1.0
+    _C.SOLVER.WEIGHT_DECAY_BIAS = None
+    _C.SOLVER.CLIP_GRADIENTS = CN({"ENABLED": False, "CLIP_TYPE": "value", "CLIP_VALUE": 1.0,
+                                   "NORM_TYPE": 2.0})
+    _C.SOLVER.AMP = CN({"ENABLED": False})
+
+    _C.TEST = CN()
+    _C.TEST.EXPECTED_RESULTS = []
+    _C.TEST.EVAL_PERIOD = 0
+    _C.TEST.DETECTIONS_PER_IMAGE = 100
+    _C.TEST.PRECISE_BN = CN({"ENABLED": False, "NUM_ITER": 200})
+
+    _C.OUTPUT_DIR = "./output"
+    _C.SEED = -1
+    _C.CUDNN_BENCHMARK = False
+    _C.VIS_PERIOD = 0
+    return _C
+
+
+AVAILABLE_TRAINERS = ["da", "adaptive_teacher", "source_free_adaptive_teacher"]
+
+
+def add_config(cfg):
+    """reference daod/config.py:8-26."""
+    _C = cfg
+    _C.TRAINER = ""
+    _C.TEST.IMS_PER_BATCH = 1
+    _C.DATASETS.TRAIN_TARGET = ()
+    _C.SOLVER.IMS_PER_BATCH_TARGET = 1
+    _C.TEST.VAL_LOSS = True
+    _C.VGG = CN()
+    _C.VGG.BN = True
+    for trainer in AVAILABLE_TRAINERS:
+        add_trainer_config(cfg, trainer)
+    add_native_config(cfg)
+
+
+def _semisup_block(_C):
+    _C.MODEL.RPN.UNSUP_LOSS_WEIGHT = 1.0
+    _C.MODEL.RPN.LOSS = "CrossEntropy"
+    _C.MODEL.ROI_HEADS.LOSS = "CrossEntropy"
+    _C.SOLVER.FACTOR_LIST = (1,)
+    _C.TEST.EVALUATOR = "COCOeval"
+    _C.SEMISUPNET = CN()
+    _C.SEMISUPNET.MLP_DIM = 128
+    _C.SEMISUPNET.BBOX_THRESHOLD = 0.7
+    _C.SEMISUPNET.PSEUDO_BBOX_SAMPLE = "thresholding"
+    _C.SEMISUPNET.TEACHER_UPDATE_ITER = 1
+    _C.SEMISUPNET.BURN_UP_STEP = 12000
+    _C.SEMISUPNET.EMA_KEEP_RATE = 0.0
+    _C.SEMISUPNET.UNSUP_LOSS_WEIGHT = 4.0
+    _C.SEMISUPNET.SUP_LOSS_WEIGHT = 0.5
+    _C.SEMISUPNET.LOSS_WEIGHT_TYPE = "standard"
+    _C.SEMISUPNET.DIS_TYPE = "res4"
+    _C.SEMISUPNET.DIS_LOSS_WEIGHT = 0.1
+    _C.SEMISUPNET.INS_DC = False
+    _C.DATALOADER.SUP_PERCENT = 100.0
+    _C.DATALOADER.RANDOM_DATA_SEED = 0
+    _C.EMAMODEL = CN()
+    _C.EMAMODEL.SUP_CONSIST = True
+
+
+def add_trainer_config(cfg, trainer):
+    """reference daod/config.py:28-142."""
+    _C = cfg
+    if trainer == "da":
+        _C.DA_FASTER = CN()
+        _C.DA_FASTER.DC_IMG_GRL_WEIGHT = 0.01
+        _C.DA_FASTER.DC_INS_GRL_WEIGHT = 0.1
+        _C.DA_FASTER.DC_CONSISTENCY_WEIGHT = 0.1
+        _C.DA_FASTER.LEVELS = ["res4"]
+        _C.DA_FASTER.ENTROPY_CONDITIONING = False
+    elif trainer == "adaptive_teacher":
+        _semisup_block(_C)
+    elif trainer == "source_free_adaptive_teacher":
+        _semisup_block(_C)
+        _C.ADAPTIVE_THRESHOLD = CN()
+        _C.ADAPTIVE_THRESHOLD.ENABLED = True
+        _C.ADAPTIVE_THRESHOLD.WARM_UP = 100
+        _C.ADAPTIVE_THRESHOLD.RESERVE = 500
+        _C.WEAK_STRONG_AUGMENT = True
+        _C.ENHANCE = True
+        _C.DOMAIN_CLASSIFIER = CN()
+        _C.DOMAIN_CLASSIFIER.ENABLED = False
+        _C.DOMAIN_CLASSIFIER.IMAGE = False
+        _C.DOMAIN_CLASSIFIER.INSTANCE = False
+        _C.STYLE = CN()
+        _C.STYLE.ENABLED = False
+        _C.STYLE.STYLE_IMAGE = None
+        _C.STYLE.VGG_MODEL = None
+        _C.STYLE.DECODER = None
+
+
+def add_native_config(cfg):
+    """Keys of this MI355X build only (documented in DESIGN.md).
+
+    SFOD.EMA.ENABLED      quirk q1: the dispatched reference trainer has the EMA call commented
+                          out (source_free_adaptive_teacher.py:581); its twins have it on.
+    SFOD.EMA.KEEP_RATE    hard-coded 0.9996 in the reference (:584).
+    SFOD.COMPUTE_DTYPE    "fp32" (parity mode, fp32 MFMA) or "bf16" (throughput mode).
+    SFOD.ELIDE_DEAD_BRANCHES  skip the zero-weighted 2nd ROI pass / BPC / domain branch.
+    """
+    _C = cfg
+    _C.SFOD = CN()
+    _C.SFOD.EMA = CN()
+    _C.SFOD.EMA.ENABLED = True
+    _C.SFOD.EMA.KEEP_RATE = 0.9996
+    _C.SFOD.COMPUTE_DTYPE = "fp32"
+    _C.SFOD.ELIDE_DEAD_BRANCHES = True
+    _C.SFOD.SYNTHETIC = CN()
+    _C.SFOD.SYNTHETIC.HEIGHT = 1024
+    _C.SFOD.SYNTHETIC.WIDTH = 2048
+    _C.SFOD.SYNTHETIC.NUM_IMAGES = 64
+    _C.SFOD.SYNTHETIC.BOXES_PER_IMAGE = 12
+
+
+def setup_cfg(config_file=None, opts=()):
+    """train_net_mt.py:34-42 ``setup`` minus default_setup's logging."""
+    cfg = get_cfg()
+    add_config(cfg)
+    if config_file:
+        cfg.merge_from_file(config_file)
+    cfg.merge_from_list(list(opts))
+    cfg.freeze()
+    return cfg

@@ -1,0 +1,990 @@
+// Detection-side kernels of the hot path: anchors, box coding, IoU matching, sampling, NMS,
+// RPN / Fast R-CNN losses and teacher post-processing.  gfx950, wave64.
+//
+// Built with -ffp-contract=off: every IoU / box expression must round exactly like the fp32
+// torch ops of the reference path (bit-exact anchor labels and NMS indices).
+#include <math.h>
+
+#include "common.h"
+
+#define SCALE_CLAMP 4.135166556742356f /* log(1000/16) */
+
+struct Box {
+  float x1, y1, x2, y2;
+};
+
+__device__ __forceinline__ Box load_box(const float* p) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  return Box{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ void store_box(float* p, Box b) {
+  *reinterpret_cast<float4*>(p) = make_float4(b.x1, b.y1, b.x2, b.y2);
+}
+
+// d2 pairwise_iou: area without +1, where(inter > 0, inter / (a1 + a2 - inter), 0)
+__device__ __forceinline__ float iou_pairwise(Box a, Box b) {
+  float area_a = (a.x2 - a.x1) * (a.y2 - a.y1);
+  float area_b = (b.x2 - b.x1) * (b.y2 - b.y1);
+  float w = fminf(a.x2, b.x2) - fmaxf(a.x1, b.x1);
+  float h = fminf(a.y2, b.y2) - fmaxf(a.y1, b.y1);
+  w = fmaxf(w, 0.f);
+  h = fmaxf(h, 0.f);
+  float inter = w * h;
+  return inter > 0.f ? inter / ((area_a + area_b) - inter) : 0.f;
+}
+
+// tv nms: inter / (Sa + Sb - inter) > thr
+__device__ __forceinline__ bool nms_suppresses(Box a, Box b, float thr) {
+  float left = fmaxf(a.x1, b.x1), right = fminf(a.x2, b.x2);
+  float top = fmaxf(a.y1, b.y1), bottom = fminf(a.y2, b.y2);
+  float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+  float inter = width * height;
+  float sa = (a.x2 - a.x1) * (a.y2 - a.y1);
+  float sb = (b.x2 - b.x1) * (b.y2 - b.y1);
+  return (inter / ((sa + sb) - inter)) > thr;
+}
+
+__device__ __forceinline__ Box anchor_at(const float* cell, int A, int Wf, int stride, int i) {
+  int a = i % A;
+  int p = i / A;
+  int x = p % Wf, y = p / Wf;
+  float sx = (float)(x * stride), sy = (float)(y * stride);
+  return Box{sx + cell[a * 4 + 0], sy + cell[a * 4 + 1], sx + cell[a * 4 + 2], sy + cell[a * 4 + 3]};
+}
+
+// Box2BoxTransform.apply_deltas (A.5)
+__device__ __forceinline__ Box apply_deltas(Box b, float d0, float d1, float d2, float d3, float wx,
+                                            float wy, float ww, float wh) {
+  float w = b.x2 - b.x1, h = b.y2 - b.y1;
+  float cx = b.x1 + 0.5f * w, cy = b.y1 + 0.5f * h;
+  float dx = d0 / wx, dy = d1 / wy, dw = d2 / ww, dh = d3 / wh;
+  dw = fminf(dw, SCALE_CLAMP);
+  dh = fminf(dh, SCALE_CLAMP);
+  float pcx = dx * w + cx, pcy = dy * h + cy;
+  float pw = expf(dw) * w, ph = expf(dh) * h;
+  return Box{pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph};
+}
+
+// Box2BoxTransform.get_deltas
+__device__ __forceinline__ void get_deltas(Box s, Box t, float wx, float wy, float ww, float wh,
+                                           float* out) {
+  float sw = s.x2 - s.x1, sh = s.y2 - s.y1;
+  float scx = s.x1 + 0.5f * sw, scy = s.y1 + 0.5f * sh;
+  float tw = t.x2 - t.x1, th = t.y2 - t.y1;
+  float tcx = t.x1 + 0.5f * tw, tcy = t.y1 + 0.5f * th;
+  out[0] = wx * (tcx - scx) / sw;
+  out[1] = wy * (tcy - scy) / sh;
+  out[2] = ww * logf(tw / sw);
+  out[3] = wh * logf(th / sh);
+}
+
+__device__ __forceinline__ Box clip_box(Box b, float h, float w) {
+  return Box{fminf(fmaxf(b.x1, 0.f), w), fminf(fmaxf(b.y1, 0.f), h), fminf(fmaxf(b.x2, 0.f), w),
+             fminf(fmaxf(b.y2, 0.f), h)};
+}
+
+// ---------------------------------------------------------------------------------------------
+// RPN decode
+// ---------------------------------------------------------------------------------------------
+__global__ void k_rpn_decode(const float* __restrict__ rpn_out, int ld, const float* __restrict__ cell,
+                             int A, int Hf, int Wf, int stride, const int32_t* __restrict__ sizes,
+                             float* __restrict__ props, float* __restrict__ scores, int32_t* flags) {
+  const int b = blockIdx.y;
+  const int NA = Hf * Wf * A;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NA) return;
+  const int a = i % A, p = i / A;
+  const float* row = rpn_out + ((int64_t)b * Hf * Wf + p) * ld;
+  const float logit = row[a];
+  const float* d = row + A + a * 4;
+  Box anc = anchor_at(cell, A, Wf, stride, i);
+  Box pb = apply_deltas(anc, d[0], d[1], d[2], d[3], 1.f, 1.f, 1.f, 1.f);
+  bool fin = isfinite(pb.x1) && isfinite(pb.y1) && isfinite(pb.x2) && isfinite(pb.y2) && isfinite(logit);
+  if (!fin) atomicOr(flags, 1);
+  pb = clip_box(pb, (float)sizes[b * 2 + 0], (float)sizes[b * 2 + 1]);
+  store_box(props + ((int64_t)b * NA + i) * 4, pb);
+  scores[(int64_t)b * NA + i] = logit;
+}
+
+extern "C" int sfod_rpn_decode(const float* rpn_out, int ld, const float* cell_anchors, int A, int B,
+                               int Hf, int Wf, int stride, const int32_t* image_sizes, float* props,
+                               float* scores, int32_t* flags, void* stream) {
+  SFOD_REQUIRE(ld >= 5 * A, "rpn_out leading dim < 5A");
+  const int NA = Hf * Wf * A;
+  dim3 grid(cdiv(NA, 256), B);
+  hipLaunchKernelGGL(k_rpn_decode, grid, dim3(256), 0, (hipStream_t)stream, rpn_out, ld, cell_anchors,
+                     A, Hf, Wf, stride, image_sizes, props, scores, flags);
+  return sfod_check_launch("rpn_decode");
+}
+
+__global__ void k_rpn_gather_topk(const float* __restrict__ props, const float* __restrict__ sscores,
+                                  const int32_t* __restrict__ sidx, int NA, int k,
+                                  float* __restrict__ cboxes, float* __restrict__ cscores,
+                                  uint8_t* __restrict__ cvalid) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= k) return;
+  const int idx = sidx[(int64_t)b * NA + j];
+  Box bx = load_box(props + ((int64_t)b * NA + idx) * 4);
+  store_box(cboxes + ((int64_t)b * k + j) * 4, bx);
+  cscores[(int64_t)b * k + j] = sscores[(int64_t)b * NA + j];
+  // Boxes.nonempty(threshold=0): strict
+  cvalid[(int64_t)b * k + j] = ((bx.x2 - bx.x1) > 0.f && (bx.y2 - bx.y1) > 0.f) ? 1 : 0;
+}
+
+extern "C" int sfod_rpn_gather_topk(const float* props, const float* sorted_scores,
+                                    const int32_t* sorted_idx, int B, int NA, int k, float* cand_boxes,
+                                    float* cand_scores, uint8_t* cand_valid, void* stream) {
+  SFOD_REQUIRE(k <= NA, "k > NA");
+  dim3 grid(cdiv(k, 256), B);
+  hipLaunchKernelGGL(k_rpn_gather_topk, grid, dim3(256), 0, (hipStream_t)stream, props, sorted_scores,
+                     sorted_idx, NA, k, cand_boxes, cand_scores, cand_valid);
+  return sfod_check_launch("rpn_gather_topk");
+}
+
+// ---------------------------------------------------------------------------------------------
+// NMS: 64x64 IoU bitmask tiles (one wavefront per row block; a column block is 64 boxes = one
+// u64 per row), then a single-workgroup greedy reduce that resolves 64 boxes at a time with
+// ballot / cross-lane reads.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_nms_mask(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
+           const int32_t* __restrict__ classes, const int32_t* __restrict__ mode,
+           const int32_t* __restrict__ n_per_image, int n, float thr, uint64_t* __restrict__ mask) {
+  const int b = blockIdx.z;
+  const int rb = blockIdx.y, cb = blockIdx.x;
+  if (cb < rb) return;  // only j > i matters
+  const int live = n_per_image ? min(n_per_image[b], n) : n;
+  const int CB = (n + 63) / 64;
+  const int lane = threadIdx.x;
+  const bool use_alt = (mode != nullptr) && (mode[b] != 0) && (alt_boxes != nullptr);
+  const float* src = (use_alt ? alt_boxes : boxes) + (int64_t)b * n * 4;
+  const bool class_test = (classes != nullptr) && !use_alt;
+  __shared__ float cbox[64 * 4];
+  __shared__ int ccls[64];
+  const int cj = cb * 64 + lane;
+  if (cj < live) {
+    *reinterpret_cast<float4*>(&cbox[lane * 4]) = *reinterpret_cast<const float4*>(src + (int64_t)cj * 4);
+    ccls[lane] = class_test ? classes[(int64_t)b * n + cj] : 0;
+  }
+  __syncthreads();
+  const int i = rb * 64 + lane;
+  if (i >= n) return;
+  uint64_t bits = 0;
+  if (i < live) {
+    Box bi = load_box(src + (int64_t)i * 4);
+    const int ci = class_test ? classes[(int64_t)b * n + i] : 0;
+    const int jmax = min(64, live - cb * 64);
+    const int jstart = (rb == cb) ? lane + 1 : 0;
+    for (int j = jstart; j < jmax; ++j) {
+      Box bj = Box{cbox[j * 4 + 0], cbox[j * 4 + 1], cbox[j * 4 + 2], cbox[j * 4 + 3]};
+      bool s = nms_suppresses(bi, bj, thr);
+      if (class_test) s = s && (ccls[j] == ci);
+      if (s) bits |= (1ull << j);
+    }
+  }
+  mask[((int64_t)b * n + i) * CB + cb] = bits;
+}
+
+__global__ void __launch_bounds__(256)
+k_nms_reduce(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ valid,
+             const int32_t* __restrict__ n_per_image, int n, int max_keep,
+             int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint64_t* remv = reinterpret_cast<uint64_t*>(smem_raw);  // [CB]
+  __shared__ uint64_t s_kept;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int live = n_per_image ? min(n_per_image[b], n) : n;
+  const int CB = (n + 63) / 64;
+  const int CBL = (live + 63) / 64;
+  const uint64_t* M = mask + (int64_t)b * n * CB;
+  // initial removal set: invalid (empty) boxes never keep and never suppress
+  for (int w = tid; w < CB; w += blockDim.x) {
+    uint64_t r = 0;
+    if (valid) {
+      for (int j = 0; j < 64; ++j) {
+        int idx = w * 64 + j;
+        if (idx < live && !valid[(int64_t)b * n + idx]) r |= (1ull << j);
+      }
+    }
+    remv[w] = r;
+  }
+  __syncthreads();
+  int nkept = 0;
+  for (int blk = 0; blk < CBL; ++blk) {
+    if (tid < 64) {
+      const int lane = tid;
+      const int i = blk * 64 + lane;
+      const uint64_t rem = remv[blk];
+      const bool alive = (i < live) && !((rem >> lane) & 1ull);
+      const uint64_t diag = (i < live) ? M[(int64_t)i * CB + blk] : 0ull;
+      uint64_t alive_mask = __ballot(alive);
+      uint64_t kept = 0;
+      int room = max_keep - nkept;
+      while (alive_mask != 0ull && room > 0) {
+        const int bpos = __builtin_ctzll(alive_mask);
+        kept |= (1ull << bpos);
+        --room;
+        const uint32_t dlo = __shfl((uint32_t)(diag & 0xffffffffull), bpos);
+        const uint32_t dhi = __shfl((uint32_t)(diag >> 32), bpos);
+        const uint64_t d = ((uint64_t)dhi << 32) | dlo;
+        alive_mask &= ~d;
+        alive_mask &= ~(1ull << bpos);
+      }
+      if ((kept >> lane) & 1ull) {
+        const int pos = nkept + __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+        keep_idx[(int64_t)b * max_keep + pos] = i;
+      }
+      if (lane == 0) s_kept = kept;
+    }
+    __syncthreads();
+    const uint64_t kept = s_kept;
+    nkept += __builtin_popcountll(kept);
+    if (nkept >= max_keep) break;
+    if (kept != 0ull) {
+      for (int w = blk + 1 + tid; w < CBL; w += blockDim.x) {
+        uint64_t acc = remv[w];
+        uint64_t kk = kept;
+        while (kk) {
+          const int bpos = __builtin_ctzll(kk);
+          kk &= kk - 1;
+          acc |= M[(int64_t)(blk * 64 + bpos) * CB + w];
+        }
+        remv[w] = acc;
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) keep_count[b] = nkept;
+}
+
+extern "C" int64_t sfod_nms_mask_bytes(int B, int n) {
+  return (int64_t)B * n * ((n + 63) / 64) * 8;
+}
+
+extern "C" int sfod_nms(const float* boxes, const float* alt_boxes, const int32_t* classes,
+                        const int32_t* mode, const uint8_t* valid, const int32_t* n_per_image, int B,
+                        int n, float thr, int max_keep, uint64_t* mask, int32_t* keep_idx,
+                        int32_t* keep_count, void* stream) {
+  SFOD_REQUIRE(B >= 1 && n >= 0 && max_keep >= 1, "nms sizes");
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    (void)hipMemsetAsync(keep_count, 0, sizeof(int32_t) * B, s);
+    return sfod_check_launch("nms(empty)");
+  }
+  const int CB = (n + 63) / 64;
+  SFOD_REQUIRE(CB * 8 <= 64 * 1024, "nms: n too large for the LDS removal set");
+  dim3 grid(CB, CB, B);
+  hipLaunchKernelGGL(k_nms_mask, grid, dim3(64), 0, s, boxes, alt_boxes, classes, mode, n_per_image, n,
+                     thr, mask);
+  int rc = sfod_check_launch("nms_mask");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(256), CB * 8, s, mask, valid, n_per_image, n, max_keep,
+                     keep_idx, keep_count);
+  return sfod_check_launch("nms_reduce");
+}
+
+__global__ void k_gather_kept(const float* __restrict__ cboxes, const float* __restrict__ cscores,
+                              const int32_t* __restrict__ keep_idx, const int32_t* __restrict__ keep_count,
+                              int n, int max_keep, float* __restrict__ oboxes, float* __restrict__ oscores) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= max_keep) return;
+  Box bx{0.f, 0.f, 0.f, 0.f};
+  float sc = 0.f;
+  if (j < keep_count[b]) {
+    const int idx = keep_idx[(int64_t)b * max_keep + j];
+    bx = load_box(cboxes + ((int64_t)b * n + idx) * 4);
+    sc = cscores[(int64_t)b * n + idx];
+  }
+  store_box(oboxes + ((int64_t)b * max_keep + j) * 4, bx);
+  if (oscores) oscores[(int64_t)b * max_keep + j] = sc;
+}
+
+extern "C" int sfod_gather_kept(const float* cand_boxes, const float* cand_scores, const int32_t* keep_idx,
+                                const int32_t* keep_count, int B, int n, int max_keep, float* out_boxes,
+                                float* out_scores, void* stream) {
+  dim3 grid(cdiv(max_keep, 256), B);
+  hipLaunchKernelGGL(k_gather_kept, grid, dim3(256), 0, (hipStream_t)stream, cand_boxes, cand_scores,
+                     keep_idx, keep_count, n, max_keep, out_boxes, out_scores);
+  return sfod_check_launch("gather_kept");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Anchor <-> GT matching (Matcher with low-quality matches)
+// ---------------------------------------------------------------------------------------------
+#define GT_MAX 256
+
+__global__ void __launch_bounds__(256)
+k_anchor_match_a(const float* __restrict__ cell, int A, int Hf, int Wf, int stride,
+                 const float* __restrict__ gt, const int32_t* __restrict__ gt_count, int Gcap,
+                 float* __restrict__ best_val, int32_t* __restrict__ matched, float* gtmax) {
+  __shared__ float sgt[GT_MAX * 4];
+  const int b = blockIdx.y;
+  const int NA = Hf * Wf * A;
+  const int G = min(gt_count[b], Gcap);
+  for (int t = threadIdx.x; t < G * 4; t += blockDim.x) sgt[t] = gt[(int64_t)b * Gcap * 4 + t];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool act = i < NA;
+  Box anc = anchor_at(cell, A, Wf, stride, act ? i : 0);
+  float best = -1.f;
+  int arg = 0;
+  for (int g = 0; g < G; ++g) {
+    Box gb = Box{sgt[g * 4], sgt[g * 4 + 1], sgt[g * 4 + 2], sgt[g * 4 + 3]};
+    float v = act ? iou_pairwise(gb, anc) : -1.f;
+    if (v > best) { best = v; arg = g; }
+    float wm = wave_max(v);
+    if ((threadIdx.x & 63) == 0 && wm >= 0.f)
+      atomicMax(reinterpret_cast<unsigned int*>(gtmax + (int64_t)b * Gcap + g), __float_as_uint(wm));
+  }
+  if (act) {
+    best_val[(int64_t)b * NA + i] = best;
+    matched[(int64_t)b * NA + i] = arg;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_anchor_match_b(const float* __restrict__ cell, int A, int Hf, int Wf, int stride,
+                 const float* __restrict__ gt, const int32_t* __restrict__ gt_count, int Gcap, float lo,
+                 float hi, const float* __restrict__ best_val, const float* __restrict__ gtmax,
+                 int8_t* __restrict__ labels) {
+  __shared__ float sgt[GT_MAX * 4];
+  __shared__ float smax[GT_MAX];
+  const int b = blockIdx.y;
+  const int NA = Hf * Wf * A;
+  const int G = min(gt_count[b], Gcap);
+  for (int t = threadIdx.x; t < G * 4; t += blockDim.x) sgt[t] = gt[(int64_t)b * Gcap * 4 + t];
+  for (int t = threadIdx.x; t < G; t += blockDim.x) smax[t] = gtmax[(int64_t)b * Gcap + t];
+  __syncthreads();
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= NA) return;
+  if (G == 0) { labels[(int64_t)b * NA + i] = 0; return; }
+  const float best = best_val[(int64_t)b * NA + i];
+  int8_t lab = (best < lo) ? 0 : ((best < hi) ? -1 : 1);
+  Box anc = anchor_at(cell, A, Wf, stride, i);
+  bool lowq = false;
+  for (int g = 0; g < G; ++g) {
+    Box gb = Box{sgt[g * 4], sgt[g * 4 + 1], sgt[g * 4 + 2], sgt[g * 4 + 3]};
+    lowq = lowq || (iou_pairwise(gb, anc) == smax[g]);
+  }
+  if (lowq) lab = 1;
+  labels[(int64_t)b * NA + i] = lab;
+}
+
+extern "C" int sfod_anchor_match(const float* cell_anchors, int A, int B, int Hf, int Wf, int stride,
+                                 const float* gt_boxes, const int32_t* gt_count, int Gcap, float lo,
+                                 float hi, int32_t* matched, int8_t* labels, float* gtmax, void* stream) {
+  SFOD_REQUIRE(Gcap <= GT_MAX, "Gcap > 256");
+  hipStream_t s = (hipStream_t)stream;
+  const int NA = Hf * Wf * A;
+  // gtmax: [B,Gcap] per-GT maxima followed by [B,NA] per-anchor maxima (scratch)
+  float* best_val = gtmax + (int64_t)B * Gcap;
+  (void)hipMemsetAsync(gtmax, 0, sizeof(float) * B * Gcap, s);
+  dim3 grid(cdiv(NA, 256), B);
+  hipLaunchKernelGGL(k_anchor_match_a, grid, dim3(256), 0, s, cell_anchors, A, Hf, Wf, stride, gt_boxes,
+                     gt_count, Gcap, best_val, matched, gtmax);
+  int rc = sfod_check_launch("anchor_match_a");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_anchor_match_b, grid, dim3(256), 0, s, cell_anchors, A, Hf, Wf, stride, gt_boxes,
+                     gt_count, Gcap, lo, hi, best_val, gtmax, labels);
+  return sfod_check_launch("anchor_match_b");
+}
+
+__global__ void __launch_bounds__(256)
+k_roi_match(const float* __restrict__ boxes, const int32_t* __restrict__ box_count, int P,
+            const float* __restrict__ gt, const int32_t* __restrict__ gt_classes,
+            const int32_t* __restrict__ gt_count, int Gcap, float thr, int K,
+            int32_t* __restrict__ matched, int32_t* __restrict__ cls) {
+  __shared__ float sgt[GT_MAX * 4];
+  const int b = blockIdx.y;
+  const int G = min(gt_count[b], Gcap);
+  for (int t = threadIdx.x; t < G * 4; t += blockDim.x) sgt[t] = gt[(int64_t)b * Gcap * 4 + t];
+  __syncthreads();
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int64_t o = (int64_t)b * P + p;
+  if (p >= box_count[b]) { matched[o] = 0; cls[o] = -2; return; }
+  if (G == 0) { matched[o] = 0; cls[o] = K; return; }
+  Box bx = load_box(boxes + o * 4);
+  float best = -1.f;
+  int arg = 0;
+  for (int g = 0; g < G; ++g) {
+    Box gb = Box{sgt[g * 4], sgt[g * 4 + 1], sgt[g * 4 + 2], sgt[g * 4 + 3]};
+    float v = iou_pairwise(gb, bx);
+    if (v > best) { best = v; arg = g; }
+  }
+  matched[o] = arg;
+  cls[o] = (best >= thr) ? gt_classes[(int64_t)b * Gcap + arg] : K;
+}
+
+extern "C" int sfod_roi_match(const float* boxes, const int32_t* box_count, int B, int P,
+                              const float* gt_boxes, const int32_t* gt_classes, const int32_t* gt_count,
+                              int Gcap, float thr, int num_classes, int32_t* matched, int32_t* cls,
+                              void* stream) {
+  SFOD_REQUIRE(Gcap <= GT_MAX, "Gcap > 256");
+  dim3 grid(cdiv(P, 256), B);
+  hipLaunchKernelGGL(k_roi_match, grid, dim3(256), 0, (hipStream_t)stream, boxes, box_count, P, gt_boxes,
+                     gt_classes, gt_count, Gcap, thr, num_classes, matched, cls);
+  return sfod_check_launch("roi_match");
+}
+
+// ---------------------------------------------------------------------------------------------
+// subsample_labels: the n candidates with the smallest (key, index).  One 1024-thread workgroup
+// per image; the n-th smallest composite is found by a bitwise search, so no sort and no host
+// round trip.
+// ---------------------------------------------------------------------------------------------
+#define SS_THREADS 1024
+
+__device__ int block_sum_i(int v, int* red) {
+  v = wave_sum_i(v);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[wid] = v;
+  __syncthreads();
+  int t = 0;
+  for (int w = 0; w < SS_THREADS / 64; ++w) t += red[w];
+  return t;
+}
+
+// which: 0 -> positive candidates, 1 -> negative candidates
+template <int MODE>
+__device__ __forceinline__ bool is_cand(const void* lab, int64_t o, int bg, int which) {
+  int v;
+  if (MODE == 0) v = (int)reinterpret_cast<const int8_t*>(lab)[o];
+  else v = reinterpret_cast<const int32_t*>(lab)[o];
+  if (MODE == 1 && v == -2) return false;  // beyond the live prefix
+  if (which == 0) return v != -1 && v != bg;
+  return v == bg;
+}
+
+template <int MODE>
+__device__ uint64_t select_threshold(const void* lab, const uint32_t* keys, int64_t base, int n, int bg,
+                                     int which, int take, int idx_bits, int* red) {
+  // smallest T with count(comp <= T) >= take, comp = (key << idx_bits) | idx
+  uint64_t T = 0;
+  for (int bit = 32 + idx_bits - 1; bit >= 0; --bit) {
+    const uint64_t trial = T | (1ull << bit);
+    int c = 0;
+    for (int i = threadIdx.x; i < n; i += SS_THREADS) {
+      if (is_cand<MODE>(lab, base + i, bg, which)) {
+        const uint64_t comp = ((uint64_t)keys[base + i] << idx_bits) | (uint64_t)i;
+        c += comp < trial;
+      }
+    }
+    c = block_sum_i(c, red);
+    if (c < take) T = trial;
+  }
+  return T;
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(SS_THREADS)
+k_subsample(void* lab, const uint32_t* __restrict__ keys, int n, int num, float pos_frac, int bg,
+            int32_t* __restrict__ out_idx, int32_t* __restrict__ out_count) {
+  __shared__ int red[SS_THREADS / 64];
+  __shared__ int scan[SS_THREADS];
+  const int b = blockIdx.x;
+  const int64_t base = (int64_t)b * n;
+  int idx_bits = 1;
+  while ((1 << idx_bits) < n) ++idx_bits;
+  int cpos = 0, cneg = 0;
+  for (int i = threadIdx.x; i < n; i += SS_THREADS) {
+    cpos += is_cand<MODE>(lab, base + i, bg, 0);
+    cneg += is_cand<MODE>(lab, base + i, bg, 1);
+  }
+  cpos = block_sum_i(cpos, red);
+  cneg = block_sum_i(cneg, red);
+  const int num_pos = min(cpos, (int)((float)num * pos_frac));
+  const int num_neg = min(cneg, num - num_pos);
+  uint64_t Tpos = ~0ull, Tneg = ~0ull;
+  if (num_pos < cpos) Tpos = select_threshold<MODE>(lab, keys, base, n, bg, 0, num_pos, idx_bits, red);
+  if (num_neg < cneg) Tneg = select_threshold<MODE>(lab, keys, base, n, bg, 1, num_neg, idx_bits, red);
+  const bool none_pos = (num_pos == 0), none_neg = (num_neg == 0);
+  // contiguous chunk per thread so that the compaction below is index-ordered
+  const int chunk = (n + SS_THREADS - 1) / SS_THREADS;
+  const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
+  int npos_local = 0, nneg_local = 0;
+  for (int i = lo; i < hi; ++i) {
+    const uint64_t comp = ((uint64_t)keys[base + i] << idx_bits) | (uint64_t)i;
+    const bool sp = !none_pos && is_cand<MODE>(lab, base + i, bg, 0) && comp <= Tpos;
+    const bool sn = !none_neg && is_cand<MODE>(lab, base + i, bg, 1) && comp <= Tneg;
+    npos_local += sp;
+    nneg_local += sn;
+  }
+  if (MODE == 0) {
+    __syncthreads();
+    int8_t* l8 = reinterpret_cast<int8_t*>(lab);
+    for (int i = lo; i < hi; ++i) {
+      const uint64_t comp = ((uint64_t)keys[base + i] << idx_bits) | (uint64_t)i;
+      const bool sp = !none_pos && is_cand<MODE>(lab, base + i, bg, 0) && comp <= Tpos;
+      const bool sn = !none_neg && is_cand<MODE>(lab, base + i, bg, 1) && comp <= Tneg;
+      l8[base + i] = sp ? 1 : (sn ? 0 : -1);
+    }
+    if (threadIdx.x == 0 && out_count) { out_count[b * 2] = num_pos; out_count[b * 2 + 1] = num_neg; }
+    return;
+  }
+  // MODE 1: ordered compaction fg then bg
+  scan[threadIdx.x] = npos_local;
+  __syncthreads();
+  for (int off = 1; off < SS_THREADS; off <<= 1) {
+    int v = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+    __syncthreads();
+    scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int ppos = scan[threadIdx.x] - npos_local;
+  __syncthreads();
+  scan[threadIdx.x] = nneg_local;
+  __syncthreads();
+  for (int off = 1; off < SS_THREADS; off <<= 1) {
+    int v = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
+    __syncthreads();
+    scan[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int pneg = num_pos + scan[threadIdx.x] - nneg_local;
+  for (int i = lo; i < hi; ++i) {
+    const uint64_t comp = ((uint64_t)keys[base + i] << idx_bits) | (uint64_t)i;
+    const bool sp = !none_pos && is_cand<MODE>(lab, base + i, bg, 0) && comp <= Tpos;
+    const bool sn = !none_neg && is_cand<MODE>(lab, base + i, bg, 1) && comp <= Tneg;
+    if (sp) out_idx[(int64_t)b * num + ppos++] = i;
+    if (sn) out_idx[(int64_t)b * num + pneg++] = i;
+  }
+  if (threadIdx.x == 0) out_count[b] = num_pos + num_neg;
+}
+
+extern "C" int sfod_subsample(void* labels_or_cls, const uint32_t* keys, int B, int n, int num,
+                              float pos_frac, int bg_label, int mode, int32_t* out_idx, int32_t* out_count,
+                              void* stream) {
+  SFOD_REQUIRE(n >= 1 && n < (1 << 24), "subsample n");
+  if (mode == 0)
+    hipLaunchKernelGGL(k_subsample<0>, dim3(B), dim3(SS_THREADS), 0, (hipStream_t)stream, labels_or_cls,
+                       keys, n, num, pos_frac, bg_label, out_idx, out_count);
+  else
+    hipLaunchKernelGGL(k_subsample<1>, dim3(B), dim3(SS_THREADS), 0, (hipStream_t)stream, labels_or_cls,
+                       keys, n, num, pos_frac, bg_label, out_idx, out_count);
+  return sfod_check_launch("subsample");
+}
+
+// ---------------------------------------------------------------------------------------------
+// RPN losses (BCE-with-logits sum over sampled anchors, L1 on positives' deltas) + gradients
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_f256(float v, float* red) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ void __launch_bounds__(256)
+k_rpn_loss(const float* __restrict__ rpn_out, int ld, const float* __restrict__ cell, int A, int Hf,
+           int Wf, int stride, const int8_t* __restrict__ labels, const int32_t* __restrict__ matched,
+           const float* __restrict__ gt, const int32_t* __restrict__ gt_count, int Gcap, float inv_norm,
+           const float* __restrict__ grad_scale, float* __restrict__ d_out, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  const int NA = Hf * Wf * A;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float lcls = 0.f, lloc = 0.f;
+  if (i < NA) {
+    const int8_t lab = labels[(int64_t)b * NA + i];
+    const int a = i % A, p = i / A;
+    const int64_t rowoff = ((int64_t)b * Hf * Wf + p) * ld;
+    if (lab >= 0) {
+      const float x = rpn_out[rowoff + a];
+      const float y = (float)lab;
+      // torch binary_cross_entropy_with_logits
+      const float max_val = fmaxf(-x, 0.f);
+      lcls = (1.f - y) * x + max_val + logf(expf(-max_val) + expf(-x - max_val));
+      if (grad_scale) {
+        const float sig = 1.f / (1.f + expf(-x));
+        d_out[rowoff + a] = (sig - y) * inv_norm * grad_scale[0];
+      }
+    }
+    if (lab == 1) {
+      const int G = min(gt_count[b], Gcap);
+      Box t{0.f, 0.f, 0.f, 0.f};
+      if (G > 0) t = load_box(gt + ((int64_t)b * Gcap + matched[(int64_t)b * NA + i]) * 4);
+      Box anc = anchor_at(cell, A, Wf, stride, i);
+      float tg[4];
+      get_deltas(anc, t, 1.f, 1.f, 1.f, 1.f, tg);
+      for (int j = 0; j < 4; ++j) {
+        const float d = rpn_out[rowoff + A + a * 4 + j] - tg[j];
+        lloc += fabsf(d);
+        if (grad_scale) {
+          const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+          d_out[rowoff + A + a * 4 + j] = sgn * inv_norm * grad_scale[1];
+        }
+      }
+    }
+  }
+  lcls = block_sum_f256(lcls, red);
+  lloc = block_sum_f256(lloc, red);
+  if (threadIdx.x == 0) {
+    const int blk = blockIdx.y * gridDim.x + blockIdx.x;
+    partial[blk * 2 + 0] = lcls;
+    partial[blk * 2 + 1] = lloc;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_sum_partials2(const float* __restrict__ partial, int nblk, float scale0, float scale1,
+                const int32_t* __restrict__ n_valid, float* __restrict__ loss) {
+  __shared__ float red[4];
+  float a = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) { a += partial[i * 2]; c += partial[i * 2 + 1]; }
+  a = block_sum_f256(a, red);
+  c = block_sum_f256(c, red);
+  if (threadIdx.x == 0) {
+    if (n_valid) {  // Fast R-CNN: loss_cls mean over rows, loss_box / max(rows, 1)
+      const float nv = (float)n_valid[0];
+      loss[0] = nv > 0.f ? a / nv : 0.f;
+      loss[1] = c / fmaxf(nv, 1.f);
+    } else {
+      loss[0] = a * scale0;
+      loss[1] = c * scale1;
+    }
+  }
+}
+
+extern "C" int sfod_rpn_loss(const float* rpn_out, int ld, const float* cell_anchors, int A, int B, int Hf,
+                             int Wf, int stride, const int8_t* labels, const int32_t* matched,
+                             const float* gt_boxes, const int32_t* gt_count, int Gcap, int batch_per_image,
+                             float* loss, const float* grad_scale, float* d_rpn_out, float* ws,
+                             void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int NA = Hf * Wf * A;
+  const float inv_norm = 1.f / (float)(batch_per_image * B);
+  if (grad_scale) {
+    SFOD_REQUIRE(d_rpn_out != nullptr, "d_rpn_out");
+    (void)hipMemsetAsync(d_rpn_out, 0, sizeof(float) * (int64_t)B * Hf * Wf * ld, s);
+  }
+  dim3 grid(cdiv(NA, 256), B);
+  hipLaunchKernelGGL(k_rpn_loss, grid, dim3(256), 0, s, rpn_out, ld, cell_anchors, A, Hf, Wf, stride,
+                     labels, matched, gt_boxes, gt_count, Gcap, inv_norm, grad_scale, d_rpn_out, ws);
+  int rc = sfod_check_launch("rpn_loss");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(256), 0, s, ws, (int)(grid.x * grid.y), inv_norm,
+                     inv_norm, (const int32_t*)nullptr, loss);
+  return sfod_check_launch("rpn_loss_sum");
+}
+
+// ---------------------------------------------------------------------------------------------
+// ROI sampling plumbing
+// ---------------------------------------------------------------------------------------------
+__global__ void k_append_gt(const float* __restrict__ props, const int32_t* __restrict__ pc, int P,
+                            const float* __restrict__ gt, const int32_t* __restrict__ gc, int Gcap,
+                            float* __restrict__ out, int32_t* __restrict__ out_count) {
+  const int b = blockIdx.y;
+  const int PT = P + Gcap;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= PT) return;
+  const int np = min(pc[b], P), ng = min(gc[b], Gcap);
+  Box bx{0.f, 0.f, 0.f, 0.f};
+  if (j < np) bx = load_box(props + ((int64_t)b * P + j) * 4);
+  else if (j < np + ng) bx = load_box(gt + ((int64_t)b * Gcap + (j - np)) * 4);
+  store_box(out + ((int64_t)b * PT + j) * 4, bx);
+  if (j == 0) out_count[b] = np + ng;
+}
+
+extern "C" int sfod_append_gt(const float* props, const int32_t* prop_count, int B, int P,
+                              const float* gt_boxes, const int32_t* gt_count, int Gcap, float* out_boxes,
+                              int32_t* out_count, void* stream) {
+  dim3 grid(cdiv(P + Gcap, 256), B);
+  hipLaunchKernelGGL(k_append_gt, grid, dim3(256), 0, (hipStream_t)stream, props, prop_count, P, gt_boxes,
+                     gt_count, Gcap, out_boxes, out_count);
+  return sfod_check_launch("append_gt");
+}
+
+__global__ void k_roi_build_samples(const float* __restrict__ boxes, const int32_t* __restrict__ cls,
+                                    const int32_t* __restrict__ matched, const int32_t* __restrict__ sidx,
+                                    const int32_t* __restrict__ scount, int P, int S,
+                                    const float* __restrict__ gt, const int32_t* __restrict__ gc, int Gcap,
+                                    float* __restrict__ rois, int32_t* __restrict__ gt_cls,
+                                    float* __restrict__ gt_box, int32_t* n_valid) {
+  const int b = blockIdx.y;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= S) return;
+  const int64_t r = (int64_t)b * S + s;
+  if (s < scount[b]) {
+    const int p = sidx[(int64_t)b * S + s];
+    Box bx = load_box(boxes + ((int64_t)b * P + p) * 4);
+    rois[r * 5 + 0] = (float)b;
+    rois[r * 5 + 1] = bx.x1; rois[r * 5 + 2] = bx.y1; rois[r * 5 + 3] = bx.x2; rois[r * 5 + 4] = bx.y2;
+    gt_cls[r] = cls[(int64_t)b * P + p];
+    Box g{0.f, 0.f, 0.f, 0.f};
+    if (min(gc[b], Gcap) > 0) g = load_box(gt + ((int64_t)b * Gcap + matched[(int64_t)b * P + p]) * 4);
+    store_box(gt_box + r * 4, g);
+  } else {
+    rois[r * 5 + 0] = -1.f;
+    rois[r * 5 + 1] = 0.f; rois[r * 5 + 2] = 0.f; rois[r * 5 + 3] = 0.f; rois[r * 5 + 4] = 0.f;
+    gt_cls[r] = -1;
+    store_box(gt_box + r * 4, Box{0.f, 0.f, 0.f, 0.f});
+  }
+  if (s == 0) atomicAdd(n_valid, scount[b]);
+}
+
+extern "C" int sfod_roi_build_samples(const float* boxes, const int32_t* cls, const int32_t* matched,
+                                      const int32_t* samp_idx, const int32_t* samp_count, int B, int P,
+                                      int S, const float* gt_boxes, const int32_t* gt_count, int Gcap,
+                                      float* rois, int32_t* gt_cls, float* gt_box, int32_t* n_valid,
+                                      void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(n_valid, 0, sizeof(int32_t), s);
+  dim3 grid(cdiv(S, 256), B);
+  hipLaunchKernelGGL(k_roi_build_samples, grid, dim3(256), 0, s, boxes, cls, matched, samp_idx, samp_count,
+                     P, S, gt_boxes, gt_count, Gcap, rois, gt_cls, gt_box, n_valid);
+  return sfod_check_launch("roi_build_samples");
+}
+
+__global__ void k_make_rois(const float* __restrict__ props, const int32_t* __restrict__ pc, int P,
+                            float* __restrict__ rois) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= P) return;
+  const int64_t r = (int64_t)b * P + j;
+  if (j < pc[b]) {
+    Box bx = load_box(props + r * 4);
+    rois[r * 5 + 0] = (float)b;
+    rois[r * 5 + 1] = bx.x1; rois[r * 5 + 2] = bx.y1; rois[r * 5 + 3] = bx.x2; rois[r * 5 + 4] = bx.y2;
+  } else {
+    rois[r * 5 + 0] = -1.f;
+    rois[r * 5 + 1] = 0.f; rois[r * 5 + 2] = 0.f; rois[r * 5 + 3] = 0.f; rois[r * 5 + 4] = 0.f;
+  }
+}
+
+extern "C" int sfod_make_rois(const float* props, const int32_t* prop_count, int B, int P, float* rois,
+                              void* stream) {
+  dim3 grid(cdiv(P, 256), B);
+  hipLaunchKernelGGL(k_make_rois, grid, dim3(256), 0, (hipStream_t)stream, props, prop_count, P, rois);
+  return sfod_check_launch("make_rois");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fast R-CNN losses: softmax cross-entropy (mean over rows) + L1 on the gt-class deltas of
+// foreground rows / rows
+// ---------------------------------------------------------------------------------------------
+#define KMAX 32
+
+__global__ void __launch_bounds__(256)
+k_frcnn_loss(const float* __restrict__ pred, int ld, int R, int K, const float* __restrict__ rois,
+             const int32_t* __restrict__ gt_cls, const float* __restrict__ gt_box,
+             const int32_t* __restrict__ n_valid, const float* __restrict__ grad_scale,
+             float* __restrict__ d_pred, float* __restrict__ partial) {
+  __shared__ float red[4];
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  float lcls = 0.f, lbox = 0.f;
+  if (r < R) {
+    const int c = gt_cls[r];
+    const float* row = pred + (int64_t)r * ld;
+    float* drow = d_pred ? d_pred + (int64_t)r * ld : nullptr;
+    if (c >= 0) {
+      float m = row[0];
+      for (int j = 1; j <= K; ++j) m = fmaxf(m, row[j]);
+      float ssum = 0.f;
+      for (int j = 0; j <= K; ++j) ssum += expf(row[j] - m);
+      const float lse = logf(ssum) + m;
+      lcls = lse - row[c];
+      const float nv = (float)n_valid[0];
+      if (grad_scale) {
+        const float gs = grad_scale[0] / nv;
+        for (int j = 0; j <= K; ++j) {
+          const float pj = expf(row[j] - lse);
+          drow[j] = (pj - (j == c ? 1.f : 0.f)) * gs;
+        }
+      }
+      if (c < K) {
+        Box rb{rois[(int64_t)r * 5 + 1], rois[(int64_t)r * 5 + 2], rois[(int64_t)r * 5 + 3],
+               rois[(int64_t)r * 5 + 4]};
+        Box gb = load_box(gt_box + (int64_t)r * 4);
+        float tg[4];
+        get_deltas(rb, gb, 10.f, 10.f, 5.f, 5.f, tg);
+        const float gs = grad_scale ? grad_scale[1] / fmaxf(nv, 1.f) : 0.f;
+        for (int j = 0; j < 4; ++j) {
+          const float d = row[K + 1 + c * 4 + j] - tg[j];
+          lbox += fabsf(d);
+          if (grad_scale) drow[K + 1 + c * 4 + j] = ((d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f)) * gs;
+        }
+      }
+    }
+  }
+  lcls = block_sum_f256(lcls, red);
+  lbox = block_sum_f256(lbox, red);
+  if (threadIdx.x == 0) { partial[blockIdx.x * 2] = lcls; partial[blockIdx.x * 2 + 1] = lbox; }
+}
+
+extern "C" int sfod_frcnn_loss(const float* pred, int ld, int R, int K, const float* rois,
+                               const int32_t* gt_cls, const float* gt_box, const int32_t* n_valid,
+                               float* loss, const float* grad_scale, float* d_pred, float* ws,
+                               void* stream) {
+  SFOD_REQUIRE(K <= KMAX && ld >= 5 * K + 1, "frcnn_loss K / ld");
+  hipStream_t s = (hipStream_t)stream;
+  if (grad_scale) {
+    SFOD_REQUIRE(d_pred != nullptr, "d_pred");
+    (void)hipMemsetAsync(d_pred, 0, sizeof(float) * (int64_t)R * ld, s);
+  }
+  const int nblk = cdiv(R, 256);
+  hipLaunchKernelGGL(k_frcnn_loss, dim3(nblk), dim3(256), 0, s, pred, ld, R, K, rois, gt_cls, gt_box,
+                     n_valid, grad_scale, d_pred, ws);
+  int rc = sfod_check_launch("frcnn_loss");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_sum_partials2, dim3(1), dim3(256), 0, s, ws, nblk, 1.f, 1.f, n_valid, loss);
+  return sfod_check_launch("frcnn_loss_sum");
+}
+
+// ---------------------------------------------------------------------------------------------
+// Teacher inference post-processing
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_frcnn_candidates(const float* __restrict__ pred, int ld, int P, int K, const float* __restrict__ props,
+                   const int32_t* __restrict__ pc, const int32_t* __restrict__ sizes, float thr,
+                   float* __restrict__ cboxes, float* __restrict__ cscores, int32_t* ccount) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int npass = 0;
+  if (j < P) {
+    const int64_t r = (int64_t)b * P + j;
+    const bool live = j < pc[b];
+    const float* row = pred + r * ld;
+    float prob[KMAX + 1];
+    Box bx[KMAX];
+    bool fin = true;
+    if (live) {
+      float m = row[0];
+      for (int c = 1; c <= K; ++c) m = fmaxf(m, row[c]);
+      float ssum = 0.f;
+      for (int c = 0; c <= K; ++c) { prob[c] = expf(row[c] - m); ssum += prob[c]; }
+      for (int c = 0; c <= K; ++c) { prob[c] = prob[c] / ssum; fin = fin && isfinite(prob[c]); }
+      Box pb = load_box(props + r * 4);
+      for (int c = 0; c < K; ++c) {
+        const float* d = row + K + 1 + c * 4;
+        bx[c] = apply_deltas(pb, d[0], d[1], d[2], d[3], 10.f, 10.f, 5.f, 5.f);
+        fin = fin && isfinite(bx[c].x1) && isfinite(bx[c].y1) && isfinite(bx[c].x2) && isfinite(bx[c].y2);
+      }
+    }
+    const float h = (float)sizes[b * 2], w = (float)sizes[b * 2 + 1];
+    for (int c = 0; c < K; ++c) {
+      const int64_t o = ((int64_t)b * P + j) * K + c;
+      const bool pass = live && fin && (prob[c] > thr);
+      Box ob = pass ? clip_box(bx[c], h, w) : Box{0.f, 0.f, 0.f, 0.f};
+      store_box(cboxes + o * 4, ob);
+      cscores[o] = pass ? prob[c] : -1.f;
+      npass += pass;
+    }
+  }
+  npass = wave_sum_i(npass);
+  if ((threadIdx.x & 63) == 0 && npass) atomicAdd(ccount + b, npass);
+}
+
+extern "C" int sfod_frcnn_candidates(const float* pred, int ld, int B, int P, int K, const float* props,
+                                     const int32_t* prop_count, const int32_t* image_sizes,
+                                     float score_thresh, float* cand_boxes, float* cand_scores,
+                                     int32_t* cand_count, void* stream) {
+  SFOD_REQUIRE(K <= KMAX && ld >= 5 * K + 1, "frcnn_candidates K / ld");
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(cand_count, 0, sizeof(int32_t) * B, s);
+  dim3 grid(cdiv(P, 256), B);
+  hipLaunchKernelGGL(k_frcnn_candidates, grid, dim3(256), 0, s, pred, ld, P, K, props, prop_count,
+                     image_sizes, score_thresh, cand_boxes, cand_scores, cand_count);
+  return sfod_check_launch("frcnn_candidates");
+}
+
+__global__ void __launch_bounds__(256)
+k_frcnn_gather(const float* __restrict__ cboxes, const int32_t* __restrict__ sidx,
+               const int32_t* __restrict__ ccount, int n, int K, float* __restrict__ sboxes,
+               int32_t* __restrict__ scls, float* maxcoord) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  float mx = 0.f;
+  if (j < n) {
+    const int idx = sidx[(int64_t)b * n + j];
+    Box bx = load_box(cboxes + ((int64_t)b * n + idx) * 4);
+    store_box(sboxes + ((int64_t)b * n + j) * 4, bx);
+    scls[(int64_t)b * n + j] = idx % K;
+    if (j < ccount[b]) mx = fmaxf(fmaxf(bx.x1, bx.y1), fmaxf(bx.x2, bx.y2));
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0)
+    atomicMax(reinterpret_cast<unsigned int*>(maxcoord + b), __float_as_uint(fmaxf(mx, 0.f)));
+}
+
+__global__ void __launch_bounds__(256)
+k_frcnn_offset(const float* __restrict__ sboxes, const int32_t* __restrict__ scls,
+               const int32_t* __restrict__ ccount, int n, int numel_limit,
+               const float* __restrict__ maxcoord, float* __restrict__ alt, int32_t* __restrict__ mode) {
+  const int b = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) mode[b] = (4 * ccount[b] > numel_limit) ? 0 : 1;
+  if (j >= n) return;
+  Box bx = load_box(sboxes + ((int64_t)b * n + j) * 4);
+  // offsets = idxs.to(boxes) * (max_coordinate + 1); boxes + offsets[:, None]
+  const float off = (float)scls[(int64_t)b * n + j] * (maxcoord[b] + 1.f);
+  store_box(alt + ((int64_t)b * n + j) * 4, Box{bx.x1 + off, bx.y1 + off, bx.x2 + off, bx.y2 + off});
+}
+
+extern "C" int sfod_frcnn_prepare_nms(const float* cand_boxes, const float* sorted_scores,
+                                      const int32_t* sorted_idx, const int32_t* cand_count, int B, int n,
+                                      int K, int numel_limit, float* s_boxes, float* s_alt_boxes,
+                                      int32_t* s_classes, int32_t* mode, float* maxcoord_ws, void* stream) {
+  (void)sorted_scores;
+  hipStream_t s = (hipStream_t)stream;
+  (void)hipMemsetAsync(maxcoord_ws, 0, sizeof(float) * B, s);
+  dim3 grid(cdiv(n, 256), B);
+  hipLaunchKernelGGL(k_frcnn_gather, grid, dim3(256), 0, s, cand_boxes, sorted_idx, cand_count, n, K,
+                     s_boxes, s_classes, maxcoord_ws);
+  int rc = sfod_check_launch("frcnn_gather");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_frcnn_offset, grid, dim3(256), 0, s, s_boxes, s_classes, cand_count, n,
+                     numel_limit, maxcoord_ws, s_alt_boxes, mode);
+  return sfod_check_launch("frcnn_offset");
+}
+
+__global__ void __launch_bounds__(128)
+k_frcnn_finalize(const float* __restrict__ sboxes, const float* __restrict__ sscores,
+                 const int32_t* __restrict__ scls, const int32_t* __restrict__ keep_idx,
+                 const int32_t* __restrict__ keep_count, int n, int max_det, float pthr,
+                 float* __restrict__ dboxes, float* __restrict__ dscores, int32_t* __restrict__ dcls,
+                 int32_t* __restrict__ dcount, float* __restrict__ gboxes, int32_t* __restrict__ gcls,
+                 int32_t* __restrict__ gcount) {
+  __shared__ int s_ng;
+  const int b = blockIdx.x;
+  if (threadIdx.x == 0) s_ng = 0;
+  __syncthreads();
+  const int nd = min(keep_count[b], max_det);
+  for (int j = threadIdx.x; j < max_det; j += blockDim.x) {
+    Box bx{0.f, 0.f, 0.f, 0.f};
+    float sc = 0.f;
+    int c = 0;
+    if (j < nd) {
+      const int pos = keep_idx[(int64_t)b * max_det + j];
+      bx = load_box(sboxes + ((int64_t)b * n + pos) * 4);
+      sc = sscores[(int64_t)b * n + pos];
+      c = scls[(int64_t)b * n + pos];
+    }
+    store_box(dboxes + ((int64_t)b * max_det + j) * 4, bx);
+    dscores[(int64_t)b * max_det + j] = sc;
+    dcls[(int64_t)b * max_det + j] = c;
+    // scores are in descending order: the pseudo labels (score > thr) are a prefix
+    const bool pg = (j < nd) && (sc > pthr);
+    store_box(gboxes + ((int64_t)b * max_det + j) * 4, pg ? bx : Box{0.f, 0.f, 0.f, 0.f});
+    gcls[(int64_t)b * max_det + j] = pg ? c : 0;
+    if (pg) atomicAdd(&s_ng, 1);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) { dcount[b] = nd; gcount[b] = s_ng; }
+}
+
+extern "C" int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_scores,
+                                   const int32_t* s_classes, const int32_t* keep_idx,
+                                   const int32_t* keep_count, int B, int n, int max_det, float pseudo_thr,
+                                   float* det_boxes, float* det_scores, int32_t* det_classes,
+                                   int32_t* det_count, float* gt_boxes, int32_t* gt_classes,
+                                   int32_t* gt_count, void* stream) {
+  hipLaunchKernelGGL(k_frcnn_finalize, dim3(B), dim3(128), 0, (hipStream_t)stream, s_boxes, sorted_scores,
+                     s_classes, keep_idx, keep_count, n, max_det, pseudo_thr, det_boxes, det_scores,
+                     det_classes, det_count, gt_boxes, gt_classes, gt_count);
+  return sfod_check_launch("frcnn_finalize");
+}

@@ -1,0 +1,760 @@
+// HBM-bound kernels of the hot path: preprocess, train-mode BatchNorm + ReLU + max-pool
+// (forward and backward), weight (re)packing, bias gradients, fused SGD + EMA.  gfx950.
+//
+// Activations are NHWC; every kernel reads/writes 16 bytes per lane along the channel axis
+// (4 x fp32 or 8 x bf16) so a wavefront covers 1 KiB of contiguous channels per instruction.
+#include "common.h"
+
+template <typename T> struct VecT;
+template <> struct VecT<float> {
+  static constexpr int N = 4;
+  typedef float4 raw;
+};
+template <> struct VecT<bf16_t> {
+  static constexpr int N = 8;
+  typedef uint4 raw;
+};
+
+template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* out);
+template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* out) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+}
+template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, float* out) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(w[i] << 16);
+    out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+  }
+}
+template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* in);
+template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* in) {
+  *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
+}
+template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const float* in) {
+  union { bf16_t h[8]; uint4 v; } u;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) u.h[i] = (bf16_t)in[i];
+  *reinterpret_cast<uint4*>(p) = u.v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 preprocess
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_preprocess(const uint8_t* const* __restrict__ imgs, const int32_t* __restrict__ sizes,
+                             int Hp, int Wp, int Cpad, float m0, float m1, float m2, float s0, float s1,
+                             float s2, T* __restrict__ out) {
+  const int b = blockIdx.z;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= Wp) return;
+  const int h = sizes[b * 2], w = sizes[b * 2 + 1];
+  T* o = out + (((int64_t)b * Hp + y) * Wp + x) * Cpad;
+  float v[3] = {0.f, 0.f, 0.f};
+  if (y < h && x < w) {
+    const uint8_t* im = imgs[b];
+    const int64_t plane = (int64_t)h * w;
+    v[0] = ((float)im[(int64_t)y * w + x] - m0) / s0;
+    v[1] = ((float)im[plane + (int64_t)y * w + x] - m1) / s1;
+    v[2] = ((float)im[2 * plane + (int64_t)y * w + x] - m2) / s2;
+  }
+  for (int c = 0; c < Cpad; ++c) o[c] = from_f32<T>(c < 3 ? v[c] : 0.f);
+}
+
+extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes, int B, int Hp, int Wp,
+                               int Cpad, const float* mean3, const float* std3, void* out, int dt,
+                               void* stream) {
+  SFOD_REQUIRE(Cpad >= 3, "Cpad < 3");
+  dim3 grid(cdiv(Wp, 256), Hp, B);
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_preprocess<float>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
+                       Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out);
+  else
+    hipLaunchKernelGGL(k_preprocess<bf16_t>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
+                       Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16_t*)out);
+  return sfod_check_launch("preprocess");
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3 BatchNorm statistics finalize.  stats[blk][0][c] = sum over the block's rows, stats[blk][1][c]
+// = sum of squared deviations from the block mean (written by the conv epilogue).  Combined in
+// fp64 with M2 = sum_b M2_b + n_b (mean_b - mean)^2  (all terms >= 0: no cancellation).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_bn_finalize(const float* __restrict__ stats, int nblocks, int rows_per_block, int M, int C,
+              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
+              float* __restrict__ rvar, float momentum, float eps, int update_running) {
+  __shared__ double red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  double acc = 0.0;
+  if (c < C)
+    for (int blk = wave; blk < nblocks; blk += 16) acc += (double)stats[((int64_t)blk * 2) * C + c];
+  red[wave][lane] = acc;
+  __syncthreads();
+  double tot = 0.0;
+  for (int w = 0; w < 16; ++w) tot += red[w][lane];
+  const double mu = tot / (double)M;
+  __syncthreads();
+  acc = 0.0;
+  if (c < C)
+    for (int blk = wave; blk < nblocks; blk += 16) {
+      const int nb = min(rows_per_block, M - blk * rows_per_block);
+      const double sb = (double)stats[((int64_t)blk * 2) * C + c];
+      const double m2 = (double)stats[((int64_t)blk * 2 + 1) * C + c];
+      const double d = sb / (double)nb - mu;
+      acc += m2 + (double)nb * d * d;
+    }
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && c < C) {
+    double m2 = 0.0;
+    for (int w = 0; w < 16; ++w) m2 += red[w][lane];
+    const double var = m2 / (double)M;
+    mean[c] = (float)mu;
+    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (update_running) {
+      const double unbiased = (M > 1) ? m2 / (double)(M - 1) : var;
+      rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
+      rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+    }
+  }
+}
+
+extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int rows_per_block, int M, int C,
+                                float* mean, float* invstd, float* running_mean, float* running_var,
+                                float momentum, float eps, int update_running, void* stream) {
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, stats, nblocks,
+                     rows_per_block, M, C, mean, invstd, running_mean, running_var, momentum, eps,
+                     update_running);
+  return sfod_check_launch("bn_finalize");
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3/K4 forward: z = relu(gamma * (y - mean) * invstd + beta), optional 2x2/2 max-pool
+// ---------------------------------------------------------------------------------------------
+template <typename T, int POOL>
+__global__ void __launch_bounds__(256)
+k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
+                   int B, int H, int W, int C) {
+  constexpr int V = VecT<T>::N;
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const int cv = C / V;
+  const int64_t total = (int64_t)B * Ho * Wo * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * V;
+    int64_t pix = t / cv;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    float sc[V], sh[V], mu[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      sc[i] = invstd[c0 + i] * gamma[c0 + i];
+      mu[i] = mean[c0 + i];
+      sh[i] = beta[c0 + i];
+    }
+    float r[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = 0.f;  // relu floor doubles as the max identity
+    const int win = POOL ? 2 : 1;
+#pragma unroll
+    for (int dy = 0; dy < win; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < win; ++dx) {
+        const int iy = POOL ? oy * 2 + dy : oy, ix = POOL ? ox * 2 + dx : ox;
+        float v[V];
+        load_vec<T>(y + (((int64_t)b * H + iy) * W + ix) * C + c0, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] = fmaxf(r[i], (v[i] - mu[i]) * sc[i] + sh[i]);
+      }
+    store_vec<T>(z + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, r);
+  }
+}
+
+static inline int ew_grid(int64_t total) {
+  int64_t g = (total + 255) / 256;
+  if (g > 256 * 16) g = 256 * 16;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, void* z, int B, int H, int W,
+                                     int C, int pool, int dt, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(C % V == 0, "bn: C not a multiple of the vector width");
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  const int grid = ew_grid((int64_t)B * Ho * Wo * (C / V));
+#define LAUNCH(T, P)                                                                                  \
+  hipLaunchKernelGGL((k_bn_relu_pool_fwd<T, P>), dim3(grid), dim3(256), 0, s, (const T*)y, mean, invstd, \
+                     gamma, beta, (T*)z, B, H, W, C)
+  if (dt == SFOD_F32) { if (pool) LAUNCH(float, 1); else LAUNCH(float, 0); }
+  else { if (pool) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 0); }
+#undef LAUNCH
+  return sfod_check_launch("bn_relu_pool_fwd");
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3/K4 backward.  Units: a 2x2 window (pool) or one pixel; leftover pixels of odd H/W (not
+// covered by a window) take part in the batch statistics with zero upstream gradient.
+//   g     = dz routed to the first max of the window, gated by relu (z_pre > 0)
+//   dbeta = sum g ; dgamma = sum g * xhat ; dy = gamma*invstd*(g - dbeta/M - xhat*dgamma/M)
+// pass 1 writes per-workgroup partial sums, pass 2 reduces them (fp64, fixed order), pass 3
+// writes dy.
+// ---------------------------------------------------------------------------------------------
+#define BNB_ROWS 64  // units per workgroup in pass 1
+
+template <typename T, int POOL>
+__device__ __forceinline__ void bn_unit_grad(const T* __restrict__ y, const T* __restrict__ dz, int b,
+                                             int oy, int ox, int H, int W, int C, int c0,
+                                             const float* mu, const float* sc, const float* sh,
+                                             float (*xhat_out)[VecT<T>::N], float (*g_out)[VecT<T>::N],
+                                             const float* invs) {
+  constexpr int V = VecT<T>::N;
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  float gz[V];
+  load_vec<T>(dz + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, gz);
+  constexpr int NW = POOL ? 4 : 1;
+  float zp[NW][V];
+#pragma unroll
+  for (int k = 0; k < NW; ++k) {
+    const int iy = POOL ? oy * 2 + (k >> 1) : oy, ix = POOL ? ox * 2 + (k & 1) : ox;
+    float v[V];
+    load_vec<T>(y + (((int64_t)b * H + iy) * W + ix) * C + c0, v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      xhat_out[k][i] = (v[i] - mu[i]) * invs[i];
+      zp[k][i] = (v[i] - mu[i]) * sc[i] + sh[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    int arg = 0;
+    float best = zp[0][i];
+#pragma unroll
+    for (int k = 1; k < NW; ++k)
+      if (zp[k][i] > best) { best = zp[k][i]; arg = k; }
+#pragma unroll
+    for (int k = 0; k < NW; ++k) g_out[k][i] = (k == arg && best > 0.f) ? gz[i] : 0.f;
+  }
+}
+
+
+#define BNB_GRID_MAX 2048
+
+template <typename T, int POOL>
+__global__ void __launch_bounds__(256)
+k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
+                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                const float* __restrict__ beta, float* __restrict__ ws, int B, int H, int W, int C) {
+  constexpr int V = VecT<T>::N;
+  constexpr int NW = POOL ? 4 : 1;
+  extern __shared__ __attribute__((aligned(16))) float sred[];  // [UL][2][C]
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const int cv = C / V;
+  const int UL = blockDim.x / cv;  // unit lanes per workgroup (cv <= 256 required)
+  const int cl = threadIdx.x % cv, ul = threadIdx.x / cv;
+  const int c0 = cl * V;
+  const int64_t units = (int64_t)B * Ho * Wo;
+  float mu[V], sc[V], sh[V], invs[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    invs[i] = invstd[c0 + i];
+    sc[i] = invs[i] * gamma[c0 + i];
+    mu[i] = mean[c0 + i];
+    sh[i] = beta[c0 + i];
+  }
+  float db[V], dg[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) { db[i] = 0.f; dg[i] = 0.f; }
+  if (ul < UL) {
+    for (int64_t u = (int64_t)blockIdx.x * UL + ul; u < units; u += (int64_t)gridDim.x * UL) {
+      const int ox = (int)(u % Wo);
+      const int64_t t = u / Wo;
+      const int oy = (int)(t % Ho);
+      const int b = (int)(t / Ho);
+      float xh[NW][V], g[NW][V];
+      bn_unit_grad<T, POOL>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
+#pragma unroll
+      for (int k = 0; k < NW; ++k)
+#pragma unroll
+        for (int i = 0; i < V; ++i) { db[i] += g[k][i]; dg[i] += g[k][i] * xh[k][i]; }
+    }
+    for (int i = 0; i < V; ++i) {
+      sred[(ul * 2 + 0) * C + c0 + i] = db[i];
+      sred[(ul * 2 + 1) * C + c0 + i] = dg[i];
+    }
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) {
+    float a = 0.f;
+    for (int l = 0; l < UL; ++l) a += sred[l * 2 * C + t];
+    ws[(int64_t)blockIdx.x * 2 * C + t] = a;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
+                  float* __restrict__ dbeta) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*C
+  if (t >= 2 * C) return;
+  double a = 0.0;
+  for (int b = 0; b < nblk; ++b) a += (double)ws[(int64_t)b * 2 * C + t];
+  if (t < C) dbeta[t] = (float)a; else dgamma[t - C] = (float)a;
+}
+
+template <typename T, int POOL>
+__global__ void __launch_bounds__(256)
+k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
+               const float* __restrict__ invstd, const float* __restrict__ gamma,
+               const float* __restrict__ beta, const float* __restrict__ dgamma,
+               const float* __restrict__ dbeta, T* __restrict__ dy, int B, int H, int W, int C) {
+  constexpr int V = VecT<T>::N;
+  constexpr int NW = POOL ? 4 : 1;
+  const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
+  const int cv = C / V;
+  const float invM = 1.f / (float)((int64_t)B * H * W);
+  const int64_t total = (int64_t)B * Ho * Wo * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * V;
+    int64_t pix = t / cv;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    float mu[V], sc[V], sh[V], invs[V], k1[V], k2[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      invs[i] = invstd[c0 + i];
+      sc[i] = invs[i] * gamma[c0 + i];
+      mu[i] = mean[c0 + i];
+      sh[i] = beta[c0 + i];
+      k1[i] = dbeta[c0 + i] * invM;
+      k2[i] = dgamma[c0 + i] * invM;
+    }
+    float xh[NW][V], g[NW][V];
+    bn_unit_grad<T, POOL>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
+#pragma unroll
+    for (int k = 0; k < NW; ++k) {
+      const int iy = POOL ? oy * 2 + (k >> 1) : oy, ix = POOL ? ox * 2 + (k & 1) : ox;
+      float o[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) o[i] = sc[i] * (g[k][i] - k1[i] - xh[k][i] * k2[i]);
+      store_vec<T>(dy + (((int64_t)b * H + iy) * W + ix) * C + c0, o);
+    }
+  }
+}
+
+// pixels of an odd-sized map that no 2x2 window covers: zero upstream gradient
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bn_bwd_leftover(const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                  const float* __restrict__ gamma, const float* __restrict__ dgamma,
+                  const float* __restrict__ dbeta, T* __restrict__ dy, int B, int H, int W, int C) {
+  constexpr int V = VecT<T>::N;
+  const int Ho = H / 2, Wo = W / 2;
+  const int cv = C / V;
+  const int la = 2 * Ho * (W - 2 * Wo);      // right column (x = W-1) for y < 2Ho
+  const int L = la + (H - 2 * Ho) * W;       // + bottom row
+  const float invM = 1.f / (float)((int64_t)B * H * W);
+  const int64_t total = (int64_t)B * L * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * V;
+    const int64_t q = t / cv;
+    const int l = (int)(q % L);
+    const int b = (int)(q / L);
+    int iy, ix;
+    if (l < la) { iy = l; ix = 2 * Wo; } else { iy = 2 * Ho; ix = l - la; }
+    float v[V], o[V];
+    const int64_t off = (((int64_t)b * H + iy) * W + ix) * C + c0;
+    load_vec<T>(y + off, v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float invs = invstd[c0 + i];
+      const float xh = (v[i] - mean[c0 + i]) * invs;
+      o[i] = invs * gamma[c0 + i] * (0.f - dbeta[c0 + i] * invM - xh * dgamma[c0 + i] * invM);
+    }
+    store_vec<T>(dy + off, o);
+  }
+}
+
+extern "C" int sfod_bn_bwd_ws_floats(int M, int C) {
+  (void)M;
+  return BNB_GRID_MAX * 2 * C;
+}
+
+extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, void* dy, float* dgamma,
+                                     float* dbeta, float* ws, int B, int H, int W, int C, int pool, int dt,
+                                     void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(C % V == 0 && C / V <= 256, "bn_bwd: unsupported channel count");
+  const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
+  const int cv = C / V, UL = 256 / cv;
+  const int64_t units = (int64_t)B * Ho * Wo;
+  int grid1 = (int)((units + UL - 1) / UL);
+  if (grid1 > BNB_GRID_MAX) grid1 = BNB_GRID_MAX;
+  if (grid1 < 1) grid1 = 1;
+  const size_t lds = sizeof(float) * UL * 2 * C;
+  const int grid3 = ew_grid(units * cv);
+#define LAUNCH(T, P)                                                                                   \
+  do {                                                                                                 \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<T, P>), dim3(grid1), dim3(256), lds, s, (const T*)dz,          \
+                       (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                        \
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, ws, grid1, C,       \
+                       dgamma, dbeta);                                                                 \
+    hipLaunchKernelGGL((k_bn_bwd_apply<T, P>), dim3(grid3), dim3(256), 0, s, (const T*)dz,             \
+                       (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (T*)dy, B, H, W, C);     \
+  } while (0)
+  if (dt == SFOD_F32) { if (pool) LAUNCH(float, 1); else LAUNCH(float, 0); }
+  else { if (pool) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 0); }
+#undef LAUNCH
+  int rc = sfod_check_launch("bn_relu_pool_bwd");
+  if (rc) return rc;
+  if (pool && ((H & 1) || (W & 1))) {
+    const int L = 2 * Ho * (W - 2 * Wo) + (H - 2 * Ho) * W;
+    const int grid = ew_grid((int64_t)B * L * cv);
+    if (dt == SFOD_F32)
+      hipLaunchKernelGGL(k_bn_bwd_leftover<float>, dim3(grid), dim3(256), 0, s, (const float*)y, mean,
+                         invstd, gamma, dgamma, dbeta, (float*)dy, B, H, W, C);
+    else
+      hipLaunchKernelGGL(k_bn_bwd_leftover<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, mean,
+                         invstd, gamma, dgamma, dbeta, (bf16_t*)dy, B, H, W, C);
+    rc = sfod_check_launch("bn_bwd_leftover");
+  }
+  return rc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// activation backward / add
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_act_bwd(T* __restrict__ dy, const T* __restrict__ y, int64_t nvec, int act) {
+  constexpr int V = VecT<T>::N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float g[V], v[V];
+    load_vec<T>(dy + t * V, g);
+    load_vec<T>(y + t * V, v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) g[i] = v[i] > 0.f ? g[i] : (act == 2 ? 0.2f * g[i] : 0.f);
+    store_vec<T>(dy + t * V, g);
+  }
+}
+
+extern "C" int sfod_act_bwd(void* dy, const void* y, int64_t n, int act, int dt, void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(n % V == 0, "act_bwd: n not a multiple of the vector width");
+  const int64_t nvec = n / V;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_act_bwd<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (float*)dy,
+                       (const float*)y, nvec, act);
+  else
+    hipLaunchKernelGGL(k_act_bwd<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)dy, (const bf16_t*)y, nvec, act);
+  return sfod_check_launch("act_bwd");
+}
+
+template <typename T>
+__global__ void k_add_inplace(T* __restrict__ a, const T* __restrict__ b, int64_t nvec) {
+  constexpr int V = VecT<T>::N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float x[V], yv[V];
+    load_vec<T>(a + t * V, x);
+    load_vec<T>(b + t * V, yv);
+#pragma unroll
+    for (int i = 0; i < V; ++i) x[i] += yv[i];
+    store_vec<T>(a + t * V, x);
+  }
+}
+
+extern "C" int sfod_add_inplace(void* a, const void* b, int64_t n, int dt, void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(n % V == 0, "add_inplace: n not a multiple of the vector width");
+  const int64_t nvec = n / V;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_add_inplace<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (float*)a, (const float*)b, nvec);
+  else
+    hipLaunchKernelGGL(k_add_inplace<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (bf16_t*)a, (const bf16_t*)b, nvec);
+  return sfod_check_launch("add_inplace");
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight packing
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void k_pack_conv_weight(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
+                                   int ks, int innerPad, int rot180) {
+  // normal : out[co][tap][ci]  (inner = Cin  -> innerPad)
+  // rot180 : out[ci][tap'][co] (inner = Cout -> innerPad), tap' = flipped tap
+  const int taps = ks * ks;
+  const int rows = rot180 ? Cin : Cout;
+  const int64_t total = (int64_t)rows * taps * innerPad;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int inner = (int)(t % innerPad);
+    const int tap = (int)((t / innerPad) % taps);
+    const int row = (int)(t / ((int64_t)innerPad * taps));
+    float v = 0.f;
+    const int innerN = rot180 ? Cout : Cin;
+    if (inner < innerN) {
+      const int co = rot180 ? inner : row, ci = rot180 ? row : inner;
+      const int st = rot180 ? (taps - 1 - tap) : tap;
+      v = w[((int64_t)co * Cin + ci) * taps + st];
+    }
+    out[t] = from_f32<T>(v);
+  }
+}
+
+extern "C" int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Cout, int Cin, int ksize,
+                                     int CinPad, int rot180, int dt, void* stream) {
+  const int rows = rot180 ? Cin : Cout;
+  const int64_t total = (int64_t)rows * ksize * ksize * CinPad;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_pack_conv_weight<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, (float*)w_packed, Cout, Cin, ksize, CinPad, rot180);
+  else
+    hipLaunchKernelGGL(k_pack_conv_weight<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, (bf16_t*)w_packed, Cout, Cin, ksize, CinPad, rot180);
+  return sfod_check_launch("pack_conv_weight");
+}
+
+__global__ void k_unpack_conv_wgrad(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
+                                    int ks, int CinPad, int accumulate) {
+  const int taps = ks * ks;
+  const int64_t total = (int64_t)Cout * Cin * taps;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int tap = (int)(t % taps);
+    const int ci = (int)((t / taps) % Cin);
+    const int co = (int)(t / ((int64_t)taps * Cin));
+    const float v = dwp[((int64_t)co * taps + tap) * CinPad + ci];
+    dw[t] = accumulate ? dw[t] + v : v;
+  }
+}
+
+extern "C" int sfod_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int Cout, int Cin, int ksize,
+                                      int CinPad, int accumulate, void* stream) {
+  const int64_t total = (int64_t)Cout * Cin * ksize * ksize;
+  hipLaunchKernelGGL(k_unpack_conv_wgrad, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dw_packed,
+                     dw_oihw, Cout, Cin, ksize, CinPad, accumulate);
+  return sfod_check_launch("unpack_conv_wgrad");
+}
+
+// nn.Linear weight [N][K]; K axis optionally permuted (c,p)->(p,c); optional transpose.
+template <typename T>
+__global__ void k_pack_fc_weight(const float* __restrict__ w, T* __restrict__ out, int N, int K, int chw_c,
+                                 int transpose, int ld) {
+  const int rows = transpose ? K : N;
+  const int64_t total = (int64_t)rows * ld;
+  const int PP = chw_c > 0 ? K / chw_c : 1;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int inner = (int)(t % ld);
+    const int row = (int)(t / ld);
+    const int n = transpose ? inner : row;
+    const int kp = transpose ? row : inner;  // permuted k index
+    float v = 0.f;
+    if (n < N && kp < K) {
+      int k = kp;
+      if (chw_c > 0) { const int p = kp / chw_c, c = kp % chw_c; k = c * PP + p; }
+      v = w[(int64_t)n * K + k];
+    }
+    out[t] = from_f32<T>(v);
+  }
+}
+
+extern "C" int sfod_pack_fc_weight(const float* w, void* out, int N, int K, int chw_c, int transpose,
+                                   int dt, void* stream);
+
+extern "C" int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose,
+                                      int ld, int dt, void* stream) {
+  SFOD_REQUIRE(ld >= (transpose ? N : K), "pack_fc_weight: ld too small");
+  const int64_t total = (int64_t)(transpose ? K : N) * ld;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_pack_fc_weight<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
+                       (float*)out, N, K, chw_c, transpose, ld);
+  else
+    hipLaunchKernelGGL(k_pack_fc_weight<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
+                       (bf16_t*)out, N, K, chw_c, transpose, ld);
+  return sfod_check_launch("pack_fc_weight");
+}
+
+extern "C" int sfod_pack_fc_weight(const float* w, void* out, int N, int K, int chw_c, int transpose,
+                                   int dt, void* stream) {
+  return sfod_pack_fc_weight_ld(w, out, N, K, chw_c, transpose, transpose ? N : K, dt, stream);
+}
+
+__global__ void k_unpack_fc_wgrad(const float* __restrict__ dwp, float* __restrict__ dw, int N, int K,
+                                  int chw_c, int ld, int accumulate) {
+  const int64_t total = (int64_t)N * K;
+  const int PP = chw_c > 0 ? K / chw_c : 1;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % K);
+    const int n = (int)(t / K);
+    int kp = k;
+    if (chw_c > 0) { const int c = k / PP, p = k % PP; kp = p * chw_c + c; }
+    const float v = dwp[(int64_t)n * ld + kp];
+    dw[t] = accumulate ? dw[t] + v : v;
+  }
+}
+
+extern "C" int sfod_unpack_fc_wgrad_ld(const float* dw_packed, float* dw, int N, int K, int chw_c, int ld,
+                                       int accumulate, void* stream) {
+  const int64_t total = (int64_t)N * K;
+  hipLaunchKernelGGL(k_unpack_fc_wgrad, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dw_packed,
+                     dw, N, K, chw_c, ld, accumulate);
+  return sfod_check_launch("unpack_fc_wgrad");
+}
+
+extern "C" int sfod_unpack_fc_wgrad(const float* dw_packed, float* dw, int N, int K, int chw_c,
+                                    int accumulate, void* stream) {
+  return sfod_unpack_fc_wgrad_ld(dw_packed, dw, N, K, chw_c, K, accumulate, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// bias gradient: column sums.  One workgroup per 64 columns, 4 waves split the rows; fixed
+// summation order (deterministic).
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bias_grad(const T* __restrict__ dy, float* __restrict__ db, int M, int N, int ld, int accumulate) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + lane;
+  float acc = 0.f;
+  if (n < N)
+    for (int m = wave; m < M; m += 4) acc += to_f32(dy[(int64_t)m * ld + n]);
+  red[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && n < N) {
+    const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    db[n] = accumulate ? db[n] + v : v;
+  }
+}
+
+extern "C" int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, int accumulate, int dt,
+                              void* stream) {
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_bias_grad<float>, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dy, db, M, N, ld, accumulate);
+  else
+    hipLaunchKernelGGL(k_bias_grad<bf16_t>, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, db, M, N, ld, accumulate);
+  return sfod_check_launch("bias_grad");
+}
+
+// ---------------------------------------------------------------------------------------------
+// K20 + K21: fused SGD(momentum, weight decay) + EMA over flat fp32 arrays, 16 B per lane
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sgd_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ t,
+          int64_t n, const float* __restrict__ lr_ptr, float momentum, float wd, float gscale, float keep,
+          float one_minus_keep, int first) {
+  const float lr = lr_ptr[0];
+  const int64_t nvec = n / 4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = first ? make_float4(0.f, 0.f, 0.f, 0.f) : reinterpret_cast<float4*>(m)[i];
+    float pp[4] = {pv.x, pv.y, pv.z, pv.w};
+    const float gg[4] = {gv.x, gv.y, gv.z, gv.w};
+    float mm[4] = {mv.x, mv.y, mv.z, mv.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gr = gg[k] * gscale + wd * pp[k];
+      mm[k] = first ? gr : mm[k] * momentum + gr;
+      pp[k] = pp[k] - lr * mm[k];
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    if (t) {
+      float4 tv = reinterpret_cast<float4*>(t)[i];
+      tv.x = pp[0] * one_minus_keep + tv.x * keep;
+      tv.y = pp[1] * one_minus_keep + tv.y * keep;
+      tv.z = pp[2] * one_minus_keep + tv.z * keep;
+      tv.w = pp[3] * one_minus_keep + tv.w * keep;
+      reinterpret_cast<float4*>(t)[i] = tv;
+    }
+  }
+  // scalar tail
+  const int64_t tail0 = nvec * 4;
+  if (blockIdx.x == 0 && threadIdx.x < (n - tail0)) {
+    const int64_t i = tail0 + threadIdx.x;
+    const float gr = g[i] * gscale + wd * p[i];
+    const float mm = first ? gr : m[i] * momentum + gr;
+    const float pp = p[i] - lr * mm;
+    p[i] = pp;
+    m[i] = mm;
+    if (t) t[i] = pp * one_minus_keep + t[i] * keep;
+  }
+}
+
+extern "C" int sfod_sgd_ema(float* param, const float* grad, float* mom, float* teacher, int64_t n,
+                            const float* lr, float momentum, float weight_decay, float grad_scale,
+                            float ema_keep, int first_step, void* stream) {
+  if (n == 0) return 0;
+  const float omk = (float)(1.0 - (double)ema_keep);
+  hipLaunchKernelGGL(k_sgd_ema, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad, mom,
+                     teacher, n, lr, momentum, weight_decay, grad_scale, ema_keep, omk, first_step);
+  return sfod_check_launch("sgd_ema");
+}
+
+__global__ void k_ema(float* __restrict__ t, const float* __restrict__ s, int64_t n, float keep, float omk) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    t[i] = s[i] * omk + t[i] * keep;
+}
+
+extern "C" int sfod_ema(float* teacher, const float* student, int64_t n, float keep, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_ema, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, teacher, student, n, keep,
+                     (float)(1.0 - (double)keep));
+  return sfod_check_launch("ema");
+}
+
+__global__ void k_fill(float* p, int64_t n, float v) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    p[i] = v;
+}
+extern "C" int sfod_fill_f32(float* p, int64_t n, float v, void* stream) {
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_fill, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, n, v);
+  return sfod_check_launch("fill");
+}
+
+template <typename S, typename D>
+__global__ void k_cast(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    d[i] = from_f32<D>(to_f32(s[i]));
+}
+extern "C" int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int dst_dt, void* stream) {
+  if (n == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(ew_grid(n)), b(256);
+  if (src_dt == SFOD_F32 && dst_dt == SFOD_BF16)
+    hipLaunchKernelGGL((k_cast<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dt == SFOD_BF16 && dst_dt == SFOD_F32)
+    hipLaunchKernelGGL((k_cast<bf16_t, float>), g, b, 0, s, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dt == SFOD_F32 && dst_dt == SFOD_F32)
+    hipLaunchKernelGGL((k_cast<float, float>), g, b, 0, s, (const float*)src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL((k_cast<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+  return sfod_check_launch("cast");
+}

@@ -1,0 +1,575 @@
+// MFMA implicit-GEMM kernels of the hot path (gfx950 / CDNA4, wave64):
+//   k_conv_fwd   y[m][n]  = act(sum_k A[m][k] * Wt[n][k] + bias[n])   conv3x3 / conv1x1 / nn.Linear,
+//                also the data-gradient (dgrad) with rotated weights      (K2, K5, K14, K18)
+//   k_conv_wgrad dw[n][k'] += sum_m dy[m][n] * A[m][k']                 weight gradient
+// A is never materialised: a 16-byte chunk of an im2col row is (pixel shifted by a tap, 4 fp32 /
+// 8 bf16 consecutive NHWC channels) and is DMA'd straight into LDS by global_load_lds; padding
+// taps and tail rows read a zero page instead.
+//
+// Tiling: 256 threads = 2x2 waves, each wave a (32*WM) x (32*WN) block of 32x32 MFMA tiles
+// (v_mfma_f32_32x32x16_bf16 in throughput mode, v_mfma_f32_32x32x2_f32 in fp32 parity mode);
+// every LDS row is 128 bytes (64 bf16 / 32 fp32 of K) and the 16-byte chunk index is XOR-swizzled
+// with (row>>1)&7 so a ds_read_b128 of one K-chunk over 32 consecutive rows is conflict-free.
+// The LDS image is lane-linear (what the DMA writes), so the swizzle is applied to the per-lane
+// SOURCE address and again on the read.  Two LDS stages: stage t+1 is in flight while stage t
+// feeds the MFMAs.
+#include "common.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];
+
+struct ConvArgs {
+  int M;          // rows = B*H*W
+  int H, W;       // spatial size (1x1 for linear layers with M = R rows)
+  int Cin;        // input channels as stored (row stride of x), multiple of the chunk width
+  int Cout;       // output channels
+  int ks;         // 1 or 3
+  int cpt_shift;  // log2(chunks per tap) when ks == 3
+  int kchunks;    // total 16-byte chunks along K = taps * Cin * sizeof(T) / 16
+  int ldy;        // row stride of y
+  int act;        // 0 none, 1 relu, 2 leaky relu 0.2
+};
+
+template <typename T> struct Chunk { static constexpr int E = 16 / sizeof(T); };
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+  __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(l), 16, 0, 0);
+}
+
+// tap of a flattened K chunk index and the channel-chunk inside it
+__device__ __forceinline__ void chunk_to_tap(int gq, int ks, int cpt_shift, int& tap, int& cc) {
+  if (ks == 1) { tap = 0; cc = gq; }
+  else { tap = gq >> cpt_shift; cc = gq & ((1 << cpt_shift) - 1); }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+
+// =============================================================================================
+// forward / dgrad / linear
+// =============================================================================================
+template <typename T, typename OutT, int WM, int WN>
+__global__ void __launch_bounds__(256)
+k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
+           OutT* __restrict__ y, float* __restrict__ stats, ConvArgs a, int tiles_n, int ntiles) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int E = Chunk<T>::E;
+  constexpr int STAGE = (BM + BN) * 128;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  // XCD-aware tile order: workgroups that share an XCD (same blockIdx % 8) walk consecutive tiles
+  int bid = blockIdx.x;
+  {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tile_n = bid % tiles_n, tile_m = bid / tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int taps = a.ks * a.ks;
+  const int HW = a.H * a.W;
+
+  // ---- per-thread DMA descriptors: AI = BM/32 A-instructions, BI = BN/32 B-instructions -------
+  constexpr int AI = BM / 32, BI = BN / 32;
+  int a_row[AI];      // row inside the tile
+  int a_oy[AI], a_ox[AI];
+  int64_t a_pix[AI];  // flat pixel index (== m) or -1
+  for (int i = 0; i < AI; ++i) {
+    const int q = wave * AI + i;
+    const int row = q * 8 + (lane >> 3);
+    a_row[i] = row;
+    const int m = m0 + row;
+    if (m < a.M) {
+      const int rem = m % HW;
+      a_oy[i] = rem / a.W;
+      a_ox[i] = rem % a.W;
+      a_pix[i] = m;
+    } else { a_pix[i] = -1; a_oy[i] = 0; a_ox[i] = 0; }
+  }
+  int b_row[BI];
+  for (int i = 0; i < BI; ++i) b_row[i] = (wave * BI + i) * 8 + (lane >> 3);
+  const int pc = lane & 7;
+  const int KT = (a.kchunks + 7) / 8;
+  const int64_t wrow_elems = (int64_t)a.kchunks * E;
+
+  auto stage_load = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + BM * 128;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int row = a_row[i];
+      const int lc = pc ^ ((row >> 1) & 7);
+      const int gq = kt * 8 + lc;
+      const void* src = g_zero_page;
+      if (a_pix[i] >= 0 && gq < a.kchunks) {
+        int tap, cc;
+        chunk_to_tap(gq, a.ks, a.cpt_shift, tap, cc);
+        if (a.ks == 1) {
+          src = x + a_pix[i] * a.Cin + (int64_t)cc * E;
+        } else {
+          const int ky = tap / 3, kx = tap - ky * 3;
+          const int iy = a_oy[i] + ky - 1, ix = a_ox[i] + kx - 1;
+          if (tap < taps && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            src = x + (a_pix[i] + (int64_t)(ky - 1) * a.W + (kx - 1)) * a.Cin + (int64_t)cc * E;
+        }
+      }
+      glds16(src, sA + (wave * AI + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int row = b_row[i];
+      const int lc = pc ^ ((row >> 1) & 7);
+      const int gq = kt * 8 + lc;
+      const int n = n0 + row;
+      const void* src = g_zero_page;
+      if (n < a.Cout && gq < a.kchunks) src = w + (int64_t)n * wrow_elems + (int64_t)gq * E;
+      glds16(src, sB + (wave * BI + i) * 1024);
+    }
+  };
+
+  // ---- fragment read offsets ------------------------------------------------------------------
+  int offA[WM], swzA[WM], offB[WN], swzB[WN];
+  for (int i = 0; i < WM; ++i) {
+    const int r = wr * 32 * WM + i * 32 + (lane & 31);
+    offA[i] = r * 128;
+    swzA[i] = (r >> 1) & 7;
+  }
+  for (int j = 0; j < WN; ++j) {
+    const int r = wc * 32 * WN + j * 32 + (lane & 31);
+    offB[j] = r * 128;
+    swzB[j] = (r >> 1) & 7;
+  }
+  const int h = lane >> 5;
+
+  f32x16 acc[WM][WN];
+  for (int i = 0; i < WM; ++i)
+    for (int j = 0; j < WN; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto stage_compute = [&](int buf) {
+    const unsigned char* sA = smem + buf * STAGE;
+    const unsigned char* sB = sA + BM * 128;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        bf16x8 af[WM], bfr[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          af[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + (((2 * s + h) ^ swzA[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          bfr[j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + (((2 * s + h) ^ swzB[j]) << 4));
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        f32x4 af[WM], bfr[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          af[i] = *reinterpret_cast<const f32x4*>(sA + offA[i] + ((c ^ swzA[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          bfr[j] = *reinterpret_cast<const f32x4*>(sB + offB[j] + ((c ^ swzB[j]) << 4));
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j) {
+              const float av = half ? (h ? af[i][3] : af[i][2]) : (h ? af[i][1] : af[i][0]);
+              const float bv = half ? (h ? bfr[j][3] : bfr[j][2]) : (h ? bfr[j][1] : bfr[j][0]);
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);
+            }
+        }
+      }
+    }
+  };
+
+  // ---- main loop: stage t+1 in flight while stage t computes -----------------------------------
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT - 1; ++kt) {
+    stage_load(kt + 1, cur ^ 1);
+    stage_compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  stage_compute(cur);
+
+  // ---- epilogue: bias + activation + store; optional per-block BN partial statistics ----------
+  float bcol[WN];
+  for (int j = 0; j < WN; ++j) {
+    const int n = n0 + wc * 32 * WN + j * 32 + (lane & 31);
+    bcol[j] = (bias != nullptr && n < a.Cout) ? bias[n] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + wc * 32 * WN + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[i][j][r] + bcol[j];
+        acc[i][j][r] = v;
+        if (m < a.M && n < a.Cout) y[(int64_t)m * a.ldy + n] = from_f32<OutT>(apply_act(v, a.act));
+      }
+    }
+
+  if (stats != nullptr) {
+    __syncthreads();  // LDS reuse
+    float* sred = reinterpret_cast<float*>(smem);  // [2 (wr)][BN]
+    const int rows_valid = min(BM, a.M - m0);
+    // pass 1: column sums
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          s += (m < a.M) ? acc[i][j][r] : 0.f;
+        }
+      s += __shfl_xor(s, 32);
+      if (h == 0) sred[wr * BN + wc * 32 * WN + j * 32 + (lane & 31)] = s;
+    }
+    __syncthreads();
+    float csum[WN], cmean[WN];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int nl = wc * 32 * WN + j * 32 + (lane & 31);
+      csum[j] = sred[nl] + sred[BN + nl];
+      cmean[j] = csum[j] / (float)rows_valid;
+    }
+    __syncthreads();
+    // pass 2: squared deviations from the block mean
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = m0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float d = acc[i][j][r] - cmean[j];
+          s += (m < a.M) ? d * d : 0.f;
+        }
+      s += __shfl_xor(s, 32);
+      if (h == 0) sred[wr * BN + wc * 32 * WN + j * 32 + (lane & 31)] = s;
+    }
+    __syncthreads();
+    if (wr == 0 && h == 0) {
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
+        const int nl = wc * 32 * WN + j * 32 + (lane & 31);
+        const int n = n0 + nl;
+        if (n < a.Cout) {
+          stats[((int64_t)tile_m * 2 + 0) * a.Cout + n] = csum[j];
+          stats[((int64_t)tile_m * 2 + 1) * a.Cout + n] = sred[nl] + sred[BN + nl];
+        }
+      }
+    }
+  }
+}
+
+static int ilog2_exact(int v) {
+  int s = 0;
+  while ((1 << s) < v) ++s;
+  return ((1 << s) == v) ? s : -1;
+}
+
+extern "C" int sfod_conv_stats_blocks(int M) { return (M + 127) / 128; }
+
+template <typename T, typename OutT>
+static int launch_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
+                           const ConvArgs& a, hipStream_t s) {
+  const int tiles_m = (a.M + 127) / 128;
+  if (a.Cout <= 64) {
+    const int tiles_n = (a.Cout + 63) / 64;
+    const int nt = tiles_m * tiles_n;
+    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 1>), dim3(nt), dim3(256), 2 * (128 + 64) * 128, s,
+                       (const T*)x, (const T*)w, bias, (OutT*)y, stats, a, tiles_n, nt);
+  } else {
+    const int tiles_n = (a.Cout + 127) / 128;
+    const int nt = tiles_m * tiles_n;
+    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 2>), dim3(nt), dim3(256), 2 * (128 + 128) * 128, s,
+                       (const T*)x, (const T*)w, bias, (OutT*)y, stats, a, tiles_n, nt);
+  }
+  return sfod_check_launch("conv_fwd");
+}
+
+extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
+                             int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
+                             int out_dt, void* stream) {
+  SFOD_REQUIRE(ksize == 1 || ksize == 3, "conv: ksize must be 1 or 3");
+  SFOD_REQUIRE(ldy >= Cout, "conv: ldy < Cout");
+  const int E = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(Cin % E == 0, "conv: Cin must be a multiple of the 16-byte chunk");
+  ConvArgs a;
+  a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.ldy = ldy; a.act = act;
+  const int cpt = Cin / E;
+  a.cpt_shift = 0;
+  if (ksize == 3) {
+    a.cpt_shift = ilog2_exact(cpt);
+    SFOD_REQUIRE(a.cpt_shift >= 0, "conv3x3: Cin/chunk must be a power of two");
+  }
+  a.kchunks = ksize * ksize * cpt;
+  if (a.M == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == SFOD_F32) {
+    SFOD_REQUIRE(out_dt == SFOD_F32, "conv: fp32 compute writes fp32");
+    return launch_conv_fwd<float, float>(x, w, bias, y, stats, a, s);
+  }
+  if (out_dt == SFOD_F32) return launch_conv_fwd<bf16_t, float>(x, w, bias, y, stats, a, s);
+  return launch_conv_fwd<bf16_t, bf16_t>(x, w, bias, y, stats, a, s);
+}
+
+// =============================================================================================
+// weight gradient.  GEMM over the pixel axis: dw[co][nf] += sum_pix dy[pix][co] * xs[pix][nf],
+// nf = flattened (tap, ci).  Both operands arrive pixel-major ([pix][channels]), i.e. transposed
+// for MFMA; in bf16 the fragments are fetched with ds_read_b64_tr_b16 (hardware transpose read),
+// in fp32 a fragment element is a plain 4-byte read.  The pixel range is split across
+// workgroups (gridDim.z) and the fp32 partial tiles are combined with float atomics
+// (128-byte contiguous segments per wave-instruction).
+// =============================================================================================
+struct WgradArgs {
+  int M, H, W;
+  int Cin, Cout, ks, cpt_shift;
+  int nchunks;   // taps * Cin / E : chunks along the flattened (tap, ci) axis
+  int lddy;
+  int Ntot;      // taps * Cin (row stride of dw)
+  int pix_per_split;
+};
+
+template <typename T, int WM, int WN>
+__global__ void __launch_bounds__(256)
+k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, WgradArgs a) {
+  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int E = Chunk<T>::E;
+  constexpr int BKP = (sizeof(T) == 2) ? 64 : 32;  // pixels per stage
+  constexpr int RA = BM * sizeof(T), RB = BN * sizeof(T);  // LDS row bytes
+  constexpr int TA = BKP * RA, TB = BKP * RB;
+  constexpr int STAGE = TA + TB;
+  constexpr int AI = TA / 1024 / 4, BI = TB / 1024 / 4;  // DMA instructions per wave
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int n0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
+  const int p_begin = blockIdx.z * a.pix_per_split;
+  const int p_end = min(a.M, p_begin + a.pix_per_split);
+  if (p_begin >= p_end) return;
+  const int taps = a.ks * a.ks;
+
+  // DMA descriptors.  A chunk at tile byte offset o: row o / R, physical chunk (o % R) / 16.
+  int a_prow[AI], a_lc[AI];
+  for (int i = 0; i < AI; ++i) {
+    const int o = (wave * AI + i) * 1024 + lane * 16;
+    const int prow = o / RA, pcol = (o % RA) >> 4;
+    a_prow[i] = prow;
+    a_lc[i] = (sizeof(T) == 2) ? (pcol ^ ((prow & 3) << 2)) : pcol;
+  }
+  int b_prow[BI], b_tap[BI], b_cc[BI], b_oy[BI], b_ox[BI];
+  bool b_ok[BI];
+  for (int i = 0; i < BI; ++i) {
+    const int o = (wave * BI + i) * 1024 + lane * 16;
+    const int prow = o / RB, pcol = (o % RB) >> 4;
+    b_prow[i] = prow;
+    const int lc = (sizeof(T) == 2) ? (pcol ^ ((prow & 3) << 2)) : pcol;
+    const int nq = n0 / E + lc;
+    int tap, cc;
+    chunk_to_tap(nq, a.ks, a.cpt_shift, tap, cc);
+    b_tap[i] = tap;
+    b_cc[i] = cc;
+    b_ok[i] = (nq < a.nchunks) && (tap < taps);
+    const int pix = p_begin + prow;
+    const int rem = pix % (a.H * a.W);
+    b_oy[i] = rem / a.W;
+    b_ox[i] = rem % a.W;
+  }
+
+  auto stage_load = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + TA;
+    const int pbase = p_begin + kt * BKP;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int pix = pbase + a_prow[i];
+      const int col = co0 + a_lc[i] * E;
+      const void* src = g_zero_page;
+      if (pix < p_end && col + E <= a.lddy && col < a.Cout) src = dy + (int64_t)pix * a.lddy + col;
+      glds16(src, sA + (wave * AI + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int pix = pbase + b_prow[i];
+      const void* src = g_zero_page;
+      if (pix < p_end && b_ok[i]) {
+        if (a.ks == 1) {
+          src = x + (int64_t)pix * a.Cin + (int64_t)b_cc[i] * E;
+        } else {
+          const int ky = b_tap[i] / 3, kx = b_tap[i] - ky * 3;
+          const int iy = b_oy[i] + ky - 1, ix = b_ox[i] + kx - 1;
+          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            src = x + ((int64_t)pix + (int64_t)(ky - 1) * a.W + (kx - 1)) * a.Cin + (int64_t)b_cc[i] * E;
+        }
+      }
+      glds16(src, sB + (wave * BI + i) * 1024);
+      // advance this row's (oy, ox) by BKP pixels for the next stage
+      if (a.ks != 1) {
+        b_ox[i] += BKP;
+        while (b_ox[i] >= a.W) {
+          b_ox[i] -= a.W;
+          if (++b_oy[i] == a.H) b_oy[i] = 0;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[WM][WN];
+  for (int i = 0; i < WM; ++i)
+    for (int j = 0; j < WN; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int h = lane >> 5;
+  // bf16 transpose-read lane roles: 16-lane group g, within-group t -> row q = t/4, cols 4*(t%4)
+  const int g16 = lane >> 4, t16 = lane & 15;
+  const int tq = t16 >> 2, tp = t16 & 3;
+
+  auto stage_compute = [&](int buf) {
+    const unsigned char* sA = smem + buf * STAGE;
+    const unsigned char* sB = sA + TA;
+    if constexpr (sizeof(T) == 2) {
+#pragma unroll
+      for (int s = 0; s < BKP / 16; ++s) {
+        s16x8 af[WM], bfr[WN];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int prow = 16 * s + 8 * h + 4 * e + tq;
+          const int sw = (prow & 3) << 6;
+#pragma unroll
+          for (int i = 0; i < WM; ++i) {
+            const int col = wr * 32 * WM + i * 32 + (g16 & 1) * 16 + 4 * tp;
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)LDS_PTR(sA + prow * RA + ((col * 2) ^ sw)));
+            af[i][4 * e + 0] = v[0]; af[i][4 * e + 1] = v[1]; af[i][4 * e + 2] = v[2]; af[i][4 * e + 3] = v[3];
+          }
+#pragma unroll
+          for (int j = 0; j < WN; ++j) {
+            const int col = wc * 32 * WN + j * 32 + (g16 & 1) * 16 + 4 * tp;
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)LDS_PTR(sB + prow * RB + ((col * 2) ^ sw)));
+            bfr[j][4 * e + 0] = v[0]; bfr[j][4 * e + 1] = v[1]; bfr[j][4 * e + 2] = v[2]; bfr[j][4 * e + 3] = v[3];
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+                __builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bfr[j]), acc[i][j], 0, 0, 0);
+      }
+    } else {
+#pragma unroll 4
+      for (int s = 0; s < BKP / 2; ++s) {
+        const int prow = 2 * s + h;
+        float af[WM], bfr[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          af[i] = *reinterpret_cast<const float*>(sA + prow * RA + (wr * 32 * WM + i * 32 + (lane & 31)) * 4);
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+          bfr[j] = *reinterpret_cast<const float*>(sB + prow * RB + (wc * 32 * WN + j * 32 + (lane & 31)) * 4);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  const int KT = (p_end - p_begin + BKP - 1) / BKP;
+  stage_load(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < KT - 1; ++kt) {
+    stage_load(kt + 1, cur ^ 1);
+    stage_compute(cur);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+  stage_compute(cur);
+
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + wc * 32 * WN + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < a.Cout && n < a.Ntot) atomicAdd(dw + (int64_t)co * a.Ntot + n, acc[i][j][r]);
+      }
+    }
+}
+
+extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
+                               int Cout, int ksize, int lddy, int dt, void* stream) {
+  SFOD_REQUIRE(ksize == 1 || ksize == 3, "wgrad: ksize must be 1 or 3");
+  const int E = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(Cin % E == 0 && lddy % E == 0, "wgrad: Cin / lddy must be multiples of the 16-byte chunk");
+  WgradArgs a;
+  a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.lddy = lddy;
+  const int cpt = Cin / E;
+  a.cpt_shift = 0;
+  if (ksize == 3) {
+    a.cpt_shift = ilog2_exact(cpt);
+    SFOD_REQUIRE(a.cpt_shift >= 0, "wgrad3x3: Cin/chunk must be a power of two");
+  }
+  a.nchunks = ksize * ksize * cpt;
+  a.Ntot = ksize * ksize * Cin;
+  if (a.M == 0) return 0;
+  const int BKP = (dt == SFOD_F32) ? 32 : 64;
+  const int tiles_n = (a.Ntot + 127) / 128, tiles_m = (Cout + 127) / 128;
+  // split the pixel axis so that the grid has ~4 workgroups per CU
+  int splits = (1024 + tiles_n * tiles_m - 1) / (tiles_n * tiles_m);
+  const int max_splits = (a.M + BKP - 1) / BKP;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int pps = (a.M + splits - 1) / splits;
+  pps = (pps + BKP - 1) / BKP * BKP;
+  splits = (a.M + pps - 1) / pps;
+  a.pix_per_split = pps;
+  dim3 grid(tiles_n, tiles_m, splits);
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL((k_conv_wgrad<float, 2, 2>), grid, dim3(256), 2 * 2 * 32 * 512, s, (const float*)x,
+                       (const float*)dy, dw, a);
+  else
+    hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, dw, a);
+  return sfod_check_launch("conv_wgrad");
+}

@@ -1,0 +1,486 @@
+"""ctypes binding of ``libsfod_hip.so`` (the C-ABI drop-in boundary, ``include/sfod_hip.h``).
+
+The prototypes are parsed from the header itself, so Python argument types can never drift
+from the declared C ABI.  There is NO CPU fallback: if the library is missing or fails to
+load, importing any compute entry point raises -- the product path fails loudly.
+
+PyTorch is used here only as the owner of device memory and streams (``tensor.data_ptr()``,
+``torch.cuda.current_stream()``).
+"""
+import ctypes
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "sfod_hip.h")
+SO_PATH = os.path.join(_HERE, "lib", "libsfod_hip.so")
+
+F32, BF16 = 0, 1
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def parse_header(path=HEADER):
+    """-> {name: (restype, [argtypes])} for every function declared in the header."""
+    src = open(path).read()
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", " ", src)
+    protos = {}
+    for m in re.finditer(r"(const\s+char\s*\*|int64_t|int)\s+(sfod_\w+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        restype = ctypes.c_char_p if "char" in ret else (ctypes.c_int64 if ret == "int64_t" else ctypes.c_int)
+        argtypes = []
+        args = args.strip()
+        if args and args != "void":
+            for a in args.split(","):
+                a = a.strip()
+                if "*" in a:
+                    argtypes.append(ctypes.c_void_p)
+                elif a.startswith("int64_t"):
+                    argtypes.append(ctypes.c_int64)
+                elif a.startswith("float"):
+                    argtypes.append(ctypes.c_float)
+                elif a.startswith("int") or a.startswith("int32_t"):
+                    argtypes.append(ctypes.c_int)
+                else:
+                    raise NativeLibraryError(f"cannot map C parameter '{a}' of {name}")
+        protos[name] = (restype, argtypes)
+    return protos
+
+
+_lib = None
+_protos = None
+
+
+def load(path=SO_PATH):
+    """Load the shared library and bind every symbol the header declares."""
+    global _lib, _protos
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise NativeLibraryError(
+            f"{path} not found: build it with `python {os.path.join(_HERE, 'csrc', 'build.py')}` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback for the hot path.")
+    lib = ctypes.CDLL(path)
+    protos = parse_header()
+    for name, (restype, argtypes) in protos.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{path} does not export {name} declared in {HEADER}") from e
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib, _protos = lib, protos
+    return lib
+
+
+def exported_symbols():
+    load()
+    return sorted(_protos)
+
+
+def _chk(rc, name):
+    if rc != 0:
+        msg = _lib.sfod_last_error().decode()
+        raise NativeLibraryError(f"{name} failed with code {rc}: {msg}")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "native ops need device tensors"
+    assert t.is_contiguous(), "native ops need contiguous tensors"
+    return t.data_ptr()
+
+
+def dt_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(dt):
+    return torch.float32 if dt == F32 else torch.bfloat16
+
+
+def chunk_elems(dt):
+    return 4 if dt == F32 else 8
+
+
+def call(name, *args):
+    """Raw call: tensors are converted to device pointers, the current stream is appended."""
+    lib = load()
+    conv = [(_p(a) if isinstance(a, torch.Tensor) else a) for a in args]
+    rc = getattr(lib, name)(*conv, _stream())
+    _chk(rc, name)
+
+
+def query(name, *args):
+    return getattr(load(), name)(*args)
+
+
+# =================================================================================================
+# tensor-level wrappers (allocate outputs with torch, call the C ABI)
+# =================================================================================================
+def preprocess(images_u8, Hp, Wp, cpad, mean, std, dt):
+    """images_u8: list of uint8 device tensors [3,h,w] -> (x [B,Hp,Wp,cpad], sizes int32 [B,2])."""
+    dev = images_u8[0].device
+    B = len(images_u8)
+    imgs = [im.contiguous() for im in images_u8]
+    ptrs = torch.tensor([im.data_ptr() for im in imgs], dtype=torch.int64).to(dev)
+    sizes = torch.tensor([[im.shape[1], im.shape[2]] for im in imgs], dtype=torch.int32).to(dev)
+    out = torch.empty(B, Hp, Wp, cpad, dtype=torch_dtype(dt), device=dev)
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    lib = load()
+    rc = lib.sfod_preprocess(ptrs.data_ptr(), sizes.data_ptr(), B, Hp, Wp, cpad,
+                             ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p),
+                             out.data_ptr(), dt, _stream())
+    _chk(rc, "sfod_preprocess")
+    out._keepalive = (imgs, ptrs)
+    return out, sizes
+
+
+def pack_conv_weight(w_oihw, cin_pad, dt, rot180=False):
+    cout, cin, ks, _ = w_oihw.shape
+    rows = cin if rot180 else cout
+    out = torch.empty(rows, ks * ks, cin_pad, dtype=torch_dtype(dt), device=w_oihw.device)
+    call("sfod_pack_conv_weight", w_oihw.contiguous(), out, cout, cin, ks, cin_pad, int(rot180), dt)
+    return out
+
+
+def unpack_conv_wgrad(dw_packed, dw_oihw, accumulate=False):
+    cout, cin, ks, _ = dw_oihw.shape
+    call("sfod_unpack_conv_wgrad", dw_packed, dw_oihw, cout, cin, ks, dw_packed.shape[-1], int(accumulate))
+
+
+def pack_fc_weight(w, dt, chw_c=0, transpose=False, ld=None):
+    n, k = w.shape
+    inner = n if transpose else k
+    ld = ld or inner
+    out = torch.empty(k if transpose else n, ld, dtype=torch_dtype(dt), device=w.device)
+    call("sfod_pack_fc_weight_ld", w.contiguous(), out, n, k, chw_c, int(transpose), ld, dt)
+    return out
+
+
+def unpack_fc_wgrad(dw_packed, dw, chw_c=0, accumulate=False):
+    n, k = dw.shape
+    call("sfod_unpack_fc_wgrad_ld", dw_packed, dw, n, k, chw_c, dw_packed.shape[-1], int(accumulate))
+
+
+def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, want_stats=False):
+    """x [B,H,W,Cin] NHWC (or [R,K] with ksize=1) -> y [B,H,W,ldy]; optional BN partial stats."""
+    dt = dt_of(x)
+    if x.dim() == 2:
+        B, H, W, cin = x.shape[0], 1, 1, x.shape[1]
+        oshape = lambda ld: (x.shape[0], ld)
+    else:
+        B, H, W, cin = x.shape
+        oshape = lambda ld: (B, H, W, ld)
+    out_dtype = out_dtype or x.dtype
+    ldy = ldy or cout
+    alloc = torch.zeros if ldy != cout else torch.empty
+    y = alloc(oshape(ldy), dtype=out_dtype, device=x.device)
+    stats = None
+    if want_stats:
+        nb = query("sfod_conv_stats_blocks", B * H * W)
+        stats = torch.empty(nb, 2, cout, dtype=torch.float32, device=x.device)
+    call("sfod_conv_fwd", x, w_packed, bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
+         F32 if out_dtype == torch.float32 else BF16)
+    return (y, stats) if want_stats else y
+
+
+def conv_wgrad(x, dy, cout, ksize, dw_packed=None):
+    """-> fp32 packed grad [Cout, taps, Cin] (accumulated into dw_packed if given)."""
+    dt = dt_of(x)
+    if x.dim() == 2:
+        B, H, W, cin = x.shape[0], 1, 1, x.shape[1]
+    else:
+        B, H, W, cin = x.shape
+    lddy = dy.shape[-1]
+    if dw_packed is None:
+        dw_packed = torch.zeros(cout, ksize * ksize, cin, dtype=torch.float32, device=x.device)
+    call("sfod_conv_wgrad", x, dy, dw_packed, B, H, W, cin, cout, ksize, lddy, dt)
+    return dw_packed
+
+
+def bias_grad(dy, n, db=None, accumulate=False):
+    m = dy.numel() // dy.shape[-1]
+    if db is None:
+        db = torch.empty(n, dtype=torch.float32, device=dy.device)
+    call("sfod_bias_grad", dy, db, m, n, dy.shape[-1], int(accumulate), dt_of(dy))
+    return db
+
+
+def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, update_running=True):
+    mean = torch.empty(C, dtype=torch.float32, device=stats.device)
+    invstd = torch.empty_like(mean)
+    call("sfod_bn_finalize", stats, stats.shape[0], 128, M, C, mean, invstd, running_mean, running_var,
+         float(momentum), float(eps), int(update_running))
+    return mean, invstd
+
+
+def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool):
+    B, H, W, C = y.shape
+    Ho, Wo = (H // 2, W // 2) if pool else (H, W)
+    z = torch.empty(B, Ho, Wo, C, dtype=y.dtype, device=y.device)
+    call("sfod_bn_relu_pool_fwd", y, mean, invstd, gamma, beta, z, B, H, W, C, int(pool), dt_of(y))
+    return z
+
+
+def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None):
+    B, H, W, C = y.shape
+    if dy is None:
+        dy = torch.empty_like(y)
+    if dgamma is None:
+        dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
+    if dbeta is None:
+        dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
+    ws = torch.empty(query("sfod_bn_bwd_ws_floats", B * H * W, C), dtype=torch.float32, device=y.device)
+    call("sfod_bn_relu_pool_bwd", dz, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, ws, B, H, W, C,
+         int(pool), dt_of(y))
+    return dy, dgamma, dbeta
+
+
+def act_bwd_(dy, y, act):
+    call("sfod_act_bwd", dy, y, dy.numel(), act, dt_of(dy))
+    return dy
+
+
+def add_(a, b):
+    call("sfod_add_inplace", a, b, a.numel(), dt_of(a))
+    return a
+
+
+def cast(src, dtype):
+    if src.dtype == dtype:
+        return src
+    dst = torch.empty(src.shape, dtype=dtype, device=src.device)
+    call("sfod_cast", src, dst, src.numel(), dt_of(src), F32 if dtype == torch.float32 else BF16)
+    return dst
+
+
+# ---- detection ops -----------------------------------------------------------------------------
+def rpn_decode(rpn_out, cell, B, Hf, Wf, stride, sizes, flags):
+    A = cell.shape[0]
+    NA = Hf * Wf * A
+    props = torch.empty(B, NA, 4, dtype=torch.float32, device=rpn_out.device)
+    scores = torch.empty(B, NA, dtype=torch.float32, device=rpn_out.device)
+    call("sfod_rpn_decode", rpn_out, rpn_out.shape[-1], cell, A, B, Hf, Wf, stride, sizes, props, scores, flags)
+    return props, scores
+
+
+_sort_ws = {}
+
+
+def segmented_sort_desc(keys):
+    """keys fp32 [B,n] -> (sorted_keys [B,n], idx int32 [B,n]); stable."""
+    B, n = keys.shape
+    dev = keys.device
+    nbytes = query("sfod_sort_ws_bytes", B, n)
+    k = (dev, nbytes)
+    if k not in _sort_ws:
+        _sort_ws[k] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    ws = _sort_ws[k]
+    out_keys = torch.empty_like(keys)
+    out_idx = torch.empty(B, n, dtype=torch.int32, device=dev)
+    call("sfod_segmented_sort_desc", keys, B, n, out_keys, out_idx, ws, nbytes)
+    return out_keys, out_idx
+
+
+def rpn_gather_topk(props, sorted_scores, sorted_idx, k):
+    B, NA, _ = props.shape
+    dev = props.device
+    cb = torch.empty(B, k, 4, dtype=torch.float32, device=dev)
+    cs = torch.empty(B, k, dtype=torch.float32, device=dev)
+    cv = torch.empty(B, k, dtype=torch.uint8, device=dev)
+    call("sfod_rpn_gather_topk", props, sorted_scores, sorted_idx, B, NA, k, cb, cs, cv)
+    return cb, cs, cv
+
+
+_mask_ws = {}
+
+
+def nms(boxes, thr, max_keep, valid=None, n_per_image=None, alt_boxes=None, classes=None, mode=None):
+    """boxes fp32 [B,n,4] sorted by descending score -> (keep_idx int32 [B,max_keep], count [B])."""
+    B, n, _ = boxes.shape
+    dev = boxes.device
+    nbytes = max(8, query("sfod_nms_mask_bytes", B, n))
+    k = (dev, nbytes)
+    if k not in _mask_ws:
+        _mask_ws[k] = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
+    mask = _mask_ws[k]
+    keep_idx = torch.zeros(B, max_keep, dtype=torch.int32, device=dev)
+    keep_count = torch.zeros(B, dtype=torch.int32, device=dev)
+    call("sfod_nms", boxes, alt_boxes, classes, mode, valid, n_per_image, B, n, float(thr), max_keep, mask,
+         keep_idx, keep_count)
+    return keep_idx, keep_count
+
+
+def gather_kept(cand_boxes, cand_scores, keep_idx, keep_count):
+    B, n, _ = cand_boxes.shape
+    max_keep = keep_idx.shape[1]
+    ob = torch.empty(B, max_keep, 4, dtype=torch.float32, device=cand_boxes.device)
+    os_ = torch.empty(B, max_keep, dtype=torch.float32, device=cand_boxes.device)
+    call("sfod_gather_kept", cand_boxes, cand_scores, keep_idx, keep_count, B, n, max_keep, ob, os_)
+    return ob, os_
+
+
+def anchor_match(cell, B, Hf, Wf, stride, gt_boxes, gt_count, lo, hi):
+    A = cell.shape[0]
+    NA = Hf * Wf * A
+    dev = gt_boxes.device
+    gcap = gt_boxes.shape[1]
+    matched = torch.empty(B, NA, dtype=torch.int32, device=dev)
+    labels = torch.empty(B, NA, dtype=torch.int8, device=dev)
+    scratch = torch.empty(B * gcap + B * NA, dtype=torch.float32, device=dev)
+    call("sfod_anchor_match", cell, A, B, Hf, Wf, stride, gt_boxes, gt_count, gcap, float(lo), float(hi),
+         matched, labels, scratch)
+    return matched, labels
+
+
+def roi_match(boxes, box_count, gt_boxes, gt_classes, gt_count, thr, num_classes):
+    B, P, _ = boxes.shape
+    matched = torch.empty(B, P, dtype=torch.int32, device=boxes.device)
+    cls = torch.empty(B, P, dtype=torch.int32, device=boxes.device)
+    call("sfod_roi_match", boxes, box_count, B, P, gt_boxes, gt_classes, gt_count, gt_boxes.shape[1],
+         float(thr), num_classes, matched, cls)
+    return matched, cls
+
+
+def subsample_rpn_(labels, keys, num, pos_frac):
+    B, n = labels.shape
+    counts = torch.empty(B, 2, dtype=torch.int32, device=labels.device)
+    call("sfod_subsample", labels, keys, B, n, num, float(pos_frac), 0, 0, None, counts)
+    return labels, counts
+
+
+def subsample_roi(cls, keys, num, pos_frac, bg_label):
+    B, n = cls.shape
+    idx = torch.zeros(B, num, dtype=torch.int32, device=cls.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=cls.device)
+    call("sfod_subsample", cls, keys, B, n, num, float(pos_frac), bg_label, 1, idx, cnt)
+    return idx, cnt
+
+
+def rpn_loss(rpn_out, cell, B, Hf, Wf, stride, labels, matched, gt_boxes, gt_count, batch_per_image,
+             grad_scale=None):
+    A = cell.shape[0]
+    NA = Hf * Wf * A
+    dev = rpn_out.device
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    nblk = (NA + 255) // 256 * B
+    ws = torch.empty(nblk * 2, dtype=torch.float32, device=dev)
+    d_out = torch.empty_like(rpn_out) if grad_scale is not None else None
+    call("sfod_rpn_loss", rpn_out, rpn_out.shape[-1], cell, A, B, Hf, Wf, stride, labels, matched, gt_boxes,
+         gt_count, gt_boxes.shape[1], batch_per_image, loss, grad_scale, d_out, ws)
+    return loss, d_out
+
+
+def append_gt(props, prop_count, gt_boxes, gt_count):
+    B, P, _ = props.shape
+    gcap = gt_boxes.shape[1]
+    out = torch.empty(B, P + gcap, 4, dtype=torch.float32, device=props.device)
+    cnt = torch.empty(B, dtype=torch.int32, device=props.device)
+    call("sfod_append_gt", props, prop_count, B, P, gt_boxes, gt_count, gcap, out, cnt)
+    return out, cnt
+
+
+def roi_build_samples(boxes, cls, matched, samp_idx, samp_count, gt_boxes, gt_count):
+    B, P, _ = boxes.shape
+    S = samp_idx.shape[1]
+    dev = boxes.device
+    rois = torch.empty(B * S, 5, dtype=torch.float32, device=dev)
+    gt_cls = torch.empty(B * S, dtype=torch.int32, device=dev)
+    gt_box = torch.empty(B * S, 4, dtype=torch.float32, device=dev)
+    n_valid = torch.empty(1, dtype=torch.int32, device=dev)
+    call("sfod_roi_build_samples", boxes, cls, matched, samp_idx, samp_count, B, P, S, gt_boxes, gt_count,
+         gt_boxes.shape[1], rois, gt_cls, gt_box, n_valid)
+    return rois, gt_cls, gt_box, n_valid
+
+
+def make_rois(props, prop_count):
+    B, P, _ = props.shape
+    rois = torch.empty(B * P, 5, dtype=torch.float32, device=props.device)
+    call("sfod_make_rois", props, prop_count, B, P, rois)
+    return rois
+
+
+def roi_align_fwd(feat, rois, pooled, scale):
+    B, H, W, C = feat.shape
+    R = rois.shape[0]
+    out = torch.empty(R, pooled * pooled, C, dtype=feat.dtype, device=feat.device)
+    call("sfod_roi_align_fwd", feat, B, H, W, C, rois, R, pooled, float(scale), out, dt_of(feat))
+    return out
+
+
+def roi_align_bwd(dout, rois, feat_shape, pooled, scale, dfeat=None):
+    B, H, W, C = feat_shape
+    if dfeat is None:
+        dfeat = torch.zeros(B, H, W, C, dtype=torch.float32, device=dout.device)
+    call("sfod_roi_align_bwd", dout, B, H, W, C, rois, rois.shape[0], pooled, float(scale), dfeat, dt_of(dout))
+    return dfeat
+
+
+def frcnn_loss(pred, K, rois, gt_cls, gt_box, n_valid, grad_scale=None):
+    R, ld = pred.shape
+    dev = pred.device
+    loss = torch.empty(2, dtype=torch.float32, device=dev)
+    ws = torch.empty(((R + 255) // 256) * 2, dtype=torch.float32, device=dev)
+    d_pred = torch.empty_like(pred) if grad_scale is not None else None
+    call("sfod_frcnn_loss", pred, ld, R, K, rois, gt_cls, gt_box, n_valid, loss, grad_scale, d_pred, ws)
+    return loss, d_pred
+
+
+def frcnn_inference(pred, K, props, prop_count, sizes, score_thresh, nms_thresh, max_det, pseudo_thr,
+                    numel_limit=20000):
+    """Teacher post-processing -> dict of fixed-capacity per-image arrays + counts."""
+    B, P, _ = props.shape
+    dev = pred.device
+    n = P * K
+    cb = torch.empty(B, n, 4, dtype=torch.float32, device=dev)
+    cs = torch.empty(B, n, dtype=torch.float32, device=dev)
+    cc = torch.empty(B, dtype=torch.int32, device=dev)
+    call("sfod_frcnn_candidates", pred, pred.shape[-1], B, P, K, props, prop_count, sizes, float(score_thresh),
+         cb, cs, cc)
+    ss, si = segmented_sort_desc(cs)
+    sb = torch.empty(B, n, 4, dtype=torch.float32, device=dev)
+    sa = torch.empty(B, n, 4, dtype=torch.float32, device=dev)
+    sc = torch.empty(B, n, dtype=torch.int32, device=dev)
+    mode = torch.empty(B, dtype=torch.int32, device=dev)
+    mx = torch.empty(B, dtype=torch.float32, device=dev)
+    call("sfod_frcnn_prepare_nms", cb, ss, si, cc, B, n, K, numel_limit, sb, sa, sc, mode, mx)
+    keep_idx, keep_count = nms(sb, nms_thresh, max_det, n_per_image=cc, alt_boxes=sa, classes=sc, mode=mode)
+    out = {
+        "det_boxes": torch.empty(B, max_det, 4, dtype=torch.float32, device=dev),
+        "det_scores": torch.empty(B, max_det, dtype=torch.float32, device=dev),
+        "det_classes": torch.empty(B, max_det, dtype=torch.int32, device=dev),
+        "det_count": torch.empty(B, dtype=torch.int32, device=dev),
+        "gt_boxes": torch.empty(B, max_det, 4, dtype=torch.float32, device=dev),
+        "gt_classes": torch.empty(B, max_det, dtype=torch.int32, device=dev),
+        "gt_count": torch.empty(B, dtype=torch.int32, device=dev),
+        "cand_count": cc, "mode": mode,
+    }
+    call("sfod_frcnn_finalize", sb, ss, sc, keep_idx, keep_count, B, n, max_det, float(pseudo_thr),
+         out["det_boxes"], out["det_scores"], out["det_classes"], out["det_count"], out["gt_boxes"],
+         out["gt_classes"], out["gt_count"])
+    return out
+
+
+def sgd_ema_(param, grad, mom, teacher, lr, momentum, weight_decay, grad_scale, ema_keep, first_step):
+    call("sfod_sgd_ema", param, grad, mom, teacher, param.numel(), lr, float(momentum), float(weight_decay),
+         float(grad_scale), float(ema_keep), int(first_step))
+
+
+def ema_(teacher, student, keep):
+    call("sfod_ema", teacher, student, teacher.numel(), float(keep))

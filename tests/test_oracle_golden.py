@@ -1,0 +1,67 @@
+"""Pin the oracle against vectors recorded from the REFERENCE itself (oracle/gen_golden.py)."""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from conftest import GOLDEN
+from util_weights import checksum, reference_vgg_state
+
+from oracle import model as om
+
+
+def _vgg_fixture():
+    return np.load(os.path.join(GOLDEN, "vgg_ref.npz"), allow_pickle=False)
+
+
+def test_reference_vgg_weights_reproduce_from_seed():
+    fx = _vgg_fixture()
+    sd = reference_vgg_state(int(fx["seed"]))
+    assert [k[len("backbone."):] for k in sd.keys()] == list(fx["keys"])
+    for k, v in sd.items():
+        key = "wsum/" + k[len("backbone."):]
+        if key in fx:
+            np.testing.assert_allclose(checksum(v), fx[key], rtol=1e-12)
+
+
+def test_oracle_vgg_matches_reference_forward_stats_and_grad():
+    fx = _vgg_fixture()
+    sd = reference_vgg_state(int(fx["seed"]))
+    sd = om.clone_state(sd, requires_grad=True)
+    cfg = om.Cfg()
+    x = torch.from_numpy(fx["input"]).clone().requires_grad_(True)
+    feats = om.vgg_forward(sd, x, cfg, training=True, return_all=True)
+    assert list(fx["out_feature_channels"]) == [64, 128, 256, 512, 512]
+    assert list(fx["out_feature_strides"]) == [2, 4, 8, 16, 32]
+    for i in range(5):
+        f = feats[f"vgg{i}"].detach()
+        assert list(f.shape) == list(fx[f"vgg{i}_shape"])
+        ref = torch.from_numpy(fx[f"vgg{i}"])
+        got = f if i >= 2 else f[:, ::8, ::4, ::4]
+        torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(checksum(f)[:2], fx[f"vgg{i}_checksum"][:2], rtol=1e-4)
+    feats["vgg4"].sum().backward()
+    torch.testing.assert_close(x.grad, torch.from_numpy(fx["input_grad"]), rtol=1e-3, atol=1e-6)
+    for k in fx.files:
+        if k.startswith("after/"):
+            name = "backbone." + k[len("after/"):]
+            torch.testing.assert_close(sd[name].detach(), torch.from_numpy(fx[k]), rtol=1e-4, atol=1e-6)
+
+
+def test_reference_dann_discriminator_fixture_is_a_plain_conv_stack():
+    """The DC_img golden (dann.py:10-29) is reproduced by plain conv3x3 + LeakyReLU(0.2) and the
+    gradient-reversal sign (dann.py:33-51): this is the oracle for the HIP conv on that module."""
+    fx = np.load(os.path.join(GOLDEN, "dann_ref.npz"), allow_pickle=False)
+    x = torch.from_numpy(fx["input"]).clone().requires_grad_(True)
+    w = {k[2:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w/")}
+    h = x
+    for name in ("conv1", "conv2", "conv3"):
+        h = F.leaky_relu(F.conv2d(h, w[name + ".weight"], w[name + ".bias"], padding=1), 0.2)
+    y = F.conv2d(h, w["classifier.weight"], w["classifier.bias"], padding=1)
+    torch.testing.assert_close(y.detach(), torch.from_numpy(fx["output"]), rtol=1e-5, atol=1e-6)
+    loss = F.binary_cross_entropy_with_logits(y, torch.zeros_like(y))
+    torch.testing.assert_close(loss.detach(), torch.from_numpy(fx["loss"]), rtol=1e-6, atol=0)
+    loss.backward()
+    # gradient_scalar(x, -1.0) flips the sign of the gradient that reaches the features
+    torch.testing.assert_close(-x.grad, torch.from_numpy(fx["input_grad"]), rtol=1e-4, atol=1e-8)

@@ -1,0 +1,202 @@
+"""Known-answer tests of the CPU oracle (hand-computed cases, SURVEY.md section 8c list)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import box_ops as B
+from oracle import model as om
+from oracle.roi_align import roi_align, roi_align_py
+
+
+def test_anchor_grid_first_and_last():
+    cell = B.cell_anchors((32, 64, 128, 256, 512), (0.5, 1.0, 2.0))
+    assert cell.shape == (15, 4)
+    # size 32, ratio 0.5: w = sqrt(1024/0.5) = 45.2548, h = 22.6274
+    np.testing.assert_allclose(cell[0].numpy(), [-22.6274, -11.3137, 22.6274, 11.3137], rtol=1e-5)
+    np.testing.assert_allclose(cell[1].numpy(), [-16, -16, 16, 16])
+    a = B.grid_anchors(18, 37, 32, cell)
+    assert a.shape == (18 * 37 * 15, 4) == (9990, 4)
+    torch.testing.assert_close(a[:15], cell)
+    # last location: x = 36*32, y = 17*32
+    torch.testing.assert_close(a[-15:], cell + torch.tensor([1152.0, 544.0, 1152.0, 544.0]))
+    # order (y, x, a): index of (y=1, x=0, a=0) is 37*15
+    torch.testing.assert_close(a[37 * 15], cell[0] + torch.tensor([0.0, 32.0, 0.0, 32.0]))
+
+
+def test_box2box_roundtrip_and_scale_clamp():
+    src = torch.tensor([[10.0, 20.0, 50.0, 80.0], [0.0, 0.0, 16.0, 16.0]])
+    tgt = torch.tensor([[12.0, 18.0, 70.0, 90.0], [4.0, 4.0, 12.0, 20.0]])
+    w = (10.0, 10.0, 5.0, 5.0)
+    d = B.get_deltas(src, tgt, w)
+    # hand: first box sw=40, sh=60, scx=30, scy=50; tw=58, th=72, tcx=41, tcy=54
+    np.testing.assert_allclose(d[0].numpy(), [10 * 11 / 40, 10 * 4 / 60, 5 * math.log(58 / 40), 5 * math.log(72 / 60)],
+                               rtol=1e-6)
+    torch.testing.assert_close(B.apply_deltas(d, src, w), tgt, rtol=1e-5, atol=1e-4)
+    big = torch.tensor([[0.0, 0.0, 100.0, 100.0]])
+    out = B.apply_deltas(big, torch.tensor([[0.0, 0.0, 10.0, 10.0]]), (1, 1, 1, 1))
+    # dw, dh clamp at log(1000/16): width = 10 * 62.5
+    np.testing.assert_allclose((out[0, 2] - out[0, 0]).item(), 625.0, rtol=1e-5)
+
+
+def test_pairwise_iou_and_matcher_low_quality_and_ties():
+    gt = torch.tensor([[0.0, 0.0, 10.0, 10.0], [20.0, 20.0, 30.0, 30.0], [100.0, 100.0, 110.0, 110.0]])
+    anchors = torch.tensor([
+        [0.0, 0.0, 10.0, 10.0],     # IoU 1 with gt0
+        [0.0, 0.0, 10.0, 5.0],      # IoU .5 with gt0  -> ignore (-1)
+        [0.0, 0.0, 10.0, 2.0],      # IoU .2 -> negative
+        [20.0, 20.0, 30.0, 26.0],   # IoU .6 with gt1: below .7 but best for gt1 -> low-quality positive
+        [20.0, 24.0, 30.0, 30.0],   # IoU .6 with gt1 (tie) -> also low-quality positive
+        [50.0, 50.0, 60.0, 60.0],   # IoU 0 with all
+    ])
+    M = B.pairwise_iou(gt, anchors)
+    np.testing.assert_allclose(M[0, :3].numpy(), [1.0, 0.5, 0.2], rtol=1e-6)
+    np.testing.assert_allclose(M[1, 3:5].numpy(), [0.6, 0.6], rtol=1e-6)
+    idx, lab = B.matcher(M, [0.3, 0.7], [0, -1, 1], True)
+    # gt2 overlaps nothing: its best IoU is 0, so EVERY anchor with IoU 0 to gt2 (all of them) is a
+    # "low-quality match" and becomes positive -- the Detectron2 Matcher quirk, reproduced.
+    assert lab.tolist() == [1, 1, 1, 1, 1, 1]
+    idx2, lab2 = B.matcher(M[:2], [0.3, 0.7], [0, -1, 1], True)
+    assert lab2.tolist() == [1, -1, 0, 1, 1, 0]
+    assert idx2.tolist()[:5] == [0, 0, 0, 1, 1]
+    assert idx2[5].item() == 0  # all-zero column: first index wins
+    _, lab3 = B.matcher(M[:2], [0.5], [0, 1], False)
+    assert lab3.tolist() == [1, 1, 0, 1, 1, 0]  # >= 0.5 is foreground
+    i0, l0 = B.matcher(torch.zeros(0, 4), [0.3, 0.7], [0, -1, 1], True)
+    assert l0.tolist() == [0, 0, 0, 0] and i0.tolist() == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("n", [1, 64, 65, 129])
+def test_nms_greedy_against_bruteforce(n):
+    g = torch.Generator().manual_seed(n)
+    xy = torch.rand(n, 2, generator=g) * 50
+    wh = torch.rand(n, 2, generator=g) * 30 + 1
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.rand(n, generator=g)
+    keep = B.nms(boxes, scores, 0.5).tolist()
+    order = torch.argsort(scores, descending=True, stable=True).tolist()
+    iou = B.pairwise_iou(boxes, boxes)
+    ref, dead = [], set()
+    for i in order:
+        if i in dead:
+            continue
+        ref.append(i)
+        for j in order:
+            if j not in dead and j != i and j not in ref and iou[i, j] > 0.5:
+                dead.add(j)
+    assert keep == ref
+
+
+def test_nms_threshold_is_strict_and_ties_are_index_ordered():
+    # IoU exactly 0.5 (box 10x10 vs 10x5 inside): not suppressed at thr 0.5
+    boxes = torch.tensor([[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 10.0, 5.0]])
+    assert B.nms(boxes, torch.tensor([0.9, 0.8]), 0.5).tolist() == [0, 1]
+    assert B.nms(boxes, torch.tensor([0.9, 0.8]), 0.49).tolist() == [0]
+    # equal scores: lower index first (stable sort)
+    b3 = torch.tensor([[0.0, 0.0, 10.0, 10.0], [100.0, 0.0, 110.0, 10.0], [0.0, 0.0, 10.0, 10.0]])
+    assert B.nms(b3, torch.tensor([0.5, 0.5, 0.5]), 0.5).tolist() == [0, 1]
+
+
+def test_batched_nms_strategies_agree_on_separated_classes():
+    g = torch.Generator().manual_seed(3)
+    xy = torch.rand(200, 2, generator=g) * 100
+    wh = torch.rand(200, 2, generator=g) * 40 + 2
+    boxes = torch.cat([xy, xy + wh], 1)
+    scores = torch.rand(200, generator=g)
+    idxs = torch.randint(0, 8, (200,), generator=g)
+    a = B.batched_nms(boxes, scores, idxs, 0.5, numel_limit=20000)   # coordinate trick
+    b = B.batched_nms(boxes, scores, idxs, 0.5, numel_limit=0)       # per-class loop
+    assert a.tolist() == b.tolist()
+    # different classes never suppress each other
+    same = torch.tensor([[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 10.0, 10.0]])
+    assert B.batched_nms(same, torch.tensor([0.9, 0.8]), torch.tensor([0, 1]), 0.5).tolist() == [0, 1]
+    assert B.batched_nms(same, torch.tensor([0.9, 0.8]), torch.tensor([1, 1]), 0.5).tolist() == [0]
+
+
+def test_roi_align_ramp_hand_checked_and_c_matches_python():
+    # feature = 4x4 ramp f(y, x) = 4y + x ; bilinear interpolation of a linear ramp is exact
+    feat = torch.arange(16, dtype=torch.float32).view(1, 1, 4, 4)
+    rois = torch.tensor([[0.0, 0.0, 0.0, 64.0, 64.0]])  # scale 1/32 -> [-.5,1.5]^2, bins of 2/7
+    out = roi_align(feat, rois, 7, 1 / 32.0, 0, True)
+    # sample centre of bin (ph, pw): y = -0.5 + (ph + .5) * 2/7 ; values clamp at 0 below 0
+    for ph in range(7):
+        for pw in range(7):
+            y = max(-0.5 + (ph + 0.5) * 2 / 7, 0.0)
+            x = max(-0.5 + (pw + 0.5) * 2 / 7, 0.0)
+            assert abs(out[0, 0, ph, pw].item() - (4 * y + x)) < 1e-5
+    g = torch.Generator().manual_seed(0)
+    feat = torch.randn(2, 3, 9, 13, generator=g)
+    rois = torch.tensor([[0, 10.0, 20.0, 200.0, 150.0], [1, -30.0, -10.0, 500.0, 400.0],
+                         [1, 100.0, 100.0, 101.0, 100.5], [0, 380.0, 250.0, 420.0, 290.0]])
+    a = roi_align(feat, rois, 7, 1 / 32.0, 0, True)
+    b = roi_align_py(feat, rois, 7, 1 / 32.0, 0, True)
+    torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
+
+
+def test_roi_align_backward_is_adjoint_of_forward():
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(1, 2, 6, 7, generator=g, requires_grad=True)
+    rois = torch.tensor([[0, 5.0, 9.0, 150.0, 120.0], [0, 40.0, 30.0, 90.0, 170.0]])
+    out = roi_align(feat, rois, 3, 1 / 32.0, 0, True)
+    w = torch.randn(out.shape, generator=g)
+    (out * w).sum().backward()
+    # finite differences on a few entries (the op is linear in feat)
+    for idx in [(0, 0, 1, 2), (0, 1, 3, 4), (0, 0, 5, 6)]:
+        e = torch.zeros_like(feat)
+        e[idx] = 1.0
+        lin = (roi_align(e, rois, 3, 1 / 32.0, 0, True) * w).sum()
+        assert abs(lin.item() - feat.grad[idx].item()) < 1e-5
+
+
+def test_subsample_is_key_ordered_and_capped():
+    labels = torch.tensor([1, 0, 0, -1, 1, 1, 0, 0], dtype=torch.int8)
+    keys = torch.tensor([5, 9, 1, 0, 5, 2, 7, 1])
+    pos, neg = B.subsample_labels(labels, 4, 0.5, 0, keys)
+    assert pos.tolist() == [0, 5]          # keys 5(idx0), 5(idx4), 2(idx5): two smallest (key, idx)
+    assert neg.tolist() == [2, 7]          # keys 9,1,7,1 -> idx 2 and 7
+    pos, neg = B.subsample_labels(labels, 100, 0.5, 0, keys)
+    assert pos.tolist() == [0, 4, 5] and neg.tolist() == [1, 2, 6, 7]
+
+
+def test_losses_on_fixed_inputs():
+    cfg = om.Cfg()
+    # Fast R-CNN: 2 rows, K = 8; row0 foreground class 2, row1 background
+    scores = torch.zeros(2, 9)
+    deltas = torch.zeros(2, 32)
+    deltas[0, 8:12] = torch.tensor([1.0, -1.0, 0.5, 0.0])
+    boxes = torch.tensor([[0.0, 0.0, 10.0, 10.0], [5.0, 5.0, 9.0, 9.0]])
+    gtb = torch.tensor([[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 0.0, 0.0]])
+    out = om.fast_rcnn_losses(scores, deltas, boxes, torch.tensor([2, 8]), gtb, cfg)
+    np.testing.assert_allclose(out["loss_cls"].item(), math.log(9), rtol=1e-6)
+    np.testing.assert_allclose(out["loss_box_reg"].item(), 2.5 / 2, rtol=1e-6)  # target deltas are 0
+    # RPN: BCE(0, 1) = ln 2 summed over 2 valid anchors, normalised by 256 * 1
+    anchors = torch.tensor([[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 20.0, 20.0], [5.0, 5.0, 7.0, 7.0]])
+    logits = torch.zeros(1, 3)
+    dl = torch.zeros(1, 3, 4)
+    labels = torch.tensor([[1, 0, -1]], dtype=torch.int8)
+    matched = anchors[None].clone()
+    out = om.rpn_losses(anchors, logits, dl, labels, matched, cfg)
+    np.testing.assert_allclose(out["loss_rpn_cls"].item(), 2 * math.log(2) / 256, rtol=1e-6)
+    assert out["loss_rpn_loc"].item() == 0.0
+
+
+def test_threshold_is_strict_ema_truncates_int_and_lr_warmup():
+    det = {"boxes": torch.zeros(3, 4), "scores": torch.tensor([0.9, 0.8, 0.7999]),
+           "classes": torch.tensor([1, 2, 3])}
+    assert om.threshold_bbox(det, 0.8)["gt_classes"].tolist() == [1]
+    t = {"a": torch.tensor([1.0]), "n": torch.tensor(3, dtype=torch.int64)}
+    s = {"a": torch.tensor([2.0]), "n": torch.tensor(7, dtype=torch.int64)}
+    om.ema_update(t, s, 0.9996)
+    np.testing.assert_allclose(t["a"].item(), 1.0004, rtol=1e-6)
+    assert t["n"].item() == 3  # 3.0016 truncated on the int64 copy (SURVEY A.17 iv)
+    assert abs(om.lr_at(0, 0.0025) - 0.0025 * 0.001) < 1e-12
+    assert abs(om.lr_at(500, 0.04) - 0.04 * (0.001 * 0.5 + 0.5)) < 1e-12
+    assert abs(om.lr_at(60000, 0.04) - 0.004) < 1e-12
+
+
+def test_sgd_zero_grad_still_decays():
+    sd = {"w": torch.tensor([1.0])}
+    bufs = {}
+    om.sgd_step(sd, {"w": torch.zeros(1)}, bufs, lr=0.1, weight_decay=1e-4)
+    np.testing.assert_allclose(sd["w"].item(), 0.99999, rtol=1e-7)
