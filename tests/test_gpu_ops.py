@@ -1,0 +1,532 @@
+"""GPU parity tests: every HIP entry point (called through the C ABI) against the CPU oracle.
+
+Integer / index outputs are compared bit-exactly; floating point within the stated tolerance
+(fp32 parity mode: 1e-4 relative as in BASELINE.json north_star; bf16 mode against an oracle fed
+bf16-rounded operands).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import box_ops as OB
+from oracle import model as om
+from oracle.roi_align import roi_align as oracle_roi_align
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _dtypes():
+    return [torch.float32, torch.bfloat16]
+
+
+# -------------------------------------------------------------------------------------------------
+# conv / linear
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", _dtypes())
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout, ks
+    (2, 9, 13, 64, 64, 3),
+    (1, 18, 37, 64, 128, 3),
+    (2, 7, 5, 128, 256, 3),
+    (1, 5, 6, 512, 512, 3),
+    (3, 16, 16, 3, 64, 3),      # first layer: Cin padded to one 16-byte chunk
+    (1, 18, 37, 512, 75, 1),    # RPN 1x1 heads fused (15 logits + 60 deltas)
+    (2, 1, 1, 256, 1024, 1),
+])
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_conv_fwd(native, dtype, shape, act):
+    B, H, W, Cin, Cout, ks = shape
+    if act == 2 and Cout != 64:
+        pytest.skip("leaky relu only needs one shape")
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    bias = torch.randn(Cout, generator=g)
+    dt = native.dt_of(torch.empty(0, dtype=dtype))
+    E = native.chunk_elems(dt)
+    cin_pad = (Cin + E - 1) // E * E
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    ref = F.conv2d(x, w, bias, padding=ks // 2)
+    ref = {0: ref, 1: F.relu(ref), 2: F.leaky_relu(ref, 0.2)}[act]
+    xd = torch.zeros(B, H, W, cin_pad, dtype=dtype, device=DEV)
+    xd[..., :Cin] = nhwc(x).to(DEV).to(dtype)
+    wp = native.pack_conv_weight(w.to(DEV), cin_pad, dt)
+    y = native.conv_fwd(xd, wp, bias.to(DEV), Cout, ks, act=act)
+    torch.cuda.synchronize()
+    got = nchw(y.float().cpu())
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(got, ref) < tol
+
+
+@pytest.mark.parametrize("dtype", _dtypes())
+def test_linear_big_k_and_ld_padding(native, dtype):
+    """fc1-shaped GEMM (K = 25088, permuted (c,p)->(p,c)) and the 41-wide predictor with ld 48."""
+    g = torch.Generator().manual_seed(5)
+    R, C, PP, N = 70, 512, 49, 256
+    K = C * PP
+    pooled = torch.randn(R, C, 7, 7, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    if dtype == torch.bfloat16:
+        pooled, w = pooled.bfloat16().float(), w.bfloat16().float()
+    ref = F.relu(F.linear(pooled.flatten(1), w, b))
+    dt = native.dt_of(torch.empty(0, dtype=dtype))
+    xp = pooled.permute(0, 2, 3, 1).reshape(R, K).contiguous().to(DEV).to(dtype)  # (p, c) order
+    wp = native.pack_fc_weight(w.to(DEV), dt, chw_c=C)
+    y = native.conv_fwd(xp, wp, b.to(DEV), N, 1, act=1)
+    tol = 2e-5 if dtype == torch.float32 else 6e-3
+    assert rel_err(y.float().cpu(), ref) < tol
+    # predictor: N = 41 -> fp32 output with ld 48
+    w2 = torch.randn(41, N, generator=g) / math.sqrt(N)
+    b2 = torch.randn(41, generator=g)
+    h = ref.to(DEV).to(dtype)
+    if dtype == torch.bfloat16:
+        w2 = w2.bfloat16().float()
+    ref2 = F.linear(h.float().cpu(), w2, b2)
+    wp2 = native.pack_fc_weight(w2.to(DEV), dt)
+    y2 = native.conv_fwd(h, wp2, b2.to(DEV), 41, 1, out_dtype=torch.float32, ldy=48)
+    assert y2.shape == (R, 48)
+    assert rel_err(y2[:, :41].cpu(), ref2) < tol
+    assert (y2[:, 41:] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", _dtypes())
+@pytest.mark.parametrize("shape", [(2, 9, 13, 64, 64, 3), (1, 11, 7, 128, 256, 3), (1, 6, 5, 512, 75, 1),
+                                   (3, 8, 8, 3, 64, 3)])
+def test_conv_dgrad_and_wgrad(native, dtype, shape):
+    B, H, W, Cin, Cout, ks = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    dy = torch.randn(B, Cout, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        x, w, dy = x.bfloat16().float(), w.bfloat16().float(), dy.bfloat16().float()
+    x.requires_grad_(True)
+    w.requires_grad_(True)
+    F.conv2d(x, w, None, padding=ks // 2).backward(dy)
+    dt = native.dt_of(torch.empty(0, dtype=dtype))
+    E = native.chunk_elems(dt)
+    cin_pad = (Cin + E - 1) // E * E
+    cout_pad = (Cout + E - 1) // E * E
+    xd = torch.zeros(B, H, W, cin_pad, dtype=dtype, device=DEV)
+    xd[..., :Cin] = nhwc(x.detach()).to(DEV).to(dtype)
+    dyd = torch.zeros(B, H, W, cout_pad, dtype=dtype, device=DEV)
+    dyd[..., :Cout] = nhwc(dy).to(DEV).to(dtype)
+    tol = 3e-5 if dtype == torch.float32 else 8e-3
+    # weight gradient
+    dwp = native.conv_wgrad(xd, dyd, Cout, ks)
+    dw = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device=DEV)
+    native.unpack_conv_wgrad(dwp, dw)
+    assert rel_err(dw.cpu(), w.grad) < tol
+    # data gradient = conv with the rotated / transposed weight
+    if Cin >= E:
+        wr = native.pack_conv_weight(w.detach().to(DEV), cout_pad, dt, rot180=True)
+        dx = native.conv_fwd(dyd, wr, None, Cin, ks)
+        assert rel_err(nchw(dx.float().cpu()), x.grad) < tol
+
+
+# -------------------------------------------------------------------------------------------------
+# BatchNorm + ReLU + pool
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", _dtypes())
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("hw", [(8, 12), (7, 9), (37, 75)])
+def test_conv_bn_relu_pool_block_fwd_bwd(native, dtype, pool, hw):
+    H, W = hw
+    B, Cin, C = 2, 64, 128
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(C, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(C, generator=g) * 0.1
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g) * 0.2
+    gamma[3] = -0.7  # negative scale: max-pool must come after the affine + relu
+    rm, rv = torch.zeros(C), torch.ones(C)
+    if dtype == torch.bfloat16:
+        x, w = x.bfloat16().float(), w.bfloat16().float()
+    with torch.no_grad():
+        yc = F.conv2d(x, w, bias, padding=1)
+        rm_ref, rv_ref = rm.clone(), rv.clone()
+        z = F.relu(F.batch_norm(yc, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+        if pool:
+            z = F.max_pool2d(z, 2, 2)
+    dz = torch.randn(z.shape, generator=g)
+    if dtype == torch.bfloat16:
+        dz = dz.bfloat16().float()
+    dt = native.dt_of(torch.empty(0, dtype=dtype))
+    xd = nhwc(x).to(DEV).to(dtype)
+    wp = native.pack_conv_weight(w.to(DEV), Cin, dt)
+    y, stats = native.conv_fwd(xd, wp, bias.to(DEV), C, 3, want_stats=True)
+    rmd, rvd = rm.to(DEV), rv.to(DEV)
+    mean, invstd = native.bn_finalize(stats, B * H * W, C, rmd, rvd, 0.1, 1e-5)
+    zd = native.bn_relu_pool_fwd(y, mean, invstd, gamma.to(DEV), beta.to(DEV), pool)
+    tol = 3e-5 if dtype == torch.float32 else 2e-2
+    assert rel_err(nchw(zd.float().cpu()), z.detach()) < tol
+    torch.testing.assert_close(rmd.cpu(), rm_ref, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5)
+    torch.testing.assert_close(rvd.cpu(), rv_ref, rtol=1e-4 if dtype == torch.float32 else 2e-2, atol=1e-5)
+    # backward of the BN+ReLU(+pool) block: dy w.r.t. the conv output, dgamma, dbeta
+    # the reference backward starts from the conv output as STORED on the device (bf16-rounded in
+    # throughput mode), so relu / arg-max decisions are taken on identical values
+    yc2 = nchw(y.float().cpu()).requires_grad_(True)
+    g2, b2 = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    z2 = F.relu(F.batch_norm(yc2, None, None, g2, b2, True, 0.1, 1e-5))
+    if pool:
+        z2 = F.max_pool2d(z2, 2, 2)
+    z2.backward(dz)
+    dzd = nhwc(dz).to(DEV).to(dtype)
+    dy, dgamma, dbeta = native.bn_relu_pool_bwd(dzd, y, mean, invstd, gamma.to(DEV), beta.to(DEV), pool)
+    btol = 1e-4 if dtype == torch.float32 else 4e-2
+    assert rel_err(dgamma.cpu(), g2.grad) < btol
+    assert rel_err(dbeta.cpu(), b2.grad) < btol
+    assert rel_err(nchw(dy.float().cpu()), yc2.grad) < btol
+
+
+# -------------------------------------------------------------------------------------------------
+# ROIAlign
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", _dtypes())
+def test_roi_align_fwd_bwd(native, dtype):
+    g = torch.Generator().manual_seed(2)
+    B, C, H, W = 2, 64, 18, 37
+    feat = torch.randn(B, C, H, W, generator=g)
+    if dtype == torch.bfloat16:
+        feat = feat.bfloat16().float()
+    n = 40
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([1100.0, 500.0])
+    wh = torch.rand(n, 2, generator=g) * torch.tensor([500.0, 300.0]) + 1
+    rois = torch.cat([torch.randint(0, B, (n, 1), generator=g).float(), xy, xy + wh], 1)
+    rois[5] = torch.tensor([1, -40.0, -30.0, 1300.0, 700.0])     # larger than the image
+    rois[6] = torch.tensor([0, 100.0, 100.0, 100.5, 100.25])     # tiny
+    rois[7, 0] = -1                                              # padding row
+    fr = feat.clone().requires_grad_(True)
+    live = rois[:, 0] >= 0
+    ref = torch.zeros(n, C, 7, 7)
+    ref[live] = oracle_roi_align(fr, rois[live], 7, 1 / 32.0, 0, True)
+    dout = torch.randn(n, C, 7, 7, generator=g)
+    if dtype == torch.bfloat16:
+        dout = dout.bfloat16().float()
+    ref.backward(dout)
+    fd = nhwc(feat).to(DEV).to(dtype)
+    out = native.roi_align_fwd(fd, rois.to(DEV), 7, 1 / 32.0)          # [R, 49, C]
+    got = out.float().cpu().view(n, 7, 7, C).permute(0, 3, 1, 2)
+    tol = 1e-5 if dtype == torch.float32 else 8e-3
+    assert rel_err(got, ref.detach()) < tol
+    dd = dout.permute(0, 2, 3, 1).reshape(n, 49, C).contiguous().to(DEV).to(dtype)
+    dfeat = native.roi_align_bwd(dd, rois.to(DEV), (B, H, W, C), 7, 1 / 32.0)
+    assert rel_err(nchw(dfeat.cpu()), fr.grad) < (1e-5 if dtype == torch.float32 else 1e-4)
+
+
+# -------------------------------------------------------------------------------------------------
+# NMS / sort / matcher / sampling: bit-exact
+# -------------------------------------------------------------------------------------------------
+def _rand_boxes(n, g, span=600.0, size=200.0):
+    xy = torch.rand(n, 2, generator=g) * span
+    wh = torch.rand(n, 2, generator=g) * size + 1
+    return torch.cat([xy, xy + wh], 1)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 129, 1000, 4097])
+def test_nms_indices_bit_exact(native, n):
+    g = torch.Generator().manual_seed(n)
+    B = 2
+    keeps = []
+    boxes = torch.stack([_rand_boxes(n, g) for _ in range(B)])
+    scores = torch.rand(B, n, generator=g)
+    scores[:, n // 2] = scores[:, 0]                 # a tie
+    valid = torch.ones(B, n, dtype=torch.uint8)
+    if n > 10:
+        boxes[0, 3, 2] = boxes[0, 3, 0]              # empty box: removed before NMS
+    ss, si = native.segmented_sort_desc(scores.to(DEV))
+    ref_order = torch.sort(scores, dim=1, descending=True, stable=True)[1]
+    assert torch.equal(si.cpu().long(), ref_order)
+    sb = torch.gather(boxes, 1, ref_order[..., None].expand(-1, -1, 4))
+    nonempty = ((sb[..., 2] - sb[..., 0]) > 0) & ((sb[..., 3] - sb[..., 1]) > 0)
+    max_keep = 300
+    keep_idx, keep_cnt = native.nms(sb.to(DEV), 0.7, max_keep, valid=nonempty.to(torch.uint8).to(DEV))
+    for b in range(B):
+        live = torch.nonzero(nonempty[b]).squeeze(1)
+        ref = live[OB.nms(sb[b][live], torch.arange(len(live), 0, -1).float(), 0.7)][:max_keep]
+        c = keep_cnt[b].item()
+        assert c == len(ref)
+        assert keep_idx[b, :c].cpu().long().tolist() == ref.tolist()
+
+
+def test_nms_exact_tie_iou_and_threshold_strictness(native):
+    boxes = torch.tensor([[[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 10.0, 5.0], [0.0, 0.0, 10.0, 10.0]]])
+    k, c = native.nms(boxes.to(DEV), 0.5, 8)
+    assert k[0, :c[0].item()].tolist() == [0, 1]     # IoU == 0.5 is kept (strict >), duplicate removed
+
+
+@pytest.mark.parametrize("G", [0, 1, 7, 100])
+def test_anchor_match_labels_bit_exact(native, G):
+    g = torch.Generator().manual_seed(G)
+    B, Hf, Wf, stride = 2, 18, 37, 32
+    cell = OB.cell_anchors((32, 64, 128, 256, 512), (0.5, 1.0, 2.0))
+    anchors = OB.grid_anchors(Hf, Wf, stride, cell)
+    gcap = 100
+    gt = torch.zeros(B, gcap, 4)
+    cnt = torch.tensor([G, max(G - 1, 0)], dtype=torch.int32)
+    for b in range(B):
+        gt[b, : cnt[b]] = _rand_boxes(int(cnt[b]), g, span=900.0, size=300.0)
+    if G >= 7:
+        gt[0, 2] = anchors[4000]                     # exact overlap -> IoU 1
+        gt[0, 3] = torch.tensor([5000.0, 5000.0, 5100.0, 5100.0])   # overlaps nothing (the all-zero quirk)
+    matched, labels = native.anchor_match(cell.to(DEV), B, Hf, Wf, stride, gt.to(DEV), cnt.to(DEV), 0.3, 0.7)
+    for b in range(B):
+        M = OB.pairwise_iou(gt[b, : cnt[b]], anchors)
+        ridx, rlab = OB.matcher(M, [0.3, 0.7], [0, -1, 1], True)
+        assert torch.equal(labels[b].cpu(), rlab)
+        assert torch.equal(matched[b].cpu().long(), ridx)
+
+
+def test_subsample_rpn_and_roi_exact(native):
+    g = torch.Generator().manual_seed(9)
+    B, n = 3, 9990
+    labels = torch.randint(-1, 2, (B, n), generator=g).to(torch.int8)
+    labels[1] = 0
+    labels[1, :40] = 1                                # fewer positives than 128
+    labels[2] = -1
+    labels[2, 5] = 0                                  # almost nothing to sample
+    keys = torch.randint(0, 2 ** 31 - 1, (B, n), generator=g, dtype=torch.int64)
+    keys[0, :2000] = 7                                # many equal keys: index breaks the tie
+    ld = labels.clone().to(DEV)
+    native.subsample_rpn_(ld, keys.to(torch.int32).to(DEV), 256, 0.5)
+    for b in range(B):
+        pos, neg = OB.subsample_labels(labels[b], 256, 0.5, 0, keys[b])
+        ref = torch.full((n,), -1, dtype=torch.int8)
+        ref[pos] = 1
+        ref[neg] = 0
+        assert torch.equal(ld[b].cpu(), ref)
+    # ROI mode
+    K = 8
+    cls = torch.randint(0, K + 1, (B, 2100), generator=g).to(torch.int32)
+    cls[:, 2050:] = -2                                # beyond the live prefix
+    cls[0, :1500] = K
+    keys = torch.randint(0, 2 ** 31 - 1, (B, 2100), generator=g, dtype=torch.int64)
+    idx, cnt = native.subsample_roi(cls.to(DEV), keys.to(torch.int32).to(DEV), 512, 0.25, K)
+    for b in range(B):
+        c = cls[b].long().clone()
+        live = c != -2
+        fg, bg = OB.subsample_labels(torch.where(live, c, torch.full_like(c, -1)), 512, 0.25, K, keys[b])
+        ref = torch.cat([fg, bg])
+        assert cnt[b].item() == len(ref)
+        assert idx[b, : len(ref)].cpu().long().tolist() == ref.tolist()
+
+
+def test_roi_match_and_sample_building(native):
+    g = torch.Generator().manual_seed(21)
+    B, P, gcap, K = 2, 300, 100, 8
+    props = torch.stack([_rand_boxes(P, g) for _ in range(B)])
+    pc = torch.tensor([300, 250], dtype=torch.int32)
+    gt = torch.zeros(B, gcap, 4)
+    gcl = torch.zeros(B, gcap, dtype=torch.int32)
+    gc = torch.tensor([6, 0], dtype=torch.int32)
+    gt[0, :6] = props[0, 10:16] + 3.0
+    gcl[0, :6] = torch.randint(0, K, (6,), generator=g).int()
+    boxes, cnt = native.append_gt(props.to(DEV), pc.to(DEV), gt.to(DEV), gc.to(DEV))
+    assert cnt.tolist() == [306, 250]
+    torch.testing.assert_close(boxes[0, 300:306].cpu(), gt[0, :6])
+    matched, cls = native.roi_match(boxes, cnt, gt.to(DEV), gcl.to(DEV), gc.to(DEV), 0.5, K)
+    M = OB.pairwise_iou(gt[0, :6], boxes[0, :306].cpu())
+    ridx, rlab = OB.matcher(M, [0.5], [0, 1], False)
+    rc = gcl[0, :6].long()[ridx]
+    rc[rlab == 0] = K
+    assert torch.equal(cls[0, :306].cpu().long(), rc)
+    assert (cls[0, 306:] == -2).all() and (cls[1, :250] == K).all() and (cls[1, 250:] == -2).all()
+    keys = torch.randint(0, 2 ** 31 - 1, (B, P + gcap), generator=g, dtype=torch.int32)
+    sidx, scnt = native.subsample_roi(cls.clone(), keys.to(DEV), 64, 0.25, K)
+    rois, gt_cls, gt_box, n_valid = native.roi_build_samples(boxes, cls, matched, sidx, scnt, gt.to(DEV), gc.to(DEV))
+    assert n_valid.item() == scnt.sum().item()
+    s0 = scnt[0].item()
+    torch.testing.assert_close(rois[:s0, 1:].cpu(), boxes[0].cpu()[sidx[0, :s0].cpu().long()])
+    assert (rois[:s0, 0] == 0).all() and (rois[64:64 + scnt[1].item(), 0] == 1).all()
+    assert torch.equal(gt_cls[:s0].cpu(), cls[0].cpu()[sidx[0, :s0].cpu().long()])
+    torch.testing.assert_close(gt_box[:s0].cpu(), gt[0][matched[0].cpu().long()[sidx[0, :s0].cpu().long()]])
+    assert (gt_box[64:] == 0).all()
+
+
+# -------------------------------------------------------------------------------------------------
+# RPN proposals, losses, teacher post-processing
+# -------------------------------------------------------------------------------------------------
+def _rpn_out(B, Hf, Wf, A, g, ld=80):
+    out = torch.zeros(B * Hf * Wf, ld)
+    out[:, :A] = torch.randn(B * Hf * Wf, A, generator=g) * 2
+    out[:, A:5 * A] = torch.randn(B * Hf * Wf, 4 * A, generator=g) * 0.5
+    return out
+
+
+def _split_rpn_out(out, B, Hf, Wf, A):
+    logits = out[:, :A].reshape(B, Hf * Wf * A)
+    deltas = out[:, A:5 * A].reshape(B, Hf * Wf * A, 4)
+    return logits, deltas
+
+
+def test_rpn_proposal_pipeline_matches_oracle(native):
+    g = torch.Generator().manual_seed(4)
+    B, Hf, Wf, stride, A = 2, 18, 37, 32, 15
+    cfg = om.Cfg(rpn_pre_topk_train=3000, rpn_post_topk_train=500)
+    cell = OB.cell_anchors(cfg.anchor_sizes, cfg.anchor_ratios)
+    anchors = OB.grid_anchors(Hf, Wf, stride, cell)
+    out = _rpn_out(B, Hf, Wf, A, g)
+    logits, deltas = _split_rpn_out(out, B, Hf, Wf, A)
+    sizes = [(600, 1200), (576, 1184)]
+    ref = om.rpn_proposals(anchors, logits, deltas, sizes, cfg, training=True)
+    szd = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    props, scores = native.rpn_decode(out.to(DEV), cell.to(DEV), B, Hf, Wf, stride, szd, flags)
+    ss, si = native.segmented_sort_desc(scores)
+    cb, cs, cv = native.rpn_gather_topk(props, ss, si, 3000)
+    keep_idx, keep_cnt = native.nms(cb, 0.7, 500, valid=cv)
+    pb, ps = native.gather_kept(cb, cs, keep_idx, keep_cnt)
+    assert flags.item() == 0
+    for b in range(B):
+        n = keep_cnt[b].item()
+        assert n == len(ref[b][0])
+        torch.testing.assert_close(pb[b, :n].cpu(), ref[b][0], rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(ps[b, :n].cpu(), ref[b][1], rtol=0, atol=0)
+        assert (pb[b, n:] == 0).all()
+
+
+def test_rpn_loss_and_grad(native):
+    g = torch.Generator().manual_seed(6)
+    B, Hf, Wf, stride, A = 2, 9, 11, 32, 15
+    cfg = om.Cfg()
+    cell = OB.cell_anchors(cfg.anchor_sizes, cfg.anchor_ratios)
+    anchors = OB.grid_anchors(Hf, Wf, stride, cell)
+    NA = Hf * Wf * A
+    out = _rpn_out(B, Hf, Wf, A, g)
+    gcap = 100
+    gt = torch.zeros(B, gcap, 4)
+    gc = torch.tensor([5, 0], dtype=torch.int32)
+    gt[0, :5] = _rand_boxes(5, g, span=250.0, size=120.0)
+    keys = torch.randint(0, 2 ** 31 - 1, (B, NA), generator=g, dtype=torch.int64)
+    labels, matched_gt = om.rpn_label_anchors(anchors, [gt[b, : gc[b]] for b in range(B)], list(keys), cfg)
+    outr = out.clone().requires_grad_(True)
+    logits, deltas = _split_rpn_out(outr, B, Hf, Wf, A)
+    ref = om.rpn_losses(anchors, logits, deltas, labels, matched_gt, cfg)
+    (ref["loss_rpn_cls"] * 0.7 + ref["loss_rpn_loc"] * 1.3).backward()
+    matched, lab = native.anchor_match(cell.to(DEV), B, Hf, Wf, stride, gt.to(DEV), gc.to(DEV), 0.3, 0.7)
+    native.subsample_rpn_(lab, keys.to(torch.int32).to(DEV), 256, 0.5)
+    assert torch.equal(lab.cpu(), labels)
+    gs = torch.tensor([0.7, 1.3], device=DEV)
+    loss, d_out = native.rpn_loss(out.to(DEV), cell.to(DEV), B, Hf, Wf, stride, lab, matched, gt.to(DEV),
+                                  gc.to(DEV), 256, grad_scale=gs)
+    np.testing.assert_allclose(loss[0].item(), ref["loss_rpn_cls"].item(), rtol=1e-5)
+    np.testing.assert_allclose(loss[1].item(), ref["loss_rpn_loc"].item(), rtol=1e-5)
+    torch.testing.assert_close(d_out.cpu(), outr.grad, rtol=1e-4, atol=1e-9)
+
+
+def test_frcnn_loss_and_grad(native):
+    g = torch.Generator().manual_seed(8)
+    R, K, ld = 300, 8, 48
+    cfg = om.Cfg()
+    pred = torch.zeros(R, ld)
+    pred[:, :41] = torch.randn(R, 41, generator=g)
+    boxes = _rand_boxes(R, g)
+    gtb = boxes + torch.randn(R, 4, generator=g) * 4
+    gtb[:, 2:] = torch.max(gtb[:, 2:], gtb[:, :2] + 1)
+    cls = torch.randint(0, K + 1, (R,), generator=g)
+    cls[250:] = -1                                      # padding rows
+    live = cls >= 0
+    pr = pred.clone().requires_grad_(True)
+    ref = om.fast_rcnn_losses(pr[live, :9], pr[live, 9:41], boxes[live], cls[live], gtb[live], cfg)
+    (ref["loss_cls"] * 1.5 + ref["loss_box_reg"] * 0.5).backward()
+    rois = torch.cat([torch.zeros(R, 1), boxes], 1)
+    nv = torch.tensor([int(live.sum())], dtype=torch.int32)
+    gs = torch.tensor([1.5, 0.5], device=DEV)
+    loss, d_pred = native.frcnn_loss(pred.to(DEV), K, rois.to(DEV), cls.int().to(DEV), gtb.to(DEV), nv.to(DEV), gs)
+    np.testing.assert_allclose(loss[0].item(), ref["loss_cls"].item(), rtol=1e-5)
+    np.testing.assert_allclose(loss[1].item(), ref["loss_box_reg"].item(), rtol=1e-5)
+    torch.testing.assert_close(d_pred.cpu(), pr.grad, rtol=1e-4, atol=1e-9)
+
+
+@pytest.mark.parametrize("limit", [20000, 400])
+def test_teacher_postprocessing_matches_oracle(native, limit):
+    """softmax + decode + clip + score>0.05 + class-wise NMS(0.5) + top-100 + score>0.8, for both
+    torchvision batched_nms strategies (coordinate trick / per-class loop)."""
+    g = torch.Generator().manual_seed(12)
+    B, P, K, ld = 2, 400, 8, 48
+    cfg = om.Cfg(nms_numel_limit=limit)
+    pc = torch.tensor([400, 333], dtype=torch.int32)
+    props = torch.stack([_rand_boxes(P, g, span=900.0, size=250.0) for _ in range(B)])
+    pred = torch.zeros(B * P, ld)
+    pred[:, :9] = torch.randn(B * P, 9, generator=g) * 3
+    pred[:, 9:41] = torch.randn(B * P, 32, generator=g) * 0.7
+    sizes = [(600, 1200), (590, 1100)]
+    scores = torch.cat([pred[b * P: b * P + pc[b], :9] for b in range(B)])
+    deltas = torch.cat([pred[b * P: b * P + pc[b], 9:41] for b in range(B)])
+    ref = om.fast_rcnn_inference(scores, deltas, [props[b, : pc[b]] for b in range(B)], sizes, cfg)
+    out = native.frcnn_inference(pred.to(DEV), K, props.to(DEV), pc.to(DEV),
+                                 torch.tensor(sizes, dtype=torch.int32, device=DEV), 0.05, 0.5, 100, 0.8,
+                                 numel_limit=limit)
+    for b in range(B):
+        n = out["det_count"][b].item()
+        assert n == len(ref[b]["scores"])
+        assert out["det_classes"][b, :n].cpu().long().tolist() == ref[b]["classes"].tolist()
+        torch.testing.assert_close(out["det_scores"][b, :n].cpu(), ref[b]["scores"], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(out["det_boxes"][b, :n].cpu(), ref[b]["boxes"], rtol=1e-5, atol=2e-3)
+        pl = om.threshold_bbox(ref[b], 0.8)
+        m = out["gt_count"][b].item()
+        assert m == len(pl["gt_classes"])
+        assert out["gt_classes"][b, :m].cpu().long().tolist() == pl["gt_classes"].tolist()
+        torch.testing.assert_close(out["gt_boxes"][b, :m].cpu(), pl["gt_boxes"], rtol=1e-5, atol=2e-3)
+
+
+# -------------------------------------------------------------------------------------------------
+# preprocess, optimiser
+# -------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", _dtypes())
+def test_preprocess(native, dtype):
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.randint(0, 256, (3, 20, 31), generator=g, dtype=torch.uint8),
+            torch.randint(0, 256, (3, 17, 33), generator=g, dtype=torch.uint8)]
+    ref, sizes = om.preprocess(imgs)
+    dt = native.dt_of(torch.empty(0, dtype=dtype))
+    cpad = native.chunk_elems(dt)
+    x, sz = native.preprocess([im.to(DEV) for im in imgs], 20, 33, cpad, om.PIXEL_MEAN, om.PIXEL_STD, dt)
+    assert sz.tolist() == [list(s) for s in sizes]
+    got = nchw(x.float().cpu())
+    if dtype == torch.float32:
+        torch.testing.assert_close(got[:, :3], ref, rtol=0, atol=0)
+    else:
+        torch.testing.assert_close(got[:, :3], ref.bfloat16().float(), rtol=0, atol=0)
+    assert (got[:, 3:] == 0).all()
+
+
+def test_sgd_ema_fused(native):
+    g = torch.Generator().manual_seed(3)
+    n = 100003
+    p = torch.randn(n, generator=g)
+    gr = torch.randn(n, generator=g)
+    t = torch.randn(n, generator=g)
+    sd = {"w": p.clone()}
+    bufs = {}
+    pd, td = p.clone().to(DEV), t.clone().to(DEV)
+    md = torch.zeros(n, device=DEV)
+    lr = torch.tensor([0.02], device=DEV)
+    tref = {"w": t.clone()}
+    for step in range(3):
+        om.sgd_step(sd, {"w": gr * (step + 1)}, bufs, lr=0.02, momentum=0.9, weight_decay=1e-4)
+        om.ema_update(tref, sd, 0.9996)
+        native.sgd_ema_(pd, (gr * (step + 1)).to(DEV), md, td, lr, 0.9, 1e-4, 1.0, 0.9996, step == 0)
+    torch.testing.assert_close(pd.cpu(), sd["w"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(md.cpu(), bufs["w"], rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(td.cpu(), tref["w"], rtol=1e-6, atol=1e-7)
