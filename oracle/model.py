@@ -372,8 +372,12 @@ def teacher_forward(sd, images_u8, cfg):
 
 
 def student_losses(sd, images_u8, gt_boxes_list, gt_classes_list, rpn_keys, roi_keys, cfg,
-                   return_aux=False):
-    """branch='supervised_target' (rcnn.py:259-312) without the dead 2nd ROI pass / BPC."""
+                   return_aux=False, proposals=None):
+    """branch='supervised_target' (rcnn.py:259-312) without the dead 2nd ROI pass / BPC.
+
+    ``proposals`` (list of (boxes, logits)) replaces the RPN's own proposals: parity tests use it
+    to give both implementations the same discrete proposal set, because a 1e-7 difference in a
+    logit can legitimately flip an NMS decision (``given_proposals`` in the reference's signature)."""
     x, sizes = preprocess(images_u8)
     feat = vgg_forward(sd, x, cfg, training=True)
     logits, deltas = rpn_head(sd, feat)
@@ -381,6 +385,9 @@ def student_losses(sd, images_u8, gt_boxes_list, gt_classes_list, rpn_keys, roi_
     labels, matched = rpn_label_anchors(anchors, gt_boxes_list, rpn_keys, cfg)
     losses = rpn_losses(anchors, logits, deltas, labels, matched, cfg)
     props = rpn_proposals(anchors, logits.detach(), deltas.detach(), sizes, cfg, training=True)
+    own_props = props
+    if proposals is not None:
+        props = proposals
     samp = roi_label_and_sample(props, gt_boxes_list, gt_classes_list, roi_keys, cfg)
     scores, bdeltas, _ = box_head(sd, feat, [s["boxes"] for s in samp], cfg)
     losses.update(fast_rcnn_losses(
@@ -388,7 +395,7 @@ def student_losses(sd, images_u8, gt_boxes_list, gt_classes_list, rpn_keys, roi_
         torch.cat([s["gt_classes"] for s in samp]), torch.cat([s["gt_boxes"] for s in samp]), cfg))
     if return_aux:
         return losses, {"feat": feat, "logits": logits, "deltas": deltas, "labels": labels,
-                        "props": props, "samp": samp, "scores": scores, "bdeltas": bdeltas}
+                        "props": props, "own_props": own_props, "samp": samp, "scores": scores, "bdeltas": bdeltas}
     return losses
 
 

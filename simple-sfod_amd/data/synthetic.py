@@ -1,0 +1,146 @@
+"""Synthetic COCO-format target data + the source-free two-crop loader contract.
+
+The reference's loader (``daod/data/build.py:289-367``, ``daod/data/common.py:199-228``,
+``daod/data/mappers/two_crop_augmentation_mapper.py:73-157``) yields, per iteration and per rank,
+``(strong_list, weak_list)`` of ``IMS_PER_BATCH_TARGET // world_size`` dicts; each dict carries
+``image`` (uint8 ``3xHxW`` BGR tensor, post ResizeShortestEdge + RandomFlip), ``instances``,
+``height``, ``width``, ``file_name``, ``image_id``.  This module reproduces that contract on
+synthetic 8-class Cityscapes-shape frames (there is no dataset / network in the build
+environment); real COCO-json loading and the strong augmentation are "next" rows
+(SURVEY.md section 8f).
+
+Frames are generated once, resized by the mapper's rule (shortest edge 600, max
+1333, PIL bilinear on uint8) and kept resident on the device; the per-iteration work is the
+random horizontal flip.
+"""
+import numpy as np
+import torch
+
+from ..structures import Boxes, Instances
+
+CITYSCAPES_CLASSES = ["person", "rider", "car", "truck", "bus", "train", "motorcycle", "bicycle"]
+
+
+def resize_shortest_edge_shape(h, w, short, max_size):
+    """d2 ResizeShortestEdge.get_output_shape."""
+    scale = short * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = short, scale * w
+    else:
+        newh, neww = scale * h, short
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh, neww = newh * scale, neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def make_frame(index, height, width, num_boxes, seed=42, num_classes=8):
+    """uint8 [3,H,W] ``randint(0,256)`` seed 42+i; boxes w,h in [32,256]."""
+    g = torch.Generator().manual_seed(seed + index)
+    img = torch.randint(0, 256, (3, height, width), generator=g, dtype=torch.uint8)
+    wh = torch.rand(num_boxes, 2, generator=g) * (256 - 32) + 32
+    xy = torch.rand(num_boxes, 2, generator=g) * torch.tensor([width, height], dtype=torch.float32)
+    boxes = torch.cat([xy, xy + wh], dim=1)
+    boxes[:, 0::2].clamp_(0, width)
+    boxes[:, 1::2].clamp_(0, height)
+    classes = torch.randint(0, num_classes, (num_boxes,), generator=g)
+    return img, boxes, classes
+
+
+def coco_record(index, height, width, boxes, classes):
+    """The dataset-dict / COCO annotation schema of cityscapes-to-coco-conversion (main.py:203-209)."""
+    return {
+        "file_name": f"synthetic/{index:06d}.png", "image_id": index, "height": height, "width": width,
+        "annotations": [{"bbox": [float(b[0]), float(b[1]), float(b[2] - b[0]), float(b[3] - b[1])],
+                         "bbox_mode": 1, "category_id": int(c), "iscrowd": 0}
+                        for b, c in zip(boxes.tolist(), classes.tolist())],
+    }
+
+
+def _resize_u8(img_chw, newh, neww):
+    from PIL import Image
+    arr = img_chw.permute(1, 2, 0).numpy()
+    out = np.asarray(Image.fromarray(arr).resize((neww, newh), Image.BILINEAR))
+    return torch.from_numpy(out.copy()).permute(2, 0, 1).contiguous()
+
+
+class SyntheticTargetDataset:
+    """N frames, mapped once (resize) and kept on `device` as uint8 CHW tensors."""
+
+    def __init__(self, cfg, device, num_images=None, train=True):
+        s = cfg.SFOD.SYNTHETIC
+        n = num_images or s.NUM_IMAGES
+        short = cfg.INPUT.MIN_SIZE_TRAIN[0] if train else cfg.INPUT.MIN_SIZE_TEST
+        max_size = cfg.INPUT.MAX_SIZE_TRAIN if train else cfg.INPUT.MAX_SIZE_TEST
+        newh, neww = resize_shortest_edge_shape(s.HEIGHT, s.WIDTH, short, max_size)
+        self.items = []
+        for i in range(n):
+            img, boxes, classes = make_frame(i, s.HEIGHT, s.WIDTH, s.BOXES_PER_IMAGE, seed=max(cfg.SEED, 0))
+            if (newh, neww) != (s.HEIGHT, s.WIDTH):
+                img = _resize_u8(img, newh, neww)
+                boxes = boxes * torch.tensor([neww / s.WIDTH, newh / s.HEIGHT] * 2)
+            self.items.append({"image": img.to(device), "boxes": boxes.to(device), "classes": classes.to(device),
+                               "height": s.HEIGHT, "width": s.WIDTH, "image_id": i,
+                               "file_name": f"synthetic/{i:06d}.png"})
+        self.size = (newh, neww)
+
+    def __len__(self):
+        return len(self.items)
+
+
+class TrainingSampler:
+    """d2 TrainingSampler: one shared-seed infinite permutation stream, rank r takes r, r+W, ..."""
+
+    def __init__(self, size, seed, rank=0, world=1, shuffle=True):
+        self.size, self.seed, self.rank, self.world, self.shuffle = size, int(seed), rank, world, shuffle
+
+    def __iter__(self):
+        g = torch.Generator().manual_seed(self.seed)
+        i = 0
+        while True:
+            perm = torch.randperm(self.size, generator=g) if self.shuffle else torch.arange(self.size)
+            for idx in perm.tolist():
+                if i % self.world == self.rank:
+                    yield idx
+                i += 1
+
+
+class TwoCropLoader:
+    """``build_detection_semisup_train_loader_two_crops_source_free``: yields (strong, weak) lists.
+
+    With ``WEAK_STRONG_AUGMENT: False`` (hot yaml) the trainer discards the strong copy
+    (source_free_adaptive_teacher.py:351-352), so both lists reference the same weakly augmented
+    tensors; strong augmentation is a "next" row."""
+
+    def __init__(self, cfg, device, rank=0, world=1, labeled=False, dataset=None):
+        total = cfg.SOLVER.IMS_PER_BATCH if labeled else cfg.SOLVER.IMS_PER_BATCH_TARGET
+        assert total > 0 and total % world == 0, \
+            "Total target batch size ({}) must be divisible by the number of gpus ({}).".format(total, world)
+        self.batch = total // world
+        self.dataset = dataset or SyntheticTargetDataset(cfg, device)
+        self.sampler = iter(TrainingSampler(len(self.dataset), max(cfg.SEED, 0), rank, world))
+        self.flip = cfg.INPUT.RANDOM_FLIP == "horizontal"
+        self.gen = torch.Generator().manual_seed(max(cfg.SEED, 0) + rank)
+        self.labeled = labeled
+
+    def _map(self, item):
+        img, boxes = item["image"], item["boxes"]
+        if self.flip and torch.rand(1, generator=self.gen).item() < 0.5:
+            img = torch.flip(img, dims=[2])
+            w = img.shape[2]
+            boxes = torch.stack([w - boxes[:, 2], boxes[:, 1], w - boxes[:, 0], boxes[:, 3]], dim=1)
+        inst = Instances((int(img.shape[1]), int(img.shape[2])))
+        inst.gt_boxes = Boxes(boxes)
+        inst.gt_classes = item["classes"]
+        return {"image": img, "instances": inst, "height": item["height"], "width": item["width"],
+                "image_id": item["image_id"], "file_name": item["file_name"]}
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        weak = [self._map(self.dataset.items[next(self.sampler)]) for _ in range(self.batch)]
+        if self.labeled:
+            return weak
+        strong = [dict(d) for d in weak]
+        return strong, weak

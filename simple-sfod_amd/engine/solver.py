@@ -1,0 +1,201 @@
+"""Optimiser, LR schedule and teacher EMA of the hot path, MI355X-first.
+
+Restates Detectron2's ``build_optimizer`` (SGD momentum 0.9, weight decay 1e-4, 0.0 for norm
+layers) + ``WarmupMultiStepLR`` and the reference's
+``_update_teacher_model`` (``daod/engine/trainers/source_free_adaptive_teacher.py:583-603``).
+
+Design: all parameters of a model live in ONE flat fp32 device buffer (the nn.Parameters are
+views into it), gradients and momentum likewise.  One fused kernel per weight-decay group
+applies  g += wd*p ; m = mu*m + g ; p -= lr*m  and -- when a teacher is attached -- the EMA
+t = (1-k)*p + k*t  in the same pass (each value read once).  The flat gradient buffer is also the
+single RCCL all-reduce payload of the data-parallel step.  The learning rate lives in a device
+scalar, so the schedule never synchronises the stream.
+"""
+import bisect
+from collections import OrderedDict
+
+import torch
+
+from .. import native
+
+
+def _is_norm_module(m):
+    return isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d, torch.nn.GroupNorm, torch.nn.LayerNorm))
+
+
+class FlatModelState:
+    """Re-homes a model's parameters / buffers into flat device buffers (views keep their names)."""
+
+    def __init__(self, model, frozen_prefixes=(), with_grad=True):
+        norm_ids = set()
+        for m in model.modules():
+            if _is_norm_module(m):
+                for p in m.parameters(recurse=False):
+                    norm_ids.add(id(p))
+        named = [(n, p) for n, p in model.named_parameters()]
+        decay = [(n, p) for n, p in named if id(p) not in norm_ids and not n.startswith(tuple(frozen_prefixes))]
+        norm = [(n, p) for n, p in named if id(p) in norm_ids and not n.startswith(tuple(frozen_prefixes))]
+        frozen = [(n, p) for n, p in named if n.startswith(tuple(frozen_prefixes))] if frozen_prefixes else []
+        self.order = decay + norm + frozen
+        dev = named[0][1].device
+
+        def pad4(n):
+            return (n + 3) // 4 * 4
+
+        self.offsets = OrderedDict()
+        off = 0
+        bounds = []
+        for group in (decay, norm, frozen):
+            for n, p in group:
+                self.offsets[n] = (off, p.numel(), tuple(p.shape))
+                off += pad4(p.numel())
+            bounds.append(off)
+        self.n_decay, self.n_norm_end, self.n_total = bounds
+        self.param = torch.zeros(max(self.n_total, 4), dtype=torch.float32, device=dev)
+        self.grad = torch.zeros_like(self.param) if with_grad else None
+        with torch.no_grad():
+            for n, p in self.order:
+                o, k, shp = self.offsets[n]
+                view = self.param[o:o + k].view(shp)
+                view.copy_(p.data)
+                p.data = view
+        self.params = OrderedDict(self.order)
+        if with_grad:
+            self.attach_grads()
+        # fp32 buffers (BN running stats) and int64 buffers (num_batches_tracked)
+        fb, ib = [], []
+        for mname, m in model.named_modules():
+            for bname, b in m._buffers.items():
+                if b is None or bname in m._non_persistent_buffers_set:
+                    continue
+                (fb if b.dtype == torch.float32 else ib).append((m, bname, b))
+        self.fbuf = torch.zeros(max(sum(pad4(b.numel()) for _, _, b in fb), 4), dtype=torch.float32, device=dev)
+        self.ibuf = torch.zeros(max(len(ib), 1), dtype=torch.int64, device=dev)
+        off = 0
+        with torch.no_grad():
+            for m, bname, b in fb:
+                view = self.fbuf[off:off + b.numel()].view(b.shape)
+                view.copy_(b)
+                m._buffers[bname] = view
+                off += pad4(b.numel())
+            for i, (m, bname, b) in enumerate(ib):
+                assert b.numel() == 1
+                view = self.ibuf[i:i + 1].view(b.shape)
+                view.copy_(b)
+                m._buffers[bname] = view
+
+    def attach_grads(self):
+        for n, p in self.order:
+            o, k, shp = self.offsets[n]
+            p.grad = self.grad[o:o + k].view(shp)
+
+
+class FusedSGD:
+    """torch.optim-like facade (zero_grad / step / param_groups / state_dict) over FlatModelState."""
+
+    def __init__(self, flat, lr, momentum=0.9, weight_decay=1e-4, weight_decay_norm=0.0):
+        self.flat = flat
+        self.momentum, self.weight_decay, self.weight_decay_norm = momentum, weight_decay, weight_decay_norm
+        self.mom = torch.zeros_like(flat.param)
+        self.lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=flat.param.device)
+        self.param_groups = [{"lr": float(lr), "initial_lr": float(lr)}]
+        self._steps = 0
+        self.teacher = None
+        self.ema_keep = 0.0
+        self.grad_scale = 1.0
+
+    def attach_teacher(self, teacher_flat, keep_rate):
+        """Fuse the teacher EMA (``_update_teacher_model``) into the parameter update."""
+        assert list(teacher_flat.offsets.items()) == list(self.flat.offsets.items()), \
+            "teacher and student must have identical parameter layouts"
+        self.teacher, self.ema_keep = teacher_flat, float(keep_rate)
+
+    def set_lr(self, lr):
+        self.param_groups[0]["lr"] = float(lr)
+        self.lr_dev.fill_(float(lr))
+
+    def zero_grad(self, set_to_none=False):
+        self.flat.grad.zero_()
+        for n, p in self.flat.order:
+            if p.grad is None or p.grad.data_ptr() != self.flat.grad.data_ptr() + 4 * self.flat.offsets[n][0]:
+                self.flat.attach_grads()
+                break
+
+    @torch.no_grad()
+    def step(self, ema=True):
+        f = self.flat
+        for n, p in f.order:  # a trainer that replaced .grad (set_to_none) still works
+            o, k, shp = f.offsets[n]
+            if p.grad is not None and p.grad.data_ptr() != f.grad.data_ptr() + 4 * o:
+                f.grad[o:o + k].view(shp).copy_(p.grad)
+                p.grad = f.grad[o:o + k].view(shp)
+        first = self._steps == 0
+        t = self.teacher.param if (self.teacher is not None and ema) else None
+        segs = [(0, f.n_decay, self.weight_decay), (f.n_decay, f.n_norm_end, self.weight_decay_norm)]
+        for a, b, wd in segs:
+            if b > a:
+                native.sgd_ema_(f.param[a:b], f.grad[a:b], self.mom[a:b], None if t is None else t[a:b],
+                                self.lr_dev, self.momentum, wd, self.grad_scale, self.ema_keep, first)
+        if t is not None:
+            if f.n_total > f.n_norm_end:  # frozen (never updated) parameters still take part in the EMA
+                native.ema_(t[f.n_norm_end:f.n_total], f.param[f.n_norm_end:f.n_total], self.ema_keep)
+            native.ema_(self.teacher.fbuf, f.fbuf, self.ema_keep)
+            k = self.ema_keep
+            # int64 buffers: float32 arithmetic, truncated on the copy back (SURVEY A.17 iv)
+            ti = self.teacher.ibuf
+            ti.copy_((f.ibuf.to(torch.float32) * (1 - k) + ti.to(torch.float32) * k).to(torch.int64))
+        self._steps += 1
+
+    def state_dict(self):
+        return {"momentum_buffer": self.mom, "steps": self._steps, "lr": self.param_groups[0]["lr"]}
+
+    def load_state_dict(self, sd):
+        self.mom.copy_(sd["momentum_buffer"])
+        self._steps = sd["steps"]
+        self.set_lr(sd["lr"])
+
+
+def build_optimizer(cfg, model):
+    """d2 build_optimizer for SOLVER.{BASE_LR,MOMENTUM,WEIGHT_DECAY,WEIGHT_DECAY_NORM}."""
+    frozen = ()
+    if "DOMAIN_CLASSIFIER" in cfg and not cfg.DOMAIN_CLASSIFIER.ENABLED:
+        # the domain branch never runs: the reference leaves these grads None and SGD skips them
+        frozen = ("DC_img.", "DC_ins.")
+    flat = FlatModelState(model, frozen_prefixes=frozen)
+    assert cfg.SOLVER.BIAS_LR_FACTOR == 1.0 and cfg.SOLVER.WEIGHT_DECAY_BIAS in (None, cfg.SOLVER.WEIGHT_DECAY)
+    assert not cfg.SOLVER.CLIP_GRADIENTS.ENABLED and not cfg.SOLVER.NESTEROV
+    return FusedSGD(flat, cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY,
+                    cfg.SOLVER.WEIGHT_DECAY_NORM)
+
+
+class WarmupMultiStepLR:
+    """d2 WarmupMultiStepLR; steps beyond MAX_ITER are dropped (the yamls list 360000 > 100000)."""
+
+    def __init__(self, optimizer, cfg):
+        self.optimizer = optimizer
+        self.base_lr = cfg.SOLVER.BASE_LR
+        self.milestones = sorted(s for s in cfg.SOLVER.STEPS if s <= cfg.SOLVER.MAX_ITER)
+        self.gamma = cfg.SOLVER.GAMMA
+        self.warmup_factor = cfg.SOLVER.WARMUP_FACTOR
+        self.warmup_iters = cfg.SOLVER.WARMUP_ITERS
+        assert cfg.SOLVER.WARMUP_METHOD == "linear" and cfg.SOLVER.LR_SCHEDULER_NAME == "WarmupMultiStepLR"
+        self.last_epoch = 0
+        self.optimizer.set_lr(self.get_lr(0))
+
+    def get_lr(self, it):
+        f = 1.0
+        if it < self.warmup_iters:
+            alpha = it / self.warmup_iters
+            f = self.warmup_factor * (1 - alpha) + alpha
+        return self.base_lr * f * self.gamma ** bisect.bisect_right(self.milestones, it)
+
+    def step(self):
+        self.last_epoch += 1
+        self.optimizer.set_lr(self.get_lr(self.last_epoch))
+
+    def state_dict(self):
+        return {"last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = sd["last_epoch"]
+        self.optimizer.set_lr(self.get_lr(self.last_epoch))

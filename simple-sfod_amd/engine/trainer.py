@@ -1,0 +1,385 @@
+"""Step drivers of the hot path: ``BaseTrainer`` (source-only) and
+``SourceFreeAdaptiveTeacherTrainer`` (teacher -> pseudo-labels -> student -> SGD -> EMA).
+
+Mirrors (reference file:line)
+  daod/engine/trainers/base.py:30-123,186-220     BaseTrainer.__init__/run_step/_write_metrics
+  daod/engine/trainers/base.py:270-337            AdaBN refinement (reset + <=1400 no-grad train-mode forwards)
+  daod/engine/trainers/source_free_adaptive_teacher.py
+      :39-94    __init__  (student + teacher from the same weights, DDP around the student)
+      :150-183  threshold_bbox      :256-280 process_pseudo_label
+      :335-581  run_step            :583-603 _update_teacher_model (EMA, keep rate 0.9996)
+  train_net_mt.py:45-87                           trainer dispatch on cfg.TRAINER
+
+MI355X-first differences (documented in DESIGN.md):
+  * no host synchronisation inside a step: pseudo-labels stay in fixed-capacity device arrays,
+    metrics are accumulated on the device and read every ``WRITER_PERIOD`` iterations
+    (the reference syncs on every ``.item()`` and gathers a pickled dict over gloo each step);
+  * DDP is replaced by one RCCL all-reduce of the flat gradient buffer (no per-parameter hooks,
+    parameters without gradient in a step are zero-filled identically on all ranks);
+  * the EMA is fused into the SGD kernel; ``SFOD.EMA.ENABLED`` exposes quirk q1 (the dispatched
+    reference trainer has the call commented out, its ``_single`` twin has it on);
+  * zero-weighted dead branches (2nd ROI pass, BPC, domain classifier) are elided
+    (``SFOD.ELIDE_DEAD_BRANCHES``).
+"""
+import json
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+from ..data.synthetic import TwoCropLoader
+from ..modeling import build_model
+from ..modeling.batched import BatchedGT
+from ..structures import Boxes, Instances
+from .solver import FlatModelState, WarmupMultiStepLR, build_optimizer
+
+WRITER_PERIOD = 20  # hooks.PeriodicWriter(period=20), source_free_adaptive_teacher.py:679
+
+
+def get_world_size():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class EventStorage:
+    """Scalars are kept as device tensors until ``flush`` (one host sync per writer period)."""
+
+    def __init__(self, start_iter=0):
+        self.iter = start_iter
+        self._pending = {}
+        self.history = []
+
+    def put_scalar(self, name, value):
+        self._pending[name] = value
+
+    def put_scalars(self, **kw):
+        self._pending.update(kw)
+
+    def flush(self):
+        if not self._pending:
+            return {}
+        names = list(self._pending)
+        vals = [v.detach().float().reshape(()) if isinstance(v, torch.Tensor) else None for v in self._pending.values()]
+        dev_vals = [v for v in vals if v is not None]
+        host = torch.stack(dev_vals).cpu().tolist() if dev_vals else []
+        out, j = {"iteration": self.iter}, 0
+        for n, v in zip(names, vals):
+            if v is None:
+                out[n] = float(self._pending[n])
+            else:
+                out[n] = host[j]
+                j += 1
+        self._pending = {}
+        self.history.append(out)
+        return out
+
+
+class BaseTrainer:
+    """Source-only training (``TRAINER: "base"``)."""
+
+    def __init__(self, cfg, data_loader=None):
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.model = self.build_model(cfg)
+        self.optimizer = self.build_optimizer(cfg, self.model)
+        self.scheduler = WarmupMultiStepLR(self.optimizer, cfg)
+        self.data_loader = data_loader or self.build_train_loader(cfg)
+        self._data_loader_iter = iter(self.data_loader)
+        self.start_iter, self.max_iter = 0, cfg.SOLVER.MAX_ITER
+        self.iter = 0
+        self.storage = EventStorage(0)
+        self.model.train()
+
+    @classmethod
+    def build_model(cls, cfg):
+        return build_model(cfg)
+
+    @classmethod
+    def build_optimizer(cls, cfg, model):
+        return build_optimizer(cfg, model)
+
+    def build_train_loader(self, cfg):
+        return TwoCropLoader(cfg, self.device, get_rank(), get_world_size(), labeled=True)
+
+    # ---- step ----------------------------------------------------------------------------------------
+    def run_step(self):
+        assert self.model.training, "[BaseTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        data = next(self._data_loader_iter)
+        data_time = time.perf_counter() - start
+        record_dict = self.model(data)
+        loss_dict = {k: v for k, v in record_dict.items() if k[:4] == "loss" and k[-3:] != "val"}
+        losses = sum(loss_dict.values())
+        metrics_dict = dict(record_dict)
+        metrics_dict["data_time"] = data_time
+        self._write_metrics(metrics_dict)
+        self.optimizer.zero_grad()
+        losses.backward()
+        self._reduce_gradients()
+        self.optimizer.step()
+
+    def _reduce_gradients(self):
+        """The one collective of the step: sum the flat gradient buffer over ranks (RCCL);
+        the 1/world averaging (DDP semantics) is folded into the fused SGD kernel."""
+        w = get_world_size()
+        if w > 1:
+            dist.all_reduce(self.optimizer.flat.grad)
+            self.optimizer.grad_scale = 1.0 / w
+
+    def _write_metrics(self, metrics_dict):
+        loss_keys = [k for k in metrics_dict if k[:4] == "loss"]
+        if loss_keys:
+            self.storage.put_scalar("total_loss", sum(metrics_dict[k].detach() for k in loss_keys))
+        self.storage.put_scalars(**{k: (v.detach() if isinstance(v, torch.Tensor) else v)
+                                    for k, v in metrics_dict.items()})
+
+    def after_step(self):
+        self.scheduler.step()
+        self.storage.iter = self.iter + 1
+        if (self.iter + 1) % WRITER_PERIOD == 0 or self.iter + 1 == self.max_iter:
+            self._flush_metrics()
+        p = self.cfg.SOLVER.CHECKPOINT_PERIOD
+        if p > 0 and (self.iter + 1) % p == 0 and get_rank() == 0 and self.cfg.OUTPUT_DIR:
+            self.save_checkpoint("model_{:07d}".format(self.iter))
+
+    def _flush_metrics(self):
+        rpn = getattr(self.model, "proposal_generator", None)
+        if rpn is not None:
+            rpn.check_finite()
+        rec = self.storage.flush()
+        rec["lr"] = self.optimizer.param_groups[0]["lr"]
+        if get_rank() == 0 and self.cfg.OUTPUT_DIR:
+            os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
+            with open(os.path.join(self.cfg.OUTPUT_DIR, "metrics.json"), "a") as f:
+                f.write(json.dumps(rec) + "\n")
+        return rec
+
+    def train(self):
+        for self.iter in range(self.start_iter, self.max_iter):
+            self.run_step()
+            self.after_step()
+
+    def state_dict_for_checkpoint(self):
+        return {"model": self.model.state_dict(), "iteration": self.iter}
+
+    def save_checkpoint(self, name):
+        os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
+        torch.save(self.state_dict_for_checkpoint(), os.path.join(self.cfg.OUTPUT_DIR, name + ".pth"))
+
+
+def threshold_bbox(proposal_bbox_inst, thres=0.7, proposal_type="roih"):
+    """Instances-level API twin of source_free_adaptive_teacher.py:150-183 (strict '>')."""
+    new = Instances(proposal_bbox_inst.image_size)
+    if proposal_type == "rpn":
+        valid = proposal_bbox_inst.objectness_logits > thres
+        new.gt_boxes = Boxes(proposal_bbox_inst.proposal_boxes.tensor[valid, :])
+        new.objectness_logits = proposal_bbox_inst.objectness_logits[valid]
+    elif proposal_type == "roih":
+        valid = proposal_bbox_inst.scores > thres
+        new.gt_boxes = Boxes(proposal_bbox_inst.pred_boxes.tensor[valid, :])
+        new.gt_classes = proposal_bbox_inst.pred_classes[valid]
+        new.scores = proposal_bbox_inst.scores[valid]
+    return new
+
+
+class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
+    def __init__(self, cfg, data_loader=None):
+        self.cfg = cfg
+        self.device = torch.device(cfg.MODEL.DEVICE)
+        self.data_loader = data_loader or self.build_train_loader(cfg)
+        self._data_loader_iter = iter(self.data_loader)
+        # student, then teacher: both start from the same weights (:51-64).  With no checkpoint
+        # to load, the teacher is initialised as a copy of the student.
+        self.model = self.build_model(cfg)
+        self.optimizer = self.build_optimizer(cfg, self.model)
+        self.model_teacher = self.build_model(cfg)
+        self.teacher_flat = FlatModelState(self.model_teacher, frozen_prefixes=self._frozen(cfg), with_grad=False)
+        self._copy_main_model()
+        self.ema_enabled = bool(cfg.SFOD.EMA.ENABLED)
+        if self.ema_enabled:
+            self.optimizer.attach_teacher(self.teacher_flat, cfg.SFOD.EMA.KEEP_RATE)
+        for p in self.model_teacher.parameters():
+            p.requires_grad_(False)
+        self.scheduler = WarmupMultiStepLR(self.optimizer, cfg)
+        self.start_iter, self.max_iter = 0, cfg.SOLVER.MAX_ITER
+        self.iter = 0
+        self.storage = EventStorage(0)
+        self.model.train()
+        self.model_teacher.train()  # quirk q2: the teacher is never put in eval mode (:385-390)
+        self.elide = bool(cfg.SFOD.ELIDE_DEAD_BRANCHES)
+
+    @staticmethod
+    def _frozen(cfg):
+        return () if cfg.DOMAIN_CLASSIFIER.ENABLED else ("DC_img.", "DC_ins.")
+
+    def build_train_loader(self, cfg):
+        return TwoCropLoader(cfg, self.device, get_rank(), get_world_size(), labeled=False)
+
+    @torch.no_grad()
+    def _copy_main_model(self):
+        """:605-617 -- teacher <- student (all parameters and buffers)."""
+        s = self.optimizer.flat
+        self.teacher_flat.param.copy_(s.param)
+        self.teacher_flat.fbuf.copy_(s.fbuf)
+        self.teacher_flat.ibuf.copy_(s.ibuf)
+
+    # ---- pseudo-labelling -------------------------------------------------------------------------
+    def process_pseudo_label(self, proposals, cur_threshold, proposal_type, pseudo_label_method=""):
+        """Instances-level API twin of :256-280 (host side; the step itself uses the fused kernel)."""
+        if pseudo_label_method != "thresholding":
+            raise ValueError("Unkown pseudo label boxes methods")
+        out = [threshold_bbox(p, thres=cur_threshold, proposal_type=proposal_type) for p in proposals]
+        return out, sum(len(p) for p in out) / max(len(out), 1)
+
+    @staticmethod
+    def remove_label(label_data):
+        for d in label_data:
+            d.pop("instances", None)
+        return label_data
+
+    @staticmethod
+    def add_label(unlabeled_data, label):
+        for i, d in enumerate(unlabeled_data):
+            d["instances"] = label.view(i) if isinstance(label, BatchedGT) else label[i]
+        return unlabeled_data
+
+    # ---- step (:335-581) ----------------------------------------------------------------------------
+    def run_step(self):
+        cfg = self.cfg
+        assert self.model.training, "[AdaptiveTeacherTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
+        if not cfg.WEAK_STRONG_AUGMENT:
+            unlabel_data_q = [dict(d) for d in unlabel_data_k]
+        data_time = time.perf_counter() - start
+        record_dict = {}
+        # 0. remove the labels of the target data (source-free)
+        unlabel_data_q = self.remove_label(unlabel_data_q)
+        unlabel_data_k = self.remove_label(unlabel_data_k)
+        # 1. pseudo-labels from the (train-mode) teacher
+        with torch.no_grad():
+            _, proposals_rpn_k, proposals_roih_k = self.model_teacher(unlabel_data_k, branch="unsup_data_weak",
+                                                                      batched=True)
+        d = proposals_roih_k.d
+        B = d["det_count"].shape[0]
+        live = torch.arange(d["det_scores"].shape[1], device=self.device)[None, :] < d["det_count"][:, None]
+        per_image = (d["det_scores"] * live).sum(1) / d["det_count"].clamp(min=1)
+        self.storage.put_scalar("roi_head/mean_confidence", per_image.mean())
+        # 2. thresholding (fused into the teacher post-processing kernel: score > BBOX_THRESHOLD)
+        cur_threshold = cfg.SEMISUPNET.BBOX_THRESHOLD
+        rpn_live = torch.arange(proposals_rpn_k.logits.shape[1], device=self.device)[None, :] < proposals_rpn_k.count[:, None]
+        self.storage.put_scalar("rpn/num_pseudo_proposals",
+                                ((proposals_rpn_k.logits > cur_threshold) & rpn_live).sum().float() / B)
+        pseudo = proposals_roih_k.pseudo_gt()
+        self.storage.put_scalar("roi_head/num_pseudo_proposals", pseudo.count.float().mean())
+        # 3. attach the pseudo-labels
+        unlabel_data_q = self.add_label(unlabel_data_q, pseudo)
+        unlabel_data_k = self.add_label(unlabel_data_k, pseudo)
+        # 5. student on the pseudo-labelled target data
+        record_all_unlabel_data, _, _, _ = self.model(unlabel_data_q, branch="supervised_target", batched=True)
+        for key, v in record_all_unlabel_data.items():
+            record_dict[key + "_pseudo"] = v
+        # 6. domain-classifier branch (:527-537): zero-weighted unless DOMAIN_CLASSIFIER.IMAGE/INSTANCE
+        dc_live = cfg.DOMAIN_CLASSIFIER.ENABLED and (cfg.DOMAIN_CLASSIFIER.IMAGE or cfg.DOMAIN_CLASSIFIER.INSTANCE)
+        if cfg.DOMAIN_CLASSIFIER.ENABLED and (dc_live or not self.elide):
+            for i in range(len(unlabel_data_q)):
+                for k, v in unlabel_data_q[i].items():
+                    unlabel_data_k[i][k + "_unlabeled"] = v
+            record_all_domain_data, _, _ = self.model(unlabel_data_k, branch="domain_classifier")
+            record_dict.update(record_all_domain_data)
+        # loss weighting (:540-564)
+        loss_dict = {}
+        for key in record_dict.keys():
+            if key.startswith("loss") and key[-3:] != "val":
+                if key == "loss_rpn_loc_pseudo" or key == "loss_box_reg_pseudo":
+                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
+                elif key == "loss_bpc_pseudo":
+                    loss_dict[key] = record_dict[key] * 0
+                elif key[-6:] == "pseudo":
+                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
+                elif (key == "loss_DC_img_s" or key == "loss_DC_img_t") and cfg.DOMAIN_CLASSIFIER.IMAGE:
+                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.DIS_LOSS_WEIGHT
+                elif (key == "loss_DC_ins_s" or key == "loss_DC_ins_t") and cfg.DOMAIN_CLASSIFIER.INSTANCE:
+                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.DIS_LOSS_WEIGHT
+                else:
+                    loss_dict[key] = record_dict[key] * 0
+        self.storage.put_scalar("calibration/bpc_loss", loss_dict["loss_bpc_pseudo"])
+        losses = sum(loss_dict.values())
+        metrics_dict = dict(loss_dict)
+        metrics_dict["data_time"] = data_time
+        self._write_metrics(metrics_dict)
+        self.optimizer.zero_grad()
+        losses.backward()
+        self._reduce_gradients()
+        self.optimizer.step(ema=self.ema_enabled)  # EMA fused: _update_teacher_model (:583-603)
+
+    def _flush_metrics(self):
+        self.model_teacher.proposal_generator.check_finite()
+        return super()._flush_metrics()
+
+    def state_dict_for_checkpoint(self):
+        """detection_ts_checkpointer.py / ts_ensemble.py: one dict, modelTeacher.* + modelStudent.*"""
+        sd = {}
+        for k, v in self.model_teacher.state_dict().items():
+            sd["modelTeacher." + k] = v
+        for k, v in self.model.state_dict().items():
+            sd["modelStudent." + k] = v
+        return {"model": sd, "iteration": self.iter, "optimizer": self.optimizer.state_dict(),
+                "scheduler": self.scheduler.state_dict()}
+
+
+class SourceFreeAdaptiveTeacherSingleTrainer(SourceFreeAdaptiveTeacherTrainer):
+    """``source_free_adaptive_teacher_single.py``: the student labels itself (:390), EMA on (:581)."""
+
+    def run_step(self):
+        teacher = self.model_teacher
+        self.model_teacher = self.model
+        try:
+            super().run_step()
+        finally:
+            self.model_teacher = teacher
+
+
+# ---- AdaBN refinement (base.py:270-337) -----------------------------------------------------------
+def reset_bn_stats(model):
+    """reset every BatchNorm2d running_mean / running_var to 0 / 1 (:318-328)."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.zero_()
+            m.running_var.fill_(1.0)
+
+
+@torch.no_grad()
+def adabn_refinement(cfg, model, data_loader, max_iters=1400):
+    """forward-only passes in train mode under no_grad: BN momentum-0.1 running-stat refresh."""
+    reset_bn_stats(model)
+    model.train()
+    it = iter(data_loader)
+    for i in range(max_iters + 1):
+        try:
+            data = next(it)
+        except StopIteration:
+            break
+        if isinstance(data, tuple):
+            data = data[1]
+        images = model.preprocess_image(data)
+        model._features(images)
+    return model
+
+
+TRAINERS = {
+    "base": BaseTrainer,
+    "source_free_adaptive_teacher": SourceFreeAdaptiveTeacherTrainer,
+    "source_free_adaptive_teacher_single": SourceFreeAdaptiveTeacherSingleTrainer,
+}
+
+
+def get_trainer_class(cfg):
+    """train_net_mt.py:48-69."""
+    if cfg.TRAINER not in TRAINERS:
+        raise ValueError(f"Trainer {cfg.TRAINER} not found.")
+    return TRAINERS[cfg.TRAINER]

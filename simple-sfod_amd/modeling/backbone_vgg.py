@@ -1,0 +1,215 @@
+"""VGG16(-BN) backbone on the HIP kernels, behind the reference's ``build_vgg_backbone`` name.
+
+Mirrors ``/root/reference/daod/modeling/meta_arch/vgg.py``: layers ``:10-24``, stage split
+``:70-74`` (``vgg0..vgg4``, strides 2..32 -- the 5th max-pool is part of ``vgg4``), init
+``:102-113``, builder ``:116-118``.  The torch.nn containers exist only to own the parameters
+under the reference's state-dict keys (``backbone.vgg{s}.{i}.*``) and to reproduce its
+initialisation draw for draw; none of their forward methods is ever called.  Compute:
+
+  conv3x3+bias (MFMA implicit GEMM, BN partial statistics in the epilogue)
+  -> BN statistics finalize (+ running-stat refresh = the AdaBN update, also under no_grad)
+  -> BN apply + ReLU (+ 2x2 max-pool) in one pass
+
+Activations are NHWC internally; the NCHW tensors this module accepts/returns are zero-copy
+channels-last views, so the Detectron2 ``Backbone`` surface is kept without layout traffic.
+"""
+import torch
+import torch.nn as nn
+
+from .. import native
+from ..registry import BACKBONE_REGISTRY
+from ..structures import ShapeSpec
+
+VGG16 = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
+STAGE_SLICES = [(0, 7), (7, 14), (14, 24), (24, 34), (34, 44)]
+
+
+def make_layers(cfg_list, batch_norm=False):
+    layers = []
+    in_channels = 3
+    for v in cfg_list:
+        if v == "M":
+            layers += [nn.MaxPool2d(kernel_size=2, stride=2)]
+        else:
+            conv2d = nn.Conv2d(in_channels, v, kernel_size=3, padding=1)
+            if batch_norm:
+                layers += [conv2d, nn.BatchNorm2d(v), nn.ReLU(inplace=True)]
+            else:
+                layers += [conv2d, nn.ReLU(inplace=True)]
+            in_channels = v
+    return nn.Sequential(*layers)
+
+
+def nhwc_from_nchw_view(x, dtype, cpad=None):
+    """NCHW-shaped tensor (any strides) -> contiguous NHWC tensor of `dtype` (channel-padded)."""
+    n, c, h, w = x.shape
+    p = x.permute(0, 2, 3, 1)
+    if cpad is not None and cpad != c:
+        out = torch.zeros(n, h, w, cpad, dtype=dtype, device=x.device)
+        out[..., :c] = p
+        return out
+    return p.to(dtype).contiguous()
+
+
+class _VGGFn(torch.autograd.Function):
+    """The whole 13-layer trunk as one autograd node (hand-written backward)."""
+
+    @staticmethod
+    def forward(ctx, module, save, x_nhwc, *params):
+        saved, outs = module._forward_impl(x_nhwc, save=save)
+        ctx.module = module
+        ctx.saved = saved
+        ctx.need_dx = False
+        return tuple(o.permute(0, 3, 1, 2) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        module = ctx.module
+        pgrads = module._backward_impl(ctx.saved, grads)
+        ctx.saved = None
+        return (None, None, None) + tuple(pgrads)
+
+
+class vgg_backbone(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        if not cfg.VGG.BN:
+            raise NotImplementedError(
+                "VGG.BN=False is not on the hot path (the reference mis-slices its stages, quirk q10)")
+        self.vgg = make_layers(VGG16, batch_norm=True)
+        self._initialize_weights()
+        chans, strides = [64, 128, 256, 512, 512], [2, 4, 8, 16, 32]
+        mods = list(self.vgg._modules.values())
+        self.stages = [nn.Sequential(*mods[a:b]) for a, b in STAGE_SLICES]
+        self._out_feature_channels, self._out_feature_strides, self._stage_names = {}, {}, []
+        for i, stage in enumerate(self.stages):
+            name = "vgg{}".format(i)
+            self.add_module(name, stage)
+            self._stage_names.append(name)
+            self._out_feature_channels[name] = chans[i]
+            self._out_feature_strides[name] = strides[i]
+        self._out_features = self._stage_names
+        del self.vgg
+        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self.bn_momentum, self.bn_eps = 0.1, 1e-5
+        # execution plan: (conv, bn, pool_after, stage_end)
+        self._plan = []
+        for s, stage in enumerate(self.stages):
+            ms = list(stage)
+            i = 0
+            while i < len(ms):
+                if isinstance(ms[i], nn.Conv2d):
+                    pool = i + 3 < len(ms) and isinstance(ms[i + 3], nn.MaxPool2d)
+                    self._plan.append([ms[i], ms[i + 1], pool, False])
+                    i += 4 if pool else 3
+                else:
+                    i += 1
+            self._plan[-1][3] = True
+
+    # ---- Detectron2 Backbone surface ------------------------------------------------------------
+    @property
+    def size_divisibility(self):
+        return 0
+
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n])
+                for n in self._out_features}
+
+    def _initialize_weights(self):
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.Linear):
+                nn.init.normal_(m.weight, 0, 0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def _param_list(self):
+        ps = []
+        for conv, bn, _, _ in self._plan:
+            ps += [conv.weight, conv.bias, bn.weight, bn.bias]
+        return ps
+
+    def forward(self, x):
+        """x: [N,3,H,W] normalised image batch (NCHW logical) or an already NHWC-packed tensor
+        tagged by ``forward_nhwc``.  Returns {"vgg0".."vgg4"} as NCHW (channels-last) views."""
+        dt = native.F32 if self.compute_dtype == torch.float32 else native.BF16
+        xn = nhwc_from_nchw_view(x, self.compute_dtype, native.chunk_elems(dt))
+        return self.forward_nhwc(xn)
+
+    def forward_nhwc(self, x_nhwc):
+        params = self._param_list()
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs = _VGGFn.apply(self, save, x_nhwc, *params)
+        return dict(zip(self._stage_names, outs))
+
+    # ---- engine -------------------------------------------------------------------------------------
+    def _forward_impl(self, x, save=True):
+        dt = native.dt_of(x)
+        training = self.training
+        saved, outs = [], []
+        for conv, bn, pool, stage_end in self._plan:
+            cin_pad = x.shape[-1]
+            cout = conv.out_channels
+            wp = native.pack_conv_weight(conv.weight.detach(), cin_pad, dt)
+            B, H, W, _ = x.shape
+            if training:
+                y, stats = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3, want_stats=True)
+                mean, invstd = native.bn_finalize(stats, B * H * W, cout, bn.running_mean, bn.running_var,
+                                                  self.bn_momentum, self.bn_eps, True)
+                bn.num_batches_tracked.add_(1)
+            else:
+                y = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3)
+                mean = bn.running_mean
+                invstd = torch.rsqrt(bn.running_var + self.bn_eps)
+            z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool)
+            if save:
+                saved.append((x, y, mean, invstd))
+            x = z
+            if stage_end:
+                outs.append(z)
+        return saved, outs
+
+    def _backward_impl(self, saved, out_grads):
+        """out_grads: grads of the 5 stage outputs (NCHW views or None) -> flat list of param grads."""
+        dtype = self.compute_dtype
+        pgrads = [None] * (4 * len(self._plan))
+        stage_of = []
+        s = 0
+        for i, (_, _, _, stage_end) in enumerate(self._plan):
+            stage_of.append(s if stage_end else None)
+            if stage_end:
+                s += 1
+        dz = None
+        for li in range(len(self._plan) - 1, -1, -1):
+            conv, bn, pool, stage_end = self._plan[li]
+            x, y, mean, invstd = saved[li]
+            if stage_end and out_grads[stage_of[li]] is not None:
+                g = out_grads[stage_of[li]].permute(0, 2, 3, 1).to(dtype).contiguous()
+                dz = g if dz is None else native.add_(dz, g)
+            if dz is None:
+                continue
+            dy, dgamma, dbeta = native.bn_relu_pool_bwd(dz, y, mean, invstd, bn.weight.detach(),
+                                                        bn.bias.detach(), pool)
+            cout, cin = conv.out_channels, conv.in_channels
+            dwp = native.conv_wgrad(x, dy, cout, 3)
+            dw = torch.empty_like(conv.weight)
+            native.unpack_conv_wgrad(dwp, dw)
+            # a conv bias followed by train-mode BN has an analytically zero gradient
+            # (sum_rows dy == 0); the reference's autograd produces rounding noise around 0.
+            pgrads[4 * li:4 * li + 4] = [dw, torch.zeros_like(conv.bias), dgamma, dbeta]
+            if li > 0:
+                dt = native.dt_of(dy)
+                wr = native.pack_conv_weight(conv.weight.detach(), cout, dt, rot180=True)
+                dz = native.conv_fwd(dy, wr, None, cin, 3)
+            del saved[li]
+        return pgrads
+
+
+@BACKBONE_REGISTRY.register()
+def build_vgg_backbone(cfg, _=None):
+    return vgg_backbone(cfg)

@@ -1,0 +1,169 @@
+"""Meta-architectures: ``GeneralizedRCNN`` (source-only training, configs #1/#2) and
+``SourceFreeAdaptiveTeacherGeneralizedRCNN`` (teacher / student of the adaptation step).
+
+Mirrors ``/root/reference/daod/modeling/meta_arch/source_free_adaptive_teacher_rcnn.py``:
+``__init__`` ``:28-71`` (DC_img / DC_ins always constructed), ``from_config`` ``:75-90``,
+branch-dispatched ``forward`` ``:106-339``:
+  * ``unsup_data_weak``   ``:314-339`` -> ``({}, proposals_rpn, proposals_roih)``
+  * ``supervised_target`` ``:259-312`` -> ``(losses, proposals_roih, [], [])``
+  * ``supervised``        ``:227-257`` -> ``(losses, [], [])``
+  * ``domain_classifier`` ``:137-210`` (zero-weighted in the hot yaml; see SFOD.ELIDE_DEAD_BRANCHES)
+and Detectron2's GeneralizedRCNN (preprocess_image: normalise + pad, A.1).
+
+Each sub-module is one autograd node with a hand-written backward (backbone, RPN losses, ROI
+losses), so ``sum(losses.values()).backward()`` in a trainer works exactly as in the reference.
+"""
+import torch
+import torch.nn as nn
+
+from .. import native
+from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY
+from ..structures import Boxes, ImageList, Instances
+from .batched import BatchedGT, gather_gt
+from .dann import DAInsHead, FCDiscriminator_img
+
+
+def build_model(cfg):
+    """d2 build_model: META_ARCH_REGISTRY.get(name)(cfg).to(cfg.MODEL.DEVICE)."""
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    if not str(cfg.MODEL.DEVICE).startswith("cuda"):
+        raise RuntimeError(
+            "MODEL.DEVICE must be a GPU: the hot path runs on HIP kernels only (no CPU fallback). "
+            "The CPU restatement lives in oracle/ and is test infrastructure.")
+    return model.to(torch.device(cfg.MODEL.DEVICE))
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNN(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.cfg = cfg
+        self.backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, None)
+        shape = self.backbone.output_shape()
+        self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, shape)
+        self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, shape)
+        self.input_format = cfg.INPUT.FORMAT
+        self.vis_period = cfg.VIS_PERIOD
+        self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
+        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self._mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
+        self._std = [float(v) for v in cfg.MODEL.PIXEL_STD]
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs, key="image"):
+        """uint8 CHW BGR images -> ImageList of the normalised, zero-padded batch.  The tensor is
+        an NCHW view of NHWC memory (channels padded to one 16-byte chunk)."""
+        imgs = [x[key].to(self.device, non_blocking=True) for x in batched_inputs]
+        for im in imgs:
+            if im.dtype != torch.uint8:
+                raise TypeError("images must be uint8 CHW tensors (the mapper's output format)")
+        hm = max(int(im.shape[1]) for im in imgs)
+        wm = max(int(im.shape[2]) for im in imgs)
+        dt = native.F32 if self.compute_dtype == torch.float32 else native.BF16
+        x, _ = native.preprocess(imgs, hm, wm, native.chunk_elems(dt), self._mean, self._std, dt)
+        sizes = [(int(im.shape[1]), int(im.shape[2])) for im in imgs]
+        return ImageList(x.permute(0, 3, 1, 2), sizes)
+
+    def _features(self, images):
+        return self.backbone.forward_nhwc(images.tensor.permute(0, 2, 3, 1))
+
+    def forward(self, batched_inputs):
+        if not self.training:
+            return self.inference(batched_inputs)
+        images = self.preprocess_image(batched_inputs)
+        gt = gather_gt(batched_inputs, self.device)
+        features = self._features(images)
+        proposals, proposal_losses = self.proposal_generator(images, features, gt, as_instances=False)
+        _, detector_losses, _, _ = self.roi_heads(images, features, proposals, gt)
+        losses = {}
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        return losses
+
+    @torch.no_grad()
+    def inference(self, batched_inputs, do_postprocess=True):
+        assert not self.training
+        images = self.preprocess_image(batched_inputs)
+        features = self._features(images)
+        proposals, _ = self.proposal_generator(images, features, None, as_instances=False)
+        results, _ = self.roi_heads(images, features, proposals, None)
+        if not do_postprocess:
+            return results
+        out = []
+        for res, inp, size in zip(results, batched_inputs, images.image_sizes):
+            h, w = inp.get("height", size[0]), inp.get("width", size[1])
+            out.append({"instances": detector_postprocess(res, h, w)})
+        return out
+
+
+def detector_postprocess(results, output_height, output_width):
+    """d2 detector_postprocess for boxes: rescale to the requested resolution, clip, drop empty."""
+    sx, sy = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((output_height, output_width), **results.get_fields())
+    boxes = out.pred_boxes.clone()
+    boxes.tensor = boxes.tensor * torch.tensor([sx, sy, sx, sy], device=boxes.tensor.device)
+    boxes.clip(out.image_size)
+    out.pred_boxes = boxes
+    return out[boxes.nonempty()]
+
+
+@META_ARCH_REGISTRY.register()
+class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        self.dis_type = cfg.SEMISUPNET.DIS_TYPE
+        self.DC_img = FCDiscriminator_img(self.backbone._out_feature_channels[self.dis_type],
+                                          compute_dtype=self.compute_dtype)
+        self.ins_dc = cfg.SEMISUPNET.INS_DC
+        if self.ins_dc:
+            self.DC_ins = DAInsHead(self.roi_heads.box_predictor.cls_score.in_features, [self.dis_type],
+                                    compute_dtype=self.compute_dtype)
+        self.elide = cfg.SFOD.ELIDE_DEAD_BRANCHES
+
+    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False, batched=False):
+        """``batched=True`` returns the fixed-capacity device containers instead of
+        ``list[Instances]`` (no host synchronisation); everything else follows the reference."""
+        if (not self.training) and (not val_mode):
+            return self.inference(batched_inputs)
+        if branch == "domain_classifier":
+            raise NotImplementedError(
+                "branch='domain_classifier' (rcnn.py:137-210) is zero-weighted in the named configs "
+                "(DOMAIN_CLASSIFIER.IMAGE/INSTANCE False) and is not built yet; trainers skip it when "
+                "SFOD.ELIDE_DEAD_BRANCHES is on")
+        images = self.preprocess_image(batched_inputs)
+        gt = gather_gt(batched_inputs, self.device)
+        features = self._features(images)
+
+        if branch in ("supervised", "supervised_target"):
+            proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt, as_instances=False)
+            _, detector_losses, _, _ = self.roi_heads(images, features, proposals_rpn, compute_loss=True,
+                                                      targets=gt, branch=branch)
+            losses = {}
+            losses.update(detector_losses)
+            losses.update(proposal_losses)
+            if branch == "supervised":
+                # loss_DC_img_s * 0.001 (rcnn.py:256) belongs to the with-source trainer (out of scope)
+                return losses, [], []
+            proposals_roih = []
+            if not self.elide:
+                with torch.no_grad():
+                    proposals_roih, _ = self.roi_heads(images, features, proposals_rpn, targets=None,
+                                                       compute_loss=False, branch=branch, as_instances=not batched)
+            # BPC (bpc_loss.py) is weighted by 0 and only logged (trainer :549-550,566): logging-only
+            # "next" row; the key is kept because the reference trainer indexes it unconditionally.
+            losses["loss_bpc"] = torch.zeros((), device=self.device)
+            return losses, proposals_roih, [], []
+
+        if branch == "unsup_data_weak":
+            proposals_rpn, _ = self.proposal_generator(images, features, None, compute_loss=False,
+                                                       as_instances=False)
+            proposals_roih, _ = self.roi_heads(images, features, proposals_rpn, targets=None, compute_loss=False,
+                                               branch=branch, as_instances=False)
+            if batched:
+                return {}, proposals_rpn, proposals_roih
+            return {}, proposals_rpn.to_instances(), proposals_roih.to_instances()
+        raise ValueError(f"unknown branch {branch}")

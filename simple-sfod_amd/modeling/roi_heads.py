@@ -1,0 +1,286 @@
+"""ROI heads on the HIP kernels behind ``StandardROIHeads`` /
+``SourceFreeAdaptiveTeacherStandardROIHeads`` / ``AdaptiveTeacherStandardROIHeads``.
+
+Mirrors ``/root/reference/daod/modeling/roi_heads/source_free_adaptive_teacher_roi_heads.py``:
+``_init_box_head`` ``:27-66``, ``forward`` ``:68-106`` (training+compute_loss -> label & sample,
+4-tuple; otherwise inference, 2-tuple), ``_forward_box`` ``:108-163``,
+``label_and_sample_proposals`` ``:165-215``; and the Detectron2 pieces it inherits (SURVEY.md
+A.11-A.13): add_ground_truth_to_proposals, Matcher [0.5], subsample 512 @ 0.25, ROIAlignV2 7x7,
+FastRCNNConvFCHead (2 FC), FastRCNNOutputLayers losses / inference.
+
+State-dict keys: ``roi_heads.box_head.fc{1,2}.*``, ``roi_heads.box_predictor.{cls_score,bbox_pred}.*``.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from .. import native
+from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
+from ..structures import ShapeSpec
+from .batched import BatchedDetections, BatchedGT, BatchedProposals
+
+
+class ROIPooler(nn.Module):
+    """Single-level ROIAlignV2 pooler (aligned=True).  Attributes read from outside
+    (source_free_adaptive_teacher_rcnn.py:190-194) are kept."""
+
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type):
+        super().__init__()
+        assert pooler_type == "ROIAlignV2" and sampling_ratio == 0 and len(scales) == 1
+        self.output_size = (output_size, output_size)
+        self.scale = scales[0]
+        min_level = -(math.log2(scales[0]))
+        self.min_level = self.max_level = int(min_level)
+        self.canonical_level = 4
+        self.canonical_box_size = 224
+
+
+@ROI_BOX_HEAD_REGISTRY.register()
+class FastRCNNConvFCHead(nn.Module):
+    """NUM_CONV 0 + NUM_FC fully connected layers with ReLU (c2_xavier_fill)."""
+
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        assert cfg.MODEL.ROI_BOX_HEAD.NUM_CONV == 0, "conv layers in the box head are not on the hot path"
+        num_fc, fc_dim = cfg.MODEL.ROI_BOX_HEAD.NUM_FC, cfg.MODEL.ROI_BOX_HEAD.FC_DIM
+        assert num_fc == 2, "the named configs use NUM_FC 2"
+        self._in = input_shape.channels * input_shape.height * input_shape.width
+        self.fcs = []
+        d = self._in
+        for k in range(num_fc):
+            fc = nn.Linear(d, fc_dim)
+            nn.init.kaiming_uniform_(fc.weight, a=1)
+            nn.init.constant_(fc.bias, 0)
+            self.add_module("fc{}".format(k + 1), fc)
+            self.fcs.append(fc)
+            d = fc_dim
+        self._out = d
+
+    @property
+    def output_shape(self):
+        return ShapeSpec(channels=self._out)
+
+
+class FastRCNNOutputLayers(nn.Module):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        d = input_shape.channels
+        self.num_classes = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        assert not cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG
+        self.cls_score = nn.Linear(d, self.num_classes + 1)
+        self.bbox_pred = nn.Linear(d, self.num_classes * 4)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in [self.cls_score, self.bbox_pred]:
+            nn.init.constant_(l.bias, 0)
+        assert tuple(cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS) == (10.0, 10.0, 5.0, 5.0)
+        assert cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA == 0.0
+        self.test_score_thresh = cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST
+        self.test_nms_thresh = cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST
+        self.test_topk_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
+
+
+class SourceFreeFastRCNNOutputLayers(FastRCNNOutputLayers):
+    """source_free_fast_rcnn.py:14 -- ``convert_bbox_scores`` only feeds the zero-weighted BPC loss
+    (quirk q6) and is a "next" row; the layers / losses / inference are the parent's."""
+
+
+class _ROILossFn(torch.autograd.Function):
+    """features (+ sampled rois) -> (loss_cls, loss_box_reg) with a hand-written backward."""
+
+    @staticmethod
+    def forward(ctx, heads, feat_nchw, samples, *params):
+        st = heads._box_forward(feat_nchw, samples["rois"])
+        loss, _ = native.frcnn_loss(st["pred"], heads.num_classes, samples["rois"], samples["gt_cls"],
+                                    samples["gt_box"], samples["n_valid"])
+        ctx.heads, ctx.st, ctx.samples = heads, st, samples
+        ctx.feat_shape = feat_nchw.shape
+        return loss[0].clone(), loss[1].clone()
+
+    @staticmethod
+    def backward(ctx, g_cls, g_box):
+        heads, st, samples = ctx.heads, ctx.st, ctx.samples
+        gs = torch.stack([g_cls.reshape(()), g_box.reshape(())]).float().contiguous()
+        _, d_pred = native.frcnn_loss(st["pred"], heads.num_classes, samples["rois"], samples["gt_cls"],
+                                      samples["gt_box"], samples["n_valid"], grad_scale=gs)
+        dfeat, pgrads = heads._box_backward(st, samples["rois"], d_pred, ctx.feat_shape)
+        ctx.st = None
+        return (None, dfeat, None) + tuple(pgrads)
+
+
+@ROI_HEADS_REGISTRY.register()
+class StandardROIHeads(nn.Module):
+    def __init__(self, cfg, input_shape):
+        super().__init__()
+        r = cfg.MODEL.ROI_HEADS
+        self.num_classes = r.NUM_CLASSES
+        self.batch_size_per_image = r.BATCH_SIZE_PER_IMAGE
+        self.positive_fraction = r.POSITIVE_FRACTION
+        self.proposal_append_gt = r.PROPOSAL_APPEND_GT
+        assert list(r.IOU_THRESHOLDS) == [r.IOU_THRESHOLDS[0]] and list(r.IOU_LABELS) == [0, 1]
+        self.iou_threshold = r.IOU_THRESHOLDS[0]
+        self.box_in_features = self.in_features = r.IN_FEATURES
+        assert len(self.in_features) == 1
+        shape = input_shape[self.in_features[0]]
+        res = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        self.box_pooler = ROIPooler(res, (1.0 / shape.stride,), cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO,
+                                    cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE)
+        self.box_head = ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(
+            cfg, ShapeSpec(channels=shape.channels, height=res, width=res))
+        self.box_predictor = self._make_predictor(cfg, self.box_head.output_shape)
+        self.pooled = res
+        self.channels = shape.channels
+        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        K = self.num_classes
+        self.pred_ld = (5 * K + 1 + 7) // 8 * 8
+        self.bbox_threshold = cfg.SEMISUPNET.BBOX_THRESHOLD if "SEMISUPNET" in cfg else 0.7
+        self.nms_numel_limit = 20000  # torchvision batched_nms switch for GPU tensors (A.6)
+        self.train_on_pred_boxes = cfg.MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES
+
+    def _make_predictor(self, cfg, shape):
+        return FastRCNNOutputLayers(cfg, shape)
+
+    def _params(self):
+        bh, bp = self.box_head, self.box_predictor
+        return [bh.fc1.weight, bh.fc1.bias, bh.fc2.weight, bh.fc2.bias, bp.cls_score.weight, bp.cls_score.bias,
+                bp.bbox_pred.weight, bp.bbox_pred.bias]
+
+    # ---- box branch: ROIAlign -> fc1 -> fc2 -> fused (cls_score | bbox_pred) -------------------------
+    def _box_forward(self, feat_nchw, rois):
+        dtype = self.compute_dtype
+        dt = native.F32 if dtype == torch.float32 else native.BF16
+        feat = feat_nchw.permute(0, 2, 3, 1).to(dtype).contiguous()
+        bh, bp = self.box_head, self.box_predictor
+        C, PP = self.channels, self.pooled * self.pooled
+        pooled = native.roi_align_fwd(feat, rois, self.pooled, self.box_pooler.scale)
+        R = pooled.shape[0]
+        x0 = pooled.view(R, PP * C)
+        w1 = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C)
+        h1 = native.conv_fwd(x0, w1, bh.fc1.bias.detach(), bh.fc1.out_features, 1, act=1)
+        w2 = native.pack_fc_weight(bh.fc2.weight.detach(), dt)
+        h2 = native.conv_fwd(h1, w2, bh.fc2.bias.detach(), bh.fc2.out_features, 1, act=1)
+        wp = torch.cat([bp.cls_score.weight.detach(), bp.bbox_pred.weight.detach()])
+        bpb = torch.cat([bp.cls_score.bias.detach(), bp.bbox_pred.bias.detach()])
+        wpp = native.pack_fc_weight(wp, dt)
+        pred = native.conv_fwd(h2, wpp, bpb, wp.shape[0], 1, out_dtype=torch.float32, ldy=self.pred_ld)
+        return {"x0": x0, "h1": h1, "h2": h2, "pred": pred, "wp": wp, "feat_shape": tuple(feat.shape)}
+
+    def _box_backward(self, st, rois, d_pred, feat_shape_nchw):
+        dtype = self.compute_dtype
+        dt = native.F32 if dtype == torch.float32 else native.BF16
+        bh, bp = self.box_head, self.box_predictor
+        K, C = self.num_classes, self.channels
+        NP = 5 * K + 1
+        d_pred_c = native.cast(d_pred, dtype)
+        # predictor
+        dwp = native.conv_wgrad(st["h2"], d_pred_c, NP, 1).view(NP, -1)
+        dbp = native.bias_grad(d_pred, NP)
+        wpt = native.pack_fc_weight(st["wp"], dt, transpose=True, ld=self.pred_ld)
+        dh2 = native.conv_fwd(d_pred_c, wpt, None, bh.fc2.out_features, 1)
+        native.act_bwd_(dh2, st["h2"], 1)
+        # fc2
+        dw2 = native.conv_wgrad(st["h1"], dh2, bh.fc2.out_features, 1).view(bh.fc2.out_features, -1)
+        db2 = native.bias_grad(dh2, bh.fc2.out_features)
+        w2t = native.pack_fc_weight(bh.fc2.weight.detach(), dt, transpose=True)
+        dh1 = native.conv_fwd(dh2, w2t, None, bh.fc2.in_features, 1)
+        native.act_bwd_(dh1, st["h1"], 1)
+        # fc1 (K axis in (p, c) order inside the kernels, (c, p) in the state dict)
+        dw1p = native.conv_wgrad(st["x0"], dh1, bh.fc1.out_features, 1).view(bh.fc1.out_features, -1)
+        dw1 = torch.empty_like(bh.fc1.weight)
+        native.unpack_fc_wgrad(dw1p, dw1, chw_c=C)
+        db1 = native.bias_grad(dh1, bh.fc1.out_features)
+        w1t = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C, transpose=True)
+        dx0 = native.conv_fwd(dh1, w1t, None, bh.fc1.in_features, 1)
+        B, H, W, _ = st["feat_shape"]
+        dfeat = native.roi_align_bwd(dx0.view(-1, self.pooled * self.pooled, C), rois, (B, H, W, C), self.pooled,
+                                     self.box_pooler.scale)
+        pgrads = [dw1, db1, dw2, db2, dwp[: K + 1].contiguous(), dbp[: K + 1].contiguous(),
+                  dwp[K + 1:].contiguous(), dbp[K + 1:].contiguous()]
+        return dfeat.permute(0, 3, 1, 2), pgrads
+
+    # ---- label_and_sample_proposals (roi_heads.py:165-215) ----------------------------------------
+    @torch.no_grad()
+    def label_and_sample_proposals(self, proposals, targets, branch="", keys=None):
+        props = proposals
+        B, P, _ = props.boxes.shape
+        if self.proposal_append_gt:
+            boxes, count = native.append_gt(props.boxes, props.count, targets.boxes, targets.count)
+        else:
+            boxes, count = props.boxes, props.count
+        matched, cls = native.roi_match(boxes, count, targets.boxes, targets.classes, targets.count,
+                                        self.iou_threshold, self.num_classes)
+        keys = keys if keys is not None else getattr(self, "_forced_keys", None)
+        if keys is None:
+            keys = torch.randint(0, 2 ** 31 - 1, (B, boxes.shape[1]), dtype=torch.int32, device=boxes.device)
+        sidx, scnt = native.subsample_roi(cls, keys, self.batch_size_per_image, self.positive_fraction,
+                                          self.num_classes)
+        rois, gt_cls, gt_box, n_valid = native.roi_build_samples(boxes, cls, matched, sidx, scnt, targets.boxes,
+                                                                 targets.count)
+        return {"rois": rois, "gt_cls": gt_cls, "gt_box": gt_box, "n_valid": n_valid, "count": scnt,
+                "sampled_idxs": sidx, "image_sizes": props.image_sizes}
+
+    @torch.no_grad()
+    def _inference(self, feat, proposals, sizes_dev=None):
+        rois = native.make_rois(proposals.boxes, proposals.count)
+        st = self._box_forward(feat, rois)
+        bp = self.box_predictor
+        if sizes_dev is None:
+            sizes_dev = torch.tensor([list(s) for s in proposals.image_sizes], dtype=torch.int32).to(feat.device)
+        out = native.frcnn_inference(st["pred"], self.num_classes, proposals.boxes, proposals.count, sizes_dev,
+                                     bp.test_score_thresh, bp.test_nms_thresh, bp.test_topk_per_image,
+                                     self.bbox_threshold, self.nms_numel_limit)
+        return BatchedDetections(out, proposals.image_sizes), st["pred"]
+
+    # ---- module surface (roi_heads.py:68-106) -------------------------------------------------------
+    def forward(self, images, features, proposals, targets=None, compute_loss=True, branch="",
+                compute_val_loss=False, as_instances=True, keys=None):
+        del images
+        feat = features[self.in_features[0]]
+        if not isinstance(proposals, BatchedProposals):
+            proposals = _proposals_from_instances(proposals, feat.device)
+        if (self.training and compute_loss) or compute_val_loss:
+            assert targets is not None
+            if not isinstance(targets, BatchedGT):
+                targets = BatchedGT.from_instances(targets, feat.device)
+            append = self.proposal_append_gt
+            if compute_val_loss and not (self.training and compute_loss):
+                self.proposal_append_gt = False
+            samples = self.label_and_sample_proposals(proposals, targets, branch=branch, keys=keys)
+            self.proposal_append_gt = append
+            l_cls, l_box = _ROILossFn.apply(self, feat, samples, *self._params())
+            losses = {"loss_cls": l_cls, "loss_box_reg": l_box}
+            return samples, losses, None, None
+        pred_instances, predictions = self._inference(feat, proposals)
+        return (pred_instances.to_instances() if as_instances else pred_instances), predictions
+
+
+def _proposals_from_instances(instances, device):
+    B = len(instances)
+    P = max(1, max(len(i) for i in instances))
+    boxes = torch.zeros(B, P, 4, dtype=torch.float32, device=device)
+    logits = torch.zeros(B, P, dtype=torch.float32, device=device)
+    cnt = torch.zeros(B, dtype=torch.int32)
+    for i, inst in enumerate(instances):
+        n = len(inst)
+        boxes[i, :n] = inst.proposal_boxes.tensor.to(device)
+        if inst.has("objectness_logits"):
+            logits[i, :n] = inst.objectness_logits.to(device)
+        cnt[i] = n
+    return BatchedProposals(boxes, logits, cnt.to(device), [i.image_size for i in instances])
+
+
+@ROI_HEADS_REGISTRY.register()
+class SourceFreeAdaptiveTeacherStandardROIHeads(StandardROIHeads):
+    def _make_predictor(self, cfg, shape):
+        if cfg.MODEL.ROI_HEADS.LOSS == "CrossEntropy":
+            return SourceFreeFastRCNNOutputLayers(cfg, shape)
+        raise ValueError("Unknown ROI head loss.")
+
+
+@ROI_HEADS_REGISTRY.register()
+class AdaptiveTeacherStandardROIHeads(StandardROIHeads):
+    def _make_predictor(self, cfg, shape):
+        if cfg.MODEL.ROI_HEADS.LOSS == "CrossEntropy":
+            return FastRCNNOutputLayers(cfg, shape)
+        raise ValueError("Unknown ROI head loss.")
