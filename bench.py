@@ -1,0 +1,189 @@
+#!/usr/bin/env python
+"""Headline benchmark: teacher+student training images/s on synthetic 1024x2048 frames.
+
+One "step" = one pass of the hot path over one batch: teacher forward (train-mode BN / AdaBN
+refresh) -> NMS pseudo-labelling -> student forward + backward -> (RCCL grad all-reduce) ->
+fused SGD + EMA.  Inputs are resident in HBM before the timed region (the mapper's output:
+uint8 CHW tensors, 1024x2048 frames resized to 600x1200 by INPUT.MIN_SIZE_TRAIN=600 of the
+named config; ``--res full`` overrides the config to feed 1024x2048 tensors).
+
+Contract: ``python bench.py --gpus N --steps K --warmup W`` (N>1 under torch.distributed.run);
+rank 0 prints ONE JSON line.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# algorithmic forward FLOPs (2 x MACs) per image, SURVEY.md section 8d
+FLOPS = {
+    "r600": {"trunk": 439.90e9, "rpn": 3.19e9, "box512": 27.42e9, "box2000": 107.12e9},
+    "full": {"trunk": 1282.85e9, "rpn": 9.82e9, "box512": 27.42e9, "box2000": 107.12e9},
+}
+PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+
+
+def step_flops(res):
+    f = FLOPS[res]
+    teacher = f["trunk"] + f["rpn"] + f["box2000"]
+    student = f["trunk"] + f["rpn"] + f["box512"]
+    return teacher + 3 * student  # student backward = 2 x forward
+
+
+def cpu_baseline(res, planted):
+    """The CPU oracle (a port: PyTorch-CPU restatement of the Detectron2 path) on ONE image."""
+    import torch
+    from oracle import model as om
+    torch.set_num_threads(os.cpu_count())
+    cfg = om.Cfg()
+    sd_t = om.init_state(cfg, seed=0)
+    if planted:
+        sd_t["roi_heads.box_predictor.cls_score.weight"] *= 60.0
+    sd_s = om.clone_state(sd_t, requires_grad=True)
+    h, w = (600, 1200) if res == "r600" else (1024, 2048)
+    g = torch.Generator().manual_seed(42)
+    img = [torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)]
+    hf, wf = h // 32, w // 32
+    rk = [torch.randint(0, 2 ** 31 - 1, (hf * wf * 15,), generator=g)]
+    ok = [torch.randint(0, 2 ** 31 - 1, (2100,), generator=g)]
+    t0 = time.perf_counter()
+    props, dets = om.teacher_forward(sd_t, img, cfg)
+    pl = [om.threshold_bbox(d, cfg.bbox_threshold) for d in dets]
+    losses = om.student_losses(sd_s, img, [p["gt_boxes"] for p in pl], [p["gt_classes"] for p in pl], rk, ok, cfg)
+    sum(losses.values()).backward()
+    grads = {k: v.grad for k, v in sd_s.items() if getattr(v, "grad", None) is not None}
+    om.sgd_step(sd_s, grads, {}, lr=0.0025 * 0.001)
+    om.ema_update(sd_t, {k: v.detach() for k, v in sd_s.items()}, 0.9996)
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / dt, 4), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 teacher+student step on 1 synthetic {h}x{w} image (oracle/, PyTorch-CPU fp32, "
+                      f"{torch.get_num_threads()} threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
+    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--res", choices=["r600", "full"], default="r600")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-planted", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with python -m torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    sfod = importlib.import_module("simple-sfod_amd")
+    sfod.native.load()
+    opts = ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", args.dtype, "SOLVER.IMS_PER_BATCH_TARGET", str(args.batch * world),
+            "SOLVER.CHECKPOINT_PERIOD", "0", "SFOD.SYNTHETIC.NUM_IMAGES", str(max(16, 2 * args.batch)),
+            "MODEL.DEVICE", f"cuda:{local_rank}"]
+    if args.res == "full":
+        opts += ["INPUT.MIN_SIZE_TRAIN", "(1024,)", "INPUT.MAX_SIZE_TRAIN", "2048"]
+    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs",
+                                             "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"), opts)
+    torch.manual_seed(cfg.SEED + rank)
+    trainer = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+    if not args.no_planted:
+        with torch.no_grad():  # "planted-label" mode: confident teacher scores
+            trainer.model.roi_heads.box_predictor.cls_score.weight.mul_(60.0)
+            trainer._copy_main_model()
+    if world > 1:  # same initial weights on every rank (DDP constructor broadcast)
+        dist.broadcast(trainer.optimizer.flat.param, 0)
+        dist.broadcast(trainer.optimizer.flat.fbuf, 0)
+        trainer._copy_main_model()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.iter = i
+        trainer.run_step()
+        trainer.scheduler.step()
+    timer = None
+    if not args.no_kernel_timer:
+        timer = sfod.native.KernelTimer()
+        sfod.native.set_timer(timer)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.iter = args.warmup + i
+        trainer.run_step()
+        trainer.scheduler.step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    sfod.native.set_timer(None)
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    rec = trainer.storage.flush()
+    if rank != 0:
+        return
+    images = args.batch * world * args.steps
+    value = images / elapsed
+    h, w = (600, 1200) if args.res == "r600" else (1024, 2048)
+    out = {
+        "metric": "teacher+student train images/s on 1024x2048 synthetic",
+        "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {
+            "workload": "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml: VGG16-BN teacher+student "
+                        "(teacher fwd + NMS pseudo-labels + student fwd/bwd + SGD + EMA), synthetic 1024x2048 8-class "
+                        f"frames -> {h}x{w} network tensors ({'INPUT.MIN_SIZE_TRAIN=600 of the config' if args.res == 'r600' else 'MIN_SIZE_TRAIN overridden to 1024'})",
+            "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+            "ema": bool(cfg.SFOD.EMA.ENABLED), "elide_zero_weight_branches": bool(cfg.SFOD.ELIDE_DEAD_BRANCHES),
+            "planted_labels": not args.no_planted,
+            "algorithmic_tflop_per_image": round(step_flops(args.res) / 1e12, 3),
+        },
+        "step_tflops_per_gpu": round(step_flops(args.res) * value / world / 1e12, 2),
+        "losses": {k: round(v, 5) for k, v in rec.items() if k.startswith("loss") or k.startswith("roi_head")},
+    }
+    if timer is not None:
+        summ = timer.summary()
+        k = summ.get("sfod_conv_fwd", {"ms": 0.0, "flops": 0.0, "launches": 0})
+        ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        out["roofline"] = {
+            "kernel": "k_conv_fwd (MFMA implicit-GEMM: conv3x3 fwd + dgrad, 1x1, linear)",
+            "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+            "frac": round(ach / PEAK[args.dtype], 4), "traffic": None,
+            "launches_per_step": k["launches"] // max(args.steps, 1),
+            "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
+            "algorithmic_gflop_per_launch": round(k["flops"] / max(k["launches"], 1) / 1e9, 3),
+            "share_of_step_time": round(k["ms"] / (1000.0 * elapsed), 4),
+        }
+        wk = summ.get("sfod_conv_wgrad")
+        if wk and wk["ms"] > 0:
+            out["roofline_wgrad"] = {"kernel": "k_conv_wgrad", "achieved": round(wk["flops"] / (wk["ms"] * 1e-3) / 1e12, 2),
+                                     "peak": PEAK[args.dtype], "unit": "TFLOP/s",
+                                     "frac": round(wk["flops"] / (wk["ms"] * 1e-3) / 1e12 / PEAK[args.dtype], 4),
+                                     "share_of_step_time": round(wk["ms"] / (1000.0 * elapsed), 4)}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.res, not args.no_planted)
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

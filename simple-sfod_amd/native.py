@@ -117,11 +117,49 @@ def chunk_elems(dt):
     return 4 if dt == F32 else 8
 
 
+class KernelTimer:
+    """Optional per-entry-point timing with HIP events recorded on the launch stream (used by
+    bench.py for the roofline figure of the dominant kernels).  ``flops`` is the algorithmic work
+    of the launch (2 x MACs of the GEMM the entry point computes)."""
+
+    def __init__(self, watch=("sfod_conv_fwd", "sfod_conv_wgrad")):
+        self.watch = set(watch)
+        self.records = []      # (name, flops, start_event, end_event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, flops, a, b in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0})
+            d["launches"] += 1
+            d["ms"] += a.elapsed_time(b)
+            d["flops"] += flops
+        return out
+
+
+_timer = None
+_pending_flops = 0.0
+
+
+def set_timer(timer):
+    global _timer
+    _timer = timer
+
+
 def call(name, *args):
     """Raw call: tensors are converted to device pointers, the current stream is appended."""
+    global _pending_flops
     lib = load()
     conv = [(_p(a) if isinstance(a, torch.Tensor) else a) for a in args]
-    rc = getattr(lib, name)(*conv, _stream())
+    if _timer is not None and name in _timer.watch:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = getattr(lib, name)(*conv, _stream())
+        b.record()
+        _timer.records.append((name, _pending_flops, a, b))
+        _pending_flops = 0.0
+    else:
+        rc = getattr(lib, name)(*conv, _stream())
     _chk(rc, name)
 
 
@@ -195,6 +233,8 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     if want_stats:
         nb = query("sfod_conv_stats_blocks", B * H * W)
         stats = torch.empty(nb, 2, cout, dtype=torch.float32, device=x.device)
+    global _pending_flops
+    _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
     call("sfod_conv_fwd", x, w_packed, bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
          F32 if out_dtype == torch.float32 else BF16)
     return (y, stats) if want_stats else y
@@ -210,6 +250,8 @@ def conv_wgrad(x, dy, cout, ksize, dw_packed=None):
     lddy = dy.shape[-1]
     if dw_packed is None:
         dw_packed = torch.zeros(cout, ksize * ksize, cin, dtype=torch.float32, device=x.device)
+    global _pending_flops
+    _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
     call("sfod_conv_wgrad", x, dy, dw_packed, B, H, W, cin, cout, ksize, lddy, dt)
     return dw_packed
 
