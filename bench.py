@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planted", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--kernel-table", action="store_true", help="stderr: per-shape table of the MFMA kernels")
     args = ap.parse_args()
 
     import torch
@@ -161,6 +162,15 @@ def main():
     }
     if timer is not None:
         summ = timer.summary()
+        if args.kernel_table:
+            agg = {}
+            for name, flops, a, b in timer.records:
+                d = agg.setdefault((name, round(flops / 1e9, 2)), [0, 0.0])
+                d[0] += 1
+                d[1] += a.elapsed_time(b)
+            for (name, gf), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"{name:18s} {gf:10.2f} GF/launch  x{n:4d}  {ms / n:8.3f} ms  {gf / (ms / n):8.1f} TF/s  "
+                      f"{100 * ms / (1000 * elapsed):5.1f}% of step", file=sys.stderr)
         k = summ.get("sfod_conv_fwd", {"ms": 0.0, "flops": 0.0, "launches": 0})
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
         out["roofline"] = {

@@ -89,7 +89,9 @@ int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, int accumula
  * (daod/engine/trainers/base.py:270-337): it runs identically under no_grad. */
 int sfod_bn_finalize(const float* stats, int nblocks, int rows_per_block, int M, int C,
                      float* mean, float* invstd, float* running_mean, float* running_var,
-                     float momentum, float eps, int update_running, void* stream);
+                     float momentum, float eps, int update_running, float* ws, void* stream);
+/* size (in floats, 8-byte aligned) of the `ws` scratch of sfod_bn_finalize */
+int sfod_bn_finalize_ws_floats(int C);
 /* z = relu(gamma*(y-mean)*invstd+beta); pool=1 additionally 2x2/2 max-pools z (floor) */
 int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* z, int B, int H, int W,

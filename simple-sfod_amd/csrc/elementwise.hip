@@ -82,55 +82,76 @@ extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes
 // ---------------------------------------------------------------------------------------------
 // K3 BatchNorm statistics finalize.  stats[blk][0][c] = sum over the block's rows, stats[blk][1][c]
 // = sum of squared deviations from the block mean (written by the conv epilogue).  Combined in
-// fp64 with M2 = sum_b M2_b + n_b (mean_b - mean)^2  (all terms >= 0: no cancellation).
+// fp64:  M2 = sum_b M2_b + sum_b s_b^2/n_b - (sum_b s_b)^2 / M .  Two launches: BNF_SPLITS x C/64
+// workgroups reduce slices of the block axis, one small kernel combines them.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024)
-k_bn_finalize(const float* __restrict__ stats, int nblocks, int rows_per_block, int M, int C,
-              float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ rmean,
-              float* __restrict__ rvar, float momentum, float eps, int update_running) {
-  __shared__ double red[16][64];
+#define BNF_SPLITS 64
+
+__global__ void __launch_bounds__(256)
+k_bn_partial(const float* __restrict__ stats, int nblocks, int rows_per_block, int M, int C,
+             double* __restrict__ part) {
+  __shared__ double red[4][3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
-  double acc = 0.0;
+  const int per = (nblocks + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  double a = 0.0, q = 0.0, m2 = 0.0;
   if (c < C)
-    for (int blk = wave; blk < nblocks; blk += 16) acc += (double)stats[((int64_t)blk * 2) * C + c];
-  red[wave][lane] = acc;
-  __syncthreads();
-  double tot = 0.0;
-  for (int w = 0; w < 16; ++w) tot += red[w][lane];
-  const double mu = tot / (double)M;
-  __syncthreads();
-  acc = 0.0;
-  if (c < C)
-    for (int blk = wave; blk < nblocks; blk += 16) {
-      const int nb = min(rows_per_block, M - blk * rows_per_block);
+    for (int blk = b0 + wave; blk < b1; blk += 4) {
+      const double nb = (double)min(rows_per_block, M - blk * rows_per_block);
       const double sb = (double)stats[((int64_t)blk * 2) * C + c];
-      const double m2 = (double)stats[((int64_t)blk * 2 + 1) * C + c];
-      const double d = sb / (double)nb - mu;
-      acc += m2 + (double)nb * d * d;
+      a += sb;
+      q += sb * sb / nb;
+      m2 += (double)stats[((int64_t)blk * 2 + 1) * C + c];
     }
-  red[wave][lane] = acc;
+  red[wave][0][lane] = a; red[wave][1][lane] = q; red[wave][2][lane] = m2;
   __syncthreads();
   if (wave == 0 && c < C) {
-    double m2 = 0.0;
-    for (int w = 0; w < 16; ++w) m2 += red[w][lane];
-    const double var = m2 / (double)M;
-    mean[c] = (float)mu;
-    invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (update_running) {
-      const double unbiased = (M > 1) ? m2 / (double)(M - 1) : var;
-      rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
-      rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
-    }
+    for (int k = 0; k < 3; ++k)
+      part[((int64_t)blockIdx.y * 3 + k) * C + c] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
   }
 }
 
+__global__ void __launch_bounds__(64)
+k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __restrict__ mean,
+           float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+           float eps, int update_running) {
+  const int c = blockIdx.x * 64 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, q = 0.0, m2 = 0.0;
+  for (int s = 0; s < nsplit; ++s) {
+    a += part[((int64_t)s * 3 + 0) * C + c];
+    q += part[((int64_t)s * 3 + 1) * C + c];
+    m2 += part[((int64_t)s * 3 + 2) * C + c];
+  }
+  const double mu = a / (double)M;
+  double tot = m2 + q - a * a / (double)M;
+  if (tot < 0.0) tot = 0.0;
+  const double var = tot / (double)M;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (update_running) {
+    const double unbiased = (M > 1) ? tot / (double)(M - 1) : var;
+    rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
+    rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+  }
+}
+
+extern "C" int sfod_bn_finalize_ws_floats(int C) { return BNF_SPLITS * 3 * C * 2; }
+
 extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int rows_per_block, int M, int C,
                                 float* mean, float* invstd, float* running_mean, float* running_var,
-                                float momentum, float eps, int update_running, void* stream) {
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream, stats, nblocks,
-                     rows_per_block, M, C, mean, invstd, running_mean, running_var, momentum, eps,
-                     update_running);
+                                float momentum, float eps, int update_running, float* ws, void* stream) {
+  SFOD_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "bn_finalize: 8-byte aligned workspace required");
+  hipStream_t s = (hipStream_t)stream;
+  int nsplit = (nblocks + 63) / 64;
+  if (nsplit > BNF_SPLITS) nsplit = BNF_SPLITS;
+  if (nsplit < 1) nsplit = 1;
+  double* part = reinterpret_cast<double*>(ws);
+  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), nsplit), dim3(256), 0, s, stats, nblocks, rows_per_block, M,
+                     C, part);
+  hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 64)), dim3(64), 0, s, part, nsplit, M, C, mean, invstd,
+                     running_mean, running_var, momentum, eps, update_running);
   return sfod_check_launch("bn_finalize");
 }
 
@@ -249,7 +270,7 @@ __device__ __forceinline__ void bn_unit_grad(const T* __restrict__ y, const T* _
 }
 
 
-#define BNB_GRID_MAX 2048
+#define BNB_GRID_MAX 1024
 
 template <typename T, int POOL>
 __global__ void __launch_bounds__(256)
@@ -305,11 +326,19 @@ k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y, const float* 
 __global__ void __launch_bounds__(256)
 k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
                   float* __restrict__ dbeta) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;  // over 2*C
-  if (t >= 2 * C) return;
+  // 64 consecutive columns of the [nblk][2C] partial matrix per workgroup; 4 waves split the rows
+  __shared__ double red[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;  // over 2*C
   double a = 0.0;
-  for (int b = 0; b < nblk; ++b) a += (double)ws[(int64_t)b * 2 * C + t];
-  if (t < C) dbeta[t] = (float)a; else dgamma[t - C] = (float)a;
+  if (t < 2 * C)
+    for (int b = wave; b < nblk; b += 4) a += (double)ws[(int64_t)b * 2 * C + t];
+  red[wave][lane] = a;
+  __syncthreads();
+  if (wave == 0 && t < 2 * C) {
+    const double v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    if (t < C) dbeta[t] = (float)v; else dgamma[t - C] = (float)v;
+  }
 }
 
 template <typename T, int POOL>
@@ -413,7 +442,7 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
   do {                                                                                                 \
     hipLaunchKernelGGL((k_bn_bwd_reduce<T, P>), dim3(grid1), dim3(256), lds, s, (const T*)dz,          \
                        (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                        \
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 256)), dim3(256), 0, s, ws, grid1, C,       \
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(256), 0, s, ws, grid1, C,       \
                        dgamma, dbeta);                                                                 \
     hipLaunchKernelGGL((k_bn_bwd_apply<T, P>), dim3(grid3), dim3(256), 0, s, (const T*)dz,             \
                        (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (T*)dy, B, H, W, C);     \

@@ -59,7 +59,10 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // =============================================================================================
 // forward / dgrad / linear
 // =============================================================================================
-template <typename T, typename OutT, int WM, int WN>
+// UT ("uniform tap"): every 8-chunk K tile lies inside ONE filter tap (Cin*sizeof(T) a multiple of
+// 128 bytes, or a 1x1 / linear layer), so tap decoding is scalar work per K tile and a lane's
+// source address is row_base + tile_delta; the general path (first layer, Cin = 3) decodes per lane.
+template <typename T, typename OutT, int WM, int WN, bool UT>
 __global__ void __launch_bounds__(256)
 k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
            OutT* __restrict__ y, float* __restrict__ stats, ConvArgs a, int tiles_n, int ntiles) {
@@ -104,9 +107,63 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   const int KT = (a.kchunks + 7) / 8;
   const int64_t wrow_elems = (int64_t)a.kchunks * E;
 
+  // hoisted per-row state of the uniform-tap path
+  int64_t a_base[AI];   // element offset of (pixel, logical chunk) in x
+  int a_lcs[AI];        // logical chunk of this lane
+  unsigned a_mask[AI];  // bit t: tap t reads inside the image (bit 0 only for 1x1)
+  int64_t b_base[BI];
+  int b_lcs[BI];
+  bool b_ok[BI];
+  if (UT) {
+    for (int i = 0; i < AI; ++i) {
+      const int lc = pc ^ ((a_row[i] >> 1) & 7);
+      a_lcs[i] = lc;
+      a_base[i] = (a_pix[i] >= 0 ? a_pix[i] : 0) * a.Cin + (int64_t)lc * E;
+      unsigned m = 0;
+      if (a_pix[i] >= 0) {
+        if (a.ks == 1) m = 1u;
+        else
+          for (int t = 0; t < 9; ++t) {
+            const int iy = a_oy[i] + t / 3 - 1, ix = a_ox[i] + t % 3 - 1;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) m |= (1u << t);
+          }
+      }
+      a_mask[i] = m;
+    }
+    for (int i = 0; i < BI; ++i) {
+      const int lc = pc ^ ((b_row[i] >> 1) & 7);
+      b_lcs[i] = lc;
+      const int n = n0 + b_row[i];
+      b_ok[i] = n < a.Cout;
+      b_base[i] = (int64_t)(b_ok[i] ? n : 0) * wrow_elems + (int64_t)lc * E;
+    }
+  }
+
   auto stage_load = [&](int kt, int buf) {
     unsigned char* sA = smem + buf * STAGE;
     unsigned char* sB = sA + BM * 128;
+    if (UT) {
+      // scalar (wave-uniform) tap decode for the whole K tile
+      const int gq0 = kt * 8;
+      int tap = 0, cc0 = gq0;
+      if (a.ks != 1) { tap = gq0 >> a.cpt_shift; cc0 = gq0 & ((1 << a.cpt_shift) - 1); }
+      const int ky = tap / 3, kx = tap - ky * 3;
+      const int64_t delta = (a.ks == 1) ? (int64_t)cc0 * E
+                                        : ((int64_t)(ky - 1) * a.W + (kx - 1)) * a.Cin + (int64_t)cc0 * E;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const bool ok = ((a_mask[i] >> tap) & 1u) && (gq0 + a_lcs[i] < a.kchunks);
+        const void* src = ok ? (const void*)(x + a_base[i] + delta) : (const void*)g_zero_page;
+        glds16(src, sA + (wave * AI + i) * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const bool ok = b_ok[i] && (gq0 + b_lcs[i] < a.kchunks);
+        const void* src = ok ? (const void*)(w + b_base[i] + (int64_t)gq0 * E) : (const void*)g_zero_page;
+        glds16(src, sB + (wave * BI + i) * 1024);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int row = a_row[i];
@@ -301,22 +358,31 @@ static int ilog2_exact(int v) {
 
 extern "C" int sfod_conv_stats_blocks(int M) { return (M + 127) / 128; }
 
-template <typename T, typename OutT>
-static int launch_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
-                           const ConvArgs& a, hipStream_t s) {
+template <typename T, typename OutT, bool UT>
+static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
+                              const ConvArgs& a, hipStream_t s) {
   const int tiles_m = (a.M + 127) / 128;
   if (a.Cout <= 64) {
     const int tiles_n = (a.Cout + 63) / 64;
     const int nt = tiles_m * tiles_n;
-    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 1>), dim3(nt), dim3(256), 2 * (128 + 64) * 128, s,
+    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 1, UT>), dim3(nt), dim3(256), 2 * (128 + 64) * 128, s,
                        (const T*)x, (const T*)w, bias, (OutT*)y, stats, a, tiles_n, nt);
   } else {
     const int tiles_n = (a.Cout + 127) / 128;
     const int nt = tiles_m * tiles_n;
-    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 2>), dim3(nt), dim3(256), 2 * (128 + 128) * 128, s,
+    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 2, UT>), dim3(nt), dim3(256), 2 * (128 + 128) * 128, s,
                        (const T*)x, (const T*)w, bias, (OutT*)y, stats, a, tiles_n, nt);
   }
   return sfod_check_launch("conv_fwd");
+}
+
+template <typename T, typename OutT>
+static int launch_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
+                           const ConvArgs& a, hipStream_t s) {
+  const int cpt = a.Cin / Chunk<T>::E;
+  const bool ut = (a.ks == 1) || (cpt % 8 == 0);
+  if (ut) return launch_conv_fwd_ut<T, OutT, true>(x, w, bias, y, stats, a, s);
+  return launch_conv_fwd_ut<T, OutT, false>(x, w, bias, y, stats, a, s);
 }
 
 extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,

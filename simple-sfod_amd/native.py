@@ -267,8 +267,9 @@ def bias_grad(dy, n, db=None, accumulate=False):
 def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, update_running=True):
     mean = torch.empty(C, dtype=torch.float32, device=stats.device)
     invstd = torch.empty_like(mean)
+    ws = torch.empty(query("sfod_bn_finalize_ws_floats", C), dtype=torch.float32, device=stats.device)
     call("sfod_bn_finalize", stats, stats.shape[0], 128, M, C, mean, invstd, running_mean, running_var,
-         float(momentum), float(eps), int(update_running))
+         float(momentum), float(eps), int(update_running), ws)
     return mean, invstd
 
 
