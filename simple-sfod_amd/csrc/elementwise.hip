@@ -658,34 +658,40 @@ extern "C" int sfod_unpack_fc_wgrad(const float* dw_packed, float* dw, int N, in
 }
 
 // ---------------------------------------------------------------------------------------------
-// bias gradient: column sums.  One workgroup per 64 columns, 4 waves split the rows; fixed
-// summation order (deterministic).
+// bias gradient: column sums.  grid = (64-column groups, row slices); 4 waves split a slice's
+// rows, lanes are consecutive columns (coalesced); slices are combined with one float atomic per
+// column (<= 64 adds per address).
 // ---------------------------------------------------------------------------------------------
+#define BG_SLICES 64
+
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_bias_grad(const T* __restrict__ dy, float* __restrict__ db, int M, int N, int ld, int accumulate) {
+k_bias_grad(const T* __restrict__ dy, float* __restrict__ db, int M, int N, int ld, int rows_per_slice) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + lane;
+  const int m0 = blockIdx.y * rows_per_slice, m1 = min(M, m0 + rows_per_slice);
   float acc = 0.f;
   if (n < N)
-    for (int m = wave; m < M; m += 4) acc += to_f32(dy[(int64_t)m * ld + n]);
+    for (int m = m0 + wave; m < m1; m += 4) acc += to_f32(dy[(int64_t)m * ld + n]);
   red[wave][lane] = acc;
   __syncthreads();
-  if (wave == 0 && n < N) {
-    const float v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
-    db[n] = accumulate ? db[n] + v : v;
-  }
+  if (wave == 0 && n < N) atomicAdd(db + n, red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane]);
 }
 
 extern "C" int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, int accumulate, int dt,
                               void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * N, s);
+  if (M == 0) return 0;
+  int slices = (M + 63) / 64;
+  if (slices > BG_SLICES) slices = BG_SLICES;
+  const int rps = (M + slices - 1) / slices;
+  dim3 grid(cdiv(N, 64), cdiv(M, rps));
   if (dt == SFOD_F32)
-    hipLaunchKernelGGL(k_bias_grad<float>, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)dy, db, M, N, ld, accumulate);
+    hipLaunchKernelGGL(k_bias_grad<float>, grid, dim3(256), 0, s, (const float*)dy, db, M, N, ld, rps);
   else
-    hipLaunchKernelGGL(k_bias_grad<bf16_t>, dim3(cdiv(N, 64)), dim3(256), 0, (hipStream_t)stream,
-                       (const bf16_t*)dy, db, M, N, ld, accumulate);
+    hipLaunchKernelGGL(k_bias_grad<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dy, db, M, N, ld, rps);
   return sfod_check_launch("bias_grad");
 }
 

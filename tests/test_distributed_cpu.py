@@ -1,0 +1,92 @@
+"""N>1 path on CPU: two gloo ranks exercise the sharding rule (TrainingSampler striding, per-rank
+batch = IMS_PER_BATCH_TARGET // world) and the one collective of the step (sum all-reduce of the
+flat gradient buffer, 1/world folded into the optimiser) -- build.py:337-343, SURVEY.md section 8e."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sfod = importlib.import_module("simple-sfod_amd")
+    from types import SimpleNamespace
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.Linear(5, 3))
+    flat = sfod.engine.FlatModelState(model)
+    # parameters are views of the flat buffer, norm params grouped after the decayed ones
+    names = [n for n, _ in flat.order]
+    assert names == ["0.weight", "0.bias", "2.weight", "2.bias", "1.weight", "1.bias"]
+    for n, p in flat.order:
+        o, k, shp = flat.offsets[n]
+        assert p.data_ptr() == flat.param.data_ptr() + 4 * o
+        assert p.grad.data_ptr() == flat.grad.data_ptr() + 4 * o
+    # rank-dependent gradients through autograd land in the flat buffer
+    x = torch.full((2, 3, 7, 7), float(rank + 1))
+    y = model[1](model[0](x)).sum() + model[2](torch.ones(1, 5) * (rank + 1)).sum()
+    y.backward()
+    local = flat.grad.clone()
+    opt = SimpleNamespace(flat=flat, grad_scale=1.0)
+    tr = SimpleNamespace(optimizer=opt)
+    sfod.engine.trainer.BaseTrainer._reduce_gradients(tr)
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    ok_sum = torch.allclose(flat.grad, sum(gathered))
+    # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream
+    s = iter(sfod.data.TrainingSampler(10, seed=7, rank=rank, world=world))
+    mine = [next(s) for _ in range(10)]
+    full = iter(sfod.data.TrainingSampler(10, seed=7, rank=0, world=1))
+    stream = [next(full) for _ in range(20)]
+    ok_sampler = mine == stream[rank::world]
+    # loader: per-rank batch and divisibility assert
+    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs",
+                                             "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"),
+                                ["SOLVER.IMS_PER_BATCH_TARGET", "4", "SFOD.SYNTHETIC.HEIGHT", "64",
+                                 "SFOD.SYNTHETIC.WIDTH", "96", "SFOD.SYNTHETIC.NUM_IMAGES", "6",
+                                 "INPUT.MIN_SIZE_TRAIN", "(32,)", "SFOD.SYNTHETIC.BOXES_PER_IMAGE", "2"])
+    loader = sfod.data.TwoCropLoader(cfg, torch.device("cpu"), rank, world)
+    strong, weak = next(loader)
+    ids = [d["image_id"] for d in weak]
+    all_ids = [None] * world
+    dist.all_gather_object(all_ids, ids)
+    ok_loader = len(weak) == 2 and weak[0]["image"].dtype == torch.uint8 and tuple(weak[0]["image"].shape) == (3, 32, 48)
+    bad = cfg.clone()
+    bad.defrost()
+    bad.SOLVER.IMS_PER_BATCH_TARGET = 3
+    try:
+        sfod.data.TwoCropLoader(bad, torch.device("cpu"), rank, world)
+        ok_assert = False
+    except AssertionError:
+        ok_assert = True
+    q.put((rank, ok_sum, opt.grad_scale, ok_sampler, ok_loader, ok_assert, all_ids))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharding_and_gradient_allreduce():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, ok_sum, gscale, ok_sampler, ok_loader, ok_assert, all_ids in res:
+        assert ok_sum and ok_sampler and ok_loader and ok_assert, (rank, ok_sum, ok_sampler, ok_loader, ok_assert)
+        assert gscale == 0.5
+    # the two ranks drew disjoint strided slices of the same permutation
+    ids = res[0][6]
+    assert len(set(ids[0]) & set(ids[1])) == 0 or len(set(ids[0] + ids[1])) <= 6

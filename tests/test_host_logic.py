@@ -1,0 +1,108 @@
+"""Host-side mirror of the reference's config / registry / structures surface (no GPU needed)."""
+import os
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOT = os.path.join(ROOT, "configs", "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml")
+SRC = os.path.join(ROOT, "configs", "faster_rcnn_VGG_cityscapes_source_new.yaml")
+
+
+def test_config_contract_hot_yaml(sfod):
+    cfg = sfod.config.setup_cfg(HOT, ["SOLVER.IMS_PER_BATCH_TARGET", "8", "INPUT.MIN_SIZE_TRAIN", "(1024,)"])
+    assert cfg.TRAINER == "source_free_adaptive_teacher"
+    assert cfg.MODEL.META_ARCHITECTURE == "SourceFreeAdaptiveTeacherGeneralizedRCNN"
+    assert cfg.MODEL.PROPOSAL_GENERATOR.NAME == "PseudoLabRPN"
+    assert cfg.MODEL.ROI_HEADS.NAME == "SourceFreeAdaptiveTeacherStandardROIHeads"
+    assert cfg.SEMISUPNET.BBOX_THRESHOLD == 0.8 and cfg.SEMISUPNET.DIS_TYPE == "vgg4" and cfg.SEMISUPNET.INS_DC
+    assert cfg.SOLVER.STEPS == (60000, 80000, 90000, 360000) and cfg.SOLVER.BASE_LR == 0.0025
+    assert cfg.DOMAIN_CLASSIFIER.ENABLED and not cfg.DOMAIN_CLASSIFIER.IMAGE and not cfg.WEAK_STRONG_AUGMENT
+    assert cfg.SOLVER.IMS_PER_BATCH_TARGET == 8 and cfg.INPUT.MIN_SIZE_TRAIN == (1024,)
+    assert cfg.MODEL.RPN.PRE_NMS_TOPK_TRAIN == 12000 and cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE == 512
+    assert cfg.TEST.VAL_LOSS is True and cfg.VGG.BN is True
+    with pytest.raises(AttributeError):
+        cfg.SEED = 1  # frozen
+    with pytest.raises(KeyError):
+        sfod.config.setup_cfg(HOT, ["SOLVER.NOT_A_KEY", "1"])
+    with pytest.raises(ValueError):
+        sfod.config.setup_cfg(HOT, ["SOLVER.BASE_LR", "abc"])
+    src = sfod.config.setup_cfg(SRC)
+    assert src.TRAINER == "base" and src.MODEL.META_ARCHITECTURE == "GeneralizedRCNN" and src.SOLVER.BASE_LR == 0.04
+
+
+def test_registries_resolve_reference_names(sfod):
+    r = sfod.registry
+    for reg, names in [(r.META_ARCH_REGISTRY, ["GeneralizedRCNN", "SourceFreeAdaptiveTeacherGeneralizedRCNN"]),
+                       (r.BACKBONE_REGISTRY, ["build_vgg_backbone"]),
+                       (r.PROPOSAL_GENERATOR_REGISTRY, ["RPN", "PseudoLabRPN"]),
+                       (r.ROI_HEADS_REGISTRY, ["StandardROIHeads", "SourceFreeAdaptiveTeacherStandardROIHeads",
+                                               "AdaptiveTeacherStandardROIHeads"]),
+                       (r.ROI_BOX_HEAD_REGISTRY, ["FastRCNNConvFCHead"])]:
+        for n in names:
+            assert reg.get(n) is not None
+    with pytest.raises(KeyError):
+        r.META_ARCH_REGISTRY.get("Nope")
+    with pytest.raises(ValueError):
+        cfg = sfod.config.setup_cfg(HOT, ["TRAINER", "da"])
+        sfod.engine.get_trainer_class(cfg)
+
+
+def test_model_state_dict_surface(sfod):
+    cfg = sfod.config.setup_cfg(HOT)
+    torch.manual_seed(0)
+    model = sfod.registry.META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    keys = list(model.state_dict().keys())
+    assert sum(p.numel() for p in model.parameters()) == 47628086
+    assert sum(1 for k in keys if k.startswith("backbone.")) == 91         # section 8a a1
+    for k in ["backbone.vgg0.0.weight", "backbone.vgg4.7.num_batches_tracked",
+              "proposal_generator.rpn_head.conv.weight", "proposal_generator.rpn_head.anchor_deltas.bias",
+              "roi_heads.box_head.fc1.weight", "roi_heads.box_predictor.bbox_pred.weight",
+              "DC_img.classifier.weight", "DC_ins.da_ins_fc3_level_vgg4.bias"]:
+        assert k in keys, k
+    assert "pixel_mean" not in keys
+    assert model.backbone.size_divisibility == 0
+    sh = model.backbone.output_shape()["vgg4"]
+    assert (sh.channels, sh.stride) == (512, 32)
+    assert model.roi_heads.box_predictor.cls_score.in_features == 1024
+    assert model.roi_heads.box_pooler.min_level == model.roi_heads.box_pooler.max_level == 5
+    with pytest.raises(RuntimeError):
+        sfod.modeling.build_model(sfod.config.setup_cfg(HOT, ["MODEL.DEVICE", "cpu"]))  # no CPU fallback
+
+
+def test_structures_and_lr_schedule(sfod):
+    S = sfod.structures
+    inst = S.Instances((10, 20))
+    inst.gt_boxes = S.Boxes(torch.tensor([[0.0, 0.0, 5.0, 5.0], [1.0, 1.0, 30.0, 30.0]]))
+    inst.gt_classes = torch.tensor([1, 2])
+    assert len(inst) == 2 and inst.has("gt_boxes") and len(inst[inst.gt_classes == 2]) == 1
+    b = inst.gt_boxes.clone()
+    b.clip((10, 20))
+    assert b.tensor[1].tolist() == [1.0, 1.0, 20.0, 10.0]
+    cat = S.Instances.cat([inst, inst])
+    assert len(cat) == 4
+    il = S.ImageList.from_tensors([torch.zeros(3, 4, 6), torch.zeros(3, 5, 3)])
+    assert tuple(il.tensor.shape) == (2, 3, 5, 6) and il.image_sizes == [(4, 6), (5, 3)]
+    cfg = sfod.config.setup_cfg(HOT)
+
+    class Opt:
+        def set_lr(self, lr):
+            self.lr = lr
+    o = Opt()
+    sched = sfod.engine.WarmupMultiStepLR(o, cfg)
+    assert abs(o.lr - 0.0025 * 0.001) < 1e-15
+    assert sched.milestones == [60000, 80000, 90000]      # 360000 > MAX_ITER is dropped
+    assert abs(sched.get_lr(1000) - 0.0025) < 1e-15 and abs(sched.get_lr(85000) - 0.0025 * 0.01) < 1e-15
+    from oracle import model as om
+    for it in (0, 1, 500, 999, 1000, 59999, 60000, 95000):
+        assert abs(sched.get_lr(it) - om.lr_at(it, 0.0025)) < 1e-15
+
+
+def test_threshold_bbox_api_twin(sfod):
+    S = sfod.structures
+    inst = S.Instances((10, 10))
+    inst.pred_boxes = S.Boxes(torch.rand(3, 4))
+    inst.scores = torch.tensor([0.9, 0.8, 0.81])
+    inst.pred_classes = torch.tensor([1, 2, 3])
+    out = sfod.engine.trainer.threshold_bbox(inst, 0.8, "roih")
+    assert out.gt_classes.tolist() == [1, 3]

@@ -1,0 +1,57 @@
+#!/usr/bin/env python
+"""CLI drop-in for the reference's ``train_net_mt.py`` (``:34-101``): same config contract
+(``--config-file X.yaml [--num-gpus N] [--eval-only] [KEY VALUE ...]``) and trainer dispatch on
+``cfg.TRAINER``.  One process per GPU: launch N>1 with
+``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train_net_mt.py ...``
+(the reference's ``launch()`` spawns the same topology itself)."""
+import argparse
+import importlib
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config-file", default="", metavar="FILE")
+    ap.add_argument("--num-gpus", type=int, default=1)
+    ap.add_argument("--eval-only", action="store_true", help="AdaBN refinement (train_net_mt.py:73-82)")
+    ap.add_argument("--resume", action="store_true")
+    ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
+    args = ap.parse_args()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.num_gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d --master-addr 127.0.0.1 "
+                         "train_net_mt.py ..." % args.num_gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    sfod = importlib.import_module("simple-sfod_amd")
+    cfg = sfod.config.setup_cfg(args.config_file, ["MODEL.DEVICE", f"cuda:{local_rank}"] + args.opts)
+    rank = int(os.environ.get("RANK", "0"))
+    torch.manual_seed(max(cfg.SEED, 0) + rank)           # d2 default_setup: seed_all_rng(SEED + rank)
+    Trainer = sfod.engine.get_trainer_class(cfg)
+    if args.eval_only:
+        model = Trainer.build_model(cfg)
+        loader = sfod.data.TwoCropLoader(cfg, torch.device(cfg.MODEL.DEVICE), rank, world, labeled=True)
+        sfod.engine.adabn_refinement(cfg, model, loader)
+        if rank == 0 and cfg.OUTPUT_DIR:
+            os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+            torch.save({"model": model.state_dict()}, os.path.join(cfg.OUTPUT_DIR, "adabn.pth"))
+        return
+    trainer = Trainer(cfg)
+    if world > 1:
+        dist.broadcast(trainer.optimizer.flat.param, 0)
+        dist.broadcast(trainer.optimizer.flat.fbuf, 0)
+        if hasattr(trainer, "_copy_main_model"):
+            trainer._copy_main_model()
+    trainer.train()
+
+
+if __name__ == "__main__":
+    main()
