@@ -62,11 +62,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // UT ("uniform tap"): every 8-chunk K tile lies inside ONE filter tap (Cin*sizeof(T) a multiple of
 // 128 bytes, or a 1x1 / linear layer), so tap decoding is scalar work per K tile and a lane's
 // source address is row_base + tile_delta; the general path (first layer, Cin = 3) decodes per lane.
-template <typename T, typename OutT, int WM, int WN, bool UT>
-__global__ void __launch_bounds__(256)
+// WR = wave rows (2 -> 128-row tile / 256 threads, 4 -> 256-row tile / 512 threads);
+// NST = LDS stages: 2 = load(t+1) || compute(t) with a full drain per K tile; 3 = two K tiles in
+// flight across raw s_barriers with a counted s_waitcnt vmcnt (the DMA queue is never drained
+// inside the loop).
+template <typename T, typename OutT, int WM, int WN, bool UT, int WR, int NST>
+__global__ void __launch_bounds__(WR * 128)
 k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
            OutT* __restrict__ y, float* __restrict__ stats, ConvArgs a, int tiles_n, int ntiles) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+  static_assert(WM == 2, "wave tile is 64 rows");
+  constexpr int NT = WR * 128;
+  constexpr int BM = WR * 32 * WM, BN = 64 * WN;
   constexpr int E = Chunk<T>::E;
   constexpr int STAGE = (BM + BN) * 128;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -84,8 +90,9 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   const int taps = a.ks * a.ks;
   const int HW = a.H * a.W;
 
-  // ---- per-thread DMA descriptors: AI = BM/32 A-instructions, BI = BN/32 B-instructions -------
-  constexpr int AI = BM / 32, BI = BN / 32;
+  // ---- per-thread DMA descriptors ---------------------------------------------------------------
+  constexpr int AI = BM / (16 * WR), BI = BN / (16 * WR);  // 1-KiB DMA instructions per wave and stage
+  static_assert(BI >= 1, "tile too narrow for this wave count");
   int a_row[AI];      // row inside the tile
   int a_oy[AI], a_ox[AI];
   int64_t a_pix[AI];  // flat pixel index (== m) or -1
@@ -259,19 +266,37 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
     }
   };
 
-  // ---- main loop: stage t+1 in flight while stage t computes -----------------------------------
-  stage_load(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < KT - 1; ++kt) {
-    stage_load(kt + 1, cur ^ 1);
-    stage_compute(cur);
+  // ---- main loop --------------------------------------------------------------------------------
+  if constexpr (NST == 2) {
+    stage_load(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    for (int kt = 0; kt < KT - 1; ++kt) {
+      stage_load(kt + 1, cur ^ 1);
+      stage_compute(cur);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+    }
+    stage_compute(cur);
+  } else {
+    // 3 stages: K tiles t+1 and t+2 are in flight while tile t feeds the MFMAs.  Per wave and stage
+    // exactly AI+BI DMA instructions are issued, so "all but the newest AI+BI" == "tile t landed".
+    stage_load(0, 0);
+    if (KT > 1) stage_load(1, 1);
+    int cur = 0, nxt = 2;
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everyone is done with tile kt-1
+      asm volatile("" ::: "memory");
+      if (kt + 2 < KT) stage_load(kt + 2, nxt);
+      stage_compute(cur);
+      cur = (cur == 2) ? 0 : cur + 1;
+      nxt = (nxt == 2) ? 0 : nxt + 1;
+    }
   }
-  stage_compute(cur);
 
   // ---- epilogue: bias + activation + store; optional per-block BN partial statistics ----------
   float bcol[WN];
@@ -279,24 +304,53 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
     const int n = n0 + wc * 32 * WN + j * 32 + (lane & 31);
     bcol[j] = (bias != nullptr && n < a.Cout) ? bias[n] : 0.f;
   }
+  constexpr bool STAGED = (sizeof(OutT) == 2);   // 2-byte outputs go through LDS for 16-byte stores
+  constexpr int CPITCH = BN * 2 + 16;            // bytes per staged row (+16: spread the banks)
+  constexpr int SRED_OFF = BM * CPITCH;          // scratch for the BN partials, behind the staged tile
+  if (STAGED) __syncthreads();                   // every wave is done with the operand stages
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
-      const int n = n0 + wc * 32 * WN + j * 32 + (lane & 31);
+      const int nl = wc * 32 * WN + j * 32 + (lane & 31);
+      const int n = n0 + nl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int m = m0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int ml = wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int m = m0 + ml;
         const float v = acc[i][j][r] + bcol[j];
         acc[i][j][r] = v;
-        if (m < a.M && n < a.Cout) y[(int64_t)m * a.ldy + n] = from_f32<OutT>(apply_act(v, a.act));
+        if (STAGED) {
+          *reinterpret_cast<OutT*>(smem + ml * CPITCH + nl * 2) = from_f32<OutT>(apply_act(v, a.act));
+        } else {
+          if (m < a.M && n < a.Cout) y[(int64_t)m * a.ldy + n] = from_f32<OutT>(apply_act(v, a.act));
+        }
       }
     }
+  if (STAGED) {
+    __syncthreads();
+    constexpr int CH_PER_ROW = BN / 8;           // 16-byte chunks per staged row
+    const bool vec_ok = (a.ldy % 8) == 0;
+    for (int c = threadIdx.x; c < BM * CH_PER_ROW; c += NT) {
+      const int row = c / CH_PER_ROW, ch = c % CH_PER_ROW;
+      const int m = m0 + row, n = n0 + ch * 8;
+      if (m >= a.M || n >= a.Cout) continue;
+      const unsigned char* src = smem + row * CPITCH + ch * 16;
+      OutT* dst = y + (int64_t)m * a.ldy + n;
+      if (vec_ok && n + 8 <= a.Cout) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+      } else {
+        for (int e = 0; e < 8 && n + e < a.Cout; ++e) dst[e] = reinterpret_cast<const OutT*>(src)[e];
+      }
+    }
+  }
 
   if (stats != nullptr) {
+    // statistics are reported per 128-row half tile: wave rows (2*hf, 2*hf+1) form half hf
     __syncthreads();  // LDS reuse
-    float* sred = reinterpret_cast<float*>(smem);  // [2 (wr)][BN]
-    const int rows_valid = min(BM, a.M - m0);
+    float* sred = reinterpret_cast<float*>(smem + SRED_OFF);  // [WR][BN]
+    const int hf = wr >> 1;
+    const int rows_valid = min(128, a.M - (m0 + hf * 128));
     // pass 1: column sums
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
@@ -316,11 +370,11 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       const int nl = wc * 32 * WN + j * 32 + (lane & 31);
-      csum[j] = sred[nl] + sred[BN + nl];
-      cmean[j] = csum[j] / (float)rows_valid;
+      csum[j] = sred[(2 * hf) * BN + nl] + sred[(2 * hf + 1) * BN + nl];
+      cmean[j] = csum[j] / (float)max(rows_valid, 1);
     }
     __syncthreads();
-    // pass 2: squared deviations from the block mean
+    // pass 2: squared deviations from the half-tile mean
 #pragma unroll
     for (int j = 0; j < WN; ++j) {
       float s = 0.f;
@@ -336,14 +390,15 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
       if (h == 0) sred[wr * BN + wc * 32 * WN + j * 32 + (lane & 31)] = s;
     }
     __syncthreads();
-    if (wr == 0 && h == 0) {
+    if ((wr & 1) == 0 && h == 0 && rows_valid > 0) {
+      const int sblk = tile_m * (BM / 128) + hf;
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
         const int nl = wc * 32 * WN + j * 32 + (lane & 31);
         const int n = n0 + nl;
         if (n < a.Cout) {
-          stats[((int64_t)tile_m * 2 + 0) * a.Cout + n] = csum[j];
-          stats[((int64_t)tile_m * 2 + 1) * a.Cout + n] = sred[nl] + sred[BN + nl];
+          stats[((int64_t)sblk * 2 + 0) * a.Cout + n] = csum[j];
+          stats[((int64_t)sblk * 2 + 1) * a.Cout + n] = sred[(2 * hf) * BN + nl] + sred[(2 * hf + 1) * BN + nl];
         }
       }
     }
@@ -358,22 +413,36 @@ static int ilog2_exact(int v) {
 
 extern "C" int sfod_conv_stats_blocks(int M) { return (M + 127) / 128; }
 
+template <typename T, typename OutT, int WN, bool UT, int WR, int NST>
+static int launch_one(const void* x, const void* w, const float* bias, void* y, float* stats,
+                      const ConvArgs& a, hipStream_t s) {
+  constexpr int BM = WR * 64, BN = 64 * WN;
+  constexpr int OPER = NST * (BM + BN) * 128;
+  constexpr int EPI = BM * (BN * 2 + 16) + WR * BN * 4;  // staged C tile + BN partial scratch
+  constexpr int LDS = OPER > EPI ? OPER : EPI;
+  auto kern = k_conv_fwd<T, OutT, 2, WN, UT, WR, NST>;
+  static bool attr_set = false;
+  if (!attr_set && LDS > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -(int)e; }
+    attr_set = true;
+  }
+  const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Cout + BN - 1) / BN;
+  const int nt = tiles_m * tiles_n;
+  hipLaunchKernelGGL(kern, dim3(nt), dim3(WR * 128), LDS, s, (const T*)x, (const T*)w, bias, (OutT*)y, stats, a,
+                     tiles_n, nt);
+  return sfod_check_launch("conv_fwd");
+}
+
 template <typename T, typename OutT, bool UT>
 static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
                               const ConvArgs& a, hipStream_t s) {
-  const int tiles_m = (a.M + 127) / 128;
-  if (a.Cout <= 64) {
-    const int tiles_n = (a.Cout + 63) / 64;
-    const int nt = tiles_m * tiles_n;
-    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 1, UT>), dim3(nt), dim3(256), 2 * (128 + 64) * 128, s,
-                       (const T*)x, (const T*)w, bias, (OutT*)y, stats, a, tiles_n, nt);
-  } else {
-    const int tiles_n = (a.Cout + 127) / 128;
-    const int nt = tiles_m * tiles_n;
-    hipLaunchKernelGGL((k_conv_fwd<T, OutT, 2, 2, UT>), dim3(nt), dim3(256), 2 * (128 + 128) * 128, s,
-                       (const T*)x, (const T*)w, bias, (OutT*)y, stats, a, tiles_n, nt);
-  }
-  return sfod_check_launch("conv_fwd");
+  if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2>(x, w, bias, y, stats, a, s);
+  // 256 x 128 tiles with a 3-stage DMA pipeline once the grid still fills the chip (>= 2 tiles / CU)
+  const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
+  if (UT && big_tiles >= 512) return launch_one<T, OutT, 2, UT, 4, 3>(x, w, bias, y, stats, a, s);
+  return launch_one<T, OutT, 2, UT, 2, 2>(x, w, bias, y, stats, a, s);
 }
 
 template <typename T, typename OutT>
@@ -426,6 +495,7 @@ struct WgradArgs {
   int lddy;
   int Ntot;      // taps * Cin (row stride of dw)
   int pix_per_split;
+  int tiles_n, tiles_m;
 };
 
 template <typename T, int WM, int WN>
@@ -441,8 +511,17 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wr = wave >> 1, wc = wave & 1;
-  const int n0 = blockIdx.x * BN, co0 = blockIdx.y * BM;
-  const int p_begin = blockIdx.z * a.pix_per_split;
+  // XCD-aware order: the workgroups of one XCD (blockIdx % 8) walk consecutive work items, and
+  // work items are split-major, so all (n, m) tiles of one pixel slice share one L2.
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt / 8, r = nt % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tiles = a.tiles_n * a.tiles_m;
+  const int split = bid / tiles, trem = bid % tiles;
+  const int n0 = (trem % a.tiles_n) * BN, co0 = (trem / a.tiles_n) * BM;
+  const int p_begin = split * a.pix_per_split;
   const int p_end = min(a.M, p_begin + a.pix_per_split);
   if (p_begin >= p_end) return;
   const int taps = a.ks * a.ks;
@@ -629,7 +708,9 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   pps = (pps + BKP - 1) / BKP * BKP;
   splits = (a.M + pps - 1) / pps;
   a.pix_per_split = pps;
-  dim3 grid(tiles_n, tiles_m, splits);
+  a.tiles_n = tiles_n;
+  a.tiles_m = tiles_m;
+  dim3 grid(tiles_n * tiles_m * splits);
   hipStream_t s = (hipStream_t)stream;
   if (dt == SFOD_F32)
     hipLaunchKernelGGL((k_conv_wgrad<float, 2, 2>), grid, dim3(256), 2 * 2 * 32 * 512, s, (const float*)x,
