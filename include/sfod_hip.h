@@ -44,19 +44,28 @@ int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes, int B, in
  * x: [B,H,W,Cin] NHWC, w: packed [Cout][KH*KW][Cin] (K contiguous), y: [B,H,W,ldy] with ldy >=
  * Cout.  KH=KW=3 pad 1 (vgg.py:18 conv3x3; d2 StandardRPNHead.conv; dann.py:14-17) or KH=KW=1
  * (1x1 convs and nn.Linear: x [R,K] -> y [R,N]).  act: 0 none, 1 ReLU, 2 LeakyReLU(0.2).
- * stats (optional, fp32 [gridM][2][Cout]): per-row-block (sum, M2) of the pre-activation output
- * for the train-mode BatchNorm that follows (vgg.py:20).  out_dt may differ from dt (e.g. fp32
+ * stats (optional, fp32 [nblk][2][Cout] followed by [nblk] row counts, nblk from
+ * sfod_conv_stats_blocks): per-row-block (sum, M2, count) of the pre-activation output for the
+ * train-mode BatchNorm that follows (vgg.py:20).  out_dt may differ from dt (e.g. fp32
  * logits out of a bf16 head).  Also used for data-gradient (dgrad) with rotated weights. */
 int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
                   int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
                   void* stream);
-/* number of row blocks (gridM) sfod_conv_fwd uses for M = B*H*W rows (size of `stats`) */
-int sfod_conv_stats_blocks(int M);
+/* number of statistics blocks nblk sfod_conv_fwd writes for this layer shape; `stats` holds
+ * nblk * (2*Cout + 1) floats */
+int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
+/* kernel selection for 3x3 bf16 convolutions: 0 auto, 1 generic implicit GEMM (im2col chunks
+ * DMA'd per tap), 2 halo-patch kernel (input patch staged once per 32-channel slice and reused by
+ * all nine taps) whenever the shape allows.  For A/B tests and benchmarks. */
+int sfod_set_conv_algo(int algo);
 
-/* weight gradient: dw[n][tap][c] (+)= sum_m dy[m][n] * x[pix(m)+tap][c]  (fp32, packed layout,
- * accumulated with float atomics into a zero-initialised buffer; split over row chunks). */
+/* weight gradient: dw[n][tap][c] += sum_m dy[m][n] * x[pix(m)+tap][c]  (fp32, packed layout, added
+ * into the caller's (zero-initialised) buffer).  3x3 bf16 layers run the halo-patch kernel: pixel
+ * splits write fp32 slabs into `ws` (sfod_conv_wgrad_ws_bytes, may be 0 -> ws unused) and are summed
+ * in a fixed order; other shapes use the generic kernel (split over row chunks, float atomics). */
+int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt);
 int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
-                    int Cout, int ksize, int lddy, int dt, void* stream);
+                    int Cout, int ksize, int lddy, int dt, void* ws, int64_t ws_bytes, void* stream);
 
 /* weight (re)packing between the reference's state-dict layouts and the kernel layouts.
  * OIHW fp32 [Cout][Cin][KH][KW] -> packed [Cout][KH*KW][CinPad] (dt); rot180=1 additionally
@@ -87,7 +96,7 @@ int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, int accumula
  * BatchNorm2d semantics of SURVEY.md A.14 (biased var to normalise, unbiased var into
  * running_var, momentum 0.1, eps 1e-5).  This is also the AdaBN running-stat refresh
  * (daod/engine/trainers/base.py:270-337): it runs identically under no_grad. */
-int sfod_bn_finalize(const float* stats, int nblocks, int rows_per_block, int M, int C,
+int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                      float* mean, float* invstd, float* running_mean, float* running_var,
                      float momentum, float eps, int update_running, float* ws, void* stream);
 /* size (in floats, 8-byte aligned) of the `ws` scratch of sfod_bn_finalize */

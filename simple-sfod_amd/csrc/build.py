@@ -20,10 +20,12 @@ SOURCES = {
     "roi_align.hip": ["-ffp-contract=off"],
     "elementwise.hip": [],
     "gemm_conv.hip": [],
+    "conv3x3_patch.hip": [],
+    "wgrad3x3_patch.hip": [],
     "sort.hip": [],
     "runtime.cpp": [],
 }
-HEADERS = ["common.h", os.path.join("..", "..", "include", "sfod_hip.h")]
+HEADERS = ["common.h", "conv_internal.h", os.path.join("..", "..", "include", "sfod_hip.h")]
 
 
 def _stale(target, deps):

@@ -1,0 +1,462 @@
+// Halo-patch 3x3 convolution (forward and data-gradient), bf16 MFMA, gfx950.
+//
+// Why not the generic implicit GEMM (gemm_conv.hip): that kernel re-fetches every input pixel once
+// per filter tap (9x) from L2 into LDS and is bound by the L2 -> LDS path, not by the matrix cores.
+// Here a workgroup owns a TH x TW patch of output pixels (<= 512) of one image and BN output
+// channels; per 32-channel slice of the input it DMAs the (TH+2) x (TW+2) halo patch into LDS ONCE
+// and feeds all nine taps from it (an A fragment row for tap (ky,kx) is just the patch row shifted
+// by ky*(TW+2)+kx).  Only the weights stream per tap.  L2 -> LDS bytes per MAC drop ~3.3x.
+//
+//   LDS   patch[2]  : 640 rows x 64 B  (32 bf16 channels / pixel), 16-byte chunk c of row r stored
+//                     at chunk c ^ ((r >> 2) & 3): any 16 rows distinct mod 16 are conflict free
+//                     for ds_read_b128
+//         B ring[4] : 8 KiB = G (tap, 32ch) slices x BN weight rows x 64 B, same swizzle
+//   waves 8 (512 threads).  G=1: BN=128, 4(M) x 2(N) waves, wave tile 128 px x 64 ch
+//                           G=2: BN=64,  8(M) x 1(N) waves, wave tile  64 px x 64 ch
+//   K loop "body" = G input slices = 9 stages; stage = G (tap, slice) pairs = 16 MFMA / wave.
+//         One s_barrier per stage.  DMA (global_load_lds, 16 B / lane) runs 3 stages ahead for the
+//         weights and up to a whole body ahead for the next patch; the queue is never drained in the
+//         loop: each stage waits with a counted s_waitcnt vmcnt(N) (tables below, derived by
+//         simulating the per-wave issue order: every wave issues the same number of DMAs per stage).
+//   epilogue: bias + activation; bf16 tiles are staged per wave through LDS for 16-byte stores;
+//         optional BatchNorm partial statistics (sum, M2, count) per workgroup (fp64 combine).
+#include "conv_internal.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+namespace {
+
+template <int J> using IC = std::integral_constant<int, J>;
+
+constexpr int PATCH_ROWS = 640;
+constexpr int PATCH_BYTES = PATCH_ROWS * 64;     // 40960
+constexpr int BRING_OFF = 2 * PATCH_BYTES;       // 81920
+constexpr int BSLOT = 8192;
+constexpr int STG_PITCH = 144;                   // staged C row: 64 bf16 + 16 B pad
+constexpr int STG_BYTES = 8 * 128 * STG_PITCH;   // 147456 (G=1: 8 waves x 128 rows)
+constexpr int PIXTAB_OFF = STG_BYTES;            // int32 [512]
+constexpr int SRED_OFF = PIXTAB_OFF + 2048;      // float [8 waves][64 cols][2] + float [8]
+constexpr int LDS_TOTAL = SRED_OFF + 8 * 64 * 2 * 4 + 32;
+
+struct P3Args {
+  const bf16_t* x;
+  const bf16_t* w;
+  const float* bias;
+  void* y;
+  float* stats;
+  int B, H, W, Cin, Cout, ldy, act;
+  int TH, TW, PW;
+  int tiles_x, tiles_y, tiles_n;
+  int nbody;    // Cin / (32 * G)
+  int ntiles;
+  int nblk;
+};
+
+// 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16), through a raw buffer
+// resource: a lane whose byte offset is >= num_records (OOB_OFF) gets zeros written -- that is how
+// padding pixels, tile overhang and channel tails are produced, without a branch or a zero page.
+constexpr unsigned OOB_OFF = 0x80000000u;
+__device__ __forceinline__ void bufload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(l), 16, (int)voff, (int)soff, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__device__ __forceinline__ float act_f(float v, int act) {
+  if (act == 1) return fmaxf(v, 0.f);
+  if (act == 2) return v > 0.f ? v : 0.2f * v;
+  return v;
+}
+
+// vmcnt immediates per stage (steady state / last body), see header comment
+template <int G> struct WaitTab;
+template <> struct WaitTab<1> {
+  static constexpr int N[9] = {2, 3, 4, 4, 4, 4, 3, 2, 2};
+  static constexpr int NL[9] = {2, 2, 2, 2, 2, 2, 2, 1, 0};
+  static constexpr int PP[9] = {1, 1, 1, 1, 1, 0, 0, 0, 0};
+};
+template <> struct WaitTab<2> {
+  static constexpr int N[9] = {1, 4, 5, 4, 1, 2, 4, 5, 4};
+  static constexpr int NL[9] = {1, 4, 5, 4, 1, 2, 2, 1, 0};
+  static constexpr int PP[9] = {2, 1, 1, 1, 0, 2, 1, 1, 1};
+};
+
+template <int G, typename OutT>
+__global__ void __launch_bounds__(512)
+k_conv3x3_patch(P3Args a) {
+  constexpr int BN = 128 / G;
+  constexpr int FM = (G == 1) ? 4 : 2;   // 32-row fragments per wave along M
+  constexpr int FN = 2;                  // 32-col fragments per wave along N
+  constexpr int WROWS = FM * 32;         // rows of a wave tile
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = (G == 1) ? (wave >> 1) : wave;
+  const int wn = (G == 1) ? (wave & 1) : 0;
+  const int h = lane >> 5;
+
+  // ---- tile decode (XCD-aware order: workgroups of one XCD walk consecutive tiles) ---------------
+  int bid = blockIdx.x;
+  {
+    const int q = a.ntiles / 8, r = a.ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tn = bid % a.tiles_n;
+  int t = bid / a.tiles_n;
+  const int txi = t % a.tiles_x;
+  t /= a.tiles_x;
+  const int tyi = t % a.tiles_y;
+  const int b = t / a.tiles_y;
+  const int mtile = (b * a.tiles_y + tyi) * a.tiles_x + txi;
+  const int x0 = txi * a.TW, y0 = tyi * a.TH, n0 = tn * BN;
+  const int PW = a.PW;
+  const int npix = a.TH * a.TW;
+  const bf16_t* ximg = a.x + (int64_t)b * a.H * a.W * a.Cin;
+  const int Ktot = 9 * a.Cin;
+
+  // ---- pixel table: tile pixel -> pixel index inside the image, -1 outside ------------------------
+  int* pixtab = reinterpret_cast<int*>(smem + PIXTAB_OFF);
+  {
+    const int p = threadIdx.x;
+    int v = -1;
+    if (p < npix) {
+      const int ty = p / a.TW, tx = p - ty * a.TW;
+      if (y0 + ty < a.H && x0 + tx < a.W) v = (y0 + ty) * a.W + (x0 + tx);
+    }
+    pixtab[p] = v;
+  }
+
+  // ---- DMA descriptors ---------------------------------------------------------------------------
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)ximg, (short)0, a.H * a.W * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.w, (short)0, a.Cout * Ktot * 2, 0x00020000);
+  unsigned poff[5];  // byte offset inside the image of this lane's 16-byte chunk (slice 0) or OOB_OFF
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const int row = (wave * 5 + k) * 16 + (lane >> 2);
+    const int lc = (lane & 3) ^ ((row >> 2) & 3);
+    const int py = row / PW, px = row - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = (py < a.TH + 2) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    poff[k] = ok ? (unsigned)(((iy * a.W + ix) * a.Cin + lc * 8) * 2) : OOB_OFF;
+  }
+  unsigned boff;  // weight byte offset of this lane's chunk for (tap 0, slice 0) or OOB_OFF
+  {
+    const int r = wave * 16 + (lane >> 2);
+    const int n = r % BN;
+    const int lc = (lane & 3) ^ ((n >> 2) & 3);
+    boff = (n0 + n < a.Cout) ? (unsigned)(((n0 + n) * Ktot + lc * 8) * 2) : OOB_OFF;
+  }
+  const int epair = (G == 2) ? (wave >> 2) : 0;  // which (tap, slice) pair of a stage this wave's B DMA feeds
+
+  auto issue_patch = [&](int k, int slice, int buf) {
+    bufload16(xres, poff[k], (unsigned)slice * 64u, smem + buf * PATCH_BYTES + (wave * 5 + k) * 1024);
+  };
+  // weights of global stage sg (= body * 9 + j)
+  auto issue_b = [&](int sg) {
+    const int gp = sg * G + epair;  // global pair index
+    const int slice = gp / 9, tap = gp - slice * 9;
+    bufload16(wres, boff, (unsigned)(tap * a.Cin + slice * 32) * 2u, smem + BRING_OFF + (sg & 3) * BSLOT + wave * 1024);
+  };
+
+  // ---- fragment addressing -------------------------------------------------------------------------
+  int rowA[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int p = wm * WROWS + i * 32 + (lane & 31);
+    rowA[i] = (p < npix) ? ((p / a.TW) * PW + (p % a.TW)) : 0;
+  }
+  int offB[FN];  // byte offset inside a (pair) slice of the B slot, k-step 0 (k-step 1 = ^32)
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = wn * 64 + j * 32 + (lane & 31);
+    offB[j] = n * 64 + ((h ^ ((n >> 2) & 3)) << 4);
+  }
+
+  f32x16 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one (tap, slice) pair: 2 k-steps of 16 channels
+  auto compute_pair = [&](int tap, const unsigned char* patch, const unsigned char* bsl) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int dtap = ky * PW + kx;
+    int addrA[FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = rowA[i] + dtap;
+      addrA[i] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 af[FM], bfr[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(patch + (addrA[i] ^ (s << 5)));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(bsl + (offB[j] ^ (s << 5)));
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- prologue: first patch + weights of stages 0..2 -----------------------------------------------
+#pragma unroll
+  for (int k = 0; k < 5; ++k) issue_patch(k, 0, 0);
+  issue_b(0);
+  issue_b(1);
+  issue_b(2);
+
+  const int nstages = a.nbody * 9;
+  for (int body = 0; body < a.nbody; ++body) {
+    const bool last = (body == a.nbody - 1);
+    const int sg0 = body * 9;
+    auto stage = [&](auto jc) {
+      constexpr int j = decltype(jc)::value;
+      if (last) wait_vm<WaitTab<G>::NL[j]>(); else wait_vm<WaitTab<G>::N[j]>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      // -- issue: patch pieces first, then the weights of stage j + 3
+      if constexpr (G == 1) {
+        if constexpr (j < 5) {
+          if (!last) issue_patch(j, body + 1, (body + 1) & 1);
+        }
+      } else {
+        // stages 0..3: second slice of this body -> buffer 1; stages 5..8: first slice of the next
+        // body -> buffer 0 (its last reader was stage 4)
+        if constexpr (j == 0) {
+          issue_patch(0, 2 * body + 1, 1);
+          issue_patch(1, 2 * body + 1, 1);
+        } else if constexpr (j < 4) {
+          issue_patch(j + 1, 2 * body + 1, 1);
+        } else if constexpr (j == 5) {
+          if (!last) { issue_patch(0, 2 * body + 2, 0); issue_patch(1, 2 * body + 2, 0); }
+        } else if constexpr (j > 5) {
+          if (!last) issue_patch(j - 4, 2 * body + 2, 0);
+        }
+      }
+      if (sg0 + j + 3 < nstages) issue_b(sg0 + j + 3);
+      // -- compute stage j
+      const unsigned char* bsl = smem + BRING_OFF + ((sg0 + j) & 3) * BSLOT;
+      if constexpr (G == 1) {
+        compute_pair(j, smem + (body & 1) * PATCH_BYTES, bsl);
+      } else {
+        compute_pair((2 * j) % 9, smem + ((2 * j) / 9) * PATCH_BYTES, bsl);
+        compute_pair((2 * j + 1) % 9, smem + ((2 * j + 1) / 9) * PATCH_BYTES, bsl + BN * 64);
+      }
+    };
+    stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{});
+    stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{}); stage(IC<8>{});
+  }
+
+  // ---- epilogue -------------------------------------------------------------------------------------
+  float bcol[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+    bcol[j] = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
+  }
+  __syncthreads();  // every wave is done reading operands; LDS is reused below
+  const int64_t ybase = (int64_t)b * a.H * a.W;
+  unsigned vmask[FM];  // bit r: row (i, r) of this lane is a real output pixel
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    unsigned m = 0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (pixtab[wm * WROWS + ml] >= 0) m |= (1u << r);
+    }
+    vmask[i] = m;
+  }
+  if constexpr (sizeof(OutT) == 2) {
+    unsigned char* stg = smem + wave * (WROWS * STG_PITCH);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int nl = j * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[i][j][r] + bcol[j];
+          acc[i][j][r] = v;
+          *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + nl * 2) = (bf16_t)act_f(v, a.act);
+        }
+      }
+    const bool vec_ok = (a.ldy % 8) == 0;
+    bf16_t* yo = reinterpret_cast<bf16_t*>(a.y);
+#pragma unroll 4
+    for (int it = 0; it < WROWS / 8; ++it) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const int pix = pixtab[wm * WROWS + row];
+      const int n = n0 + wn * 64 + ch * 8;
+      if (pix < 0 || n >= a.Cout) continue;
+      const unsigned char* src = stg + row * STG_PITCH + ch * 16;
+      bf16_t* dst = yo + (ybase + pix) * a.ldy + n;
+      if (vec_ok && n + 8 <= a.Cout) {
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+      } else {
+        for (int e = 0; e < 8 && n + e < a.Cout; ++e) dst[e] = reinterpret_cast<const bf16_t*>(src)[e];
+      }
+    }
+  } else {
+    float* yo = reinterpret_cast<float*>(a.y);
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int pix = pixtab[wm * WROWS + ml];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+          const float v = acc[i][j][r] + bcol[j];
+          acc[i][j][r] = v;
+          if (pix >= 0 && n < a.Cout) yo[(ybase + pix) * a.ldy + n] = act_f(v, a.act);
+        }
+      }
+  }
+
+  if (a.stats != nullptr) {
+    // per-wave (count, sum, M2) of the pre-activation values, combined over the workgroup in fp64
+    float* sred = reinterpret_cast<float*>(smem + SRED_OFF);     // [wave][64][2]
+    float* scnt = sred + 8 * 64 * 2;                              // [wave]
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) cnt += __builtin_popcount(vmask[i]);
+    cnt += __shfl_xor(cnt, 32);
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += ((vmask[i] >> r) & 1u) ? acc[i][j][r] : 0.f;
+      s += __shfl_xor(s, 32);
+      const float mean = s * inv;
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[i][j][r] - mean;
+          q += ((vmask[i] >> r) & 1u) ? d * d : 0.f;
+        }
+      q += __shfl_xor(q, 32);
+      if (h == 0) {
+        sred[(wave * 64 + j * 32 + (lane & 31)) * 2 + 0] = s;
+        sred[(wave * 64 + j * 32 + (lane & 31)) * 2 + 1] = q;
+      }
+    }
+    if (lane == 0) scnt[wave] = (float)cnt;
+    __syncthreads();
+    if (threadIdx.x < BN) {
+      const int col = threadIdx.x;           // column of the workgroup tile
+      const int cwn = (G == 1) ? (col >> 6) : 0;
+      const int cl = col & 63;
+      constexpr int NWM = (G == 1) ? 4 : 8;
+      double n_tot = 0.0, s_tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < NWM; ++k) {
+        const int wv = (G == 1) ? (k * 2 + cwn) : k;
+        n_tot += (double)scnt[wv];
+        s_tot += (double)sred[(wv * 64 + cl) * 2 + 0];
+      }
+      const double mu = n_tot > 0.0 ? s_tot / n_tot : 0.0;
+      double m2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NWM; ++k) {
+        const int wv = (G == 1) ? (k * 2 + cwn) : k;
+        const double nk = (double)scnt[wv];
+        if (nk > 0.0) {
+          const double d = (double)sred[(wv * 64 + cl) * 2 + 0] / nk - mu;
+          m2 += (double)sred[(wv * 64 + cl) * 2 + 1] + nk * d * d;
+        }
+      }
+      const int n = n0 + col;
+      if (n < a.Cout) {
+        a.stats[((int64_t)mtile * 2 + 0) * a.Cout + n] = (float)s_tot;
+        a.stats[((int64_t)mtile * 2 + 1) * a.Cout + n] = (float)m2;
+      }
+      if (col == 0 && tn == 0) a.stats[(int64_t)a.nblk * 2 * a.Cout + mtile] = (float)n_tot;
+    }
+  }
+}
+
+}  // namespace
+
+// Tile shape: maximise covered-output efficiency under TH*TW <= 512 and (TH+2)*(TW+2) <= 640.
+P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
+  P3Plan p;
+  p.ok = 0;
+  if (H < 1 || W < 1 || B < 1) return p;
+  p.G = (Cout <= 64) ? 2 : 1;
+  if (Cin % (32 * p.G) != 0) return p;
+  if ((int64_t)H * W * Cin >= (int64_t)1 << 30 || (int64_t)Cout * 9 * Cin >= (int64_t)1 << 30) return p;  // 32-bit byte offsets
+  double best = -1.0;
+  for (int tw = 4; tw <= 128 && tw <= W + 3; ++tw) {
+    int th = 512 / tw;
+    while (th > 1 && (th + 2) * (tw + 2) > PATCH_ROWS) --th;
+    if (th > H) th = H;
+    if (th < 1 || (th + 2) * (tw + 2) > PATCH_ROWS) continue;
+    const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+    // even out the rows so that the last tile row is not nearly empty
+    th = (H + ty - 1) / ty;
+    const double eff = (double)H * W / ((double)ty * tx * 512.0);
+    // tie-break towards wide tiles (longer contiguous runs per patch row)
+    const double score = eff + 1e-6 * tw;
+    if (score > best) { best = score; p.TH = th; p.TW = tw; p.tiles_y = ty; p.tiles_x = tx; }
+  }
+  if (best < 0.0) return p;
+  p.tiles_n = (Cout + (128 / p.G) - 1) / (128 / p.G);
+  p.nblk = B * p.tiles_y * p.tiles_x;
+  p.ok = 1;
+  return p;
+}
+
+int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
+                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s) {
+  P3Args a;
+  a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = y; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.act = act;
+  a.TH = p.TH; a.TW = p.TW; a.PW = p.TW + 2;
+  a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.tiles_n = p.tiles_n;
+  a.nbody = Cin / (32 * p.G);
+  a.ntiles = B * p.tiles_y * p.tiles_x * p.tiles_n;
+  a.nblk = p.nblk;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* ks[4] = {(const void*)k_conv3x3_patch<1, bf16_t>, (const void*)k_conv3x3_patch<1, float>,
+                         (const void*)k_conv3x3_patch<2, bf16_t>, (const void*)k_conv3x3_patch<2, float>};
+    for (int i = 0; i < 4; ++i) {
+      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+      if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute(p3): %s", hipGetErrorString(e)); return -(int)e; }
+    }
+    attr_set = true;
+  }
+  dim3 grid(a.ntiles), blk(512);
+  if (p.G == 1) {
+    if (out_f32) hipLaunchKernelGGL((k_conv3x3_patch<1, float>), grid, blk, LDS_TOTAL, s, a);
+    else hipLaunchKernelGGL((k_conv3x3_patch<1, bf16_t>), grid, blk, LDS_TOTAL, s, a);
+  } else {
+    if (out_f32) hipLaunchKernelGGL((k_conv3x3_patch<2, float>), grid, blk, LDS_TOTAL, s, a);
+    else hipLaunchKernelGGL((k_conv3x3_patch<2, bf16_t>), grid, blk, LDS_TOTAL, s, a);
+  }
+  return sfod_check_launch("conv3x3_patch");
+}

@@ -1,0 +1,35 @@
+// Internal (non-ABI) interface between gemm_conv.hip (the sfod_conv_* entry points) and the
+// halo-patch 3x3 kernels in conv3x3_patch.hip / wgrad3x3_rows.hip.
+#pragma once
+#include "common.h"
+
+// ---- forward / dgrad 3x3, bf16 -----------------------------------------------------------------
+// Tile plan of the halo-patch kernel for one layer shape; ok == 0 -> shape not supported, use the
+// generic implicit-GEMM kernel.
+struct P3Plan {
+  int ok;
+  int G;                 // 1: 128 output channels / workgroup, 2: 64
+  int TH, TW;            // output pixels per tile (TH*TW <= 512, (TH+2)*(TW+2) <= 640)
+  int tiles_y, tiles_x, tiles_n;
+  int nblk;              // BatchNorm statistics blocks = B * tiles_y * tiles_x
+};
+P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout);
+int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
+                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s);
+
+// BatchNorm statistics buffer layout shared by every conv kernel:
+//   stats[blk][0][c] = sum over the block's valid rows, stats[blk][1][c] = sum of squared deviations
+//   from the block mean, and, behind the nblk*2*C sums, counts[blk] = number of valid rows (float).
+
+// ---- weight gradient 3x3, bf16 -------------------------------------------------------------------
+struct W3Plan {
+  int ok;
+  int CO;                // 32-channel output fragments per workgroup: 4 (128 channels) or 2 (Cout <= 64)
+  int TH, TW, tiles_y, tiles_x;
+  int co_tiles, ci_tiles;
+  int tiles_per_split, nsplit, nslab;
+  int64_t ws_bytes;      // fp32 partial slabs [nslab][Cout][9][Cin]
+};
+W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy);
+int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
+                   int Cin, int Cout, int lddy, hipStream_t s);

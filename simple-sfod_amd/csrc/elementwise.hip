@@ -81,24 +81,26 @@ extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes
 
 // ---------------------------------------------------------------------------------------------
 // K3 BatchNorm statistics finalize.  stats[blk][0][c] = sum over the block's rows, stats[blk][1][c]
-// = sum of squared deviations from the block mean (written by the conv epilogue).  Combined in
+// = sum of squared deviations from the block mean, counts[blk] (behind the sums) = rows of the block
+// (all written by the conv epilogue).  Combined in
 // fp64:  M2 = sum_b M2_b + sum_b s_b^2/n_b - (sum_b s_b)^2 / M .  Two launches: BNF_SPLITS x C/64
 // workgroups reduce slices of the block axis, one small kernel combines them.
 // ---------------------------------------------------------------------------------------------
 #define BNF_SPLITS 64
 
 __global__ void __launch_bounds__(256)
-k_bn_partial(const float* __restrict__ stats, int nblocks, int rows_per_block, int M, int C,
-             double* __restrict__ part) {
+k_bn_partial(const float* __restrict__ stats, int nblocks, int C, double* __restrict__ part) {
   __shared__ double red[4][3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int per = (nblocks + gridDim.y - 1) / gridDim.y;
   const int b0 = blockIdx.y * per, b1 = min(nblocks, b0 + per);
+  const float* counts = stats + (int64_t)nblocks * 2 * C;
   double a = 0.0, q = 0.0, m2 = 0.0;
   if (c < C)
     for (int blk = b0 + wave; blk < b1; blk += 4) {
-      const double nb = (double)min(rows_per_block, M - blk * rows_per_block);
+      const double nb = (double)counts[blk];
+      if (nb <= 0.0) continue;
       const double sb = (double)stats[((int64_t)blk * 2) * C + c];
       a += sb;
       q += sb * sb / nb;
@@ -139,7 +141,7 @@ k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __r
 
 extern "C" int sfod_bn_finalize_ws_floats(int C) { return BNF_SPLITS * 3 * C * 2; }
 
-extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int rows_per_block, int M, int C,
+extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                                 float* mean, float* invstd, float* running_mean, float* running_var,
                                 float momentum, float eps, int update_running, float* ws, void* stream) {
   SFOD_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "bn_finalize: 8-byte aligned workspace required");
@@ -148,8 +150,7 @@ extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int rows_per_bl
   if (nsplit > BNF_SPLITS) nsplit = BNF_SPLITS;
   if (nsplit < 1) nsplit = 1;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), nsplit), dim3(256), 0, s, stats, nblocks, rows_per_block, M,
-                     C, part);
+  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), nsplit), dim3(256), 0, s, stats, nblocks, C, part);
   hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 64)), dim3(64), 0, s, part, nsplit, M, C, mean, invstd,
                      running_mean, running_var, momentum, eps, update_running);
   return sfod_check_launch("bn_finalize");

@@ -13,7 +13,7 @@
 // The LDS image is lane-linear (what the DMA writes), so the swizzle is applied to the per-lane
 // SOURCE address and again on the read.  Two LDS stages: stage t+1 is in flight while stage t
 // feeds the MFMAs.
-#include "common.h"
+#include "conv_internal.h"
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -401,6 +401,9 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
           stats[((int64_t)sblk * 2 + 1) * a.Cout + n] = sred[(2 * hf) * BN + nl] + sred[(2 * hf + 1) * BN + nl];
         }
       }
+      // row count of the block, behind the [nblk][2][Cout] sums
+      if (tile_n == 0 && wc == 0 && lane == 0)
+        stats[(int64_t)((a.M + 127) / 128) * 2 * a.Cout + sblk] = (float)rows_valid;
     }
   }
 }
@@ -411,7 +414,22 @@ static int ilog2_exact(int v) {
   return ((1 << s) == v) ? s : -1;
 }
 
-extern "C" int sfod_conv_stats_blocks(int M) { return (M + 127) / 128; }
+static int g_conv_algo = 0;  // 0 auto, 1 generic implicit GEMM only, 2 halo-patch kernel whenever the shape allows
+extern "C" int sfod_set_conv_algo(int algo) { g_conv_algo = algo; return 0; }
+
+static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, int dt) {
+  if (ksize != 3 || dt != SFOD_BF16 || !p.ok || g_conv_algo == 1) return false;
+  if (g_conv_algo == 2) return true;
+  // small maps (e.g. the 18x37 RPN head): too few 512-pixel tiles to fill the chip, the 128-row
+  // generic tiles do better there
+  return (int64_t)B * p.tiles_y * p.tiles_x * p.tiles_n >= 128;
+}
+
+extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
+  const P3Plan p = (ksize == 3 && dt == SFOD_BF16) ? sfod_p3_plan(B, H, W, Cin, Cout) : P3Plan{};
+  if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;
+  return (B * H * W + 127) / 128;
+}
 
 template <typename T, typename OutT, int WN, bool UT, int WR, int NST>
 static int launch_one(const void* x, const void* w, const float* bias, void* y, float* stats,
@@ -461,6 +479,13 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
   SFOD_REQUIRE(ldy >= Cout, "conv: ldy < Cout");
   const int E = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(Cin % E == 0, "conv: Cin must be a multiple of the 16-byte chunk");
+  if ((int64_t)B * H * W == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (ksize == 3 && dt == SFOD_BF16) {
+    const P3Plan p = sfod_p3_plan(B, H, W, Cin, Cout);
+    if (use_patch_kernel(p, B, H, W, ksize, dt))
+      return sfod_p3_launch(p, x, w, bias, y, stats, B, H, W, Cin, Cout, ldy, act, out_dt == SFOD_F32, s);
+  }
   ConvArgs a;
   a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.ldy = ldy; a.act = act;
   const int cpt = Cin / E;
@@ -470,8 +495,6 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
     SFOD_REQUIRE(a.cpt_shift >= 0, "conv3x3: Cin/chunk must be a power of two");
   }
   a.kchunks = ksize * ksize * cpt;
-  if (a.M == 0) return 0;
-  hipStream_t s = (hipStream_t)stream;
   if (dt == SFOD_F32) {
     SFOD_REQUIRE(out_dt == SFOD_F32, "conv: fp32 compute writes fp32");
     return launch_conv_fwd<float, float>(x, w, bias, y, stats, a, s);
@@ -681,11 +704,33 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
     }
 }
 
+static bool use_patch_wgrad(const W3Plan& p, int ksize, int dt) {
+  if (ksize != 3 || dt != SFOD_BF16 || !p.ok || g_conv_algo == 1) return false;
+  if (g_conv_algo == 2) return true;
+  // tiny problems: not enough pixel tiles to give every (co, ci) block a few tiles per split
+  return p.nsplit * p.tiles_per_split >= 16;
+}
+
+extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
+  if (ksize != 3 || dt != SFOD_BF16) return 0;
+  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
+  return use_patch_wgrad(p, ksize, dt) ? p.ws_bytes : 0;
+}
+
 extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
-                               int Cout, int ksize, int lddy, int dt, void* stream) {
+                               int Cout, int ksize, int lddy, int dt, void* ws, int64_t ws_bytes,
+                               void* stream) {
   SFOD_REQUIRE(ksize == 1 || ksize == 3, "wgrad: ksize must be 1 or 3");
   const int E = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(Cin % E == 0 && lddy % E == 0, "wgrad: Cin / lddy must be multiples of the 16-byte chunk");
+  if ((int64_t)B * H * W == 0) return 0;
+  if (ksize == 3 && dt == SFOD_BF16) {
+    const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
+    if (use_patch_wgrad(p, ksize, dt)) {
+      SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
+      return sfod_w3_launch(p, x, dy, dw, ws, B, H, W, Cin, Cout, lddy, (hipStream_t)stream);
+    }
+  }
   WgradArgs a;
   a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.lddy = lddy;
   const int cpt = Cin / E;

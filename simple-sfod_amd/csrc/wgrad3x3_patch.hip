@@ -1,0 +1,381 @@
+// Halo-patch 3x3 weight gradient, bf16 MFMA, gfx950.
+//
+//   dw[co][tap][ci] = sum_pixels dy[pix][co] * x[pix + tap][ci]          (GEMM K axis = pixels)
+//
+// The generic kernel (gemm_conv.hip) streams an im2col slice of x per (tap, ci) tile, i.e. every
+// input pixel crosses L2 -> LDS nine times per output tile, and resolves its split-K with float
+// atomics.  Here a workgroup owns a (CO x 32 output channels) x (64 input channels) x 9 taps block
+// of dw and walks TH x TW pixel tiles (<= 256 pixels) of the images: per tile the (TH+2) x (TW+2)
+// halo patch of x is DMA'd into LDS once and all nine taps read it at shifted rows; dy streams in
+// 64-pixel chunks.  Partial results of the pixel splits go to fp32 slabs with plain stores and a
+// second kernel sums the slabs in a fixed order (deterministic, no atomics).
+//
+//   LDS   both operands are pixel-major and stored as 32-channel "planes" with 64-byte rows: a
+//         ds_read_b64_tr_b16 (hardware transpose) of one wave half touches 4 consecutive rows x 64 B
+//         = all 64 banks once -> conflict free without a swizzle, for any tap shift, and the kx
+//         shift is an immediate offset.
+//           x patch[2] : 2 planes x 384 rows x 64 B = 48 KiB each
+//           dy ring[3] : CO planes x 64 rows x 64 B (16 KiB for CO = 4)
+//   waves 8.  CO=4: wave = (co fragment 0..3, ci fragment 0..1), nine 32x32 accumulators (one per tap)
+//             CO=2: (Cout <= 64) waves 0-3 / 4-7 take the even / odd half of the k-steps of every
+//                   chunk and write separate slabs
+//   K loop body = one pixel tile = 4 stages (64-pixel chunks of dy); one s_barrier per stage; DMA
+//         (buffer_load ... lds, out-of-range lanes read zeros) runs two chunks / one whole patch
+//         ahead behind counted s_waitcnt vmcnt(N).
+#include "conv_internal.h"
+#include <type_traits>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+namespace {
+
+template <int J> using IC = std::integral_constant<int, J>;
+
+constexpr int XROWS = 384;                       // patch capacity (pixels incl. halo)
+constexpr int XPLANE = XROWS * 64;               // 24576
+constexpr int XBUF = 2 * XPLANE;                 // 49152
+constexpr int DY_OFF = 2 * XBUF;                 // 98304
+constexpr int DYSLOT = 4 * 64 * 64;              // 16384 (CO = 4 planes)
+constexpr int TAB_OFF = DY_OFF + 3 * DYSLOT;     // 147456
+constexpr int TABP_OFF = TAB_OFF;                // u16 [256]  tile pixel -> patch row (tap 0,0)
+constexpr int TABT_OFF = TAB_OFF + 512;          // u16 [256]  tile pixel -> ty<<8|tx, 0xffff outside the tile
+constexpr int TABR_OFF = TAB_OFF + 1024;         // u16 [384]  patch row -> py<<8|px, 0xffff unused
+constexpr int LDS_TOTAL = TAB_OFF + 1024 + 768;
+constexpr unsigned OOB_OFF = 0x80000000u;
+
+struct W3Args {
+  const bf16_t* x;
+  const bf16_t* dy;
+  float* slab;
+  int B, H, W, Cin, Cout, lddy;
+  int TH, TW, PW;
+  int tiles_y, tiles_x;      // per image
+  int ntiles;                // B * tiles_y * tiles_x
+  int tiles_per_split;
+  int co_tiles, ci_tiles, nsplit;
+};
+
+__device__ __forceinline__ void bufload16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff, void* l) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(l), 16, (int)voff, (int)soff, 0, 0);
+}
+template <int N> __device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// ds_read_b64_tr_b16 through inline asm: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in front of the
+// builtin form whenever an LDS-DMA is in flight, which would drain the prefetch queue every stage.
+// The asm form is invisible to the waitcnt pass, so the consumer waits with wait_lgkm<N>() below
+// (LDS returns in order) followed by a sched_barrier so that no MFMA is hoisted above the wait.
+template <int OFF> __device__ __forceinline__ s16x4 tr_read(unsigned addr) {
+  s16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+  return v;
+}
+template <int N> __device__ __forceinline__ void wait_lgkm() {
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ bf16x8 cat8(s16x4 a, s16x4 b) {
+  return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int CO>
+__global__ void __launch_bounds__(512)
+k_wgrad3x3_patch(W3Args a) {
+  constexpr int ND = CO / 2;                 // dy DMA instructions per wave and chunk
+  constexpr int KG = (CO == 4) ? 1 : 2;      // k-step groups (CO=2: two wave groups split the k-steps)
+  constexpr int KS = 4 / KG;                 // k-steps (16 pixels) per wave and chunk
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wco = (CO == 4) ? (wave >> 1) : ((wave >> 1) & 1);
+  const int wci = wave & 1;
+  const int kg = (CO == 4) ? 0 : (wave >> 2);
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, t16 = lane & 15;
+  const int tq = t16 >> 2, tp = t16 & 3;
+
+  // ---- work decode: blockIdx -> (split, co tile, ci tile); XCD-aware so that the workgroups of one
+  // XCD share the pixel range (x / dy lines are then L2 hits for all (co, ci) tiles of the split)
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt / 8, r = nt % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int pairs = a.co_tiles * a.ci_tiles;
+  const int split = bid / pairs;
+  const int pr = bid - split * pairs;
+  const int co0 = (pr / a.ci_tiles) * (CO * 32), ci0 = (pr % a.ci_tiles) * 64;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const int PW = a.PW;
+  const int npix = a.TH * a.TW;
+
+  // ---- lookup tables ---------------------------------------------------------------------------------
+  unsigned short* tabP = reinterpret_cast<unsigned short*>(smem + TABP_OFF);
+  unsigned short* tabT = reinterpret_cast<unsigned short*>(smem + TABT_OFF);
+  unsigned short* tabR = reinterpret_cast<unsigned short*>(smem + TABR_OFF);
+  if (threadIdx.x < 256) {
+    const int p = threadIdx.x;
+    if (p < npix) {
+      const int ty = p / a.TW, tx = p - ty * a.TW;
+      tabP[p] = (unsigned short)(ty * PW + tx);
+      tabT[p] = (unsigned short)((ty << 8) | tx);
+    } else {
+      tabP[p] = 0;
+      tabT[p] = 0xffff;
+    }
+  }
+  if (threadIdx.x < XROWS) {
+    const int r = threadIdx.x;
+    const int py = r / PW, px = r - py * PW;
+    tabR[r] = (py < a.TH + 2) ? (unsigned short)((py << 8) | px) : (unsigned short)0xffff;
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.x, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.dy, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.lddy * 2), 0x00020000);
+
+  // per-lane constant parts of the DMA descriptors
+  // patch piece k (0..5): instruction q = wave*6+k -> plane q/24, rows 16*(q%24) + lane/4, chunk lane%4
+  int pr_pack[6];   // py<<8|px of this lane's patch row, or 0xffff
+  int pr_col[6];    // channel offset (elements) of this lane's chunk, -1 if beyond Cin
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int q = wave * 6 + k;
+    const int plane = q / 24, row = (q % 24) * 16 + (lane >> 2);
+    pr_pack[k] = tabR[row];
+    const int c = ci0 + plane * 32 + (lane & 3) * 8;
+    pr_col[k] = (c < a.Cin) ? c : -1;
+  }
+  // dy piece i (0..ND-1): instruction q = wave*ND+i -> plane q/4, rows 16*(q%4) + lane/4
+  int dy_col[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int q = wave * ND + i;
+    const int c = co0 + (q >> 2) * 32 + (lane & 3) * 8;
+    dy_col[i] = (c + 8 <= a.lddy && c < a.Cout) ? c : -1;
+  }
+
+  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
+    const int per = a.tiles_y * a.tiles_x;
+    b = t / per;
+    const int r = t - b * per;
+    const int tyi = r / a.tiles_x;
+    y0 = tyi * a.TH;
+    x0 = (r - tyi * a.tiles_x) * a.TW;
+  };
+  auto issue_patch = [&](int k, int t, int buf) {
+    int b, y0, x0;
+    tile_origin(t, b, y0, x0);
+    const int py = pr_pack[k] >> 8, px = pr_pack[k] & 255;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = pr_pack[k] != 0xffff && pr_col[k] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    const unsigned off = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + pr_col[k]) * 2) : OOB_OFF;
+    bufload16(xres, off, 0u, smem + buf * XBUF + (wave * 6 + k) * 1024);
+  };
+  // dy chunk c of tile t into ring slot
+  auto issue_dy = [&](int t, int c, int slot) {
+    int b, y0, x0;
+    tile_origin(t, b, y0, x0);
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int q = wave * ND + i;
+      const int row = (q & 3) * 16 + (lane >> 2);
+      const int tt = tabT[c * 64 + row];
+      const int ty = tt >> 8, tx = tt & 255;
+      const bool ok = tt != 0xffff && dy_col[i] >= 0 && y0 + ty < a.H && x0 + tx < a.W;
+      const unsigned off = ok ? (unsigned)((((b * a.H + y0 + ty) * a.W + x0 + tx) * a.lddy + dy_col[i]) * 2) : OOB_OFF;
+      bufload16(dres, off, 0u, smem + DY_OFF + slot * DYSLOT + q * 1024);
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // lane parts of the fragment addresses
+  const int cbb = (g1 * 16 + 4 * tp) * 2;                       // byte column inside a 64-byte plane row
+  const int a_lane = wco * 4096 + (8 * h + tq) * 64 + cbb;       // dy: + slot base + (16 s + 4 e) * 64
+  const int b_lane = wci * XPLANE + cbb;                         // x : + buffer base + row * 64
+
+  // LDS byte addresses are 32-bit offsets from the start of the dynamic LDS segment (the kernel has
+  // no static LDS, so the segment starts at LDS address 0).
+  auto compute_chunk = [&](int c, int xb_off, int dyb_off) {
+#pragma unroll
+    for (int sl = 0; sl < KS; ++sl) {
+      const int s = kg * KS + sl;   // k-step inside the chunk (kg is wave-uniform)
+      // pixels of this lane's two transposed reads: p = 64 c + 16 s + 8 h + 4 e + tq
+      const int p0 = c * 64 + s * 16 + 8 * h + tq;
+      const unsigned rx0 = (unsigned)(xb_off + tabP[p0] * 64 + b_lane);
+      const unsigned rx1 = (unsigned)(xb_off + tabP[p0 + 4] * 64 + b_lane);
+      const unsigned ra = (unsigned)(dyb_off + a_lane + s * 1024);
+      const s16x4 a0 = tr_read<0>(ra), a1 = tr_read<256>(ra);
+      s16x4 q[2][6];
+      // group ky = 0
+      q[0][0] = tr_read<0>(rx0);   q[0][1] = tr_read<0>(rx1);
+      q[0][2] = tr_read<64>(rx0);  q[0][3] = tr_read<64>(rx1);
+      q[0][4] = tr_read<128>(rx0); q[0][5] = tr_read<128>(rx1);
+#pragma unroll
+      for (int ky = 0; ky < 3; ++ky) {
+        if (ky < 2) {
+          const unsigned r0 = rx0 + (ky + 1) * PW * 64, r1 = rx1 + (ky + 1) * PW * 64;
+          q[(ky + 1) & 1][0] = tr_read<0>(r0);   q[(ky + 1) & 1][1] = tr_read<0>(r1);
+          q[(ky + 1) & 1][2] = tr_read<64>(r0);  q[(ky + 1) & 1][3] = tr_read<64>(r1);
+          q[(ky + 1) & 1][4] = tr_read<128>(r0); q[(ky + 1) & 1][5] = tr_read<128>(r1);
+          wait_lgkm<6>();
+        } else {
+          wait_lgkm<0>();
+        }
+        const bf16x8 af = cat8(a0, a1);
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx)
+          acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
+              af, cat8(q[ky & 1][2 * kx], q[ky & 1][2 * kx + 1]), acc[ky * 3 + kx], 0, 0, 0);
+      }
+    }
+  };
+
+  if (t_begin < t_end) {
+    // ---- prologue: patch of the first tile, dy chunks 0 and 1 ---------------------------------------
+#pragma unroll
+    for (int k = 0; k < 6; ++k) issue_patch(k, t_begin, 0);
+    issue_dy(t_begin, 0, 0);
+    issue_dy(t_begin, 1, 1);
+    int gc = 0;  // global chunk counter (ring slot = gc % 3)
+    for (int t = t_begin; t < t_end; ++t) {
+      const bool last = (t == t_end - 1);
+      const int xbuf = (t - t_begin) & 1;
+      auto stage = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        constexpr int N = (c == 0) ? ND : (c == 3 ? 1 + ND : 2 + ND);
+        constexpr int NL = (c == 3) ? 0 : ND;
+        if (last) wait_vm<NL>(); else wait_vm<N>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (!last) {
+          if constexpr (c == 0) { issue_patch(0, t + 1, xbuf ^ 1); issue_patch(1, t + 1, xbuf ^ 1); }
+          else if constexpr (c == 1) { issue_patch(2, t + 1, xbuf ^ 1); issue_patch(3, t + 1, xbuf ^ 1); }
+          else if constexpr (c == 2) issue_patch(4, t + 1, xbuf ^ 1);
+          else issue_patch(5, t + 1, xbuf ^ 1);
+        }
+        {
+          // dy chunk two stages ahead
+          constexpr int c2 = (c + 2) & 3;
+          const int t2 = (c >= 2) ? t + 1 : t;
+          int slot = gc + 2;
+          slot -= (slot >= 3) ? 3 : 0;
+          slot -= (slot >= 3) ? 3 : 0;
+          if (t2 < t_end) issue_dy(t2, c2, slot);
+        }
+        compute_chunk(c, xbuf * XBUF, DY_OFF + gc * DYSLOT);
+        gc = (gc == 2) ? 0 : gc + 1;
+      };
+      stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{});
+    }
+  }
+
+  // ---- write the partial block into this split's slab ----------------------------------------------------
+  const int slab_idx = split * KG + kg;
+  float* out = a.slab + (int64_t)slab_idx * a.Cout * 9 * a.Cin;
+  const int ci = ci0 + wci * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < a.Cout && ci < a.Cin) out[((int64_t)co * 9 + t) * a.Cin + ci] = acc[t][r];
+    }
+}
+
+// dw[i] (+)= sum_s slab[s][i], fixed order
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int nslab, int64_t stride4) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(dw)[i];
+    for (int k = 0; k < nslab; ++k) {
+      const float4 v = reinterpret_cast<const float4*>(slab)[k * stride4 + i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = s;
+  }
+}
+
+}  // namespace
+
+W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy) {
+  W3Plan p;
+  p.ok = 0;
+  if (B < 1 || H < 1 || W < 1) return p;
+  if (Cin % 32 != 0 || Cout % 32 != 0 || lddy % 8 != 0) return p;
+  if ((int64_t)B * H * W * Cin >= ((int64_t)1 << 30) || (int64_t)B * H * W * lddy >= ((int64_t)1 << 30)) return p;
+  double best = -1.0;
+  for (int tw = 4; tw <= 128 && tw <= W + 3; ++tw) {
+    int th = 256 / tw;
+    while (th > 1 && (th + 2) * (tw + 2) > XROWS) --th;
+    if (th > H) th = H;
+    if (th < 1 || (th + 2) * (tw + 2) > XROWS || th + 2 > 255 || tw + 2 > 255) continue;
+    const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+    th = (H + ty - 1) / ty;
+    const double eff = (double)H * W / ((double)ty * tx * 256.0);
+    const double score = eff + 1e-6 * tw;
+    if (score > best) { best = score; p.TH = th; p.TW = tw; p.tiles_y = ty; p.tiles_x = tx; }
+  }
+  if (best < 0.0) return p;
+  p.CO = (Cout <= 64) ? 2 : 4;
+  p.co_tiles = (Cout + p.CO * 32 - 1) / (p.CO * 32);
+  p.ci_tiles = (Cin + 63) / 64;
+  const int pairs = p.co_tiles * p.ci_tiles;
+  const int ntiles = B * p.tiles_y * p.tiles_x;
+  // one workgroup per CU (LDS-bound occupancy): aim at 256 workgroups; the slabs the splits write
+  // (and the reduction reads back) are kept below 128 MiB
+  int ns = 256 / pairs;
+  if (ns < 1) ns = 1;
+  const int64_t slab_bytes = (int64_t)Cout * 9 * Cin * 4 * (Cout <= 64 ? 2 : 1);
+  while (ns > 1 && ns * slab_bytes > ((int64_t)128 << 20)) --ns;
+  if (ns > ntiles) ns = ntiles;
+  p.tiles_per_split = (ntiles + ns - 1) / ns;
+  p.nsplit = (ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+  p.nslab = p.nsplit * (p.CO == 2 ? 2 : 1);
+  p.ws_bytes = (int64_t)p.nslab * Cout * 9 * Cin * 4;
+  p.ok = 1;
+  return p;
+}
+
+int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
+                   int Cin, int Cout, int lddy, hipStream_t s) {
+  W3Args a;
+  a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ws;
+  a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy;
+  a.TH = p.TH; a.TW = p.TW; a.PW = p.TW + 2;
+  a.tiles_y = p.tiles_y; a.tiles_x = p.tiles_x;
+  a.ntiles = B * p.tiles_y * p.tiles_x;
+  a.tiles_per_split = p.tiles_per_split;
+  a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.nsplit = p.nsplit;
+  static bool attr_set = false;
+  if (!attr_set) {
+    const void* ks[2] = {(const void*)k_wgrad3x3_patch<4>, (const void*)k_wgrad3x3_patch<2>};
+    for (int i = 0; i < 2; ++i) {
+      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+      if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute(w3): %s", hipGetErrorString(e)); return -(int)e; }
+    }
+    attr_set = true;
+  }
+  dim3 grid(p.co_tiles * p.ci_tiles * p.nsplit), blk(512);
+  if (p.CO == 4) hipLaunchKernelGGL(k_wgrad3x3_patch<4>, grid, blk, LDS_TOTAL, s, a);
+  else hipLaunchKernelGGL(k_wgrad3x3_patch<2>, grid, blk, LDS_TOTAL, s, a);
+  int rc = sfod_check_launch("wgrad3x3_patch");
+  if (rc) return rc;
+  const int64_t n = (int64_t)Cout * 9 * Cin;  // multiple of 4 (Cin % 32 == 0)
+  int g = (int)((n / 4 + 255) / 256);
+  if (g > 2048) g = 2048;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4);
+  return sfod_check_launch("wgrad_reduce");
+}

@@ -167,6 +167,11 @@ def query(name, *args):
     return getattr(load(), name)(*args)
 
 
+def set_conv_algo(algo):
+    """0 auto, 1 generic implicit GEMM, 2 halo-patch kernel whenever the shape allows (3x3 bf16)."""
+    load().sfod_set_conv_algo(int(algo))
+
+
 # =================================================================================================
 # tensor-level wrappers (allocate outputs with torch, call the C ABI)
 # =================================================================================================
@@ -231,13 +236,26 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     y = alloc(oshape(ldy), dtype=out_dtype, device=x.device)
     stats = None
     if want_stats:
-        nb = query("sfod_conv_stats_blocks", B * H * W)
-        stats = torch.empty(nb, 2, cout, dtype=torch.float32, device=x.device)
+        nb = query("sfod_conv_stats_blocks", B, H, W, cin, cout, ksize, dt)
+        stats = torch.empty(nb * (2 * cout + 1), dtype=torch.float32, device=x.device)
+        stats.nblk = nb
     global _pending_flops
     _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
     call("sfod_conv_fwd", x, w_packed, bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
          F32 if out_dtype == torch.float32 else BF16)
     return (y, stats) if want_stats else y
+
+
+_ws_cache = {}
+
+
+def _workspace(dev, nbytes):
+    """Grow-only scratch buffer per device (stream-ordered reuse: every user runs on the current stream)."""
+    cur = _ws_cache.get(dev)
+    if cur is None or cur.numel() < nbytes:
+        cur = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+        _ws_cache[dev] = cur
+    return cur
 
 
 def conv_wgrad(x, dy, cout, ksize, dw_packed=None):
@@ -250,9 +268,11 @@ def conv_wgrad(x, dy, cout, ksize, dw_packed=None):
     lddy = dy.shape[-1]
     if dw_packed is None:
         dw_packed = torch.zeros(cout, ksize * ksize, cin, dtype=torch.float32, device=x.device)
+    nbytes = query("sfod_conv_wgrad_ws_bytes", B, H, W, cin, cout, ksize, lddy, dt)
+    ws = _workspace(x.device, nbytes) if nbytes > 0 else None
     global _pending_flops
     _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
-    call("sfod_conv_wgrad", x, dy, dw_packed, B, H, W, cin, cout, ksize, lddy, dt)
+    call("sfod_conv_wgrad", x, dy, dw_packed, B, H, W, cin, cout, ksize, lddy, dt, ws, nbytes)
     return dw_packed
 
 
@@ -268,7 +288,7 @@ def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, 
     mean = torch.empty(C, dtype=torch.float32, device=stats.device)
     invstd = torch.empty_like(mean)
     ws = torch.empty(query("sfod_bn_finalize_ws_floats", C), dtype=torch.float32, device=stats.device)
-    call("sfod_bn_finalize", stats, stats.shape[0], 128, M, C, mean, invstd, running_mean, running_var,
+    call("sfod_bn_finalize", stats, stats.nblk, M, C, mean, invstd, running_mean, running_var,
          float(momentum), float(eps), int(update_running), ws)
     return mean, invstd
 

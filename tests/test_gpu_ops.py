@@ -76,6 +76,56 @@ def test_conv_fwd(native, dtype, shape, act):
     assert rel_err(got, ref) < tol
 
 
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout  -- halo-patch kernel: tile overhang, N tails, both workgroup shapes
+    (2, 37, 75, 64, 128),     # G=1, 2 body iterations
+    (1, 20, 50, 64, 64),      # G=2 (64 output channels / workgroup), 1 body
+    (1, 33, 40, 128, 64),     # G=2, 2 bodies
+    (2, 9, 13, 32, 200),      # G=1, single 32-channel slice, Cout tail (200 = 128 + 72)
+    (1, 70, 150, 96, 136),    # several tiles per image in x and y, 3 slices
+    (3, 5, 6, 256, 256),      # tiny maps, 8 slices
+])
+@pytest.mark.parametrize("variant", ["plain", "relu_stats", "f32out"])
+def test_conv3x3_patch_kernel(native, shape, variant):
+    """k_conv3x3_patch (forced) against F.conv2d on bf16-rounded operands and against the generic
+    implicit-GEMM kernel; BatchNorm partial statistics through sfod_bn_finalize."""
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = (torch.randn(B, Cin, H, W, generator=g) + 0.3).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)).bfloat16().float()
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=1)
+    xd = nhwc(x).to(DEV).bfloat16()
+    wp = native.pack_conv_weight(w.to(DEV), Cin, native.BF16)
+    try:
+        native.set_conv_algo(2)
+        assert native.query("sfod_conv_stats_blocks", B, H, W, Cin, Cout, 3, native.BF16) < (B * H * W + 127) // 128 + B * 64
+        if variant == "plain":
+            y = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
+            assert rel_err(nchw(y.float().cpu()), ref) < 6e-3
+            if Cin & (Cin - 1) == 0:  # the generic kernel needs a power-of-two channel count
+                native.set_conv_algo(1)
+                y_gen = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
+                # same bf16 products, fp32 accumulation in a different order
+                assert rel_err(y.float().cpu(), y_gen.float().cpu()) < 4e-3
+        elif variant == "relu_stats":
+            y, stats = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3, act=1, want_stats=True)
+            assert rel_err(nchw(y.float().cpu()), F.relu(ref)) < 6e-3
+            rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+            mean, invstd = native.bn_finalize(stats, B * H * W, Cout, rm, rv, 0.1, 1e-5)
+            m_ref = ref.mean(dim=(0, 2, 3))
+            v_ref = ref.var(dim=(0, 2, 3), unbiased=False)
+            torch.testing.assert_close(mean.cpu(), m_ref, rtol=2e-3, atol=2e-3)
+            torch.testing.assert_close(invstd.cpu(), torch.rsqrt(v_ref + 1e-5), rtol=3e-3, atol=1e-4)
+        else:
+            y = native.conv_fwd(xd, wp, None, Cout, 3, out_dtype=torch.float32, ldy=Cout + 8)
+            assert y.shape[-1] == Cout + 8
+            assert rel_err(nchw(y[..., :Cout].cpu()), ref - bias.view(1, -1, 1, 1)) < 2e-3
+            assert (y[..., Cout:] == 0).all()
+    finally:
+        native.set_conv_algo(0)
+
+
 @pytest.mark.parametrize("dtype", _dtypes())
 def test_linear_big_k_and_ld_padding(native, dtype):
     """fc1-shaped GEMM (K = 25088, permuted (c,p)->(p,c)) and the 41-wide predictor with ld 48."""
@@ -141,6 +191,38 @@ def test_conv_dgrad_and_wgrad(native, dtype, shape):
         wr = native.pack_conv_weight(w.detach().to(DEV), cout_pad, dt, rot180=True)
         dx = native.conv_fwd(dyd, wr, None, Cin, ks)
         assert rel_err(nchw(dx.float().cpu()), x.grad) < tol
+
+
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout -- halo-patch weight gradient: tile overhang, channel tails, both variants
+    (2, 37, 75, 64, 128),
+    (1, 20, 50, 64, 64),      # CO=2 variant (Cout <= 64): two k-step groups, two slabs per split
+    (1, 33, 40, 128, 64),
+    (2, 9, 13, 32, 96),       # single 32-channel plane of x, Cout tail inside a 128 tile
+    (1, 70, 150, 96, 160),    # several tiles per image, 2 co tiles, 2 ci tiles (second half empty)
+    (3, 5, 6, 256, 256),
+])
+def test_conv3x3_patch_wgrad(native, shape):
+    """k_wgrad3x3_patch + slab reduction (forced) against autograd on bf16-rounded operands."""
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(B, Cin, H, W, generator=g).bfloat16().float()
+    dy = torch.randn(B, Cout, H, W, generator=g).bfloat16().float()
+    w = torch.zeros(Cout, Cin, 3, 3, requires_grad=True)
+    F.conv2d(x, w, None, padding=1).backward(dy)
+    xd = nhwc(x).to(DEV).bfloat16()
+    dyd = nhwc(dy).to(DEV).bfloat16()
+    try:
+        native.set_conv_algo(2)
+        assert native.query("sfod_conv_wgrad_ws_bytes", B, H, W, Cin, Cout, 3, Cout, native.BF16) > 0
+        dwp = native.conv_wgrad(xd, dyd, Cout, 3)
+        dwp2 = native.conv_wgrad(xd, dyd, Cout, 3)
+    finally:
+        native.set_conv_algo(0)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
+    native.unpack_conv_wgrad(dwp, dw)
+    assert rel_err(dw.cpu(), w.grad) < 2e-5 * math.sqrt(B * H * W) / 10 + 1e-4
+    assert torch.equal(dwp, dwp2), "slab reduction must be deterministic"
 
 
 # -------------------------------------------------------------------------------------------------
