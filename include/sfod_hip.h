@@ -201,7 +201,8 @@ int sfod_make_rois(const float* props, const int32_t* prop_count, int B, int P, 
  * features.  out: [R, PH*PW, C] (dt).  rois with batch index < 0 produce zeros. */
 int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, const float* rois, int R,
                        int pooled, float scale, void* out, int dt, void* stream);
-/* dfeat fp32 [B,H,W,C], accumulated with float atomics (zero-init by the caller) */
+/* dfeat fp32 [B,H,W,C] += adjoint of the forward (zero-init by the caller); one workgroup per ROI,
+ * separable interpolation weights, one float atomic per footprint pixel and channel */
 int sfod_roi_align_bwd(const void* dout, int B, int H, int W, int C, const float* rois, int R,
                        int pooled, float scale, float* dfeat, int dt, void* stream);
 

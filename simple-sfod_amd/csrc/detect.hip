@@ -259,6 +259,107 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ vali
   if (tid == 0) keep_count[b] = nkept;
 }
 
+// Wide greedy reduce for n <= 16384 (CB <= 256 column words): 16 wavefronts per image.  The
+// serial part is the chain block -> kept bits -> removal words of the later blocks; everything off
+// that chain is prefetched: while wave 0 resolves block blk (scalar loop over the alive bits, diagonal
+// words by v_readlane), all 16 waves already hold the mask words of block blk+1 in registers (thread
+// = 4 rows x up to 4 column words, loaded unconditionally), so once the kept bits are known a thread
+// only ORs the words of kept rows and publishes them with one LDS atomic OR per column.
+__global__ void __launch_bounds__(1024)
+k_nms_reduce_wide(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ valid,
+                  const int32_t* __restrict__ n_per_image, int n, int max_keep,
+                  int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem_raw);  // [CB]
+  __shared__ unsigned long long s_kept;
+  const int b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int live = n_per_image ? min(n_per_image[b], n) : n;
+  const int CB = (n + 63) / 64;
+  const int CBL = (live + 63) / 64;
+  const uint64_t* M = mask + (int64_t)b * n * CB;
+  for (int w = tid; w < CB; w += blockDim.x) {
+    unsigned long long r = 0;
+    if (valid) {
+      for (int j = 0; j < 64; ++j) {
+        const int idx = w * 64 + j;
+        if (idx < live && !valid[(int64_t)b * n + idx]) r |= (1ull << j);
+      }
+    }
+    remv[w] = r;
+  }
+  __syncthreads();
+
+  // rows wave + 16 q (q < 4) of a block, columns lane + 64 k (k < 4)
+  uint64_t preA[4][4], preB[4][4], diagA = 0, diagB = 0;
+  auto prefetch = [&](int blk, uint64_t (&pre)[4][4], uint64_t& diag) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int row = blk * 64 + wave + 16 * q;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int col = lane + 64 * k;
+        pre[q][k] = (row < live && col > blk && col < CBL) ? M[(int64_t)row * CB + col] : 0ull;
+      }
+    }
+    if (wave == 0) {
+      const int i = blk * 64 + lane;
+      diag = (i < live) ? M[(int64_t)i * CB + blk] : 0ull;
+    }
+  };
+  int nkept = 0;
+  bool done = false;
+  auto step = [&](int blk, uint64_t (&pre)[4][4], uint64_t diag) {
+    if (wave == 0) {
+      const int i = blk * 64 + lane;
+      const unsigned long long rem = remv[blk];
+      const bool alive = (i < live) && !((rem >> lane) & 1ull);
+      unsigned long long alive_mask = __ballot(alive);
+      unsigned long long kept = 0;
+      int room = max_keep - nkept;
+      const uint32_t dlo = (uint32_t)(diag & 0xffffffffull), dhi = (uint32_t)(diag >> 32);
+      while (alive_mask != 0ull && room > 0) {
+        const int bpos = __builtin_ctzll(alive_mask);
+        kept |= (1ull << bpos);
+        --room;
+        const unsigned long long d = ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dhi, bpos) << 32) |
+                                     (unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)dlo, bpos);
+        alive_mask &= ~d;
+        alive_mask &= ~(1ull << bpos);
+      }
+      if ((kept >> lane) & 1ull) {
+        const int pos = nkept + __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+        keep_idx[(int64_t)b * max_keep + pos] = i;
+      }
+      if (lane == 0) s_kept = kept;
+    }
+    __syncthreads();
+    const unsigned long long kept = s_kept;
+    nkept += __builtin_popcountll(kept);
+    if (nkept >= max_keep) { done = true; return; }
+    if (kept != 0ull) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        unsigned long long acc = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((kept >> (wave + 16 * q)) & 1ull) acc |= pre[q][k];
+        if (acc != 0ull) atomicOr(&remv[lane + 64 * k], acc);
+      }
+    }
+    __syncthreads();
+  };
+  if (CBL > 0) prefetch(0, preA, diagA);
+  for (int blk = 0; blk < CBL && !done; blk += 2) {
+    if (blk + 1 < CBL) prefetch(blk + 1, preB, diagB);
+    step(blk, preA, diagA);
+    if (done || blk + 1 >= CBL) break;
+    if (blk + 2 < CBL) prefetch(blk + 2, preA, diagA);
+    step(blk + 1, preB, diagB);
+  }
+  if (tid == 0) keep_count[b] = nkept;
+}
+
 extern "C" int64_t sfod_nms_mask_bytes(int B, int n) {
   return (int64_t)B * n * ((n + 63) / 64) * 8;
 }
@@ -280,8 +381,12 @@ extern "C" int sfod_nms(const float* boxes, const float* alt_boxes, const int32_
                      thr, mask);
   int rc = sfod_check_launch("nms_mask");
   if (rc) return rc;
-  hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(256), CB * 8, s, mask, valid, n_per_image, n, max_keep,
-                     keep_idx, keep_count);
+  if (CB <= 256)
+    hipLaunchKernelGGL(k_nms_reduce_wide, dim3(B), dim3(1024), CB * 8, s, mask, valid, n_per_image, n, max_keep,
+                       keep_idx, keep_count);
+  else
+    hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(256), CB * 8, s, mask, valid, n_per_image, n, max_keep,
+                       keep_idx, keep_count);
   return sfod_check_launch("nms_reduce");
 }
 

@@ -88,9 +88,10 @@ extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes
 // ---------------------------------------------------------------------------------------------
 #define BNF_SPLITS 64
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_bn_partial(const float* __restrict__ stats, int nblocks, int C, double* __restrict__ part) {
-  __shared__ double red[4][3][64];
+  // 16 waves split the blocks of this slice; lanes are consecutive channels (coalesced rows)
+  __shared__ double red[16][3][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   const int per = (nblocks + gridDim.y - 1) / gridDim.y;
@@ -98,34 +99,46 @@ k_bn_partial(const float* __restrict__ stats, int nblocks, int C, double* __rest
   const float* counts = stats + (int64_t)nblocks * 2 * C;
   double a = 0.0, q = 0.0, m2 = 0.0;
   if (c < C)
-    for (int blk = b0 + wave; blk < b1; blk += 4) {
+    for (int blk = b0 + wave; blk < b1; blk += 16) {
       const double nb = (double)counts[blk];
-      if (nb <= 0.0) continue;
       const double sb = (double)stats[((int64_t)blk * 2) * C + c];
-      a += sb;
-      q += sb * sb / nb;
-      m2 += (double)stats[((int64_t)blk * 2 + 1) * C + c];
+      const double mb = (double)stats[((int64_t)blk * 2 + 1) * C + c];
+      if (nb > 0.0) {
+        a += sb;
+        q += sb * sb / nb;
+        m2 += mb;
+      }
     }
   red[wave][0][lane] = a; red[wave][1][lane] = q; red[wave][2][lane] = m2;
   __syncthreads();
-  if (wave == 0 && c < C) {
-    for (int k = 0; k < 3; ++k)
-      part[((int64_t)blockIdx.y * 3 + k) * C + c] = red[0][k][lane] + red[1][k][lane] + red[2][k][lane] + red[3][k][lane];
+  if (wave < 3 && c < C) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][wave][lane];
+    part[((int64_t)blockIdx.y * 3 + wave) * C + c] = v;
   }
 }
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __restrict__ mean,
            float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
            float eps, int update_running) {
-  const int c = blockIdx.x * 64 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[4][3][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
   double a = 0.0, q = 0.0, m2 = 0.0;
-  for (int s = 0; s < nsplit; ++s) {
-    a += part[((int64_t)s * 3 + 0) * C + c];
-    q += part[((int64_t)s * 3 + 1) * C + c];
-    m2 += part[((int64_t)s * 3 + 2) * C + c];
-  }
+  if (c < C)
+    for (int s = wave; s < nsplit; s += 4) {
+      a += part[((int64_t)s * 3 + 0) * C + c];
+      q += part[((int64_t)s * 3 + 1) * C + c];
+      m2 += part[((int64_t)s * 3 + 2) * C + c];
+    }
+  red[wave][0][lane] = a; red[wave][1][lane] = q; red[wave][2][lane] = m2;
+  __syncthreads();
+  if (wave != 0 || c >= C) return;
+  a = red[0][0][lane] + red[1][0][lane] + red[2][0][lane] + red[3][0][lane];
+  q = red[0][1][lane] + red[1][1][lane] + red[2][1][lane] + red[3][1][lane];
+  m2 = red[0][2][lane] + red[1][2][lane] + red[2][2][lane] + red[3][2][lane];
   const double mu = a / (double)M;
   double tot = m2 + q - a * a / (double)M;
   if (tot < 0.0) tot = 0.0;
@@ -146,12 +159,12 @@ extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                                 float momentum, float eps, int update_running, float* ws, void* stream) {
   SFOD_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "bn_finalize: 8-byte aligned workspace required");
   hipStream_t s = (hipStream_t)stream;
-  int nsplit = (nblocks + 63) / 64;
+  int nsplit = (nblocks + 63) / 64;   // >= 64 blocks (4 per wave) per slice
   if (nsplit > BNF_SPLITS) nsplit = BNF_SPLITS;
   if (nsplit < 1) nsplit = 1;
   double* part = reinterpret_cast<double*>(ws);
-  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), nsplit), dim3(256), 0, s, stats, nblocks, C, part);
-  hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 64)), dim3(64), 0, s, part, nsplit, M, C, mean, invstd,
+  hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), nsplit), dim3(1024), 0, s, stats, nblocks, C, part);
+  hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 64)), dim3(256), 0, s, part, nsplit, M, C, mean, invstd,
                      running_mean, running_var, momentum, eps, update_running);
   return sfod_check_launch("bn_finalize");
 }
@@ -324,20 +337,31 @@ k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y, const float* 
   }
 }
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
                   float* __restrict__ dbeta) {
-  // 64 consecutive columns of the [nblk][2C] partial matrix per workgroup; 4 waves split the rows
-  __shared__ double red[4][64];
+  // 64 consecutive columns of the [nblk][2C] partial matrix per workgroup; 16 waves split the rows
+  // (4 independent loads in flight per lane), fixed summation order
+  __shared__ double red[16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int t = blockIdx.x * 64 + lane;  // over 2*C
-  double a = 0.0;
-  if (t < 2 * C)
-    for (int b = wave; b < nblk; b += 4) a += (double)ws[(int64_t)b * 2 * C + t];
-  red[wave][lane] = a;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  if (t < 2 * C) {
+    int b = wave;
+    for (; b + 48 < nblk; b += 64) {
+      a0 += (double)ws[(int64_t)b * 2 * C + t];
+      a1 += (double)ws[(int64_t)(b + 16) * 2 * C + t];
+      a2 += (double)ws[(int64_t)(b + 32) * 2 * C + t];
+      a3 += (double)ws[(int64_t)(b + 48) * 2 * C + t];
+    }
+    for (; b < nblk; b += 16) a0 += (double)ws[(int64_t)b * 2 * C + t];
+  }
+  red[wave][lane] = (a0 + a1) + (a2 + a3);
   __syncthreads();
   if (wave == 0 && t < 2 * C) {
-    const double v = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][lane];
     if (t < C) dbeta[t] = (float)v; else dgamma[t - C] = (float)v;
   }
 }
@@ -443,7 +467,7 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
   do {                                                                                                 \
     hipLaunchKernelGGL((k_bn_bwd_reduce<T, P>), dim3(grid1), dim3(256), lds, s, (const T*)dz,          \
                        (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                        \
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(256), 0, s, ws, grid1, C,       \
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws, grid1, C,       \
                        dgamma, dbeta);                                                                 \
     hipLaunchKernelGGL((k_bn_bwd_apply<T, P>), dim3(grid3), dim3(256), 0, s, (const T*)dz,             \
                        (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (T*)dy, B, H, W, C);     \

@@ -316,6 +316,35 @@ def test_roi_align_fwd_bwd(native, dtype):
     assert rel_err(nchw(dfeat.cpu()), fr.grad) < (1e-5 if dtype == torch.float32 else 1e-4)
 
 
+def test_roi_align_many_rois_unordered_images(native):
+    """C = 512 (one 16-byte vector per lane), 2500 ROIs in random image order (the backward compacts
+    its image's ROIs in segments of 1024) and padding rows sprinkled in between."""
+    g = torch.Generator().manual_seed(9)
+    B, C, H, W = 3, 512, 18, 37
+    feat = torch.randn(B, C, H, W, generator=g).bfloat16().float()
+    n = 2500
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([1100.0, 500.0])
+    wh = torch.rand(n, 2, generator=g) * torch.tensor([400.0, 250.0]) + 1
+    rois = torch.cat([torch.randint(0, B, (n, 1), generator=g).float(), xy, xy + wh], 1)
+    rois[::97, 0] = -1
+    live = rois[:, 0] >= 0
+    fr = feat.clone().requires_grad_(True)
+    ref = torch.zeros(n, C, 7, 7)
+    ref[live] = oracle_roi_align(fr, rois[live], 7, 1 / 32.0, 0, True)
+    dout = torch.randn(n, C, 7, 7, generator=g).bfloat16().float()
+    ref.backward(dout)
+    fd = nhwc(feat).to(DEV).bfloat16()
+    out = native.roi_align_fwd(fd, rois.to(DEV), 7, 1 / 32.0)
+    got = out.float().cpu().view(n, 7, 7, C).permute(0, 3, 1, 2)
+    assert rel_err(got, ref.detach()) < 8e-3
+    dd = dout.permute(0, 2, 3, 1).reshape(n, 49, C).contiguous().to(DEV).bfloat16()
+    dfeat = native.roi_align_bwd(dd, rois.to(DEV), (B, H, W, C), 7, 1 / 32.0)
+    assert rel_err(nchw(dfeat.cpu()), fr.grad) < 1e-4
+    # accumulate semantics: a second call adds onto the first result
+    dfeat2 = native.roi_align_bwd(dd, rois.to(DEV), (B, H, W, C), 7, 1 / 32.0, dfeat=dfeat.clone())
+    assert rel_err(dfeat2.cpu(), 2 * dfeat.cpu()) < 1e-5
+
+
 # -------------------------------------------------------------------------------------------------
 # NMS / sort / matcher / sampling: bit-exact
 # -------------------------------------------------------------------------------------------------
@@ -346,6 +375,25 @@ def test_nms_indices_bit_exact(native, n):
     for b in range(B):
         live = torch.nonzero(nonempty[b]).squeeze(1)
         ref = live[OB.nms(sb[b][live], torch.arange(len(live), 0, -1).float(), 0.7)][:max_keep]
+        c = keep_cnt[b].item()
+        assert c == len(ref)
+        assert keep_idx[b, :c].cpu().long().tolist() == ref.tolist()
+
+
+@pytest.mark.parametrize("n,max_keep,dense", [(9990, 2000, False), (9990, 2000, True), (16000, 100, True),
+                                              (16384, 16384, False), (20000, 2000, True)])
+def test_nms_large_bit_exact(native, n, max_keep, dense):
+    """The hot-path sizes: 9990 / 16000 candidates (16-wave reduce with prefetched mask rows, early
+    exit at max_keep) and n > 16384 (single-wave-resolve fallback kernel)."""
+    g = torch.Generator().manual_seed(n + max_keep)
+    B = 2
+    span = 250.0 if dense else 1100.0
+    boxes = torch.stack([_rand_boxes(n, g, span=span, size=220.0) for _ in range(B)])
+    npi = torch.tensor([n, n - 1234], dtype=torch.int32)
+    keep_idx, keep_cnt = native.nms(boxes.to(DEV), 0.7, max_keep, n_per_image=npi.to(DEV))
+    for b in range(B):
+        m = int(npi[b])
+        ref = OB.nms(boxes[b, :m], torch.arange(m, 0, -1).float(), 0.7)[:max_keep]
         c = keep_cnt[b].item()
         assert c == len(ref)
         assert keep_idx[b, :c].cpu().long().tolist() == ref.tolist()
