@@ -101,7 +101,8 @@ int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                      float momentum, float eps, int update_running, float* ws, void* stream);
 /* size (in floats, 8-byte aligned) of the `ws` scratch of sfod_bn_finalize */
 int sfod_bn_finalize_ws_floats(int C);
-/* z = relu(gamma*(y-mean)*invstd+beta); pool=1 additionally 2x2/2 max-pools z (floor) */
+/* z = relu(gamma*(y-mean)*invstd+beta); `pool` is a flag word: bit 0 additionally 2x2/2 max-pools z
+ * (floor), bit 1 drops the ReLU (d2 BottleneckBlock conv3 / shortcut norms, no activation) */
 int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* z, int B, int H, int W,
                           int C, int pool, int dt, void* stream);
@@ -112,6 +113,18 @@ int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, cons
                           float* dbeta, float* ws, int B, int H, int W, int C, int pool, int dt,
                           void* stream);
 int sfod_bn_bwd_ws_floats(int M, int C);
+/* ---- ResNet-101-C4 backbone helpers (d2 build_resnet_backbone selected by the r101 yaml's missing
+ * BACKBONE.NAME, configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28) ----
+ * out = act(a + b), act 0/1: residual join of BottleneckBlock (relu(conv3(x) + shortcut(x))) */
+int sfod_add_act(const void* a, const void* b, void* out, int64_t n, int act, int dt, void* stream);
+/* backward=0: dst [B,ceil(H/2),ceil(W/2),C] = src [B,H,W,C] at even pixels (data movement of a 1x1
+ * stride-2 conv, STRIDE_IN_1X1); backward=1: the adjoint (dst [B,H,W,C] zero except even pixels) */
+int sfod_subsample2(const void* src, void* dst, int B, int H, int W, int C, int backward, int dt,
+                    void* stream);
+/* im2col of BasicStem's 7x7 stride-2 pad-3 conv: out [B,Ho,Wo,Kpad], column (ky*7+kx)*3+c */
+int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, void* stream);
+/* BasicStem max_pool2d(kernel 3, stride 2, padding 1), forward (the stem is frozen) */
+int sfod_maxpool3s2(const void* x, void* y, int B, int H, int W, int C, int dt, void* stream);
 /* elementwise: dx = dy * (y > 0) (ReLU) or dy * (y > 0 ? 1 : 0.2) (LeakyReLU) in place on dy */
 int sfod_act_bwd(void* dy, const void* y, int64_t n, int act, int dt, void* stream);
 /* a += b  (fp32 or bf16 elementwise) */

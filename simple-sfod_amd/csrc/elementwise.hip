@@ -172,7 +172,7 @@ extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
 // ---------------------------------------------------------------------------------------------
 // K3/K4 forward: z = relu(gamma * (y - mean) * invstd + beta), optional 2x2/2 max-pool
 // ---------------------------------------------------------------------------------------------
-template <typename T, int POOL>
+template <typename T, int POOL, int RELU>
 __global__ void __launch_bounds__(256)
 k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
                    const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
@@ -198,7 +198,7 @@ k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, cons
     }
     float r[V];
 #pragma unroll
-    for (int i = 0; i < V; ++i) r[i] = 0.f;  // relu floor doubles as the max identity
+    for (int i = 0; i < V; ++i) r[i] = RELU ? 0.f : -3.0e38f;  // relu floor doubles as the max identity
     const int win = POOL ? 2 : 1;
 #pragma unroll
     for (int dy = 0; dy < win; ++dy)
@@ -223,17 +223,23 @@ static inline int ew_grid(int64_t total) {
 
 extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, void* z, int B, int H, int W,
-                                     int C, int pool, int dt, void* stream) {
+                                     int C, int pool_flags, int dt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "bn: C not a multiple of the vector width");
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   const int grid = ew_grid((int64_t)B * Ho * Wo * (C / V));
-#define LAUNCH(T, P)                                                                                  \
-  hipLaunchKernelGGL((k_bn_relu_pool_fwd<T, P>), dim3(grid), dim3(256), 0, s, (const T*)y, mean, invstd, \
+#define LAUNCH(T, P, R)                                                                                  \
+  hipLaunchKernelGGL((k_bn_relu_pool_fwd<T, P, R>), dim3(grid), dim3(256), 0, s, (const T*)y, mean, invstd, \
                      gamma, beta, (T*)z, B, H, W, C)
-  if (dt == SFOD_F32) { if (pool) LAUNCH(float, 1); else LAUNCH(float, 0); }
-  else { if (pool) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 0); }
+  if (dt == SFOD_F32) {
+    if (norelu) { if (pool) LAUNCH(float, 1, 0); else LAUNCH(float, 0, 0); }
+    else { if (pool) LAUNCH(float, 1, 1); else LAUNCH(float, 0, 1); }
+  } else {
+    if (norelu) { if (pool) LAUNCH(bf16_t, 1, 0); else LAUNCH(bf16_t, 0, 0); }
+    else { if (pool) LAUNCH(bf16_t, 1, 1); else LAUNCH(bf16_t, 0, 1); }
+  }
 #undef LAUNCH
   return sfod_check_launch("bn_relu_pool_fwd");
 }
@@ -248,7 +254,7 @@ extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const flo
 // ---------------------------------------------------------------------------------------------
 #define BNB_ROWS 64  // units per workgroup in pass 1
 
-template <typename T, int POOL>
+template <typename T, int POOL, int RELU>
 __device__ __forceinline__ void bn_unit_grad(const T* __restrict__ y, const T* __restrict__ dz, int b,
                                              int oy, int ox, int H, int W, int C, int c0,
                                              const float* mu, const float* sc, const float* sh,
@@ -279,14 +285,14 @@ __device__ __forceinline__ void bn_unit_grad(const T* __restrict__ y, const T* _
     for (int k = 1; k < NW; ++k)
       if (zp[k][i] > best) { best = zp[k][i]; arg = k; }
 #pragma unroll
-    for (int k = 0; k < NW; ++k) g_out[k][i] = (k == arg && best > 0.f) ? gz[i] : 0.f;
+    for (int k = 0; k < NW; ++k) g_out[k][i] = (k == arg && (!RELU || best > 0.f)) ? gz[i] : 0.f;
   }
 }
 
 
 #define BNB_GRID_MAX 1024
 
-template <typename T, int POOL>
+template <typename T, int POOL, int RELU>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
                 const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -318,7 +324,7 @@ k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y, const float* 
       const int oy = (int)(t % Ho);
       const int b = (int)(t / Ho);
       float xh[NW][V], g[NW][V];
-      bn_unit_grad<T, POOL>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
+      bn_unit_grad<T, POOL, RELU>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
 #pragma unroll
       for (int k = 0; k < NW; ++k)
 #pragma unroll
@@ -366,7 +372,7 @@ k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restri
   }
 }
 
-template <typename T, int POOL>
+template <typename T, int POOL, int RELU>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
                const float* __restrict__ invstd, const float* __restrict__ gamma,
@@ -397,7 +403,7 @@ k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* _
       k2[i] = dgamma[c0 + i] * invM;
     }
     float xh[NW][V], g[NW][V];
-    bn_unit_grad<T, POOL>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
+    bn_unit_grad<T, POOL, RELU>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
       const int iy = POOL ? oy * 2 + (k >> 1) : oy, ix = POOL ? ox * 2 + (k & 1) : ox;
@@ -450,9 +456,10 @@ extern "C" int sfod_bn_bwd_ws_floats(int M, int C) {
 
 extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, void* dy, float* dgamma,
-                                     float* dbeta, float* ws, int B, int H, int W, int C, int pool, int dt,
+                                     float* dbeta, float* ws, int B, int H, int W, int C, int pool_flags, int dt,
                                      void* stream) {
   hipStream_t s = (hipStream_t)stream;
+  const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0 && C / V <= 256, "bn_bwd: unsupported channel count");
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
@@ -463,17 +470,22 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
   if (grid1 < 1) grid1 = 1;
   const size_t lds = sizeof(float) * UL * 2 * C;
   const int grid3 = ew_grid(units * cv);
-#define LAUNCH(T, P)                                                                                   \
+#define LAUNCH(T, P, R)                                                                                \
   do {                                                                                                 \
-    hipLaunchKernelGGL((k_bn_bwd_reduce<T, P>), dim3(grid1), dim3(256), lds, s, (const T*)dz,          \
+    hipLaunchKernelGGL((k_bn_bwd_reduce<T, P, R>), dim3(grid1), dim3(256), lds, s, (const T*)dz,       \
                        (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                        \
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws, grid1, C,       \
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws, grid1, C,      \
                        dgamma, dbeta);                                                                 \
-    hipLaunchKernelGGL((k_bn_bwd_apply<T, P>), dim3(grid3), dim3(256), 0, s, (const T*)dz,             \
+    hipLaunchKernelGGL((k_bn_bwd_apply<T, P, R>), dim3(grid3), dim3(256), 0, s, (const T*)dz,          \
                        (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (T*)dy, B, H, W, C);     \
   } while (0)
-  if (dt == SFOD_F32) { if (pool) LAUNCH(float, 1); else LAUNCH(float, 0); }
-  else { if (pool) LAUNCH(bf16_t, 1); else LAUNCH(bf16_t, 0); }
+  if (dt == SFOD_F32) {
+    if (norelu) { if (pool) LAUNCH(float, 1, 0); else LAUNCH(float, 0, 0); }
+    else { if (pool) LAUNCH(float, 1, 1); else LAUNCH(float, 0, 1); }
+  } else {
+    if (norelu) { if (pool) LAUNCH(bf16_t, 1, 0); else LAUNCH(bf16_t, 0, 0); }
+    else { if (pool) LAUNCH(bf16_t, 1, 1); else LAUNCH(bf16_t, 0, 1); }
+  }
 #undef LAUNCH
   int rc = sfod_check_launch("bn_relu_pool_bwd");
   if (rc) return rc;
@@ -546,6 +558,187 @@ extern "C" int sfod_add_inplace(void* a, const void* b, int64_t n, int dt, void*
     hipLaunchKernelGGL(k_add_inplace<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
                        (bf16_t*)a, (const bf16_t*)b, nvec);
   return sfod_check_launch("add_inplace");
+}
+
+// ---------------------------------------------------------------------------------------------
+// ResNet-C4 helpers (d2 build_resnet_backbone: BasicStem + BottleneckBlock)
+// ---------------------------------------------------------------------------------------------
+// out = act(a + b): the residual join of a bottleneck block (relu(conv3_bn(x) + shortcut))
+template <typename T>
+__global__ void k_add_act(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ o, int64_t nvec, int act) {
+  constexpr int V = VecT<T>::N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float x[V], y[V];
+    load_vec<T>(a + t * V, x);
+    load_vec<T>(b + t * V, y);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float v = x[i] + y[i];
+      x[i] = act ? fmaxf(v, 0.f) : v;
+    }
+    store_vec<T>(o + t * V, x);
+  }
+}
+
+extern "C" int sfod_add_act(const void* a, const void* b, void* out, int64_t n, int act, int dt, void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(n % V == 0, "add_act: n not a multiple of the vector width");
+  const int64_t nvec = n / V;
+  if (nvec == 0) return 0;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_add_act<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                       (const float*)b, (float*)out, nvec, act);
+  else
+    hipLaunchKernelGGL(k_add_act<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, nvec, act);
+  return sfod_check_launch("add_act");
+}
+
+// stride-2 pixel subsampling (the data movement of a 1x1 stride-2 convolution) and its adjoint
+template <typename T, int BWD>
+__global__ void k_subsample2(const T* __restrict__ src, T* __restrict__ dst, int B, int H, int W, int C) {
+  // fwd: dst [B,Ho,Wo,C] = src [B,H,W,C] at even pixels; bwd: dst [B,H,W,C] = src [B,Ho,Wo,C] at even pixels, else 0
+  constexpr int V = VecT<T>::N;
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int cv = C / V;
+  const int64_t total = BWD ? (int64_t)B * H * W * cv : (int64_t)B * Ho * Wo * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * V;
+    int64_t pix = t / cv;
+    const int wd = BWD ? W : Wo, hd = BWD ? H : Ho;
+    const int x = (int)(pix % wd);
+    pix /= wd;
+    const int y = (int)(pix % hd);
+    const int b = (int)(pix / hd);
+    float v[V];
+    if (BWD) {
+      if ((x & 1) == 0 && (y & 1) == 0) load_vec<T>(src + (((int64_t)b * Ho + y / 2) * Wo + x / 2) * C + c0, v);
+      else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) v[i] = 0.f;
+      }
+      store_vec<T>(dst + (((int64_t)b * H + y) * W + x) * C + c0, v);
+    } else {
+      load_vec<T>(src + (((int64_t)b * H + 2 * y) * W + 2 * x) * C + c0, v);
+      store_vec<T>(dst + (((int64_t)b * Ho + y) * Wo + x) * C + c0, v);
+    }
+  }
+}
+
+extern "C" int sfod_subsample2(const void* src, void* dst, int B, int H, int W, int C, int backward, int dt,
+                               void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(C % V == 0, "subsample2: C not a multiple of the vector width");
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  const int64_t total = backward ? (int64_t)B * H * W * (C / V) : (int64_t)B * Ho * Wo * (C / V);
+  if (total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 g(ew_grid(total)), blk(256);
+  if (dt == SFOD_F32) {
+    if (backward) hipLaunchKernelGGL((k_subsample2<float, 1>), g, blk, 0, s, (const float*)src, (float*)dst, B, H, W, C);
+    else hipLaunchKernelGGL((k_subsample2<float, 0>), g, blk, 0, s, (const float*)src, (float*)dst, B, H, W, C);
+  } else {
+    if (backward) hipLaunchKernelGGL((k_subsample2<bf16_t, 1>), g, blk, 0, s, (const bf16_t*)src, (bf16_t*)dst, B, H, W, C);
+    else hipLaunchKernelGGL((k_subsample2<bf16_t, 0>), g, blk, 0, s, (const bf16_t*)src, (bf16_t*)dst, B, H, W, C);
+  }
+  return sfod_check_launch("subsample2");
+}
+
+// im2col of the 7x7 stride-2 pad-3 stem convolution: out [B,Ho,Wo,Kpad], k = (ky*7+kx)*3 + c for the
+// first 147 columns, zeros up to Kpad.  The stem is frozen (FREEZE_AT=2), so only the forward exists;
+// the GEMM itself (K = Kpad, N = 64, FrozenBN folded into the weights, ReLU) runs on sfod_conv_fwd.
+template <typename T>
+__global__ void k_im2col_stem(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int Cp, int Kpad) {
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int kv = Kpad / 8;   // 8-element groups per row
+  const int64_t total = (int64_t)B * Ho * Wo * kv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int g = (int)(t % kv);
+    int64_t pix = t / kv;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    T v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = g * 8 + e;
+      float val = 0.f;
+      if (k < 147) {
+        const int tap = k / 3, c = k - tap * 3;
+        const int ky = tap / 7, kx = tap - ky * 7;
+        const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = to_f32(x[(((int64_t)b * H + iy) * W + ix) * Cp + c]);
+      }
+      v[e] = from_f32<T>(val);
+    }
+    T* o = out + t * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = v[e];
+  }
+}
+
+extern "C" int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, void* stream) {
+  SFOD_REQUIRE(Kpad >= 152 && Kpad % 8 == 0 && Cp >= 3, "im2col_stem: Kpad must be a multiple of 8 >= 152");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)B * Ho * Wo * (Kpad / 8);
+  if (total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_im2col_stem<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, (float*)out, B, H,
+                       W, Cp, Kpad);
+  else
+    hipLaunchKernelGGL(k_im2col_stem<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)out, B,
+                       H, W, Cp, Kpad);
+  return sfod_check_launch("im2col_stem");
+}
+
+// max-pool 3x3 stride 2 pad 1 (BasicStem), forward only
+template <typename T>
+__global__ void k_maxpool3s2(const T* __restrict__ x, T* __restrict__ y, int B, int H, int W, int C) {
+  constexpr int V = VecT<T>::N;
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int cv = C / V;
+  const int64_t total = (int64_t)B * Ho * Wo * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * V;
+    int64_t pix = t / cv;
+    const int ox = (int)(pix % Wo);
+    pix /= Wo;
+    const int oy = (int)(pix % Ho);
+    const int b = (int)(pix / Ho);
+    float r[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) r[i] = -3.0e38f;
+    for (int dy = -1; dy <= 1; ++dy)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int iy = 2 * oy + dy, ix = 2 * ox + dx;
+        if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+        float v[V];
+        load_vec<T>(x + (((int64_t)b * H + iy) * W + ix) * C + c0, v);
+#pragma unroll
+        for (int i = 0; i < V; ++i) r[i] = fmaxf(r[i], v[i]);
+      }
+    store_vec<T>(y + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, r);
+  }
+}
+
+extern "C" int sfod_maxpool3s2(const void* x, void* y, int B, int H, int W, int C, int dt, void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(C % V == 0, "maxpool3s2: C not a multiple of the vector width");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / V);
+  if (total == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_maxpool3s2<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, (float*)y, B, H, W, C);
+  else
+    hipLaunchKernelGGL(k_maxpool3s2<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, (const bf16_t*)x, (bf16_t*)y, B, H, W, C);
+  return sfod_check_launch("maxpool3s2");
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -33,9 +33,14 @@ class FlatModelState:
                 for p in m.parameters(recurse=False):
                     norm_ids.add(id(p))
         named = [(n, p) for n, p in model.named_parameters()]
-        decay = [(n, p) for n, p in named if id(p) not in norm_ids and not n.startswith(tuple(frozen_prefixes))]
-        norm = [(n, p) for n, p in named if id(p) in norm_ids and not n.startswith(tuple(frozen_prefixes))]
-        frozen = [(n, p) for n, p in named if n.startswith(tuple(frozen_prefixes))] if frozen_prefixes else []
+        pref = tuple(frozen_prefixes)
+
+        def is_frozen(n, p):  # not optimised: named prefixes, or requires_grad False (d2 freeze())
+            return (bool(pref) and n.startswith(pref)) or not p.requires_grad
+
+        decay = [(n, p) for n, p in named if id(p) not in norm_ids and not is_frozen(n, p)]
+        norm = [(n, p) for n, p in named if id(p) in norm_ids and not is_frozen(n, p)]
+        frozen = [(n, p) for n, p in named if is_frozen(n, p)]
         self.order = decay + norm + frozen
         dev = named[0][1].device
 

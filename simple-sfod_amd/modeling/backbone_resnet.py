@@ -1,0 +1,341 @@
+"""ResNet-C4 backbone (ResNet-50/101, ``res4`` output) on the HIP kernels, behind Detectron2's
+``build_resnet_backbone`` name.
+
+The reference selects this backbone by NOT naming one
+(``/root/reference/configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28``: ``RESNETS.DEPTH
+101``, ``NORM BN``, default ``BACKBONE.NAME = build_resnet_backbone``, ``FREEZE_AT 2``); the module
+itself lives in Detectron2 (not vendored), restated here from its published structure (SURVEY.md
+8a row a2, Appendix A.14):
+
+  BasicStem        conv 7x7 s2 p3 (3->64, no bias) + norm + ReLU + max_pool 3x3 s2 p1
+  BottleneckBlock  conv1 1x1 (stride here: STRIDE_IN_1X1) -> norm -> ReLU -> conv2 3x3 -> norm -> ReLU
+                   -> conv3 1x1 -> norm ; (+ shortcut 1x1 conv + norm when channels change) ; ReLU
+  stages           res2 (3 blocks, 256 ch, stride 4), res3 (4, 512, /8), res4 (6 | 23, 1024, /16)
+  freeze           FREEZE_AT=2: stem + res2 frozen, their norms become FrozenBatchNorm2d (affine);
+                   res3 / res4 keep live BatchNorm2d (train mode: batch statistics + running-stat
+                   refresh = the AdaBN update, also under no_grad for the teacher)
+
+State-dict keys follow Detectron2 (``backbone.stem.conv1.{weight,norm.*}``,
+``backbone.res{2,3,4}.{i}.{conv1,conv2,conv3,shortcut}.{weight,norm.*}``).  The torch modules only own
+parameters; compute:
+
+  frozen stem/res2  FrozenBN folded into the packed weights (scale) and the bias (shift): one conv
+                    kernel per layer with fused ReLU; the 7x7 stem runs as im2col + MFMA GEMM
+  live blocks       conv (+ BN partial statistics in the epilogue) -> finalize -> BN apply (+ReLU);
+                    residual join relu(a + b); hand-written backward (BN, wgrad, dgrad per conv)
+  stride-2 1x1      even-pixel subsampling shared by conv1 and the shortcut, then plain GEMMs
+"""
+import torch
+import torch.nn as nn
+
+from .. import native
+from ..registry import BACKBONE_REGISTRY
+from ..structures import ShapeSpec
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """d2 FrozenBatchNorm2d: buffers only; y = x * (w * rsqrt(var + eps)) + (b - mean * w * rsqrt(var + eps))."""
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features, self.eps = num_features, eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def scale_shift(self):
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale, self.bias - self.running_mean * scale
+
+
+class Conv2d(nn.Conv2d):
+    """d2 layers.Conv2d: a bias-free conv that owns its norm as ``.norm``."""
+
+    def __init__(self, cin, cout, k, stride=1, padding=0, norm=None):
+        super().__init__(cin, cout, kernel_size=k, stride=stride, padding=padding, bias=False)
+        self.norm = norm
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")  # c2_msra_fill
+
+
+def _norm(kind, ch):
+    if kind == "BN":
+        return nn.BatchNorm2d(ch)
+    if kind == "FrozenBN":
+        return FrozenBatchNorm2d(ch)
+    raise NotImplementedError(f"RESNETS.NORM={kind}")
+
+
+class BasicStem(nn.Module):
+    def __init__(self, cin, cout, norm):
+        super().__init__()
+        self.conv1 = Conv2d(cin, cout, 7, stride=2, padding=3, norm=_norm(norm, cout))
+        self.in_channels, self.out_channels, self.stride = cin, cout, 4
+
+
+class BottleneckBlock(nn.Module):
+    def __init__(self, cin, cout, bottleneck, stride, norm, stride_in_1x1=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = cin, cout, stride
+        self.shortcut = Conv2d(cin, cout, 1, stride=stride, norm=_norm(norm, cout)) if cin != cout else None
+        s1, s3 = (stride, 1) if stride_in_1x1 else (1, stride)
+        if s3 != 1:
+            raise NotImplementedError("stride in the 3x3 conv (STRIDE_IN_1X1=False) is not on the hot path")
+        self.conv1 = Conv2d(cin, bottleneck, 1, stride=s1, norm=_norm(norm, bottleneck))
+        self.conv2 = Conv2d(bottleneck, bottleneck, 3, stride=s3, padding=1, norm=_norm(norm, bottleneck))
+        self.conv3 = Conv2d(bottleneck, cout, 1, norm=_norm(norm, cout))
+
+    def convs(self):
+        cs = [self.conv1, self.conv2, self.conv3]
+        return cs + ([self.shortcut] if self.shortcut is not None else [])
+
+
+def _freeze(module):
+    """d2 CNNBlockBase.freeze: requires_grad False + BatchNorm -> FrozenBatchNorm2d (same statistics)."""
+    for p in module.parameters():
+        p.requires_grad = False
+    for m in module.modules():
+        if isinstance(m, Conv2d) and isinstance(m.norm, nn.BatchNorm2d):
+            f = FrozenBatchNorm2d(m.norm.num_features, m.norm.eps)
+            f.weight.copy_(m.norm.weight.data)
+            f.bias.copy_(m.norm.bias.data)
+            f.running_mean.copy_(m.norm.running_mean)
+            f.running_var.copy_(m.norm.running_var)
+            m.norm = f
+
+
+class _ResNetFn(torch.autograd.Function):
+    """The whole trunk as one autograd node (hand-written backward through the live stages)."""
+
+    @staticmethod
+    def forward(ctx, module, save, x_nhwc, *params):
+        saved, outs = module._forward_impl(x_nhwc, save=save)
+        ctx.module, ctx.saved = module, saved
+        return tuple(o.permute(0, 3, 1, 2) for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        pgrads = ctx.module._backward_impl(ctx.saved, grads)
+        ctx.saved = None
+        return (None, None, None) + tuple(pgrads)
+
+
+class ResNet(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        r = cfg.MODEL.RESNETS
+        depth = r.DEPTH
+        blocks_per_stage = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3], 152: [3, 8, 36, 3]}[depth]
+        assert r.NUM_GROUPS == 1 and r.RES5_DILATION == 1, "plain bottleneck ResNets only"
+        self.norm_kind = r.NORM
+        out_features = list(r.OUT_FEATURES)
+        names = ["res2", "res3", "res4", "res5"]
+        last = max(names.index(f) for f in out_features)
+        self.stem = BasicStem(3, r.STEM_OUT_CHANNELS, r.NORM)
+        cin, cout, bott = r.STEM_OUT_CHANNELS, r.RES2_OUT_CHANNELS, r.NUM_GROUPS * r.WIDTH_PER_GROUP
+        self.stage_names = []
+        self._out_feature_channels, self._out_feature_strides = {}, {}
+        stride_total = 4
+        for si in range(last + 1):
+            first_stride = 1 if si == 0 else 2
+            blocks = []
+            for bi in range(blocks_per_stage[si]):
+                blocks.append(BottleneckBlock(cin, cout, bott, first_stride if bi == 0 else 1, r.NORM,
+                                              r.STRIDE_IN_1X1))
+                cin = cout
+            stride_total *= first_stride
+            self.add_module(names[si], nn.Sequential(*blocks))
+            self.stage_names.append(names[si])
+            self._out_feature_channels[names[si]] = cout
+            self._out_feature_strides[names[si]] = stride_total
+            cout, bott = cout * 2, bott * 2
+        self._out_features = out_features
+        # d2 build_resnet_backbone: freeze_at >= 1 freezes the stem, >= k+1 freezes res{k+1}
+        self.freeze_at = cfg.MODEL.BACKBONE.FREEZE_AT
+        self.frozen = set()
+        if self.freeze_at >= 1:
+            _freeze(self.stem)
+            self.frozen.add("stem")
+        for i, n in enumerate(self.stage_names, start=2):
+            if self.freeze_at >= i:
+                _freeze(getattr(self, n))
+                self.frozen.add(n)
+        for n in self.stage_names:
+            if n not in self.frozen and self.norm_kind != "BN":
+                raise NotImplementedError("trainable stages need RESNETS.NORM=BN (the named r101 config)")
+        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self.bn_momentum = 0.1
+
+    # ---- Detectron2 Backbone surface -----------------------------------------------------------------
+    @property
+    def size_divisibility(self):
+        return 0
+
+    def output_shape(self):
+        return {n: ShapeSpec(channels=self._out_feature_channels[n], stride=self._out_feature_strides[n])
+                for n in self._out_features}
+
+    def _live_blocks(self):
+        return [b for n in self.stage_names if n not in self.frozen for b in getattr(self, n)]
+
+    def _param_list(self):
+        ps = []
+        for blk in self._live_blocks():
+            for c in blk.convs():
+                ps += [c.weight, c.norm.weight, c.norm.bias]
+        return ps
+
+    def forward(self, x):
+        dt = native.F32 if self.compute_dtype == torch.float32 else native.BF16
+        n, c, h, w = x.shape
+        xn = torch.zeros(n, h, w, native.chunk_elems(dt), dtype=self.compute_dtype, device=x.device)
+        xn[..., :c] = x.permute(0, 2, 3, 1)
+        return self.forward_nhwc(xn)
+
+    def forward_nhwc(self, x_nhwc):
+        params = self._param_list()
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs = _ResNetFn.apply(self, save, x_nhwc, *params)
+        return dict(zip(self._out_features, outs))
+
+    # ---- engine ------------------------------------------------------------------------------------------
+    def _frozen_conv(self, x, conv, act, dt):
+        """conv + FrozenBN (+ReLU) as one kernel: scale folded into the weights, shift as the bias."""
+        scale, shift = conv.norm.scale_shift()
+        w = conv.weight.detach() * scale.view(-1, 1, 1, 1)
+        k = conv.kernel_size[0]
+        wp = native.pack_conv_weight(w, x.shape[-1], dt)
+        return native.conv_fwd(x, wp, shift.contiguous(), conv.out_channels, k, act=act)
+
+    def _stem_forward(self, x, dt):
+        conv = self.stem.conv1
+        assert isinstance(conv.norm, FrozenBatchNorm2d), "the stem is frozen on the hot path (FREEZE_AT >= 1)"
+        scale, shift = conv.norm.scale_shift()
+        w = (conv.weight.detach() * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(conv.out_channels, 147)
+        kpad = 192
+        wk = torch.zeros(conv.out_channels, kpad, dtype=torch.float32, device=x.device)
+        wk[:, :147] = w
+        cols = native.im2col_stem(x, kpad)
+        B, Ho, Wo, _ = cols.shape
+        wp = native.pack_fc_weight(wk, dt)
+        y = native.conv_fwd(cols.view(B * Ho * Wo, kpad), wp, shift.contiguous(), conv.out_channels, 1, act=1)
+        return native.maxpool3s2(y.view(B, Ho, Wo, conv.out_channels))
+
+    def _live_conv_bn(self, x, conv, relu, dt):
+        bn = conv.norm
+        k = conv.kernel_size[0]
+        wp = native.pack_conv_weight(conv.weight.detach(), x.shape[-1], dt)
+        B, H, W, _ = x.shape
+        if self.training:
+            y, stats = native.conv_fwd(x, wp, None, conv.out_channels, k, want_stats=True)
+            mean, invstd = native.bn_finalize(stats, B * H * W, conv.out_channels, bn.running_mean, bn.running_var,
+                                              self.bn_momentum, bn.eps, True)
+            bn.num_batches_tracked.add_(1)
+        else:
+            y = native.conv_fwd(x, wp, None, conv.out_channels, k)
+            mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
+        z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False, relu=relu)
+        return y, mean, invstd, z
+
+    def _block_forward(self, blk, x, live, dt):
+        """-> (block output, saved activations or None)."""
+        xs = native.subsample2(x) if blk.stride == 2 else x
+        if not live:
+            sc = x if blk.shortcut is None else self._frozen_conv(xs, blk.shortcut, 0, dt)
+            o = self._frozen_conv(xs, blk.conv1, 1, dt)
+            o = self._frozen_conv(o, blk.conv2, 1, dt)
+            o = self._frozen_conv(o, blk.conv3, 0, dt)
+            return native.add_act(o, sc, 1), None
+        y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt)
+        y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt)
+        y3, m3, i3, t3 = self._live_conv_bn(a2, blk.conv3, False, dt)
+        if blk.shortcut is not None:
+            ys, ms, is_, ts = self._live_conv_bn(xs, blk.shortcut, False, dt)
+        else:
+            ys = ms = is_ = None
+            ts = x
+        out = native.add_act(t3, ts, 1)
+        return out, (x.shape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out)
+
+    def _forward_impl(self, x, save=True):
+        dt = native.dt_of(x)
+        saved, outs = [], {}
+        x = self._stem_forward(x, dt)
+        for name in self.stage_names:
+            live = name not in self.frozen
+            for blk in getattr(self, name):
+                x, sv = self._block_forward(blk, x, live, dt)
+                if live and save:
+                    saved.append(sv)
+            if name in self._out_features:
+                outs[name] = x
+        return saved, [outs[n] for n in self._out_features]
+
+    def _conv_bwd(self, g, x_in, y, mean, invstd, conv, relu, need_dx):
+        """grad wrt the norm output -> (dx or None, [dw, dgamma, dbeta])."""
+        bn = conv.norm
+        k = conv.kernel_size[0]
+        dy, dgamma, dbeta = native.bn_relu_pool_bwd(g, y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False,
+                                                    relu=relu)
+        dwp = native.conv_wgrad(x_in, dy, conv.out_channels, k)
+        dw = torch.empty_like(conv.weight)
+        native.unpack_conv_wgrad(dwp, dw)
+        dx = None
+        if need_dx:
+            wr = native.pack_conv_weight(conv.weight.detach(), conv.out_channels, native.dt_of(dy), rot180=True)
+            dx = native.conv_fwd(dy, wr, None, conv.in_channels, k)
+        return dx, [dw, dgamma, dbeta]
+
+    def _block_backward(self, blk, sv, dout, need_dx=True):
+        """dout (grad of the block output, consumed) -> (dx or None, [dw, dgamma, dbeta] per conv)."""
+        (xshape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out) = sv
+        g = native.act_bwd_(dout, out, 1)                      # through the joining ReLU
+        da2, p3 = self._conv_bwd(g, a2, y3, m3, i3, blk.conv3, False, True)
+        da1, p2 = self._conv_bwd(da2, a1, y2, m2, i2, blk.conv2, True, True)
+        dxs, p1 = self._conv_bwd(da1, xs, y1, m1, i1, blk.conv1, True, need_dx)
+        ps = []
+        if blk.shortcut is not None:
+            dsc, ps = self._conv_bwd(g, xs, ys, ms, is_, blk.shortcut, False, need_dx)
+            if need_dx:
+                dxs = native.add_(dxs, dsc)
+        elif need_dx:
+            dxs = native.add_(dxs, g)
+        dx = None
+        if need_dx:
+            dx = native.subsample2_bwd(dxs, xshape) if blk.stride == 2 else dxs
+        return dx, p1 + p2 + p3 + ps
+
+    def _backward_impl(self, saved, out_grads):
+        blocks = self._live_blocks()
+        assert len(saved) == len(blocks)
+        # only the last requested feature feeds the heads on the C4 path; earlier ones would add here
+        live_names = [n for n in self.stage_names if n not in self.frozen]
+        block_stage = [n for n in live_names for _ in getattr(self, n)]
+        stage_last = {n: max(i for i, s in enumerate(block_stage) if s == n) for n in live_names}
+        gmap = {n: g for n, g in zip(self._out_features, out_grads) if g is not None}
+        pg = {}
+        dx = None
+        for bi in range(len(blocks) - 1, -1, -1):
+            blk = blocks[bi]
+            name = block_stage[bi]
+            if stage_last[name] == bi and name in gmap:
+                g_in = gmap[name].permute(0, 2, 3, 1).to(self.compute_dtype).contiguous()
+                dx = g_in if dx is None else native.add_(dx, g_in)
+            if dx is None:
+                saved[bi] = None
+                continue
+            dx, pg[bi] = self._block_backward(blk, saved[bi], dx, need_dx=bi > 0)  # first live block: frozen input
+            saved[bi] = None
+        out = []
+        for bi, blk in enumerate(blocks):
+            if bi in pg:
+                out += pg[bi]
+            else:
+                for c in blk.convs():
+                    out += [None, None, None]
+        return out
+
+
+@BACKBONE_REGISTRY.register()
+def build_resnet_backbone(cfg, _=None):
+    return ResNet(cfg)

@@ -293,15 +293,16 @@ def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, 
     return mean, invstd
 
 
-def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool):
+def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True):
     B, H, W, C = y.shape
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     z = torch.empty(B, Ho, Wo, C, dtype=y.dtype, device=y.device)
-    call("sfod_bn_relu_pool_fwd", y, mean, invstd, gamma, beta, z, B, H, W, C, int(pool), dt_of(y))
+    call("sfod_bn_relu_pool_fwd", y, mean, invstd, gamma, beta, z, B, H, W, C, int(pool) | (0 if relu else 2),
+         dt_of(y))
     return z
 
 
-def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None):
+def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None, relu=True):
     B, H, W, C = y.shape
     if dy is None:
         dy = torch.empty_like(y)
@@ -311,7 +312,7 @@ def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=
         dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
     ws = torch.empty(query("sfod_bn_bwd_ws_floats", B * H * W, C), dtype=torch.float32, device=y.device)
     call("sfod_bn_relu_pool_bwd", dz, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, ws, B, H, W, C,
-         int(pool), dt_of(y))
+         int(pool) | (0 if relu else 2), dt_of(y))
     return dy, dgamma, dbeta
 
 
@@ -323,6 +324,40 @@ def act_bwd_(dy, y, act):
 def add_(a, b):
     call("sfod_add_inplace", a, b, a.numel(), dt_of(a))
     return a
+
+
+def add_act(a, b, act=1):
+    out = torch.empty_like(a)
+    call("sfod_add_act", a, b, out, a.numel(), int(act), dt_of(a))
+    return out
+
+
+def subsample2(x):
+    B, H, W, C = x.shape
+    y = torch.empty(B, (H + 1) // 2, (W + 1) // 2, C, dtype=x.dtype, device=x.device)
+    call("sfod_subsample2", x, y, B, H, W, C, 0, dt_of(x))
+    return y
+
+
+def subsample2_bwd(dy, full_shape):
+    B, H, W, C = full_shape
+    dx = torch.empty(B, H, W, C, dtype=dy.dtype, device=dy.device)
+    call("sfod_subsample2", dy, dx, B, H, W, C, 1, dt_of(dy))
+    return dx
+
+
+def im2col_stem(x, kpad=192):
+    B, H, W, Cp = x.shape
+    out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, kpad, dtype=x.dtype, device=x.device)
+    call("sfod_im2col_stem", x, out, B, H, W, Cp, kpad, dt_of(x))
+    return out
+
+
+def maxpool3s2(x):
+    B, H, W, C = x.shape
+    y = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, C, dtype=x.dtype, device=x.device)
+    call("sfod_maxpool3s2", x, y, B, H, W, C, dt_of(x))
+    return y
 
 
 def cast(src, dtype):
