@@ -25,10 +25,22 @@ FLOPS = {
     "r600": {"trunk": 439.90e9, "rpn": 3.19e9, "box512": 27.42e9, "box2000": 107.12e9},
     "full": {"trunk": 1282.85e9, "rpn": 9.82e9, "box512": 27.42e9, "box2000": 107.12e9},
 }
+# ResNet-101-C4 (BASELINE config #5): stem + res2 are frozen (FREEZE_AT=2) -> no backward through them
+FLOPS_R101 = {
+    "r600": {"trunk": 198.14e9, "frozen": 19.2e9 + 3.4e9, "rpn": 54.14e9, "box256": 54.80e9, "box2000": 428.15e9},
+    "full": {"trunk": 571.43e9, "frozen": 55.8e9 + 9.9e9, "rpn": 155.63e9, "box256": 54.80e9, "box2000": 428.15e9},
+}
+YAML = {"vgg": "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml",
+        "r101": "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml"}
 PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
 
 
-def step_flops(res):
+def step_flops(res, model="vgg"):
+    if model == "r101":
+        f = FLOPS_R101[res]
+        teacher = f["trunk"] + f["rpn"] + f["box2000"]
+        student = f["trunk"] + f["rpn"] + f["box256"]
+        return teacher + student + 2 * (student - f["frozen"])
     f = FLOPS[res]
     teacher = f["trunk"] + f["rpn"] + f["box2000"]
     student = f["trunk"] + f["rpn"] + f["box512"]
@@ -73,6 +85,8 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
     ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
     ap.add_argument("--res", choices=["r600", "full"], default="r600")
+    ap.add_argument("--model", choices=["vgg", "r101"], default="vgg",
+                    help="vgg: the headline VGG16-BN config; r101: r101_c4_..._source_free.yaml (BASELINE config #5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planted", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
@@ -98,8 +112,7 @@ def main():
             "MODEL.DEVICE", f"cuda:{local_rank}"]
     if args.res == "full":
         opts += ["INPUT.MIN_SIZE_TRAIN", "(1024,)", "INPUT.MAX_SIZE_TRAIN", "2048"]
-    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs",
-                                             "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"), opts)
+    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs", YAML[args.model]), opts)
     torch.manual_seed(cfg.SEED + rank)
     trainer = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
     if not args.no_planted:
@@ -149,15 +162,15 @@ def main():
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {
-            "workload": "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml: VGG16-BN teacher+student "
+            "workload": f"{YAML[args.model]}: {'VGG16-BN' if args.model == 'vgg' else 'ResNet-101-C4'} teacher+student "
                         "(teacher fwd + NMS pseudo-labels + student fwd/bwd + SGD + EMA), synthetic 1024x2048 8-class "
                         f"frames -> {h}x{w} network tensors ({'INPUT.MIN_SIZE_TRAIN=600 of the config' if args.res == 'r600' else 'MIN_SIZE_TRAIN overridden to 1024'})",
             "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
             "ema": bool(cfg.SFOD.EMA.ENABLED), "elide_zero_weight_branches": bool(cfg.SFOD.ELIDE_DEAD_BRANCHES),
             "planted_labels": not args.no_planted,
-            "algorithmic_tflop_per_image": round(step_flops(args.res) / 1e12, 3),
+            "algorithmic_tflop_per_image": round(step_flops(args.res, args.model) / 1e12, 3),
         },
-        "step_tflops_per_gpu": round(step_flops(args.res) * value / world / 1e12, 2),
+        "step_tflops_per_gpu": round(step_flops(args.res, args.model) * value / world / 1e12, 2),
         "losses": {k: round(v, 5) for k, v in rec.items() if k.startswith("loss") or k.startswith("roi_head")},
     }
     if timer is not None:
