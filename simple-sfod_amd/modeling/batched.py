@@ -69,11 +69,11 @@ class InstancesRef:
         return self.batch.to_instances()[self.index]
 
 
-def gather_gt(batched_inputs, device):
+def gather_gt(batched_inputs, device, key="instances"):
     """``[x["instances"] for x in batched_inputs]`` -> BatchedGT (or None)."""
-    if "instances" not in batched_inputs[0]:
+    if key not in batched_inputs[0]:
         return None
-    insts = [x["instances"] for x in batched_inputs]
+    insts = [x[key] for x in batched_inputs]
     if all(isinstance(i, InstancesRef) for i in insts):
         b = insts[0].batch
         if all(i.batch is b for i in insts) and [i.index for i in insts] == list(range(len(b))):

@@ -20,7 +20,7 @@ from .. import native
 from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY
 from ..structures import Boxes, ImageList, Instances
 from .batched import BatchedGT, gather_gt
-from .dann import DAInsHead, FCDiscriminator_img
+from .dann import DAInsHead, FCDiscriminator_img, dc_img_loss
 
 
 def build_model(cfg):
@@ -130,10 +130,7 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
         if (not self.training) and (not val_mode):
             return self.inference(batched_inputs)
         if branch == "domain_classifier":
-            raise NotImplementedError(
-                "branch='domain_classifier' (rcnn.py:137-210) is zero-weighted in the named configs "
-                "(DOMAIN_CLASSIFIER.IMAGE/INSTANCE False) and is not built yet; trainers skip it when "
-                "SFOD.ELIDE_DEAD_BRANCHES is on")
+            return self._forward_domain_classifier(batched_inputs)
         images = self.preprocess_image(batched_inputs)
         gt = gather_gt(batched_inputs, self.device)
         features = self._features(images)
@@ -167,3 +164,35 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
                 return {}, proposals_rpn, proposals_roih
             return {}, proposals_rpn.to_instances(), proposals_roih.to_instances()
         raise ValueError(f"unknown branch {branch}")
+
+    def _forward_domain_classifier(self, batched_inputs):
+        """rcnn.py:137-210.  ``image`` is the source-side sample (label 0), ``image_unlabeled`` the target
+        (label 1); both pass the backbone with gradients, the discriminator sees them through the
+        gradient-reversal layer.  Instance-level losses (INS_DC) are reported forward-only (dropout off)."""
+        losses = {}
+        feats = {}
+        for key, label, tag in (("image", 0, "s"), ("image_unlabeled", 1, "t")):
+            images = self.preprocess_image(batched_inputs, key=key)
+            features = self._features(images)
+            feats[tag] = (images, features)
+            losses["loss_DC_img_" + tag] = dc_img_loss(self.DC_img, features[self.dis_type], label)
+        if self.ins_dc:
+            if self.cfg.DOMAIN_CLASSIFIER.INSTANCE:
+                raise NotImplementedError("DOMAIN_CLASSIFIER.INSTANCE=True: the instance-level discriminator has no "
+                                          "backward yet (its loss is zero-weighted in the named configs)")
+            rh = self.roi_heads
+            with torch.no_grad():
+                for tag, label, gkey in (("s", 0, "instances"), ("t", 1, "instances_unlabeled")):
+                    images, features = feats[tag]
+                    gt = gather_gt(batched_inputs, self.device, key=gkey)
+                    props, _ = self.proposal_generator(images, features, None, compute_loss=False, as_instances=False)
+                    feat = features[rh.in_features[0]]
+                    if gt is not None:
+                        rois = rh.label_and_sample_proposals(props, gt, branch="domain_classifier")["rois"]
+                    else:
+                        rois = native.make_rois(props.boxes, props.count)
+                    z = self.DC_ins(rh._box_forward(feat, rois)["h2"])[:, 0]
+                    live = (rois[:, 0] >= 0).float()
+                    bce = torch.clamp(z, min=0) - z * float(label) + torch.log1p(torch.exp(-z.abs()))
+                    losses["loss_DC_ins_" + tag] = (bce * live).sum() / live.sum().clamp(min=1)
+        return losses, [], []
