@@ -99,6 +99,38 @@ def test_dann_modules_match_reference_golden(sfod, native):
     assert rel_err(yi, torch.from_numpy(fx["ins_output"])) < 2e-5
 
 
+def test_adabn_refinement_refreshes_running_stats_like_the_oracle(sfod, native):
+    """base.py:270-337: reset every BN buffer to (0, 1), then train-mode no-grad forwards refresh the
+    running statistics with momentum 0.1 (the weights do not move)."""
+    cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "fp32"])
+    torch.manual_seed(3)
+    model = sfod.modeling.build_model(cfg).train()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k].zero_()
+        if k.endswith("running_var"):
+            sd[k].fill_(1.0)
+    batches = [make_inputs(2, 96, 160, 0, seed=s, with_gt=False) for s in (1, 2, 3)]
+    for b in batches:
+        for d in b:
+            d["image"] = d["image"].to(DEV)
+    w0 = model.backbone.vgg2[0].weight.detach().clone()
+    sfod.engine.adabn_refinement(cfg, model, batches)
+    for b in batches:
+        with torch.no_grad():
+            om.vgg_forward(sd, om.preprocess([d["image"].cpu() for d in b])[0], om.Cfg(), training=True)
+    assert torch.equal(w0, model.backbone.vgg2[0].weight.detach())
+    n = 0
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            torch.testing.assert_close(v.cpu(), sd[k], rtol=2e-4, atol=1e-6)
+            n += 1
+        if k.endswith("num_batches_tracked") and k.startswith("backbone"):
+            assert int(v) == 3
+    assert n == 26
+
+
 def test_dc_img_loss_backward_matches_reference_golden(sfod, native):
     """GRL(-1) -> FCDiscriminator_img -> BCE-with-logits(label 0) with the hand-written backward, against
     loss / input gradient / parameter gradients recorded from the reference's own dann.py
