@@ -77,6 +77,23 @@ def cpu_baseline(res, planted):
                       f"{torch.get_num_threads()} threads), {dt:.1f} s"}
 
 
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py).
+    bench.py cannot collect counters itself; the figure is per launch like `achieved`."""
+    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        for row in json.load(open(path)):
+            if kernel_substr in row["kernel"]:
+                return {"hbm_read_MB_per_launch": row["hbm_read_MB_per_launch"],
+                        "hbm_write_MB_per_launch": row["hbm_write_MB_per_launch"], "source": "profiles/pmc_hbm_traffic_latest.json"}
+    except Exception:
+        return None
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -184,17 +201,26 @@ def main():
             for (name, gf), (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"{name:18s} {gf:10.2f} GF/launch  x{n:4d}  {ms / n:8.3f} ms  {gf / (ms / n):8.1f} TF/s  "
                       f"{100 * ms / (1000 * elapsed):5.1f}% of step", file=sys.stderr)
-        k = summ.get("sfod_conv_fwd", {"ms": 0.0, "flops": 0.0, "launches": 0})
+        key = "sfod_conv_fwd:patch3x3" if "sfod_conv_fwd:patch3x3" in summ else "sfod_conv_fwd:gemm"
+        k = summ.get(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
+        kname = ("k_conv3x3_patch (halo-patch MFMA conv3x3 fwd + dgrad)" if key.endswith("patch3x3")
+                 else "k_conv_fwd (MFMA implicit GEMM)")
         out["roofline"] = {
-            "kernel": "k_conv_fwd (MFMA implicit-GEMM: conv3x3 fwd + dgrad, 1x1, linear)",
+            "kernel": kname,
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK[args.dtype], 4), "traffic": None,
+            "frac": round(ach / PEAK[args.dtype], 4), "traffic": pmc_traffic("k_conv3x3_patchILi1E" if key.endswith("patch3x3") else "k_conv_fwd"),
             "launches_per_step": k["launches"] // max(args.steps, 1),
             "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
             "algorithmic_gflop_per_launch": round(k["flops"] / max(k["launches"], 1) / 1e9, 3),
             "share_of_step_time": round(k["ms"] / (1000.0 * elapsed), 4),
         }
+        g = summ.get("sfod_conv_fwd:gemm")
+        if g and g["ms"] > 0 and key.endswith("patch3x3"):
+            out["roofline_gemm"] = {"kernel": "k_conv_fwd (generic implicit GEMM: 1x1 / linear / first layer)",
+                                    "achieved": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2), "peak": PEAK[args.dtype],
+                                    "unit": "TFLOP/s", "frac": round(g["flops"] / (g["ms"] * 1e-3) / 1e12 / PEAK[args.dtype], 4),
+                                    "share_of_step_time": round(g["ms"] / (1000.0 * elapsed), 4)}
         wk = summ.get("sfod_conv_wgrad")
         if wk and wk["ms"] > 0:
             out["roofline_wgrad"] = {"kernel": "k_conv_wgrad", "achieved": round(wk["flops"] / (wk["ms"] * 1e-3) / 1e12, 2),

@@ -425,6 +425,11 @@ static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, in
   return (int64_t)B * p.tiles_y * p.tiles_x * p.tiles_n >= 128;
 }
 
+extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
+  const P3Plan p = (ksize == 3 && dt == SFOD_BF16) ? sfod_p3_plan(B, H, W, Cin, Cout) : P3Plan{};
+  return use_patch_kernel(p, B, H, W, ksize, dt) ? 2 : 1;
+}
+
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
   const P3Plan p = (ksize == 3 && dt == SFOD_BF16) ? sfod_p3_plan(B, H, W, Cin, Cout) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;

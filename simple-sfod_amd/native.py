@@ -123,7 +123,7 @@ class KernelTimer:
     of the launch (2 x MACs of the GEMM the entry point computes)."""
 
     def __init__(self, watch=("sfod_conv_fwd", "sfod_conv_wgrad")):
-        self.watch = set(watch)
+        self.watch = set(watch)   # entry points; records are keyed "<entry>[:<kernel tag>]"
         self.records = []      # (name, flops, start_event, end_event)
 
     def summary(self):
@@ -139,6 +139,7 @@ class KernelTimer:
 
 _timer = None
 _pending_flops = 0.0
+_pending_tag = ""
 
 
 def set_timer(timer):
@@ -156,7 +157,7 @@ def call(name, *args):
         a.record()
         rc = getattr(lib, name)(*conv, _stream())
         b.record()
-        _timer.records.append((name, _pending_flops, a, b))
+        _timer.records.append((name + _pending_tag, _pending_flops, a, b))
         _pending_flops = 0.0
     else:
         rc = getattr(lib, name)(*conv, _stream())
@@ -239,10 +240,13 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
         nb = query("sfod_conv_stats_blocks", B, H, W, cin, cout, ksize, dt)
         stats = torch.empty(nb * (2 * cout + 1), dtype=torch.float32, device=x.device)
         stats.nblk = nb
-    global _pending_flops
+    global _pending_flops, _pending_tag
     _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
+    if _timer is not None:
+        _pending_tag = ":patch3x3" if query("sfod_conv_fwd_algo", B, H, W, cin, cout, ksize, dt) == 2 else ":gemm"
     call("sfod_conv_fwd", x, w_packed, bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
          F32 if out_dtype == torch.float32 else BF16)
+    _pending_tag = ""
     return (y, stats) if want_stats else y
 
 

@@ -8,7 +8,7 @@ def load(pattern, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = r["Kernel_Name"].split("(")[0][:60]
+            name = r["Kernel_Name"][:96]
             a = agg[name]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
@@ -28,7 +28,7 @@ rows.sort(reverse=True)
 out = []
 for us, k, n, rd, wr, avg in rows[:14]:
     gbs = (rd + wr) / (avg * 1e-6) / 1e9 if avg > 0 else 0
-    print(f"{k:60s} x{n:4d} avg {avg:9.1f} us  read {rd/1e6:9.2f} MB  write {wr/1e6:9.2f} MB  -> {gbs:8.1f} GB/s")
+    print(f"{k[:70]:70s} x{n:4d} avg {avg:9.1f} us  read {rd/1e6:9.2f} MB  write {wr/1e6:9.2f} MB  -> {gbs:8.1f} GB/s")
     out.append({"kernel": k, "launches": n, "avg_us": round(avg, 1), "hbm_read_MB_per_launch": round(rd / 1e6, 3),
                 "hbm_write_MB_per_launch": round(wr / 1e6, 3), "GBps": round(gbs, 1)})
 if len(sys.argv) > 3:
