@@ -399,6 +399,23 @@ def test_nms_large_bit_exact(native, n, max_keep, dense):
         assert keep_idx[b, :c].cpu().long().tolist() == ref.tolist()
 
 
+@pytest.mark.parametrize("n", [2, 100, 9990, 16000, 16384, 20000])
+def test_segmented_sort_stable_descending_with_ties(native, n):
+    """LDS bitonic sort (n <= 16384) and the radix fallback: order identical to
+    torch.sort(descending=True, stable=True), incl. heavy ties, +-0.0, -inf / +inf."""
+    g = torch.Generator().manual_seed(n)
+    B = 3
+    scores = torch.randn(B, n, generator=g)
+    scores[0] = torch.randint(0, 7, (n,), generator=g).float()          # heavy ties
+    scores[1, ::5] = -1.0                                               # the "filtered candidate" marker
+    if n > 10:
+        scores[2, 3], scores[2, 7], scores[2, 5], scores[2, 9] = 0.0, -0.0, float("inf"), float("-inf")
+    ss, si = native.segmented_sort_desc(scores.to(DEV))
+    ref_v, ref_i = torch.sort(scores, dim=1, descending=True, stable=True)
+    assert torch.equal(si.cpu().long(), ref_i)
+    assert torch.equal(ss.cpu(), ref_v)
+
+
 def test_nms_exact_tie_iou_and_threshold_strictness(native):
     boxes = torch.tensor([[[0.0, 0.0, 10.0, 10.0], [0.0, 0.0, 10.0, 5.0], [0.0, 0.0, 10.0, 10.0]]])
     k, c = native.nms(boxes.to(DEV), 0.5, 8)
