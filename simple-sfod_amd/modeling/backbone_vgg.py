@@ -197,11 +197,17 @@ class vgg_backbone(nn.Module):
                                                         bn.bias.detach(), pool)
             cout, cin = conv.out_channels, conv.in_channels
             dwp = native.conv_wgrad(x, dy, cout, 3)
-            dw = torch.empty_like(conv.weight)
-            native.unpack_conv_wgrad(dwp, dw)
+            sink = native.grad_sink(conv.weight)
+            if sink is not None:
+                native.unpack_conv_wgrad(dwp, sink, accumulate=True)   # straight into the flat gradient
+                dw = None
+            else:
+                dw = torch.empty_like(conv.weight)
+                native.unpack_conv_wgrad(dwp, dw)
             # a conv bias followed by train-mode BN has an analytically zero gradient
             # (sum_rows dy == 0); the reference's autograd produces rounding noise around 0.
-            pgrads[4 * li:4 * li + 4] = [dw, torch.zeros_like(conv.bias), dgamma, dbeta]
+            db = None if native.grad_sink(conv.bias) is not None else torch.zeros_like(conv.bias)
+            pgrads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
             if li > 0:
                 dt = native.dt_of(dy)
                 wr = native.pack_conv_weight(conv.weight.detach(), cout, dt, rot180=True)

@@ -187,8 +187,13 @@ class StandardROIHeads(nn.Module):
         native.act_bwd_(dh1, st["h1"], 1)
         # fc1 (K axis in (p, c) order inside the kernels, (c, p) in the state dict)
         dw1p = native.conv_wgrad(st["x0"], dh1, bh.fc1.out_features, 1).view(bh.fc1.out_features, -1)
-        dw1 = torch.empty_like(bh.fc1.weight)
-        native.unpack_fc_wgrad(dw1p, dw1, chw_c=C)
+        dw1 = native.grad_sink(bh.fc1.weight)
+        if dw1 is not None:     # 103 MB: accumulate straight into the flat gradient, nothing for autograd to add
+            native.unpack_fc_wgrad(dw1p, dw1, chw_c=C, accumulate=True)
+            dw1 = None
+        else:
+            dw1 = torch.empty_like(bh.fc1.weight)
+            native.unpack_fc_wgrad(dw1p, dw1, chw_c=C)
         db1 = native.bias_grad(dh1, bh.fc1.out_features)
         w1t = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C, transpose=True)
         dx0 = native.conv_fwd(dh1, w1t, None, bh.fc1.in_features, 1)

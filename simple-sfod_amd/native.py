@@ -203,6 +203,16 @@ def pack_conv_weight(w_oihw, cin_pad, dt, rot180=False):
     return out
 
 
+def grad_sink(param):
+    """The tensor a hand-written backward may ACCUMULATE a parameter gradient into directly (the
+    parameter's view of the flat gradient buffer, zeroed by zero_grad), or None -> return the gradient to
+    autograd instead.  Saves the temporary and autograd's separate accumulate kernel per parameter."""
+    g = getattr(param, "grad", None)
+    if g is not None and g.is_cuda and g.dtype == torch.float32 and g.is_contiguous() and g.shape == param.shape:
+        return g
+    return None
+
+
 def unpack_conv_wgrad(dw_packed, dw_oihw, accumulate=False):
     cout, cin, ks, _ = dw_oihw.shape
     call("sfod_unpack_conv_wgrad", dw_packed, dw_oihw, cout, cin, ks, dw_packed.shape[-1], int(accumulate))
