@@ -78,6 +78,41 @@ class EventStorage:
         return out
 
 
+class GradientReducer:
+    """Sum all-reduce of the flat gradient buffer in two phases so that communication overlaps the
+    backbone backward: ``launch_early()`` (called when the backbone's backward starts, i.e. when every
+    gradient of the heads is final) starts an asynchronous all-reduce of the contiguous heads slice
+    [lo, hi) on the collective's own stream; ``finish()`` waits for it and reduces the rest.  xGMI is
+    point-to-point, so one large message per phase (not 25 MB DDP buckets) keeps every link busy."""
+
+    def __init__(self, flat, prefixes=("proposal_generator.", "roi_heads.")):
+        self.flat = flat
+        self.work = None
+        inside = [(o, o + k) for n, (o, k, _) in flat.offsets.items() if n.startswith(tuple(prefixes))]
+        self.lo, self.hi = (min(a for a, _ in inside), max(b for _, b in inside)) if inside else (0, 0)
+        # the slice must contain nothing but head parameters (named_parameters order keeps modules together)
+        for n, (o, k, _) in flat.offsets.items():
+            if self.lo <= o < self.hi and not n.startswith(tuple(prefixes)):
+                self.lo = self.hi = 0
+        self.hi = min((self.hi + 3) // 4 * 4, flat.grad.numel())
+
+    def launch_early(self):
+        if self.work is None and self.hi > self.lo and get_world_size() > 1:
+            self.work = dist.all_reduce(self.flat.grad[self.lo:self.hi], async_op=True)
+
+    def finish(self):
+        g = self.flat.grad
+        if self.work is None:
+            dist.all_reduce(g)
+            return
+        if self.lo > 0:
+            dist.all_reduce(g[: self.lo])
+        if self.hi < g.numel():
+            dist.all_reduce(g[self.hi:])
+        self.work.wait()
+        self.work = None
+
+
 class BaseTrainer:
     """Source-only training (``TRAINER: "base"``)."""
 
@@ -86,6 +121,7 @@ class BaseTrainer:
         self.device = torch.device(cfg.MODEL.DEVICE)
         self.model = self.build_model(cfg)
         self.optimizer = self.build_optimizer(cfg, self.model)
+        self._attach_reducer()
         self.scheduler = WarmupMultiStepLR(self.optimizer, cfg)
         self.data_loader = data_loader or self.build_train_loader(cfg)
         self._data_loader_iter = iter(self.data_loader)
@@ -93,6 +129,18 @@ class BaseTrainer:
         self.iter = 0
         self.storage = EventStorage(0)
         self.model.train()
+
+    def _attach_reducer(self):
+        """N > 1: overlap the heads' gradient all-reduce with the backbone backward.  The backbone's autograd
+        node calls ``_pre_backward`` when its backward starts -- every gradient of the RPN / ROI heads is final
+        by then, unless a live domain-classifier branch adds a second pass through the backbone."""
+        cfg = self.cfg
+        dc_live = ("DOMAIN_CLASSIFIER" in cfg and cfg.DOMAIN_CLASSIFIER.ENABLED and
+                   (cfg.DOMAIN_CLASSIFIER.IMAGE or cfg.DOMAIN_CLASSIFIER.INSTANCE or not cfg.SFOD.ELIDE_DEAD_BRANCHES))
+        self._reducer = None
+        if get_world_size() > 1 and not dc_live:
+            self._reducer = GradientReducer(self.optimizer.flat)
+            self.model.backbone._pre_backward = self._reducer.launch_early
 
     @classmethod
     def build_model(cls, cfg):
@@ -123,11 +171,17 @@ class BaseTrainer:
         self.optimizer.step()
 
     def _reduce_gradients(self):
-        """The one collective of the step: sum the flat gradient buffer over ranks (RCCL);
-        the 1/world averaging (DDP semantics) is folded into the fused SGD kernel."""
+        """The one exchange step: sum the flat gradient buffer over ranks (RCCL); the 1/world averaging
+        (DDP semantics) is folded into the fused SGD kernel.  With a GradientReducer attached the heads'
+        slice (RPN + ROI heads, ~117 MB of the 190 MB) is already in flight: it was launched when the
+        backbone backward started and overlaps it."""
         w = get_world_size()
         if w > 1:
-            dist.all_reduce(self.optimizer.flat.grad)
+            red = getattr(self, "_reducer", None)
+            if red is not None:
+                red.finish()
+            else:
+                dist.all_reduce(self.optimizer.flat.grad)
             self.optimizer.grad_scale = 1.0 / w
 
     def _write_metrics(self, metrics_dict):
@@ -196,6 +250,7 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         # to load, the teacher is initialised as a copy of the student.
         self.model = self.build_model(cfg)
         self.optimizer = self.build_optimizer(cfg, self.model)
+        self._attach_reducer()
         self.model_teacher = self.build_model(cfg)
         self.teacher_flat = FlatModelState(self.model_teacher, frozen_prefixes=self._frozen(cfg), with_grad=False)
         self._copy_main_model()

@@ -306,6 +306,9 @@ class ResNet(nn.Module):
         return dx, p1 + p2 + p3 + ps
 
     def _backward_impl(self, saved, out_grads):
+        hook = getattr(self, "_pre_backward", None)
+        if hook is not None:
+            hook()   # e.g. GradientReducer.launch_early: the heads' gradients are final now
         blocks = self._live_blocks()
         assert len(saved) == len(blocks)
         # only the last requested feature feeds the heads on the C4 path; earlier ones would add here

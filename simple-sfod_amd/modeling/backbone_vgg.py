@@ -176,6 +176,9 @@ class vgg_backbone(nn.Module):
 
     def _backward_impl(self, saved, out_grads):
         """out_grads: grads of the 5 stage outputs (NCHW views or None) -> flat list of param grads."""
+        hook = getattr(self, "_pre_backward", None)
+        if hook is not None:
+            hook()   # e.g. GradientReducer.launch_early: the heads' gradients are final now
         dtype = self.compute_dtype
         pgrads = [None] * (4 * len(self._plan))
         stage_of = []

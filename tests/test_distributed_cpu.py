@@ -41,6 +41,18 @@ def _worker(rank, world, port, q):
     gathered = [torch.zeros_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     ok_sum = torch.allclose(flat.grad, sum(gathered))
+    # two-phase reducer: the "heads" slice (here module 2) goes first and asynchronously, the rest afterwards
+    flat.grad.copy_(local)
+    red = sfod.engine.trainer.GradientReducer(flat, prefixes=("2.",))
+    o2, k2, _ = flat.offsets["2.weight"]
+    assert red.lo == o2 and red.hi >= flat.offsets["2.bias"][0] + flat.offsets["2.bias"][1]
+    red.launch_early()
+    tr2 = SimpleNamespace(optimizer=opt, _reducer=red)
+    sfod.engine.trainer.BaseTrainer._reduce_gradients(tr2)
+    ok_sum = ok_sum and torch.allclose(flat.grad, sum(gathered)) and red.work is None
+    # a slice that is not purely head parameters disables the early phase (plain single all-reduce)
+    red_bad = sfod.engine.trainer.GradientReducer(flat, prefixes=("0.weight", "2."))
+    ok_sum = ok_sum and red_bad.lo == red_bad.hi == 0
     # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream
     s = iter(sfod.data.TrainingSampler(10, seed=7, rank=rank, world=world))
     mine = [next(s) for _ in range(10)]
