@@ -39,6 +39,10 @@ int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes, int B, in
                     int Cpad, const float* mean3, const float* std3, void* out, int dt,
                     void* stream);
 
+/* horizontal flip of a uint8 [C,H,W] image: the RandomFlip(0.5, horizontal) of the weak augmentation
+ * (d2 build_augmentation; daod/data/mappers/two_crop_augmentation_mapper.py:73-157), on device */
+int sfod_hflip_u8(const void* src, void* dst, int C, int H, int W, void* stream);
+
 /* ---- K2/K5/K14/K18: implicit-GEMM convolution / linear layer on MFMA.
  * y[m, n] = act( sum_{tap, c} x[pix(m) + tap][c] * w[n][tap][c] + bias[n] ),  m = (b, oy, ox)
  * x: [B,H,W,Cin] NHWC, w: packed [Cout][KH*KW][Cin] (K contiguous), y: [B,H,W,ldy] with ldy >=

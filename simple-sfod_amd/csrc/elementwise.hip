@@ -79,6 +79,40 @@ extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes
   return sfod_check_launch("preprocess");
 }
 
+static inline int ew_grid(int64_t total);
+
+// horizontal flip of a uint8 [C,H,W] image (d2 RandomFlip in the weak augmentation): 16 output
+// bytes per thread, read as the mirrored 16 bytes and byte-reversed
+__global__ void __launch_bounds__(256)
+k_hflip_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows, int W) {
+  const int chunks = (W + 15) / 16;
+  const int64_t total = (int64_t)rows * chunks;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(t / chunks), c = (int)(t % chunks);
+    const int x0 = c * 16;
+    const uint8_t* s = src + (int64_t)r * W;
+    uint8_t* d = dst + (int64_t)r * W;
+    const int n = min(16, W - x0);
+    uint8_t v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = (i < n) ? s[W - 1 - (x0 + i)] : (uint8_t)0;
+    if (n == 16 && ((W & 15) == 0)) {
+      *reinterpret_cast<uint4*>(d + x0) = *reinterpret_cast<const uint4*>(v);
+    } else {
+      for (int i = 0; i < n; ++i) d[x0 + i] = v[i];
+    }
+  }
+}
+
+extern "C" int sfod_hflip_u8(const void* src, void* dst, int C, int H, int W, void* stream) {
+  if ((int64_t)C * H * W == 0) return 0;
+  const int64_t total = (int64_t)C * H * ((W + 15) / 16);
+  hipLaunchKernelGGL(k_hflip_u8, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
+                     (uint8_t*)dst, C * H, W);
+  return sfod_check_launch("hflip_u8");
+}
+
 // ---------------------------------------------------------------------------------------------
 // K3 BatchNorm statistics finalize.  stats[blk][0][c] = sum over the block's rows, stats[blk][1][c]
 // = sum of squared deviations from the block mean, counts[blk] (behind the sums) = rows of the block
@@ -181,6 +215,38 @@ k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, cons
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const int cv = C / V;
   const int64_t total = (int64_t)B * Ho * Wo * cv;
+  if constexpr (!POOL) {
+    // no pooling: z and y share one layout, and when the grid stride is a multiple of the channel-vector
+    // count a thread keeps ONE channel vector for its whole grid-stride walk: no index arithmetic, the
+    // affine coefficients live in registers
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (stride % cv == 0) {
+      int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      const int c0 = (int)(t % cv) * V;
+      float sc[V], sh[V], mu[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        sc[i] = invstd[c0 + i] * gamma[c0 + i];
+        mu[i] = mean[c0 + i];
+        sh[i] = beta[c0 + i];
+      }
+      for (; t < total; t += 2 * stride) {
+        float v0[V], v1[V];
+        const bool two = t + stride < total;
+        load_vec<T>(y + t * V, v0);
+        if (two) load_vec<T>(y + (t + stride) * V, v1);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float a = (v0[i] - mu[i]) * sc[i] + sh[i], b2 = (v1[i] - mu[i]) * sc[i] + sh[i];
+          v0[i] = RELU ? fmaxf(a, 0.f) : a;
+          v1[i] = RELU ? fmaxf(b2, 0.f) : b2;
+        }
+        store_vec<T>(z + t * V, v0);
+        if (two) store_vec<T>(z + (t + stride) * V, v1);
+      }
+      return;
+    }
+  }
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int c0 = (int)(t % cv) * V;
@@ -319,6 +385,20 @@ k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y, const float* 
   for (int i = 0; i < V; ++i) { db[i] = 0.f; dg[i] = 0.f; }
   if (ul < UL) {
     for (int64_t u = (int64_t)blockIdx.x * UL + ul; u < units; u += (int64_t)gridDim.x * UL) {
+      if constexpr (!POOL) {   // flat: unit u is pixel u
+        float v[V], gz[V];
+        load_vec<T>(y + u * C + c0, v);
+        load_vec<T>(dz + u * C + c0, gz);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xh = (v[i] - mu[i]) * invs[i];
+          const float zp = (v[i] - mu[i]) * sc[i] + sh[i];
+          const float gg = (!RELU || zp > 0.f) ? gz[i] : 0.f;
+          db[i] += gg;
+          dg[i] += gg * xh;
+        }
+        continue;
+      }
       const int ox = (int)(u % Wo);
       const int64_t t = u / Wo;
       const int oy = (int)(t % Ho);
@@ -384,6 +464,37 @@ k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* _
   const int cv = C / V;
   const float invM = 1.f / (float)((int64_t)B * H * W);
   const int64_t total = (int64_t)B * Ho * Wo * cv;
+  if constexpr (!POOL) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    if (stride % cv == 0) {   // flat walk with a fixed channel vector per thread (see the forward kernel)
+      int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+      const int c0 = (int)(t % cv) * V;
+      float mu[V], sc[V], sh[V], invs[V], k1[V], k2[V];
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        invs[i] = invstd[c0 + i];
+        sc[i] = invs[i] * gamma[c0 + i];
+        mu[i] = mean[c0 + i];
+        sh[i] = beta[c0 + i];
+        k1[i] = dbeta[c0 + i] * invM;
+        k2[i] = dgamma[c0 + i] * invM;
+      }
+      for (; t < total; t += stride) {
+        float v[V], gz[V], o[V];
+        load_vec<T>(y + t * V, v);
+        load_vec<T>(dz + t * V, gz);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+          const float xh = (v[i] - mu[i]) * invs[i];
+          const float zp = (v[i] - mu[i]) * sc[i] + sh[i];
+          const float g = (!RELU || zp > 0.f) ? gz[i] : 0.f;
+          o[i] = sc[i] * (g - k1[i] - xh * k2[i]);
+        }
+        store_vec<T>(dy + t * V, o);
+      }
+      return;
+    }
+  }
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
        t += (int64_t)gridDim.x * blockDim.x) {
     const int c0 = (int)(t % cv) * V;

@@ -16,6 +16,8 @@ random horizontal flip.
 import numpy as np
 import torch
 
+from .. import native
+
 from ..structures import Boxes, Instances
 
 CITYSCAPES_CLASSES = ["person", "rider", "car", "truck", "bus", "train", "motorcycle", "bicycle"]
@@ -126,7 +128,7 @@ class TwoCropLoader:
     def _map(self, item):
         img, boxes = item["image"], item["boxes"]
         if self.flip and torch.rand(1, generator=self.gen).item() < 0.5:
-            img = torch.flip(img, dims=[2])
+            img = native.hflip_u8(img) if img.is_cuda else torch.flip(img, dims=[2])
             w = img.shape[2]
             boxes = torch.stack([w - boxes[:, 2], boxes[:, 1], w - boxes[:, 0], boxes[:, 3]], dim=1)
         inst = Instances((int(img.shape[1]), int(img.shape[2])))

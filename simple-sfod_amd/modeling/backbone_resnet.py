@@ -110,6 +110,7 @@ class _ResNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, save, x_nhwc, *params):
         saved, outs = module._forward_impl(x_nhwc, save=save)
+        ctx.set_materialize_grads(False)   # unused stage outputs arrive as None, not as zero tensors
         ctx.module, ctx.saved = module, saved
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
 

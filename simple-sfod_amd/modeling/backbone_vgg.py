@@ -57,6 +57,7 @@ class _VGGFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, save, x_nhwc, *params):
         saved, outs = module._forward_impl(x_nhwc, save=save)
+        ctx.set_materialize_grads(False)   # unused stage outputs arrive as None, not as zero tensors to copy / add
         ctx.module = module
         ctx.saved = saved
         ctx.need_dx = False

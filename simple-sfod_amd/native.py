@@ -195,6 +195,15 @@ def preprocess(images_u8, Hp, Wp, cpad, mean, std, dt):
     return out, sizes
 
 
+def hflip_u8(img):
+    """uint8 [C,H,W] device image -> horizontally flipped copy."""
+    assert img.dtype == torch.uint8 and img.dim() == 3
+    img = img.contiguous()
+    out = torch.empty_like(img)
+    call("sfod_hflip_u8", img, out, img.shape[0], img.shape[1], img.shape[2])
+    return out
+
+
 def pack_conv_weight(w_oihw, cin_pad, dt, rot180=False):
     cout, cin, ks, _ = w_oihw.shape
     rows = cin if rot180 else cout
