@@ -62,7 +62,8 @@ int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, in
  * DMA'd per tap), 2 halo-patch kernel (input patch staged once per 32-channel slice and reused by
  * all nine taps) whenever the shape allows.  For A/B tests and benchmarks. */
 int sfod_set_conv_algo(int algo);
-/* which kernel sfod_conv_fwd runs for this shape: 1 generic implicit GEMM, 2 halo-patch */
+/* which kernel sfod_conv_fwd runs for this shape: 1 generic implicit GEMM, 2 halo-patch, 3 first-layer
+ * kernel (Cin = one padded 8-channel chunk, Cout = 64, bf16) */
 int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
 
 /* weight gradient: dw[n][tap][c] += sum_m dy[m][n] * x[pix(m)+tap][c]  (fp32, packed layout, added

@@ -22,6 +22,7 @@ SOURCES = {
     "gemm_conv.hip": [],
     "conv3x3_patch.hip": [],
     "wgrad3x3_patch.hip": [],
+    "conv_first.hip": [],
     "sort.hip": [],
     "runtime.cpp": [],
 }

@@ -1,0 +1,200 @@
+// First VGG layer (conv1_1: 3 -> 64 channels, 3x3, pad 1) on bf16 MFMA, gfx950.
+//
+// The input has 3 real channels padded to one 16-byte chunk (8 bf16), so an im2col row is 9 taps x 8
+// channels = 72 values and the layer is bound by writing its 64-channel output, not by arithmetic.  The
+// generic implicit GEMM spends 0.48 ms on it (per-lane tap decoding, 128-row tiles, half-empty K tiles).
+// Here: workgroup = 8 x 32 output pixels, 4 waves (two image rows each); the 10 x 34 halo patch is staged
+// in LDS as one 16-byte chunk per pixel, so an A fragment of k-step s (taps 2s, 2s+1) is ONE conflict-free
+// ds_read_b128 per lane; all ten weight fragments live in registers for the whole (grid-stride) tile loop.
+// Epilogue as in conv3x3_patch.hip: bias, per-wave LDS staging for 16-byte stores, BatchNorm (sum, M2,
+// count) per workgroup.
+#include "conv_internal.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+constexpr int TH = 8, TW = 32, PW = TW + 2, PH = TH + 2;
+constexpr int PATCH_BYTES = PH * PW * 16;            // 5440
+constexpr int STG_OFF = 5632;                        // staged C tiles: 4 waves x 64 rows x 144 B
+constexpr int STG_PITCH = 144;
+constexpr int SRED_OFF = STG_OFF + 4 * 64 * STG_PITCH;   // float [4][64][2] + float [4]
+constexpr int LDS_BYTES = SRED_OFF + 4 * 64 * 2 * 4 + 16;
+
+struct F1Args {
+  const bf16_t* x;     // [B,H,W,8]
+  const bf16_t* w;     // [64][9][8]
+  const float* bias;
+  bf16_t* y;           // [B,H,W,ldy]
+  float* stats;
+  int B, H, W, ldy, act;
+  int tiles_y, tiles_x, ntiles;
+};
+
+__global__ void __launch_bounds__(256)
+k_conv_first(F1Args a) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, l31 = lane & 31;
+
+  // weight fragments: bq[j][s] = w[j*32 + l31][tap 2s+h][0..7], zeros for the padding tap 9
+  bf16x8 bq[2][5];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int tap = 2 * s + h;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (tap < 9) v = *reinterpret_cast<const uint4*>(a.w + ((j * 32 + l31) * 9 + tap) * 8);
+      bq[j][s] = __builtin_bit_cast(bf16x8, v);
+    }
+  float bcol[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) bcol[j] = a.bias ? a.bias[j * 32 + l31] : 0.f;
+
+  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    int t = tile;
+    const int txi = t % a.tiles_x;
+    t /= a.tiles_x;
+    const int tyi = t % a.tiles_y;
+    const int b = t / a.tiles_y;
+    const int x0 = txi * TW, y0 = tyi * TH;
+    const bf16_t* ximg = a.x + (int64_t)b * a.H * a.W * 8;
+    __syncthreads();   // previous tile's LDS users are done
+    for (int p = threadIdx.x; p < PH * PW; p += 256) {
+      const int py = p / PW, px = p - py * PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = *reinterpret_cast<const uint4*>(ximg + ((int64_t)iy * a.W + ix) * 8);
+      *reinterpret_cast<uint4*>(smem + p * 16) = v;
+    }
+    __syncthreads();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+      const int tap = 2 * s + h;               // per-lane tap (two taps per k-step)
+      const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (2 * wave + i + ky) * PW + l31 + kx;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (tap < 9) v = *reinterpret_cast<const uint4*>(smem + row * 16);
+        const bf16x8 af = __builtin_bit_cast(bf16x8, v);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bq[j][s], acc[i][j], 0, 0, 0);
+      }
+    }
+    // ---- epilogue: rows of M-fragment i are the 32 pixels of image row y0 + 2*wave + i
+    unsigned char* stg = smem + STG_OFF + wave * (64 * STG_PITCH);
+    unsigned vmask[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned m = 0;
+      const int iy = y0 + 2 * wave + i;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (iy < a.H && x0 + px < a.W) m |= (1u << r);
+      }
+      vmask[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const float v = acc[i][j][r] + bcol[j];
+          acc[i][j][r] = v;
+          const float o = (a.act == 1) ? fmaxf(v, 0.f) : v;
+          *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + (j * 32 + l31) * 2) = (bf16_t)o;
+        }
+    // same-wave readback (LDS is in order per wave): 8 rows x 128 B per instruction
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = it * 8 + (lane >> 3), ch = lane & 7;
+      const int iy = y0 + 2 * wave + (row >> 5), ix = x0 + (row & 31);
+      if (iy < a.H && ix < a.W) {
+        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * STG_PITCH + ch * 16);
+        *reinterpret_cast<uint4*>(a.y + (((int64_t)b * a.H + iy) * a.W + ix) * a.ldy + ch * 8) = v;
+      }
+    }
+    if (a.stats != nullptr) {
+      float* sred = reinterpret_cast<float*>(smem + SRED_OFF);   // [wave][64][2]
+      float* scnt = sred + 4 * 64 * 2;
+      int cnt = __builtin_popcount(vmask[0]) + __builtin_popcount(vmask[1]);
+      cnt += __shfl_xor(cnt, 32);
+      const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float sm = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sm += ((vmask[i] >> r) & 1u) ? acc[i][j][r] : 0.f;
+        sm += __shfl_xor(sm, 32);
+        const float mean = sm * inv;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[i][j][r] - mean;
+            q += ((vmask[i] >> r) & 1u) ? d * d : 0.f;
+          }
+        q += __shfl_xor(q, 32);
+        if (h == 0) {
+          sred[(wave * 64 + j * 32 + l31) * 2 + 0] = sm;
+          sred[(wave * 64 + j * 32 + l31) * 2 + 1] = q;
+        }
+      }
+      if (lane == 0) scnt[wave] = (float)cnt;
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int col = threadIdx.x;
+        double n_tot = 0.0, s_tot = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { n_tot += (double)scnt[k]; s_tot += (double)sred[(k * 64 + col) * 2]; }
+        const double mu = n_tot > 0.0 ? s_tot / n_tot : 0.0;
+        double m2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const double nk = (double)scnt[k];
+          if (nk > 0.0) {
+            const double d = (double)sred[(k * 64 + col) * 2] / nk - mu;
+            m2 += (double)sred[(k * 64 + col) * 2 + 1] + nk * d * d;
+          }
+        }
+        a.stats[((int64_t)tile * 2 + 0) * 64 + col] = (float)s_tot;
+        a.stats[((int64_t)tile * 2 + 1) * 64 + col] = (float)m2;
+        if (col == 0) a.stats[(int64_t)a.ntiles * 2 * 64 + tile] = (float)n_tot;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int sfod_f1_nblk(int B, int H, int W) { return B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
+
+int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int B, int H, int W,
+                   int ldy, int act, hipStream_t s) {
+  F1Args a;
+  a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.stats = stats;
+  a.B = B; a.H = H; a.W = W; a.ldy = ldy; a.act = act;
+  a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
+  a.ntiles = B * a.tiles_y * a.tiles_x;
+  int grid = a.ntiles < 256 * 8 ? a.ntiles : 256 * 8;
+  hipLaunchKernelGGL(k_conv_first, dim3(grid), dim3(256), 0, s, a);
+  return sfod_check_launch("conv_first");
+}

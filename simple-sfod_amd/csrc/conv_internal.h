@@ -33,3 +33,8 @@ struct W3Plan {
 W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy);
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, hipStream_t s);
+
+// ---- first layer (Cin = one padded chunk of 8, Cout = 64), bf16 ------------------------------------------
+int sfod_f1_nblk(int B, int H, int W);
+int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int B, int H, int W,
+                   int ldy, int act, hipStream_t s);

@@ -425,12 +425,20 @@ static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, in
   return (int64_t)B * p.tiles_y * p.tiles_x * p.tiles_n >= 128;
 }
 
+// first VGG layer: 3 real channels in one 8-wide chunk, 64 outputs, bf16 in / bf16 out
+static bool use_first_kernel(int B, int H, int W, int Cin, int Cout, int ksize, int dt, int ldy, int out_dt) {
+  return ksize == 3 && dt == SFOD_BF16 && out_dt == SFOD_BF16 && Cin == 8 && Cout == 64 && ldy % 8 == 0 &&
+         g_conv_algo != 1 && (int64_t)B * H * W >= 4096;
+}
+
 extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, SFOD_BF16)) return 3;
   const P3Plan p = (ksize == 3 && dt == SFOD_BF16) ? sfod_p3_plan(B, H, W, Cin, Cout) : P3Plan{};
   return use_patch_kernel(p, B, H, W, ksize, dt) ? 2 : 1;
 }
 
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, SFOD_BF16)) return sfod_f1_nblk(B, H, W);
   const P3Plan p = (ksize == 3 && dt == SFOD_BF16) ? sfod_p3_plan(B, H, W, Cin, Cout) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;
   return (B * H * W + 127) / 128;
@@ -486,6 +494,8 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
   SFOD_REQUIRE(Cin % E == 0, "conv: Cin must be a multiple of the 16-byte chunk");
   if ((int64_t)B * H * W == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, ldy, out_dt))
+    return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, s);
   if (ksize == 3 && dt == SFOD_BF16) {
     const P3Plan p = sfod_p3_plan(B, H, W, Cin, Cout);
     if (use_patch_kernel(p, B, H, W, ksize, dt))

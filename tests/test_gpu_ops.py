@@ -126,6 +126,40 @@ def test_conv3x3_patch_kernel(native, shape, variant):
         native.set_conv_algo(0)
 
 
+@pytest.mark.parametrize("hw", [(50, 70), (64, 96), (9, 500)])
+@pytest.mark.parametrize("stats", [False, True])
+def test_conv_first_layer_kernel(native, hw, stats):
+    """k_conv_first (3 real channels in one 8-wide chunk -> 64): image edges, tiles hanging over the
+    right / bottom border, BatchNorm statistics; against F.conv2d and the generic kernel."""
+    H, W = hw
+    B, Cin, Cout = 2, 3, 64
+    g = torch.Generator().manual_seed(H + W)
+    x = (torch.randn(B, Cin, H, W, generator=g) * 50).bfloat16().float()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / 5).bfloat16().float()
+    bias = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x, w, bias, padding=1)
+    xd = torch.zeros(B, H, W, 8, dtype=torch.bfloat16, device=DEV)
+    xd[..., :3] = nhwc(x).to(DEV).bfloat16()
+    wp = native.pack_conv_weight(w.to(DEV), 8, native.BF16)
+    assert native.query("sfod_conv_fwd_algo", B, H, W, 8, Cout, 3, native.BF16) == 3
+    if stats:
+        y, st = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3, want_stats=True)
+        rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+        mean, invstd = native.bn_finalize(st, B * H * W, Cout, rm, rv, 0.1, 1e-5)
+        torch.testing.assert_close(mean.cpu(), ref.mean(dim=(0, 2, 3)), rtol=2e-3, atol=2e-2)
+        torch.testing.assert_close(invstd.cpu(), torch.rsqrt(ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5), rtol=3e-3,
+                                   atol=1e-5)
+    else:
+        y = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
+    assert rel_err(nchw(y.float().cpu()), ref) < 6e-3
+    try:
+        native.set_conv_algo(1)
+        y_gen = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
+    finally:
+        native.set_conv_algo(0)
+    assert rel_err(y.float().cpu(), y_gen.float().cpu()) < 4e-3
+
+
 @pytest.mark.parametrize("dtype", _dtypes())
 def test_linear_big_k_and_ld_padding(native, dtype):
     """fc1-shaped GEMM (K = 25088, permuted (c,p)->(p,c)) and the 41-wide predictor with ld 48."""

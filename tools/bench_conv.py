@@ -27,7 +27,7 @@ def main():
     H0, W0 = (600, 1200) if args.res == "r600" else (1024, 2048)
     B = args.batch
     layers = [  # name, H, W, Cin, Cout
-        ("conv1_2", H0, W0, 64, 64), ("conv2_1", H0 // 2, W0 // 2, 64, 128), ("conv2_2", H0 // 2, W0 // 2, 128, 128),
+        ("conv1_1", H0, W0, 8, 64), ("conv1_2", H0, W0, 64, 64), ("conv2_1", H0 // 2, W0 // 2, 64, 128), ("conv2_2", H0 // 2, W0 // 2, 128, 128),
         ("conv3_1", H0 // 4, W0 // 4, 128, 256), ("conv3_2", H0 // 4, W0 // 4, 256, 256),
         ("conv4_1", H0 // 8, W0 // 8, 256, 512), ("conv4_2", H0 // 8, W0 // 8, 512, 512),
         ("conv5_1", H0 // 16, W0 // 16, 512, 512), ("rpn", H0 // 32, W0 // 32, 512, 512),
