@@ -369,3 +369,45 @@ def test_config1_source_training_step_matches_oracle(sfod, native):
     tr._data_loader_iter = iter([data])
     tr.run_step()
     tr.after_step()
+
+
+def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native):
+    """The N>1 code path on the one GPU a test box has: a 1-rank RCCL group, the world-size query patched to
+    2 so that the trainer attaches the GradientReducer -- the heads' slice is all-reduced asynchronously from
+    the backbone's backward hook, the rest afterwards, 1/world folded into SGD.  Checks stream ordering and
+    bookkeeping (a 1-rank all-reduce is the identity), not the wire."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    T = sfod.engine.trainer
+    orig = T.get_world_size
+    try:
+        T.get_world_size = lambda: 2
+        cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "bf16", "SOLVER.IMS_PER_BATCH_TARGET", "2",
+                                   "SFOD.SYNTHETIC.HEIGHT", "256", "SFOD.SYNTHETIC.WIDTH", "512",
+                                   "SFOD.SYNTHETIC.NUM_IMAGES", "4", "INPUT.MIN_SIZE_TRAIN", "(192,)",
+                                   "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0"])
+        torch.manual_seed(0)
+        loader = sfod.data.TwoCropLoader(cfg, torch.device("cuda"), 0, 1)
+        tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg, data_loader=loader)
+        red = tr._reducer
+        assert red is not None and 0 < red.lo < red.hi <= tr.optimizer.flat.grad.numel()
+        names = [n for n, (o, k, _) in tr.optimizer.flat.offsets.items() if red.lo <= o < red.hi]
+        assert names and all(n.startswith(("proposal_generator.", "roi_heads.")) for n in names)
+        launched = []
+        orig_launch = red.launch_early
+        red.launch_early = lambda: (launched.append(1), orig_launch())[1]
+        tr.model.backbone._pre_backward = red.launch_early
+        p0 = tr.optimizer.flat.param.clone()
+        tr.train()
+        assert len(launched) == 2 and red.work is None
+        assert tr.optimizer.grad_scale == 0.5
+        assert torch.isfinite(tr.optimizer.flat.param).all() and not torch.equal(p0, tr.optimizer.flat.param)
+    finally:
+        T.get_world_size = orig
+        if created:
+            dist.destroy_process_group()
