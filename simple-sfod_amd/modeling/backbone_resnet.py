@@ -200,13 +200,25 @@ class ResNet(nn.Module):
         return dict(zip(self._out_features, outs))
 
     # ---- engine ------------------------------------------------------------------------------------------
-    def _frozen_conv(self, x, conv, act, dt):
-        """conv + FrozenBN (+ReLU) as one kernel: scale folded into the weights, shift as the bias."""
+    def _frozen_packed(self, conv, cin_pad, dt):
+        """(packed weights with the FrozenBN scale folded in, shift) of a frozen conv, cached: frozen tensors
+        only change through load_state_dict / EMA copies, which bump their version counters."""
+        key = (conv.weight._version, conv.norm.weight._version, conv.norm.bias._version,
+               conv.norm.running_mean._version, conv.norm.running_var._version, conv.weight.data_ptr(), cin_pad, dt)
+        hit = getattr(conv, "_packed_cache", None)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
         scale, shift = conv.norm.scale_shift()
         w = conv.weight.detach() * scale.view(-1, 1, 1, 1)
-        k = conv.kernel_size[0]
-        wp = native.pack_conv_weight(w, x.shape[-1], dt)
-        return native.conv_fwd(x, wp, shift.contiguous(), conv.out_channels, k, act=act)
+        wp = native.pack_conv_weight(w, cin_pad, dt)
+        shift = shift.contiguous()
+        conv._packed_cache = (key, wp, shift)
+        return wp, shift
+
+    def _frozen_conv(self, x, conv, act, dt):
+        """conv + FrozenBN (+ReLU) as one kernel: scale folded into the weights, shift as the bias."""
+        wp, shift = self._frozen_packed(conv, x.shape[-1], dt)
+        return native.conv_fwd(x, wp, shift, conv.out_channels, conv.kernel_size[0], act=act)
 
     def _stem_forward(self, x, dt):
         conv = self.stem.conv1

@@ -231,7 +231,8 @@ class StandardROIHeads(nn.Module):
         st = self._box_forward(feat, rois)
         bp = self.box_predictor
         if sizes_dev is None:
-            sizes_dev = torch.tensor([list(s) for s in proposals.image_sizes], dtype=torch.int32).to(feat.device)
+            sizes_dev = native.dev_const(tuple((int(s[0]), int(s[1])) for s in proposals.image_sizes), torch.int32,
+                                         feat.device)
         out = native.frcnn_inference(st["pred"], self.num_classes, proposals.boxes, proposals.count, sizes_dev,
                                      bp.test_score_thresh, bp.test_nms_thresh, bp.test_topk_per_image,
                                      self.bbox_threshold, self.nms_numel_limit)

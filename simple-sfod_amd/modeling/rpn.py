@@ -159,7 +159,7 @@ class RPN(nn.Module):
         return {"feat": feat, "t": t, "rpn_out": rpn_out, "w1": w1, "shape": (B, Hf, Wf)}
 
     def _sizes_dev(self, image_sizes, device):
-        return torch.tensor([list(s) for s in image_sizes], dtype=torch.int32).to(device, non_blocking=True)
+        return native.dev_const(tuple((int(s[0]), int(s[1])) for s in image_sizes), torch.int32, device)
 
     def _proposals(self, st, image_sizes, sizes_dev=None):
         B, Hf, Wf = st["shape"]
