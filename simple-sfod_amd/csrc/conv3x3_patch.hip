@@ -22,6 +22,7 @@
 //         optional BatchNorm partial statistics (sum, M2, count) per workgroup (fp64 combine).
 #include "conv_internal.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -32,15 +33,29 @@ namespace {
 
 template <int J> using IC = std::integral_constant<int, J>;
 
-constexpr int PATCH_ROWS = 640;
-constexpr int PATCH_BYTES = PATCH_ROWS * 64;     // 40960
-constexpr int BRING_OFF = 2 * PATCH_BYTES;       // 81920
 constexpr int BSLOT = 8192;
 constexpr int STG_PITCH = 144;                   // staged C row: 64 bf16 + 16 B pad
-constexpr int STG_BYTES = 8 * 128 * STG_PITCH;   // 147456 (G=1: 8 waves x 128 rows)
-constexpr int PIXTAB_OFF = STG_BYTES;            // int32 [512]
-constexpr int SRED_OFF = PIXTAB_OFF + 2048;      // float [8 waves][64 cols][2] + float [8]
-constexpr int LDS_TOTAL = SRED_OFF + 8 * 64 * 2 * 4 + 32;
+
+// LDS layout of one kernel variant.  FM = 32-row fragments per wave along M:
+//   G=1: FM 4 (512-pixel tile), G=2: FM 2 (512-pixel tile) or FM 1 (256-pixel tile, ~76 KiB of LDS so that
+//   TWO workgroups share a CU: the 64-channel layers are bound by streaming their input / output, and a
+//   second resident workgroup overlaps one tile's prologue / epilogue with the other's MFMA loop).
+template <int G, int FM> struct Lay {
+  static constexpr bool SMALL = (G == 1) ? (FM == 2) : (FM == 1);   // 256-pixel tile, two workgroups per CU
+  static constexpr int NPW = SMALL ? 3 : 5;                     // patch DMA pieces (1 KiB) per wave and slice
+  static constexpr int PATCH_ROWS = NPW * 8 * 16;               // 640 | 384 pixels incl. halo
+  static constexpr int PATCH_BYTES = PATCH_ROWS * 64;
+  static constexpr int D = SMALL ? 2 : 3;                       // stages the weight DMA runs ahead
+  static constexpr int NBS = D + 1;                             // weight ring slots
+  static constexpr int BRING_OFF = 2 * PATCH_BYTES;
+  static constexpr int OPER = BRING_OFF + NBS * BSLOT;
+  static constexpr int WROWS = FM * 32;
+  static constexpr int STG = 8 * WROWS * STG_PITCH;             // staged C tiles overlay the operand buffers
+  static constexpr int PIXTAB_OFF = (OPER > STG) ? OPER : STG;  // int32 [512]
+  static constexpr int SRED_OFF = PIXTAB_OFF + 2048;            // float [8 waves][64 cols][2] + float [8]
+  static constexpr int TOTAL = SRED_OFF + 8 * 64 * 2 * 4 + 32;
+};
+constexpr int PATCH_ROWS_BIG = 640, PATCH_ROWS_SMALL = 384;
 
 struct P3Args {
   const bf16_t* x;
@@ -74,26 +89,35 @@ __device__ __forceinline__ float act_f(float v, int act) {
   return v;
 }
 
-// vmcnt immediates per stage (steady state / last body), see header comment
-template <int G> struct WaitTab;
-template <> struct WaitTab<1> {
+// vmcnt immediates per stage (steady state / last body), see header comment.  Derived by simulating the
+// per-wave DMA issue order (patch pieces, then the weights of stage j + D) of each variant.
+template <int G, int FM> struct WaitTab;
+template <> struct WaitTab<1, 4> {
   static constexpr int N[9] = {2, 3, 4, 4, 4, 4, 3, 2, 2};
   static constexpr int NL[9] = {2, 2, 2, 2, 2, 2, 2, 1, 0};
-  static constexpr int PP[9] = {1, 1, 1, 1, 1, 0, 0, 0, 0};
 };
-template <> struct WaitTab<2> {
+template <> struct WaitTab<2, 2> {
   static constexpr int N[9] = {1, 4, 5, 4, 1, 2, 4, 5, 4};
   static constexpr int NL[9] = {1, 4, 5, 4, 1, 2, 2, 1, 0};
-  static constexpr int PP[9] = {2, 1, 1, 1, 0, 2, 1, 1, 1};
+};
+template <> struct WaitTab<1, 2> {   // 256-pixel tile: 3 patch pieces per slice (stages 0-2), weights 2 stages ahead
+  static constexpr int N[9] = {1, 2, 2, 2, 1, 1, 1, 1, 1};
+  static constexpr int NL[9] = {1, 1, 1, 1, 1, 1, 1, 1, 0};
+};
+template <> struct WaitTab<2, 1> {   // 3 patch pieces per slice (stages 0-2 / 5-7), weights 2 stages ahead
+  static constexpr int N[9] = {1, 2, 2, 2, 1, 1, 2, 2, 2};
+  static constexpr int NL[9] = {1, 2, 2, 2, 1, 1, 1, 1, 0};
 };
 
-template <int G, typename OutT>
-__global__ void __launch_bounds__(512)
+template <int G, int FM, typename OutT>
+__global__ void __launch_bounds__(512, (Lay<G, FM>::SMALL ? 4 : 2))   // 2nd arg: waves per SIMD (small tiles: 2 workgroups / CU)
 k_conv3x3_patch(P3Args a) {
+  using L = Lay<G, FM>;
   constexpr int BN = 128 / G;
-  constexpr int FM = (G == 1) ? 4 : 2;   // 32-row fragments per wave along M
   constexpr int FN = 2;                  // 32-col fragments per wave along N
   constexpr int WROWS = FM * 32;         // rows of a wave tile
+  constexpr int NPW = L::NPW, PATCH_BYTES = L::PATCH_BYTES, BRING_OFF = L::BRING_OFF, D = L::D, NBS = L::NBS;
+  constexpr int PIXTAB_OFF = L::PIXTAB_OFF, SRED_OFF = L::SRED_OFF;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63;
@@ -138,10 +162,10 @@ k_conv3x3_patch(P3Args a) {
       (void*)ximg, (short)0, a.H * a.W * a.Cin * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
       (void*)a.w, (short)0, a.Cout * Ktot * 2, 0x00020000);
-  unsigned poff[5];  // byte offset inside the image of this lane's 16-byte chunk (slice 0) or OOB_OFF
+  unsigned poff[NPW];  // byte offset inside the image of this lane's 16-byte chunk (slice 0) or OOB_OFF
 #pragma unroll
-  for (int k = 0; k < 5; ++k) {
-    const int row = (wave * 5 + k) * 16 + (lane >> 2);
+  for (int k = 0; k < NPW; ++k) {
+    const int row = (wave * NPW + k) * 16 + (lane >> 2);
     const int lc = (lane & 3) ^ ((row >> 2) & 3);
     const int py = row / PW, px = row - py * PW;
     const int iy = y0 - 1 + py, ix = x0 - 1 + px;
@@ -158,13 +182,13 @@ k_conv3x3_patch(P3Args a) {
   const int epair = (G == 2) ? (wave >> 2) : 0;  // which (tap, slice) pair of a stage this wave's B DMA feeds
 
   auto issue_patch = [&](int k, int slice, int buf) {
-    bufload16(xres, poff[k], (unsigned)slice * 64u, smem + buf * PATCH_BYTES + (wave * 5 + k) * 1024);
+    bufload16(xres, poff[k], (unsigned)slice * 64u, smem + buf * PATCH_BYTES + (wave * NPW + k) * 1024);
   };
   // weights of global stage sg (= body * 9 + j)
   auto issue_b = [&](int sg) {
     const int gp = sg * G + epair;  // global pair index
     const int slice = gp / 9, tap = gp - slice * 9;
-    bufload16(wres, boff, (unsigned)(tap * a.Cin + slice * 32) * 2u, smem + BRING_OFF + (sg & 3) * BSLOT + wave * 1024);
+    bufload16(wres, boff, (unsigned)(tap * a.Cin + slice * 32) * 2u, smem + BRING_OFF + (sg % NBS) * BSLOT + wave * 1024);
   };
 
   // ---- fragment addressing -------------------------------------------------------------------------
@@ -214,12 +238,11 @@ k_conv3x3_patch(P3Args a) {
     }
   };
 
-  // ---- prologue: first patch + weights of stages 0..2 -----------------------------------------------
+  // ---- prologue: first patch + weights of the first D stages ---------------------------------------------
 #pragma unroll
-  for (int k = 0; k < 5; ++k) issue_patch(k, 0, 0);
-  issue_b(0);
-  issue_b(1);
-  issue_b(2);
+  for (int k = 0; k < NPW; ++k) issue_patch(k, 0, 0);
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_b(d);
 
   const int nstages = a.nbody * 9;
   for (int body = 0; body < a.nbody; ++body) {
@@ -227,15 +250,15 @@ k_conv3x3_patch(P3Args a) {
     const int sg0 = body * 9;
     auto stage = [&](auto jc) {
       constexpr int j = decltype(jc)::value;
-      if (last) wait_vm<WaitTab<G>::NL[j]>(); else wait_vm<WaitTab<G>::N[j]>();
+      if (last) wait_vm<WaitTab<G, FM>::NL[j]>(); else wait_vm<WaitTab<G, FM>::N[j]>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      // -- issue: patch pieces first, then the weights of stage j + 3
+      // -- issue: patch pieces first, then the weights of stage j + D
       if constexpr (G == 1) {
-        if constexpr (j < 5) {
+        if constexpr (j < NPW) {
           if (!last) issue_patch(j, body + 1, (body + 1) & 1);
         }
-      } else {
+      } else if constexpr (FM == 2) {
         // stages 0..3: second slice of this body -> buffer 1; stages 5..8: first slice of the next
         // body -> buffer 0 (its last reader was stage 4)
         if constexpr (j == 0) {
@@ -248,10 +271,14 @@ k_conv3x3_patch(P3Args a) {
         } else if constexpr (j > 5) {
           if (!last) issue_patch(j - 4, 2 * body + 2, 0);
         }
+      } else {
+        // 256-pixel tile: 3 pieces per slice, one per stage
+        if constexpr (j < 3) issue_patch(j, 2 * body + 1, 1);
+        else if constexpr (j >= 5 && j < 8) { if (!last) issue_patch(j - 5, 2 * body + 2, 0); }
       }
-      if (sg0 + j + 3 < nstages) issue_b(sg0 + j + 3);
+      if (sg0 + j + D < nstages) issue_b(sg0 + j + D);
       // -- compute stage j
-      const unsigned char* bsl = smem + BRING_OFF + ((sg0 + j) & 3) * BSLOT;
+      const unsigned char* bsl = smem + BRING_OFF + ((sg0 + j) % NBS) * BSLOT;
       if constexpr (G == 1) {
         compute_pair(j, smem + (body & 1) * PATCH_BYTES, bsl);
       } else {
@@ -401,7 +428,10 @@ k_conv3x3_patch(P3Args a) {
 
 }  // namespace
 
-// Tile shape: maximise covered-output efficiency under TH*TW <= 512 and (TH+2)*(TW+2) <= 640.
+// Tile shape: maximise covered-output efficiency under TH*TW <= BM and (TH+2)*(TW+2) <= patch capacity
+// (BM 512 / 640 rows, or 256 / 384 rows for the two-workgroups-per-CU variant of the 64-channel layers).
+static int g_p3_small = -1;   // -1 auto (small tiles for Cout <= 64), 0 never, 1 = auto; SFOD_P3_SMALL overrides (A/B runs)
+
 P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   P3Plan p;
   p.ok = 0;
@@ -409,16 +439,25 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   p.G = (Cout <= 64) ? 2 : 1;
   if (Cin % (32 * p.G) != 0) return p;
   if ((int64_t)H * W * Cin >= (int64_t)1 << 30 || (int64_t)Cout * 9 * Cin >= (int64_t)1 << 30) return p;  // 32-bit byte offsets
+  if (g_p3_small < 0) {
+    const char* e = getenv("SFOD_P3_SMALL");
+    g_p3_small = e ? atoi(e) : 1;
+  }
+  static const char* e1 = getenv("SFOD_P3_SMALL_G1");       // experiment hook
+  const bool small1 = e1 ? atoi(e1) != 0 : false;
+  p.FM = (p.G == 1) ? (small1 ? 2 : 4) : (g_p3_small ? 1 : 2);
+  const int BM = (p.G == 1 ? 4 : 8) * p.FM * 32;
+  const int cap = (BM == 256) ? PATCH_ROWS_SMALL : PATCH_ROWS_BIG;
   double best = -1.0;
   for (int tw = 4; tw <= 128 && tw <= W + 3; ++tw) {
-    int th = 512 / tw;
-    while (th > 1 && (th + 2) * (tw + 2) > PATCH_ROWS) --th;
+    int th = BM / tw;
+    while (th > 1 && (th + 2) * (tw + 2) > cap) --th;
     if (th > H) th = H;
-    if (th < 1 || (th + 2) * (tw + 2) > PATCH_ROWS) continue;
+    if (th < 1 || (th + 2) * (tw + 2) > cap) continue;
     const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
     // even out the rows so that the last tile row is not nearly empty
     th = (H + ty - 1) / ty;
-    const double eff = (double)H * W / ((double)ty * tx * 512.0);
+    const double eff = (double)H * W / ((double)ty * tx * (double)BM);
     // tie-break towards wide tiles (longer contiguous runs per patch row)
     const double score = eff + 1e-6 * tw;
     if (score > best) { best = score; p.TH = th; p.TW = tw; p.tiles_y = ty; p.tiles_x = tx; }
@@ -428,6 +467,20 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   p.nblk = B * p.tiles_y * p.tiles_x;
   p.ok = 1;
   return p;
+}
+
+template <int G, int FM, typename OutT>
+static int p3_launch_one(const P3Args& a, hipStream_t s) {
+  auto kern = k_conv3x3_patch<G, FM, OutT>;
+  constexpr int LDS = Lay<G, FM>::TOTAL;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute(p3): %s", hipGetErrorString(e)); return -(int)e; }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(512), LDS, s, a);
+  return sfod_check_launch("conv3x3_patch");
 }
 
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
@@ -440,23 +493,8 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
   a.nbody = Cin / (32 * p.G);
   a.ntiles = B * p.tiles_y * p.tiles_x * p.tiles_n;
   a.nblk = p.nblk;
-  static bool attr_set = false;
-  if (!attr_set) {
-    const void* ks[4] = {(const void*)k_conv3x3_patch<1, bf16_t>, (const void*)k_conv3x3_patch<1, float>,
-                         (const void*)k_conv3x3_patch<2, bf16_t>, (const void*)k_conv3x3_patch<2, float>};
-    for (int i = 0; i < 4; ++i) {
-      hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-      if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute(p3): %s", hipGetErrorString(e)); return -(int)e; }
-    }
-    attr_set = true;
-  }
-  dim3 grid(a.ntiles), blk(512);
-  if (p.G == 1) {
-    if (out_f32) hipLaunchKernelGGL((k_conv3x3_patch<1, float>), grid, blk, LDS_TOTAL, s, a);
-    else hipLaunchKernelGGL((k_conv3x3_patch<1, bf16_t>), grid, blk, LDS_TOTAL, s, a);
-  } else {
-    if (out_f32) hipLaunchKernelGGL((k_conv3x3_patch<2, float>), grid, blk, LDS_TOTAL, s, a);
-    else hipLaunchKernelGGL((k_conv3x3_patch<2, bf16_t>), grid, blk, LDS_TOTAL, s, a);
-  }
-  return sfod_check_launch("conv3x3_patch");
+  if (p.G == 1 && p.FM == 2) return out_f32 ? p3_launch_one<1, 2, float>(a, s) : p3_launch_one<1, 2, bf16_t>(a, s);
+  if (p.G == 1) return out_f32 ? p3_launch_one<1, 4, float>(a, s) : p3_launch_one<1, 4, bf16_t>(a, s);
+  if (p.FM == 2) return out_f32 ? p3_launch_one<2, 2, float>(a, s) : p3_launch_one<2, 2, bf16_t>(a, s);
+  return out_f32 ? p3_launch_one<2, 1, float>(a, s) : p3_launch_one<2, 1, bf16_t>(a, s);
 }

@@ -9,7 +9,8 @@
 struct P3Plan {
   int ok;
   int G;                 // 1: 128 output channels / workgroup, 2: 64
-  int TH, TW;            // output pixels per tile (TH*TW <= 512, (TH+2)*(TW+2) <= 640)
+  int FM;                // 32-row fragments per wave: 4 (G=1), 2 or 1 (G=2: 512- or 256-pixel tiles)
+  int TH, TW;            // output pixels per tile (TH*TW <= 512 | 256, (TH+2)*(TW+2) <= 640 | 384)
   int tiles_y, tiles_x, tiles_n;
   int nblk;              // BatchNorm statistics blocks = B * tiles_y * tiles_x
 };

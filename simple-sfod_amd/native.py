@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sfod_hip.h")
-SO_PATH = os.path.join(_HERE, "lib", "libsfod_hip.so")
+SO_PATH = os.environ.get("SFOD_HIP_LIB", os.path.join(_HERE, "lib", "libsfod_hip.so"))   # override: kernel A/B builds
 
 F32, BF16 = 0, 1
 
