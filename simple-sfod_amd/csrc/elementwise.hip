@@ -940,9 +940,68 @@ __global__ void k_pack_fc_weight(const float* __restrict__ w, T* __restrict__ ou
 extern "C" int sfod_pack_fc_weight(const float* w, void* out, int N, int K, int chw_c, int transpose,
                                    int dt, void* stream);
 
+// fc1-shaped weights (K = C x PP in (c, p) order in the state dict, (p, c) in the kernels): the naive gather
+// above reads with a stride of PP elements.  These two kernels go through an LDS tile so that both the read
+// (contiguous (c, p) runs of one output row) and the write (contiguous c / contiguous n) are coalesced.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pack_fc_chw(const float* __restrict__ w, T* __restrict__ out, int N, int C, int PP, int ld) {
+  // block = (row n, 64 channels): tile[c][p], out[n][p*C + c]
+  extern __shared__ float tile[];     // [64][PP]
+  const int n = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cw = min(64, C - c0);
+  const float* src = w + (int64_t)n * C * PP + (int64_t)c0 * PP;
+  for (int i = threadIdx.x; i < cw * PP; i += 256) tile[i] = src[i];
+  __syncthreads();
+  T* dst = out + (int64_t)n * ld;
+  for (int j = threadIdx.x; j < PP * 64; j += 256) {
+    const int p = j >> 6, cl = j & 63;
+    if (cl < cw) dst[(int64_t)p * C + c0 + cl] = from_f32<T>(tile[cl * PP + p]);
+  }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pack_fc_chw_t(const float* __restrict__ w, T* __restrict__ out, int N, int C, int PP, int ld) {
+  // block = (64 rows n, 4 channels): tile[n][c][p], out[(p*C + c)][n]
+  extern __shared__ float tile[];     // [64][4*PP + 1]
+  const int n0 = blockIdx.y * 64, c0 = blockIdx.x * 4;
+  const int nw = min(64, N - n0), cw = min(4, C - c0);
+  const int run = cw * PP, pitch = 4 * PP + 1;
+  for (int i = threadIdx.x; i < nw * run; i += 256) {
+    const int nl = i / run, r = i - nl * run;
+    tile[nl * pitch + r] = w[(int64_t)(n0 + nl) * C * PP + (int64_t)c0 * PP + r];
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < run * 64; j += 256) {
+    const int r = j >> 6, nl = j & 63;          // r = cl * PP + p
+    if (nl < nw) {
+      const int cl = r / PP, p = r - cl * PP;
+      out[((int64_t)p * C + c0 + cl) * ld + n0 + nl] = from_f32<T>(tile[nl * pitch + r]);
+    }
+  }
+}
+
 extern "C" int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose,
                                       int ld, int dt, void* stream) {
   SFOD_REQUIRE(ld >= (transpose ? N : K), "pack_fc_weight: ld too small");
+  if (chw_c > 0 && K % chw_c == 0 && K / chw_c <= 64 && (int64_t)N * K >= (1 << 20) &&
+      ld == (transpose ? N : K)) {
+    const int C = chw_c, PP = K / chw_c;
+    hipStream_t s = (hipStream_t)stream;
+    if (!transpose) {
+      const dim3 grid(cdiv(C, 64), N);
+      const size_t lds = (size_t)64 * PP * 4;
+      if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld);
+      else hipLaunchKernelGGL(k_pack_fc_chw<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld);
+    } else {
+      const dim3 grid(cdiv(C, 4), cdiv(N, 64));
+      const size_t lds = (size_t)64 * (4 * PP + 1) * 4;
+      if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw_t<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld);
+      else hipLaunchKernelGGL(k_pack_fc_chw_t<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld);
+    }
+    return sfod_check_launch("pack_fc_weight(chw)");
+  }
   const int64_t total = (int64_t)(transpose ? K : N) * ld;
   if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_pack_fc_weight<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
