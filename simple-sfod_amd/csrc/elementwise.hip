@@ -1032,8 +1032,30 @@ __global__ void k_unpack_fc_wgrad(const float* __restrict__ dwp, float* __restri
   }
 }
 
+__global__ void __launch_bounds__(256)
+k_unpack_fc_chw(const float* __restrict__ dwp, float* __restrict__ dw, int C, int PP, int ld, int accumulate) {
+  // block = (row n, 64 channels): read dwp[n][p*C + c] (coalesced over c), write dw[n][c*PP + p] (one contiguous run)
+  extern __shared__ float tile[];     // [64][PP]
+  const int n = blockIdx.y, c0 = blockIdx.x * 64;
+  const int cw = min(64, C - c0);
+  const float* src = dwp + (int64_t)n * ld;
+  for (int j = threadIdx.x; j < PP * 64; j += 256) {
+    const int p = j >> 6, cl = j & 63;
+    if (cl < cw) tile[cl * PP + p] = src[(int64_t)p * C + c0 + cl];
+  }
+  __syncthreads();
+  float* dst = dw + (int64_t)n * C * PP + (int64_t)c0 * PP;
+  for (int i = threadIdx.x; i < cw * PP; i += 256) dst[i] = accumulate ? dst[i] + tile[i] : tile[i];
+}
+
 extern "C" int sfod_unpack_fc_wgrad_ld(const float* dw_packed, float* dw, int N, int K, int chw_c, int ld,
                                        int accumulate, void* stream) {
+  if (chw_c > 0 && K % chw_c == 0 && K / chw_c <= 64 && (int64_t)N * K >= (1 << 20)) {
+    const int C = chw_c, PP = K / chw_c;
+    hipLaunchKernelGGL(k_unpack_fc_chw, dim3(cdiv(C, 64), N), dim3(256), (size_t)64 * PP * 4, (hipStream_t)stream,
+                       dw_packed, dw, C, PP, ld, accumulate);
+    return sfod_check_launch("unpack_fc_wgrad(chw)");
+  }
   const int64_t total = (int64_t)N * K;
   hipLaunchKernelGGL(k_unpack_fc_wgrad, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dw_packed,
                      dw, N, K, chw_c, ld, accumulate);
