@@ -175,7 +175,11 @@ def _student_vs_oracle(sfod, B, H, W, ngt, dtype, seed):
     model = sfod.modeling.build_model(cfg).train()
     sd = oracle_state(model)
     ocfg = om.Cfg()
-    inputs = make_inputs(B, H, W, ngt, seed)
+    if isinstance(H, (list, tuple)):   # ragged batch: per-image sizes, padded to the batch maximum by preprocess
+        inputs = [make_inputs(1, h, w, [ngt[i]], seed + 17 * i)[0] for i, (h, w) in enumerate(zip(H, W))]
+        H, W = max(H), max(W)
+    else:
+        inputs = make_inputs(B, H, W, ngt, seed)
     Hf, Wf = H // 32, W // 32
     g = torch.Generator().manual_seed(seed + 1)
     rpn_keys = torch.randint(0, 2 ** 31 - 1, (B, Hf * Wf * 15), generator=g, dtype=torch.int64)
@@ -248,6 +252,17 @@ def test_student_losses_and_gradients_match_oracle_fp32(sfod, native):
             torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6)
         if "num_batches_tracked" in name:
             assert buf.item() == sd[name].item() == 1
+
+
+def test_student_ragged_batch_and_image_without_gt_fp32(sfod, native):
+    """Edge cases of the batch contract: images of different sizes (zero-padded to the batch maximum, boxes
+    clipped to each image's own size) and an image with no (pseudo-)ground truth at all."""
+    model, sd, losses, losses_ref = _student_vs_oracle(sfod, 3, [160, 128, 96], [224, 256, 192], [3, 0, 1], "fp32", 5)
+    for k, v in losses_ref.items():
+        np.testing.assert_allclose(losses[k].item(), v.item(), rtol=1e-4, atol=1e-6, err_msg=k)
+    for name in ("roi_heads.box_head.fc2.weight", "proposal_generator.rpn_head.conv.weight"):
+        p = dict(model.named_parameters())[name]
+        assert rel_err(p.grad, sd[name].grad) < 2e-3, name
 
 
 def test_student_bf16_mode_tracks_the_fp32_oracle(sfod, native):
