@@ -472,7 +472,7 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
   if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2>(x, w, bias, y, stats, a, s);
   // 256 x 128 tiles with a 3-stage DMA pipeline once the grid still fills the chip (>= 2 tiles / CU)
   const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
-  if (UT && big_tiles >= 512) return launch_one<T, OutT, 2, UT, 4, 3>(x, w, bias, y, stats, a, s);
+  if (UT && big_tiles >= 384) return launch_one<T, OutT, 2, UT, 4, 3>(x, w, bias, y, stats, a, s);
   return launch_one<T, OutT, 2, UT, 2, 2>(x, w, bias, y, stats, a, s);
 }
 
