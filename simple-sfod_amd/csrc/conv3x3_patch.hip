@@ -436,7 +436,14 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   P3Plan p;
   p.ok = 0;
   if (H < 1 || W < 1 || B < 1) return p;
-  p.G = (Cout <= 64) ? 2 : 1;
+  // Workgroup shape.  Measured per layer (tools/bench_conv.py, interleaved A/B): the 256-pixel x 64-channel
+  // variant (76 KiB of LDS, 115 VGPRs -> two workgroups per CU, which overlap each other's prologue /
+  // epilogue / barrier stalls) beats the 512 x 128 tile on every VGG / RPN shape (-3 ... -17 %, the 18x37
+  // RPN head -60 %) except the long-K 512 -> 512 layers on large maps (+3 %), although it streams the weights
+  // four times as often.  SFOD_P3_G2_MAXC (A/B hook) restricts the small variant to Cout <= that value.
+  static const char* eg = getenv("SFOD_P3_G2_MAXC");
+  const bool big = eg ? (Cout > atoi(eg)) : (Cout >= 512 && Cin >= 512 && (int64_t)B * H * W >= 65536);
+  p.G = (!big && Cin % 64 == 0) ? 2 : 1;
   if (Cin % (32 * p.G) != 0) return p;
   if ((int64_t)H * W * Cin >= (int64_t)1 << 30 || (int64_t)Cout * 9 * Cin >= (int64_t)1 << 30) return p;  // 32-bit byte offsets
   if (g_p3_small < 0) {
