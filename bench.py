@@ -221,8 +221,9 @@ def main():
                                     "achieved": round(g["flops"] / (g["ms"] * 1e-3) / 1e12, 2), "peak": PEAK[args.dtype],
                                     "unit": "TFLOP/s", "frac": round(g["flops"] / (g["ms"] * 1e-3) / 1e12 / PEAK[args.dtype], 4),
                                     "share_of_step_time": round(g["ms"] / (1000.0 * elapsed), 4)}
-        wk = summ.get("sfod_conv_wgrad")
-        if wk and wk["ms"] > 0:
+        wk = {k2: sum(summ[n][k2] for n in ("sfod_conv_wgrad", "sfod_conv_wgrad_oihw") if n in summ)
+              for k2 in ("launches", "ms", "flops")}
+        if wk["ms"] > 0:
             out["roofline_wgrad"] = {"kernel": "k_conv_wgrad", "achieved": round(wk["flops"] / (wk["ms"] * 1e-3) / 1e12, 2),
                                      "peak": PEAK[args.dtype], "unit": "TFLOP/s",
                                      "frac": round(wk["flops"] / (wk["ms"] * 1e-3) / 1e12 / PEAK[args.dtype], 4),

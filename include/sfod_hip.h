@@ -73,6 +73,14 @@ int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt
 int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt);
 int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
                     int Cout, int ksize, int lddy, int dt, void* ws, int64_t ws_bytes, void* stream);
+/* the same gradient written straight in the state-dict layout OIHW [Cout][Cin][3][3] (fp32): overwritten
+ * (accumulate 0) or added into (accumulate 1, e.g. the parameter's slice of the flat gradient buffer).
+ * Only for shapes the halo-patch kernel serves (sfod_conv_wgrad_oihw_supported != 0): its slab
+ * reduction does the layout change, so neither a packed temporary nor its zero fill exist. */
+int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt);
+int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin,
+                         int Cout, int ksize, int lddy, int dt, int accumulate, void* ws,
+                         int64_t ws_bytes, void* stream);
 
 /* weight (re)packing between the reference's state-dict layouts and the kernel layouts.
  * OIHW fp32 [Cout][Cin][KH][KW] -> packed [Cout][KH*KW][CinPad] (dt); rot180=1 additionally
@@ -105,7 +113,10 @@ int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, int accumula
  * (daod/engine/trainers/base.py:270-337): it runs identically under no_grad. */
 int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                      float* mean, float* invstd, float* running_mean, float* running_var,
-                     float momentum, float eps, int update_running, float* ws, void* stream);
+                     float momentum, float eps, int update_running, int64_t* num_batches_tracked,
+                     float* ws, void* stream);
+/* num_batches_tracked: the BatchNorm buffer of that name (device int64 scalar), incremented by one when
+ * update_running != 0; may be NULL. */
 /* size (in floats, 8-byte aligned) of the `ws` scratch of sfod_bn_finalize */
 int sfod_bn_finalize_ws_floats(int C);
 /* z = relu(gamma*(y-mean)*invstd+beta); `pool` is a flag word: bit 0 additionally 2x2/2 max-pools z
@@ -114,11 +125,13 @@ int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* z, int B, int H, int W,
                           int C, int pool, int dt, void* stream);
 /* backward of the block above.  dz: grad w.r.t. block output; y: saved conv output; returns dy
- * (grad w.r.t. conv output), dgamma, dbeta.  ws: fp32 workspace [nblk*2*C] (see ws query). */
+ * (grad w.r.t. conv output), dgamma, dbeta.  ws: fp32 workspace [nblk*2*C] (see ws query).
+ * dgamma_acc / dbeta_acc (may be NULL): the parameters' gradient accumulators (+= this call's dgamma /
+ * dbeta), so the caller needs no separate accumulate pass per BatchNorm layer. */
 int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* dy, float* dgamma,
-                          float* dbeta, float* ws, int B, int H, int W, int C, int pool, int dt,
-                          void* stream);
+                          float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
+                          int W, int C, int pool, int dt, void* stream);
 int sfod_bn_bwd_ws_floats(int M, int C);
 /* ---- ResNet-101-C4 backbone helpers (d2 build_resnet_backbone selected by the r101 yaml's missing
  * BACKBONE.NAME, configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28) ----

@@ -156,8 +156,9 @@ k_bn_partial(const float* __restrict__ stats, int nblocks, int C, double* __rest
 __global__ void __launch_bounds__(256)
 k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __restrict__ mean,
            float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
-           float eps, int update_running) {
+           float eps, int update_running, long long* __restrict__ nbt) {
   __shared__ double red[4][3][64];
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // BatchNorm's num_batches_tracked
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double a = 0.0, q = 0.0, m2 = 0.0;
@@ -190,7 +191,8 @@ extern "C" int sfod_bn_finalize_ws_floats(int C) { return BNF_SPLITS * 3 * C * 2
 
 extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                                 float* mean, float* invstd, float* running_mean, float* running_var,
-                                float momentum, float eps, int update_running, float* ws, void* stream) {
+                                float momentum, float eps, int update_running, int64_t* num_batches_tracked,
+                                float* ws, void* stream) {
   SFOD_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "bn_finalize: 8-byte aligned workspace required");
   hipStream_t s = (hipStream_t)stream;
   int nsplit = (nblocks + 63) / 64;   // >= 64 blocks (4 per wave) per slice
@@ -199,7 +201,8 @@ extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
   double* part = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), nsplit), dim3(1024), 0, s, stats, nblocks, C, part);
   hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 64)), dim3(256), 0, s, part, nsplit, M, C, mean, invstd,
-                     running_mean, running_var, momentum, eps, update_running);
+                     running_mean, running_var, momentum, eps, update_running,
+                     update_running ? (long long*)num_batches_tracked : (long long*)nullptr);
   return sfod_check_launch("bn_finalize");
 }
 
@@ -425,7 +428,7 @@ k_bn_bwd_reduce(const T* __restrict__ dz, const T* __restrict__ y, const float* 
 
 __global__ void __launch_bounds__(1024)
 k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restrict__ dgamma,
-                  float* __restrict__ dbeta) {
+                  float* __restrict__ dbeta, float* __restrict__ dgamma_acc, float* __restrict__ dbeta_acc) {
   // 64 consecutive columns of the [nblk][2C] partial matrix per workgroup; 16 waves split the rows
   // (4 independent loads in flight per lane), fixed summation order
   __shared__ double red[16][64];
@@ -448,7 +451,13 @@ k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restri
     double v = 0.0;
 #pragma unroll
     for (int w = 0; w < 16; ++w) v += red[w][lane];
-    if (t < C) dbeta[t] = (float)v; else dgamma[t - C] = (float)v;
+    if (t < C) {
+      dbeta[t] = (float)v;
+      if (dbeta_acc != nullptr) dbeta_acc[t] += (float)v;
+    } else {
+      dgamma[t - C] = (float)v;
+      if (dgamma_acc != nullptr) dgamma_acc[t - C] += (float)v;
+    }
   }
 }
 
@@ -567,8 +576,8 @@ extern "C" int sfod_bn_bwd_ws_floats(int M, int C) {
 
 extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, void* dy, float* dgamma,
-                                     float* dbeta, float* ws, int B, int H, int W, int C, int pool_flags, int dt,
-                                     void* stream) {
+                                     float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
+                                     int W, int C, int pool_flags, int dt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
   const int V = (dt == SFOD_F32) ? 4 : 8;
@@ -586,7 +595,7 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
     hipLaunchKernelGGL((k_bn_bwd_reduce<T, P, R>), dim3(grid1), dim3(256), lds, s, (const T*)dz,       \
                        (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                        \
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws, grid1, C,      \
-                       dgamma, dbeta);                                                                 \
+                       dgamma, dbeta, dgamma_acc, dbeta_acc);                                          \
     hipLaunchKernelGGL((k_bn_bwd_apply<T, P, R>), dim3(grid3), dim3(256), 0, s, (const T*)dz,          \
                        (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (T*)dy, B, H, W, C);     \
   } while (0)

@@ -732,6 +732,22 @@ extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Co
   return use_patch_wgrad(p, ksize, dt) ? p.ws_bytes : 0;
 }
 
+extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
+  if (ksize != 3 || dt != SFOD_BF16 || (int64_t)B * H * W == 0) return 0;
+  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
+  return use_patch_wgrad(p, ksize, dt) ? 1 : 0;
+}
+
+extern "C" int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin,
+                                    int Cout, int ksize, int lddy, int dt, int accumulate, void* ws,
+                                    int64_t ws_bytes, void* stream) {
+  SFOD_REQUIRE(sfod_conv_wgrad_oihw_supported(B, H, W, Cin, Cout, ksize, lddy, dt),
+               "wgrad_oihw: shape not served by the halo-patch kernel (query sfod_conv_wgrad_oihw_supported)");
+  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
+  SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
+  return sfod_w3_launch(p, x, dy, dw_oihw, ws, B, H, W, Cin, Cout, lddy, accumulate ? 2 : 1, (hipStream_t)stream);
+}
+
 extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
                                int Cout, int ksize, int lddy, int dt, void* ws, int64_t ws_bytes,
                                void* stream) {
@@ -743,7 +759,7 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
     const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
     if (use_patch_wgrad(p, ksize, dt)) {
       SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
-      return sfod_w3_launch(p, x, dy, dw, ws, B, H, W, Cin, Cout, lddy, (hipStream_t)stream);
+      return sfod_w3_launch(p, x, dy, dw, ws, B, H, W, Cin, Cout, lddy, 0, (hipStream_t)stream);
     }
   }
   WgradArgs a;

@@ -295,16 +295,35 @@ k_wgrad3x3_patch(W3Args a) {
     }
 }
 
-// dw[i] (+)= sum_s slab[s][i], fixed order
+// dw[i] (+)= sum_s slab[s][i], fixed order.  MODE 0: dw is the packed [Cout][9][Cin] gradient (accumulated into);
+// MODE 1 / 2: dw is the state-dict layout OIHW [Cout][Cin][3][3], overwritten (1) or accumulated into (2) -- the
+// unpack pass and the zero fill of a packed temporary are folded into this reduction.
+template <int MODE>
 __global__ void __launch_bounds__(256)
-k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int nslab, int64_t stride4) {
+k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int nslab, int64_t stride4, int Cin) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    float4 s = reinterpret_cast<const float4*>(dw)[i];
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int64_t o = 0;
+    if constexpr (MODE == 0) {
+      s = reinterpret_cast<const float4*>(dw)[i];
+    } else {
+      const int64_t e = i * 4;                       // packed element (co, tap, ci .. ci+3)
+      const int ci = (int)(e % Cin);
+      const int64_t ct = e / Cin;
+      const int tap = (int)(ct % 9);
+      const int64_t co = ct / 9;
+      o = (co * Cin + ci) * 9 + tap;
+      if constexpr (MODE == 2) { s.x = dw[o]; s.y = dw[o + 9]; s.z = dw[o + 18]; s.w = dw[o + 27]; }
+    }
     for (int k = 0; k < nslab; ++k) {
       const float4 v = reinterpret_cast<const float4*>(slab)[k * stride4 + i];
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
-    reinterpret_cast<float4*>(dw)[i] = s;
+    if constexpr (MODE == 0) {
+      reinterpret_cast<float4*>(dw)[i] = s;
+    } else {
+      dw[o] = s.x; dw[o + 9] = s.y; dw[o + 18] = s.z; dw[o + 27] = s.w;
+    }
   }
 }
 
@@ -350,7 +369,7 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy) {
 }
 
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
-                   int Cin, int Cout, int lddy, hipStream_t s) {
+                   int Cin, int Cout, int lddy, int out_mode, hipStream_t s) {
   W3Args a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ws;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy;
@@ -376,6 +395,11 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
   const int64_t n = (int64_t)Cout * 9 * Cin;  // multiple of 4 (Cin % 32 == 0)
   int g = (int)((n / 4 + 255) / 256);
   if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4);
+  if (out_mode == 0)
+    hipLaunchKernelGGL(k_wgrad_reduce<0>, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4, Cin);
+  else if (out_mode == 1)
+    hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4, Cin);
+  else
+    hipLaunchKernelGGL(k_wgrad_reduce<2>, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4, Cin);
   return sfod_check_launch("wgrad_reduce");
 }

@@ -242,8 +242,8 @@ class ResNet(nn.Module):
         if self.training:
             y, stats = native.conv_fwd(x, wp, None, conv.out_channels, k, want_stats=True)
             mean, invstd = native.bn_finalize(stats, B * H * W, conv.out_channels, bn.running_mean, bn.running_var,
-                                              self.bn_momentum, bn.eps, True)
-            bn.num_batches_tracked.add_(1)
+                                              self.bn_momentum, bn.eps, True,
+                                              num_batches_tracked=bn.num_batches_tracked)
         else:
             y = native.conv_fwd(x, wp, None, conv.out_channels, k)
             mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
@@ -288,11 +288,14 @@ class ResNet(nn.Module):
         """grad wrt the norm output -> (dx or None, [dw, dgamma, dbeta])."""
         bn = conv.norm
         k = conv.kernel_size[0]
+        gsink, bsink = native.grad_sink(bn.weight), native.grad_sink(bn.bias)
+        direct_bn = gsink is not None and bsink is not None
         dy, dgamma, dbeta = native.bn_relu_pool_bwd(g, y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False,
-                                                    relu=relu)
-        dwp = native.conv_wgrad(x_in, dy, conv.out_channels, k)
-        dw = torch.empty_like(conv.weight)
-        native.unpack_conv_wgrad(dwp, dw)
+                                                    relu=relu, dgamma_acc=gsink if direct_bn else None,
+                                                    dbeta_acc=bsink if direct_bn else None)
+        if direct_bn:
+            dgamma = dbeta = None
+        dw = native.conv_weight_grad(x_in, dy, conv.weight)
         dx = None
         if need_dx:
             wr = native.pack_conv_weight(conv.weight.detach(), conv.out_channels, native.dt_of(dy), rot180=True)

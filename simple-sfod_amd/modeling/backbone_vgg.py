@@ -161,8 +161,8 @@ class vgg_backbone(nn.Module):
             if training:
                 y, stats = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3, want_stats=True)
                 mean, invstd = native.bn_finalize(stats, B * H * W, cout, bn.running_mean, bn.running_var,
-                                                  self.bn_momentum, self.bn_eps, True)
-                bn.num_batches_tracked.add_(1)
+                                                  self.bn_momentum, self.bn_eps, True,
+                                                  num_batches_tracked=bn.num_batches_tracked)
             else:
                 y = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3)
                 mean = bn.running_mean
@@ -197,17 +197,18 @@ class vgg_backbone(nn.Module):
                 dz = g if dz is None else native.add_(dz, g)
             if dz is None:
                 continue
+            # parameter gradients go straight into the flat gradient buffer when the parameter has one
+            # (grad_sink): no temporaries, no per-parameter accumulate kernels in autograd
+            gsink, bsink = native.grad_sink(bn.weight), native.grad_sink(bn.bias)
+            direct_bn = gsink is not None and bsink is not None
             dy, dgamma, dbeta = native.bn_relu_pool_bwd(dz, y, mean, invstd, bn.weight.detach(),
-                                                        bn.bias.detach(), pool)
+                                                        bn.bias.detach(), pool,
+                                                        dgamma_acc=gsink if direct_bn else None,
+                                                        dbeta_acc=bsink if direct_bn else None)
+            if direct_bn:
+                dgamma = dbeta = None
             cout, cin = conv.out_channels, conv.in_channels
-            dwp = native.conv_wgrad(x, dy, cout, 3)
-            sink = native.grad_sink(conv.weight)
-            if sink is not None:
-                native.unpack_conv_wgrad(dwp, sink, accumulate=True)   # straight into the flat gradient
-                dw = None
-            else:
-                dw = torch.empty_like(conv.weight)
-                native.unpack_conv_wgrad(dwp, dw)
+            dw = native.conv_weight_grad(x, dy, conv.weight)
             # a conv bias followed by train-mode BN has an analytically zero gradient
             # (sum_rows dy == 0); the reference's autograd produces rounding noise around 0.
             db = None if native.grad_sink(conv.bias) is not None else torch.zeros_like(conv.bias)

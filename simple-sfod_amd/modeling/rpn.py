@@ -216,9 +216,7 @@ class RPN(nn.Module):
         # 3x3 conv
         h = self.rpn_head
         dt4 = dt_.view(B, Hf, Wf, C)
-        dwp = native.conv_wgrad(st["feat"], dt4, C, 3)
-        dw0 = torch.empty_like(h.conv.weight)
-        native.unpack_conv_wgrad(dwp, dw0)
+        dw0 = native.conv_weight_grad(st["feat"], dt4, h.conv.weight)
         db0 = native.bias_grad(dt_, C)
         wr = native.pack_conv_weight(h.conv.weight.detach(), C, dt, rot180=True)
         dfeat = native.conv_fwd(dt4, wr, None, C, 3)

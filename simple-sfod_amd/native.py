@@ -128,7 +128,7 @@ class KernelTimer:
     bench.py for the roofline figure of the dominant kernels).  ``flops`` is the algorithmic work
     of the launch (2 x MACs of the GEMM the entry point computes)."""
 
-    def __init__(self, watch=("sfod_conv_fwd", "sfod_conv_wgrad")):
+    def __init__(self, watch=("sfod_conv_fwd", "sfod_conv_wgrad", "sfod_conv_wgrad_oihw")):
         self.watch = set(watch)   # entry points; records are keyed "<entry>[:<kernel tag>]"
         self.records = []      # (name, flops, start_event, end_event)
 
@@ -323,6 +323,46 @@ def conv_wgrad(x, dy, cout, ksize, dw_packed=None):
     return dw_packed
 
 
+def conv_wgrad_oihw_supported(x, dy, cout, ksize):
+    if x.dim() != 4:
+        return False
+    B, H, W, cin = x.shape
+    return bool(query("sfod_conv_wgrad_oihw_supported", B, H, W, cin, cout, ksize, dy.shape[-1], dt_of(x)))
+
+
+def conv_wgrad_oihw(x, dy, dw_oihw, accumulate=False):
+    """3x3 weight gradient written straight into the state-dict layout (e.g. ``grad_sink(conv.weight)``)."""
+    cout, cin, ksize, _ = dw_oihw.shape
+    B, H, W, cinp = x.shape
+    assert cinp == cin and dw_oihw.is_contiguous() and dw_oihw.dtype == torch.float32
+    lddy = dy.shape[-1]
+    dt = dt_of(x)
+    nbytes = query("sfod_conv_wgrad_ws_bytes", B, H, W, cin, cout, ksize, lddy, dt)
+    ws = _workspace(x.device, nbytes)
+    global _pending_flops
+    _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
+    call("sfod_conv_wgrad_oihw", x, dy, dw_oihw, B, H, W, cin, cout, ksize, lddy, dt, int(accumulate), ws, nbytes)
+    return dw_oihw
+
+
+def conv_weight_grad(x, dy, weight):
+    """dL/dweight of a conv whose state-dict weight is ``weight`` (OIHW).  Accumulated straight into
+    ``grad_sink(weight)`` when the parameter has one (returns None: nothing for autograd to add), else
+    returned as a new tensor."""
+    cout, cin, k, _ = weight.shape
+    sink = grad_sink(weight)
+    if sink is not None and k == 3 and x.shape[-1] == cin and conv_wgrad_oihw_supported(x, dy, cout, 3):
+        conv_wgrad_oihw(x, dy, sink, accumulate=True)     # the slab reduction writes OIHW directly
+        return None
+    dwp = conv_wgrad(x, dy, cout, k)
+    if sink is not None:
+        unpack_conv_wgrad(dwp, sink, accumulate=True)
+        return None
+    dw = torch.empty_like(weight)
+    unpack_conv_wgrad(dwp, dw)
+    return dw
+
+
 def bias_grad(dy, n, db=None, accumulate=False):
     m = dy.numel() // dy.shape[-1]
     if db is None:
@@ -331,12 +371,14 @@ def bias_grad(dy, n, db=None, accumulate=False):
     return db
 
 
-def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, update_running=True):
+def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, update_running=True,
+                num_batches_tracked=None):
+    """``num_batches_tracked`` (int64 scalar buffer) is incremented in the same launch when given."""
     mean = torch.empty(C, dtype=torch.float32, device=stats.device)
     invstd = torch.empty_like(mean)
     ws = torch.empty(query("sfod_bn_finalize_ws_floats", C), dtype=torch.float32, device=stats.device)
     call("sfod_bn_finalize", stats, stats.nblk, M, C, mean, invstd, running_mean, running_var,
-         float(momentum), float(eps), int(update_running), ws)
+         float(momentum), float(eps), int(update_running), num_batches_tracked, ws)
     return mean, invstd
 
 
@@ -349,7 +391,9 @@ def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True):
     return z
 
 
-def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None, relu=True):
+def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None, relu=True,
+                     dgamma_acc=None, dbeta_acc=None):
+    """``dgamma_acc`` / ``dbeta_acc``: gradient accumulators (see ``grad_sink``) updated in the same launch."""
     B, H, W, C = y.shape
     if dy is None:
         dy = torch.empty_like(y)
@@ -358,7 +402,8 @@ def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=
     if dbeta is None:
         dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
     ws = torch.empty(query("sfod_bn_bwd_ws_floats", B * H * W, C), dtype=torch.float32, device=y.device)
-    call("sfod_bn_relu_pool_bwd", dz, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, ws, B, H, W, C,
+    call("sfod_bn_relu_pool_bwd", dz, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, dgamma_acc, dbeta_acc, ws,
+         B, H, W, C,
          int(pool) | (0 if relu else 2), dt_of(y))
     return dy, dgamma, dbeta
 

@@ -257,6 +257,41 @@ def test_conv3x3_patch_wgrad(native, shape):
     native.unpack_conv_wgrad(dwp, dw)
     assert rel_err(dw.cpu(), w.grad) < 2e-5 * math.sqrt(B * H * W) / 10 + 1e-4
     assert torch.equal(dwp, dwp2), "slab reduction must be deterministic"
+    # the same gradient reduced straight into the state-dict layout (overwrite, then accumulate)
+    try:
+        native.set_conv_algo(2)
+        assert native.conv_wgrad_oihw_supported(xd, dyd, Cout, 3)
+        direct = torch.full((Cout, Cin, 3, 3), float("nan"), dtype=torch.float32, device=DEV)
+        native.conv_wgrad_oihw(xd, dyd, direct, accumulate=False)
+        acc = torch.ones(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
+        native.conv_wgrad_oihw(xd, dyd, acc, accumulate=True)
+    finally:
+        native.set_conv_algo(0)
+    assert torch.equal(direct, dw), "OIHW reduction must equal packed reduction + unpack bit for bit"
+    assert torch.allclose(acc, dw + 1.0, rtol=0, atol=1e-6 * float(dw.abs().max()) + 1e-6)
+
+
+def test_bn_fused_accumulators(native):
+    """sfod_bn_finalize bumps num_batches_tracked; sfod_bn_relu_pool_bwd adds dgamma / dbeta into the
+    gradient accumulators it is given (what autograd's per-parameter accumulate would have done)."""
+    B, H, W, C = 2, 9, 11, 64
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(B, H, W, C, generator=g).to(DEV)
+    dz = torch.randn(B, H, W, C, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    wp = native.pack_conv_weight(torch.randn(C, C, 3, 3, generator=g).to(DEV) * 0.05, C, native.F32)
+    yc, stats = native.conv_fwd(y, wp, None, C, 3, want_stats=True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    nbt = torch.tensor(41, dtype=torch.int64, device=DEV)
+    mean, invstd = native.bn_finalize(stats, B * H * W, C, rm, rv, 0.1, 1e-5, True, num_batches_tracked=nbt)
+    assert int(nbt) == 42
+    native.bn_finalize(stats, B * H * W, C, rm, rv, 0.1, 1e-5, False, num_batches_tracked=nbt)
+    assert int(nbt) == 42, "no running-stat update -> no batch counted"
+    _, dgam, dbet = native.bn_relu_pool_bwd(dz, yc, mean, invstd, gamma, beta, False)
+    ga, ba = torch.full((C,), 2.0, device=DEV), torch.full((C,), -1.0, device=DEV)
+    _, dgam2, dbet2 = native.bn_relu_pool_bwd(dz, yc, mean, invstd, gamma, beta, False, dgamma_acc=ga, dbeta_acc=ba)
+    assert torch.equal(dgam, dgam2) and torch.equal(dbet, dbet2)
+    assert torch.allclose(ga, dgam + 2.0, rtol=0, atol=1e-5) and torch.allclose(ba, dbet - 1.0, rtol=0, atol=1e-5)
 
 
 # -------------------------------------------------------------------------------------------------
