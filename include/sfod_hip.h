@@ -62,6 +62,9 @@ int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, in
  * DMA'd per tap), 2 halo-patch kernel (input patch staged once per 32-channel slice and reused by
  * all nine taps) whenever the shape allows.  For A/B tests and benchmarks. */
 int sfod_set_conv_algo(int algo);
+/* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
+ * 4 = 512 x 64 (applied where the channel counts allow it).  For A/B runs and parity tests. */
+int sfod_set_conv3x3_variant(int variant);
 /* which kernel sfod_conv_fwd runs for this shape: 1 generic implicit GEMM, 2 halo-patch, 3 first-layer
  * kernel (Cin = one padded 8-channel chunk, Cout = 64, bf16) */
 int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt);

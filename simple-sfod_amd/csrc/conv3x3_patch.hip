@@ -220,7 +220,9 @@ k_conv3x3_patch(P3Args a) {
     int addrA[FM];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int row = rowA[i] + dtap;
+      int ra = rowA[i];
+      asm volatile("" : "+v"(ra));   // keeps the 9 x FM tap addresses from being hoisted out of the K loop (VGPRs)
+      const int row = ra + dtap;
       addrA[i] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
     }
 #pragma unroll
@@ -428,31 +430,43 @@ k_conv3x3_patch(P3Args a) {
 
 }  // namespace
 
-// Tile shape: maximise covered-output efficiency under TH*TW <= BM and (TH+2)*(TW+2) <= patch capacity
-// (BM 512 / 640 rows, or 256 / 384 rows for the two-workgroups-per-CU variant of the 64-channel layers).
-static int g_p3_small = -1;   // -1 auto (small tiles for Cout <= 64), 0 never, 1 = auto; SFOD_P3_SMALL overrides (A/B runs)
+// Workgroup shape + tile shape.  Variants (all 8 waves):
+//   1  G=1 FM=4  512 px x 128 ch, wave tile 128 x 64, one workgroup per CU (112 KiB of LDS, 212 VGPRs)
+//   2  G=1 FM=2  256 px x 128 ch, wave tile  64 x 64, two workgroups per CU (72 KiB, 114 VGPRs)
+//   3  G=2 FM=1  256 px x  64 ch, wave tile  32 x 64, two workgroups per CU (76 KiB,  72 VGPRs)
+//   4  G=2 FM=2  512 px x  64 ch, wave tile  64 x 64, one workgroup per CU
+// Measured per layer (tools/bench_conv.py, interleaved A/B; profiles/r1q_conv_variants.txt): two resident
+// workgroups overlap each other's prologue / epilogue / barrier stalls, which beats the larger tiles' lower
+// L2 -> LDS traffic on every VGG shape; between the two small shapes the 64 x 64 wave tile needs one LDS
+// fragment read per MFMA instead of 1.5 (the 32 x 64 tile keeps the LDS array ~100 % busy at full MFMA rate)
+// and wins by 7-18 % wherever its 128-channel tiles still fill the chip (>= 512 workgroups).
+// SFOD_P3_VARIANT=1..4 / sfod_set_conv3x3_variant force a shape where the channel counts allow it (A/B, tests).
+static int g_p3_variant = -1;   // -1: not initialised (SFOD_P3_VARIANT or 0 = auto)
+
+extern "C" int sfod_set_conv3x3_variant(int variant) {
+  g_p3_variant = (variant >= 1 && variant <= 4) ? variant : 0;
+  return 0;
+}
 
 P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   P3Plan p;
   p.ok = 0;
   if (H < 1 || W < 1 || B < 1) return p;
-  // Workgroup shape.  Measured per layer (tools/bench_conv.py, interleaved A/B): the 256-pixel x 64-channel
-  // variant (76 KiB of LDS, 115 VGPRs -> two workgroups per CU, which overlap each other's prologue /
-  // epilogue / barrier stalls) beats the 512 x 128 tile on every VGG / RPN shape (-3 ... -17 %, the 18x37
-  // RPN head -60 %) except the long-K 512 -> 512 layers on large maps (+3 %), although it streams the weights
-  // four times as often.  SFOD_P3_G2_MAXC (A/B hook) restricts the small variant to Cout <= that value.
-  static const char* eg = getenv("SFOD_P3_G2_MAXC");
-  const bool big = eg ? (Cout > atoi(eg)) : (Cout >= 512 && Cin >= 512 && (int64_t)B * H * W >= 65536);
-  p.G = (!big && Cin % 64 == 0) ? 2 : 1;
+  if (g_p3_variant < 0) {
+    const char* ev = getenv("SFOD_P3_VARIANT");
+    g_p3_variant = ev ? atoi(ev) : 0;
+  }
+  int variant = g_p3_variant;
+  if (variant < 1 || variant > 4) {
+    const int64_t mt = ((int64_t)B * H * W + 255) / 256;          // 256-pixel tiles (lower bound)
+    const int64_t wg128 = mt * ((Cout + 127) / 128);
+    variant = (Cout > 64 && wg128 >= 512) ? 2 : 3;
+  }
+  if ((variant == 3 || variant == 4) && Cin % 64 != 0) variant = (variant == 3) ? 2 : 1;
+  p.G = (variant <= 2) ? 1 : 2;
+  p.FM = (variant == 1) ? 4 : (variant == 3 ? 1 : 2);
   if (Cin % (32 * p.G) != 0) return p;
   if ((int64_t)H * W * Cin >= (int64_t)1 << 30 || (int64_t)Cout * 9 * Cin >= (int64_t)1 << 30) return p;  // 32-bit byte offsets
-  if (g_p3_small < 0) {
-    const char* e = getenv("SFOD_P3_SMALL");
-    g_p3_small = e ? atoi(e) : 1;
-  }
-  static const char* e1 = getenv("SFOD_P3_SMALL_G1");       // experiment hook
-  const bool small1 = e1 ? atoi(e1) != 0 : false;
-  p.FM = (p.G == 1) ? (small1 ? 2 : 4) : (g_p3_small ? 1 : 2);
   const int BM = (p.G == 1 ? 4 : 8) * p.FM * 32;
   const int cap = (BM == 256) ? PATCH_ROWS_SMALL : PATCH_ROWS_BIG;
   double best = -1.0;

@@ -179,6 +179,11 @@ def set_conv_algo(algo):
     load().sfod_set_conv_algo(int(algo))
 
 
+def set_conv3x3_variant(variant):
+    """Workgroup shape of the halo-patch kernel: 0 auto, 1..4 see include/sfod_hip.h (A/B runs, tests)."""
+    load().sfod_set_conv3x3_variant(int(variant))
+
+
 # =================================================================================================
 # tensor-level wrappers (allocate outputs with torch, call the C ABI)
 # =================================================================================================

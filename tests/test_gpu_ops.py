@@ -86,7 +86,8 @@ def test_conv_fwd(native, dtype, shape, act):
     (3, 5, 6, 256, 256),      # tiny maps, 8 slices
 ])
 @pytest.mark.parametrize("variant", ["plain", "relu_stats", "f32out"])
-def test_conv3x3_patch_kernel(native, shape, variant):
+@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4])   # workgroup shape: auto, 512x128, 256x128, 256x64, 512x64
+def test_conv3x3_patch_kernel(native, shape, variant, wg):
     """k_conv3x3_patch (forced) against F.conv2d on bf16-rounded operands and against the generic
     implicit-GEMM kernel; BatchNorm partial statistics through sfod_bn_finalize."""
     B, H, W, Cin, Cout = shape
@@ -99,6 +100,7 @@ def test_conv3x3_patch_kernel(native, shape, variant):
     wp = native.pack_conv_weight(w.to(DEV), Cin, native.BF16)
     try:
         native.set_conv_algo(2)
+        native.set_conv3x3_variant(wg)
         assert native.query("sfod_conv_stats_blocks", B, H, W, Cin, Cout, 3, native.BF16) < (B * H * W + 127) // 128 + B * 64
         if variant == "plain":
             y = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
@@ -124,6 +126,7 @@ def test_conv3x3_patch_kernel(native, shape, variant):
             assert (y[..., Cout:] == 0).all()
     finally:
         native.set_conv_algo(0)
+        native.set_conv3x3_variant(0)
 
 
 @pytest.mark.parametrize("hw", [(50, 70), (64, 96), (9, 500)])

@@ -20,6 +20,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--variants", action="store_true",
+                    help="time the halo-patch kernel's workgroup shapes 1..4 (and auto = 0) instead of algo 1 vs 2")
     args = ap.parse_args()
     sfod = importlib.import_module("simple-sfod_amd")
     native = sfod.native
@@ -43,6 +45,28 @@ def main():
         w = (torch.randn(Cout, 9, Cin, device=dev, generator=g) / (3 * Cin ** 0.5)).bfloat16()
         bias = torch.randn(Cout, device=dev, generator=g)
         flops = 2.0 * B * H * W * Cout * 9 * Cin
+        if args.variants:
+            native.set_conv_algo(2)
+            vt = {v: [] for v in (0, 1, 2, 3, 4)}
+            for r in range(args.rounds + 1):
+                for v in vt:
+                    native.set_conv3x3_variant(v)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    native.conv_fwd(x, w, bias, Cout, 3, want_stats=True)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r > 0:
+                        vt[v].append(e0.elapsed_time(e1))
+            native.set_conv3x3_variant(0)
+            native.set_conv_algo(0)
+            names = {0: "auto", 1: "512x128", 2: "256x128", 3: "256x64", 4: "512x64"}
+            line = f"{name:9s} {B}x{H}x{W} {Cin:4d}->{Cout:4d} {flops / 1e9:8.1f} GF"
+            for v in vt:
+                t = sorted(vt[v])[len(vt[v]) // 2]
+                line += f" | {names[v]} {t:6.3f} ms {flops / t / 1e9:6.0f}"
+            print(line, flush=True)
+            continue
         res = {}
         algos = [1, 2]
         times = {a: [] for a in algos}
