@@ -79,8 +79,13 @@ __device__ __forceinline__ void bufload16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(l), 16, (int)voff, (int)soff, 0, 0);
 }
 
+// Stage wait: this wave's DMAs up to the counted point have landed AND its own LDS reads have returned.
+// The lgkmcnt(0) matters: the compiler sinks a stage's last fragment reads + MFMAs below the next
+// s_barrier; a read that is merely issued when its wave arrives at the barrier can still be in the LDS
+// queue when another wave's DMA (issued right after the barrier) overwrites that ring slot / patch
+// buffer -- nothing orders a ds_read against an incoming LDS-DMA (seen as rare wrong tiles under load).
 template <int N> __device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
 __device__ __forceinline__ float act_f(float v, int act) {

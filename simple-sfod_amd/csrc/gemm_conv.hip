@@ -287,8 +287,10 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
     if (KT > 1) stage_load(1, 1);
     int cur = 0, nxt = 2;
     for (int kt = 0; kt < KT; ++kt) {
-      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // lgkmcnt(0): this wave's fragment reads of tile kt-1 have returned before anyone's DMA may overwrite
+      // that buffer (the compiler sinks the last reads + MFMAs below the barrier otherwise)
+      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everyone is done with tile kt-1
       asm volatile("" ::: "memory");
       if (kt + 2 < KT) stage_load(kt + 2, nxt);

@@ -129,6 +129,33 @@ def test_conv3x3_patch_kernel(native, shape, variant, wg):
         native.set_conv3x3_variant(0)
 
 
+@pytest.mark.parametrize("wg", [1, 2, 3, 4])
+def test_conv3x3_patch_under_load_is_deterministic(native, wg):
+    """Full-chip launch (thousands of workgroups, two per CU for the small shapes): every workgroup shape must
+    be run-to-run bit-identical and agree with the generic kernel.  Guards the DMA-vs-pending-ds_read hazard of
+    the counted-wait pipeline (a stage's last fragment reads must have RETURNED before the barrier that lets
+    other waves' DMA overwrite the ring slot), which only shows under load."""
+    B, H, W, Cin, Cout = 8, 150, 300, 256, 256
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = torch.randn(B, H, W, Cin, device=DEV, generator=g).bfloat16()
+    w = (torch.randn(Cout, 9, Cin, device=DEV, generator=g) / (3 * Cin ** 0.5)).bfloat16()
+    bias = torch.randn(Cout, device=DEV, generator=g)
+    try:
+        native.set_conv_algo(1)
+        ref = native.conv_fwd(x, w, bias, Cout, 3).float()
+        native.set_conv_algo(2)
+        native.set_conv3x3_variant(wg)
+        ys = [native.conv_fwd(x, w, bias, Cout, 3, want_stats=True)[0] for _ in range(6)]
+        torch.cuda.synchronize()
+    finally:
+        native.set_conv_algo(0)
+        native.set_conv3x3_variant(0)
+    for y in ys[1:]:
+        assert torch.equal(ys[0], y), "patch conv is not run-to-run deterministic"
+    # same bf16 products, fp32 accumulation in another order: a few outputs differ by one bf16 ulp
+    assert rel_err(ys[0].float(), ref) < 2e-4
+
+
 @pytest.mark.parametrize("hw", [(50, 70), (64, 96), (9, 500)])
 @pytest.mark.parametrize("stats", [False, True])
 def test_conv_first_layer_kernel(native, hw, stats):
