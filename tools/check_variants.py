@@ -27,3 +27,26 @@ for (B, H, W, Cin, Cout) in [(8, 300, 600, 128, 128), (8, 150, 300, 256, 256), (
         print(f"{B}x{H}x{W} {Cin}->{Cout} variant {v}: deterministic={same} (max differing elems {nbad}) rel diff vs generic {rel:.2e}, gross errors {big}", flush=True)
     native.set_conv3x3_variant(0)
     native.set_conv_algo(0)
+
+# ---- weight gradient (halo-patch slabs) and the generic 3-stage GEMM (fc1-sized) under load ---------------
+for (B, H, W, Cin, Cout) in [(8, 150, 300, 256, 256), (8, 300, 600, 64, 128), (8, 600, 1200, 64, 64)]:
+    g = torch.Generator(device=dev).manual_seed(2)
+    x = torch.randn(B, H, W, Cin, device=dev, generator=g).bfloat16()
+    dy = torch.randn(B, H, W, Cout, device=dev, generator=g).bfloat16()
+    native.set_conv_algo(1)
+    ref = native.conv_wgrad(x, dy, Cout, 3)
+    native.set_conv_algo(2)
+    ds = [native.conv_wgrad(x, dy, Cout, 3) for _ in range(5)]
+    native.set_conv_algo(0)
+    torch.cuda.synchronize()
+    same = all(torch.equal(ds[0], d) for d in ds[1:])
+    print(f"wgrad {B}x{H}x{W} {Cin}->{Cout}: deterministic={same} rel diff vs generic {((ds[0] - ref).norm() / ref.norm()).item():.2e}", flush=True)
+M, K, N = 16000, 25088, 1024
+g = torch.Generator(device=dev).manual_seed(3)
+a = torch.randn(M, K, device=dev, generator=g).bfloat16()
+wt = (torch.randn(N, K, device=dev, generator=g) / K ** 0.5).bfloat16()
+ys = [native.conv_fwd(a, wt, None, N, 1, act=1) for _ in range(5)]
+torch.cuda.synchronize()
+ref = torch.relu(a[:2048].float() @ wt.float().t())
+print(f"gemm {M}x{K}x{N}: deterministic={all(torch.equal(ys[0], y) for y in ys[1:])} "
+      f"rel diff vs torch (first 2048 rows) {((ys[0][:2048].float() - ref).norm() / ref.norm()).item():.2e}", flush=True)
