@@ -584,12 +584,86 @@ __device__ uint64_t select_threshold(const void* lab, const uint32_t* keys, int6
   return T;
 }
 
+// The same threshold without the 32 + idx_bits passes: the keys are uniform random 32-bit numbers, so a
+// histogram of their top 12 bits (LDS atomics) locates the bin that holds the take-th smallest composite,
+// and only that bin's few candidates are ranked exactly.  Two coalesced passes over the keys.  Falls back to
+// the bitwise search when the bin overflows the list (non-uniform keys).  Bit-identical result by definition
+// (T = the take-th smallest composite; composites are distinct).
+#define SS_BINS 4096
+#define SS_LIST 1024
+
+__device__ int block_incl_scan_i(int v, int* red) {
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(v, o);
+    if (lane >= o) v += u;
+  }
+  __syncthreads();
+  if (lane == 63) red[wid] = v;
+  __syncthreads();
+  int pre = 0;
+  for (int w = 0; w < wid; ++w) pre += red[w];
+  return v + pre;
+}
+
+template <int MODE>
+__device__ bool select_threshold_hist(const void* lab, const uint32_t* keys, int64_t base, int n, int bg,
+                                      int which, int take, int idx_bits, int* hist, unsigned long long* list,
+                                      int* red, int* misc, unsigned long long* result) {
+  for (int i = threadIdx.x; i < SS_BINS; i += SS_THREADS) hist[i] = 0;
+  if (threadIdx.x == 0) { misc[0] = 0; misc[1] = -1; misc[2] = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += SS_THREADS)
+    if (is_cand<MODE>(lab, base + i, bg, which)) atomicAdd(&hist[keys[base + i] >> 20], 1);
+  __syncthreads();
+  {
+    const int b0 = threadIdx.x * (SS_BINS / SS_THREADS);
+    int h[SS_BINS / SS_THREADS], sum = 0;
+#pragma unroll
+    for (int k = 0; k < SS_BINS / SS_THREADS; ++k) { h[k] = hist[b0 + k]; sum += h[k]; }
+    const int incl = block_incl_scan_i(sum, red);
+    int run = incl - sum;                       // candidates in bins before b0
+    if (run < take && take <= incl) {           // exactly one thread: its bins contain the take-th smallest
+#pragma unroll
+      for (int k = 0; k < SS_BINS / SS_THREADS; ++k) {
+        if (run < take && take <= run + h[k]) { misc[1] = b0 + k; misc[2] = run; }
+        run += h[k];
+      }
+    }
+  }
+  __syncthreads();
+  const int bstar = misc[1], below = misc[2];
+  const int r = take - below;                   // rank (1-based) inside the bin
+  for (int i = threadIdx.x; i < n; i += SS_THREADS) {
+    const uint32_t k = keys[base + i];
+    if ((int)(k >> 20) == bstar && is_cand<MODE>(lab, base + i, bg, which)) {
+      const int p = atomicAdd(&misc[0], 1);
+      if (p < SS_LIST) list[p] = ((unsigned long long)k << idx_bits) | (unsigned long long)i;
+    }
+  }
+  __syncthreads();
+  const int m = misc[0];
+  if (bstar < 0 || m > SS_LIST) return false;
+  for (int t = threadIdx.x; t < m; t += SS_THREADS) {
+    const unsigned long long v = list[t];
+    int rank = 0;
+    for (int j = 0; j < m; ++j) rank += list[j] < v;
+    if (rank == r - 1) *result = v;
+  }
+  __syncthreads();
+  return true;
+}
+
 template <int MODE>
 __global__ void __launch_bounds__(SS_THREADS)
 k_subsample(void* lab, const uint32_t* __restrict__ keys, int n, int num, float pos_frac, int bg,
             int32_t* __restrict__ out_idx, int32_t* __restrict__ out_count) {
   __shared__ int red[SS_THREADS / 64];
-  __shared__ int scan[SS_THREADS];
+  __shared__ int hist[SS_BINS];
+  __shared__ unsigned long long list[SS_LIST];
+  __shared__ int misc[4];
+  __shared__ unsigned long long thr[2];
   const int b = blockIdx.x;
   const int64_t base = (int64_t)b * n;
   int idx_bits = 1;
@@ -604,9 +678,27 @@ k_subsample(void* lab, const uint32_t* __restrict__ keys, int n, int num, float 
   const int num_pos = min(cpos, (int)((float)num * pos_frac));
   const int num_neg = min(cneg, num - num_pos);
   uint64_t Tpos = ~0ull, Tneg = ~0ull;
-  if (num_pos < cpos) Tpos = select_threshold<MODE>(lab, keys, base, n, bg, 0, num_pos, idx_bits, red);
-  if (num_neg < cneg) Tneg = select_threshold<MODE>(lab, keys, base, n, bg, 1, num_neg, idx_bits, red);
+  if (num_pos < cpos && num_pos > 0) {
+    if (select_threshold_hist<MODE>(lab, keys, base, n, bg, 0, num_pos, idx_bits, hist, list, red, misc, &thr[0])) Tpos = thr[0];
+    else Tpos = select_threshold<MODE>(lab, keys, base, n, bg, 0, num_pos, idx_bits, red);
+  }
+  if (num_neg < cneg && num_neg > 0) {
+    if (select_threshold_hist<MODE>(lab, keys, base, n, bg, 1, num_neg, idx_bits, hist, list, red, misc, &thr[1])) Tneg = thr[1];
+    else Tneg = select_threshold<MODE>(lab, keys, base, n, bg, 1, num_neg, idx_bits, red);
+  }
   const bool none_pos = (num_pos == 0), none_neg = (num_neg == 0);
+  if (MODE == 0) {
+    // in-place label rewrite: no ordering needed, coalesced strided loop
+    int8_t* l8 = reinterpret_cast<int8_t*>(lab);
+    for (int i = threadIdx.x; i < n; i += SS_THREADS) {
+      const uint64_t comp = ((uint64_t)keys[base + i] << idx_bits) | (uint64_t)i;
+      const bool sp = !none_pos && is_cand<MODE>(lab, base + i, bg, 0) && comp <= Tpos;
+      const bool sn = !none_neg && is_cand<MODE>(lab, base + i, bg, 1) && comp <= Tneg;
+      l8[base + i] = sp ? 1 : (sn ? 0 : -1);
+    }
+    if (threadIdx.x == 0 && out_count) { out_count[b * 2] = num_pos; out_count[b * 2 + 1] = num_neg; }
+    return;
+  }
   // contiguous chunk per thread so that the compaction below is index-ordered
   const int chunk = (n + SS_THREADS - 1) / SS_THREADS;
   const int lo = threadIdx.x * chunk, hi = min(n, lo + chunk);
@@ -618,38 +710,9 @@ k_subsample(void* lab, const uint32_t* __restrict__ keys, int n, int num, float 
     npos_local += sp;
     nneg_local += sn;
   }
-  if (MODE == 0) {
-    __syncthreads();
-    int8_t* l8 = reinterpret_cast<int8_t*>(lab);
-    for (int i = lo; i < hi; ++i) {
-      const uint64_t comp = ((uint64_t)keys[base + i] << idx_bits) | (uint64_t)i;
-      const bool sp = !none_pos && is_cand<MODE>(lab, base + i, bg, 0) && comp <= Tpos;
-      const bool sn = !none_neg && is_cand<MODE>(lab, base + i, bg, 1) && comp <= Tneg;
-      l8[base + i] = sp ? 1 : (sn ? 0 : -1);
-    }
-    if (threadIdx.x == 0 && out_count) { out_count[b * 2] = num_pos; out_count[b * 2 + 1] = num_neg; }
-    return;
-  }
   // MODE 1: ordered compaction fg then bg
-  scan[threadIdx.x] = npos_local;
-  __syncthreads();
-  for (int off = 1; off < SS_THREADS; off <<= 1) {
-    int v = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
-    __syncthreads();
-    scan[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int ppos = scan[threadIdx.x] - npos_local;
-  __syncthreads();
-  scan[threadIdx.x] = nneg_local;
-  __syncthreads();
-  for (int off = 1; off < SS_THREADS; off <<= 1) {
-    int v = (threadIdx.x >= off) ? scan[threadIdx.x - off] : 0;
-    __syncthreads();
-    scan[threadIdx.x] += v;
-    __syncthreads();
-  }
-  int pneg = num_pos + scan[threadIdx.x] - nneg_local;
+  int ppos = block_incl_scan_i(npos_local, red) - npos_local;
+  int pneg = num_pos + block_incl_scan_i(nneg_local, red) - nneg_local;
   for (int i = lo; i < hi; ++i) {
     const uint64_t comp = ((uint64_t)keys[base + i] << idx_bits) | (uint64_t)i;
     const bool sp = !none_pos && is_cand<MODE>(lab, base + i, bg, 0) && comp <= Tpos;

@@ -543,7 +543,8 @@ def test_anchor_match_labels_bit_exact(native, G):
         assert torch.equal(matched[b].cpu().long(), ridx)
 
 
-def test_subsample_rpn_and_roi_exact(native):
+@pytest.mark.parametrize("n_equal", [2000, 7000])   # 7000 equal keys overflow the histogram bin's list: bitwise fallback
+def test_subsample_rpn_and_roi_exact(native, n_equal):
     g = torch.Generator().manual_seed(9)
     B, n = 3, 9990
     labels = torch.randint(-1, 2, (B, n), generator=g).to(torch.int8)
@@ -552,7 +553,7 @@ def test_subsample_rpn_and_roi_exact(native):
     labels[2] = -1
     labels[2, 5] = 0                                  # almost nothing to sample
     keys = torch.randint(0, 2 ** 31 - 1, (B, n), generator=g, dtype=torch.int64)
-    keys[0, :2000] = 7                                # many equal keys: index breaks the tie
+    keys[0, :n_equal] = 7                             # many equal keys: index breaks the tie
     ld = labels.clone().to(DEV)
     native.subsample_rpn_(ld, keys.to(torch.int32).to(DEV), 256, 0.5)
     for b in range(B):
