@@ -203,14 +203,44 @@ def dev_const(values, dtype, device):
     return t
 
 
+_PIN_SLOTS, _PIN_WIDTH = 32, 64
+_pin_ring = {}
+
+
+def _pinned_upload_i64(values, dev):
+    """Small int64 host vector -> device tensor through a ring of pinned staging slots (asynchronous
+    host-to-device copy on the current stream).  A slot is reused only after the copy that read it has
+    completed (its event), so the host may run any number of steps ahead."""
+    n = len(values)
+    if n > _PIN_WIDTH:
+        return torch.tensor(values, dtype=torch.int64).to(dev)
+    st = _pin_ring.get(dev)
+    if st is None:
+        st = {"buf": torch.empty(_PIN_SLOTS, _PIN_WIDTH, dtype=torch.int64).pin_memory(), "ev": [None] * _PIN_SLOTS,
+              "next": 0}
+        _pin_ring[dev] = st
+    i = st["next"]
+    st["next"] = (i + 1) % _PIN_SLOTS
+    if st["ev"][i] is not None:
+        st["ev"][i].synchronize()
+    slot = st["buf"][i, :n]
+    slot.copy_(torch.tensor(values, dtype=torch.int64))
+    out = slot.to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    st["ev"][i] = ev
+    return out
+
+
 def preprocess(images_u8, Hp, Wp, cpad, mean, std, dt):
     """images_u8: list of uint8 device tensors [3,h,w] -> (x [B,Hp,Wp,cpad], sizes int32 [B,2])."""
     dev = images_u8[0].device
     B = len(images_u8)
     imgs = [im.contiguous() for im in images_u8]
-    # pointer table built on the device from per-image cached 1-element tensors: no host-to-device copy (a
-    # pageable copy is a stream synchronisation) unless an image is seen for the first time
-    ptrs = torch.cat([dev_const((im.data_ptr(),), torch.int64, dev) for im in imgs])
+    # pointer table: written into a pinned staging slot and copied asynchronously (a pageable copy blocks
+    # the host until the stream drains, and the image addresses change whenever the allocator hands out
+    # another block, so caching them by value still missed every other step)
+    ptrs = _pinned_upload_i64([im.data_ptr() for im in imgs], dev)
     sizes = dev_const(tuple((int(im.shape[1]), int(im.shape[2])) for im in imgs), torch.int32, dev)
     out = torch.empty(B, Hp, Wp, cpad, dtype=torch_dtype(dt), device=dev)
     m = (ctypes.c_float * 3)(*mean)
