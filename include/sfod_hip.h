@@ -90,6 +90,12 @@ int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oihw, int B, i
  * swaps in/out channels and flips the taps: the dgrad weight [Cin][KH*KW][Cout]. */
 int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Cout, int Cin, int ksize,
                           int CinPad, int rot180, int dt, void* stream);
+/* every conv weight of a model in one launch.  desc (device, int64): n entries of 8 values
+ * {src fp32 OIHW pointer, dst packed pointer, Cout, Cin, ksize, innerPad, rot180, first_block}, where
+ * first_block is the running sum of sfod_pack_conv_weights_blocks over the preceding entries;
+ * total_blocks = the sum over all entries.  Same layouts as sfod_pack_conv_weight. */
+int sfod_pack_conv_weights_blocks(int Cout, int Cin, int ksize, int innerPad, int rot180);
+int sfod_pack_conv_weights_multi(const int64_t* desc, int n, int total_blocks, int dt, void* stream);
 /* packed fp32 grad [Cout][taps][CinPad] -> OIHW fp32 grad (accumulate=0: overwrite) */
 int sfod_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int Cout, int Cin, int ksize,
                            int CinPad, int accumulate, void* stream);

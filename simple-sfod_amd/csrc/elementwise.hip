@@ -901,6 +901,57 @@ extern "C" int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Co
   return sfod_check_launch("pack_conv_weight");
 }
 
+// All conv weights of a model in ONE launch.  desc: n entries of 8 int64
+// {src (fp32 OIHW), dst (packed, dt), Cout, Cin, ks, innerPad, rot180, first_block}; entry e owns the
+// workgroups [first_block[e], first_block[e+1]) (desc[n*8 + 7] = total), PACK_PER_BLOCK elements each.
+#define PACK_PER_BLOCK 2048
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_pack_conv_weights_multi(const long long* __restrict__ desc, int n) {
+  int e = 0;
+  while (e + 1 < n && (int)desc[(e + 1) * 8 + 7] <= (int)blockIdx.x) ++e;   // uniform: scalar loads
+  const float* __restrict__ w = reinterpret_cast<const float*>(desc[e * 8 + 0]);
+  T* __restrict__ out = reinterpret_cast<T*>(desc[e * 8 + 1]);
+  const int Cout = (int)desc[e * 8 + 2], Cin = (int)desc[e * 8 + 3], ks = (int)desc[e * 8 + 4];
+  const int innerPad = (int)desc[e * 8 + 5], rot180 = (int)desc[e * 8 + 6];
+  const int taps = ks * ks;
+  const int rows = rot180 ? Cin : Cout;
+  const int innerN = rot180 ? Cout : Cin;
+  const int64_t total = (int64_t)rows * taps * innerPad;
+  const int64_t t0 = (int64_t)((int)blockIdx.x - (int)desc[e * 8 + 7]) * PACK_PER_BLOCK;
+#pragma unroll
+  for (int k = 0; k < PACK_PER_BLOCK / 256; ++k) {
+    const int64_t t = t0 + k * 256 + threadIdx.x;
+    if (t >= total) break;
+    const int inner = (int)(t % innerPad);
+    const int tap = (int)((t / innerPad) % taps);
+    const int row = (int)(t / ((int64_t)innerPad * taps));
+    float v = 0.f;
+    if (inner < innerN) {
+      const int co = rot180 ? inner : row, ci = rot180 ? row : inner;
+      const int st = rot180 ? (taps - 1 - tap) : tap;
+      v = w[((int64_t)co * Cin + ci) * taps + st];
+    }
+    out[t] = from_f32<T>(v);
+  }
+}
+
+extern "C" int sfod_pack_conv_weights_blocks(int Cout, int Cin, int ksize, int innerPad, int rot180) {
+  const int64_t total = (int64_t)(rot180 ? Cin : Cout) * ksize * ksize * innerPad;
+  return (int)((total + PACK_PER_BLOCK - 1) / PACK_PER_BLOCK);
+}
+
+extern "C" int sfod_pack_conv_weights_multi(const int64_t* desc, int n, int total_blocks, int dt, void* stream) {
+  SFOD_REQUIRE(n >= 1 && total_blocks >= 1, "pack_multi: empty table");
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_pack_conv_weights_multi<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)desc, n);
+  else
+    hipLaunchKernelGGL(k_pack_conv_weights_multi<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)desc, n);
+  return sfod_check_launch("pack_conv_weights_multi");
+}
+
 __global__ void k_unpack_conv_wgrad(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
                                     int ks, int CinPad, int accumulate) {
   const int taps = ks * ks;

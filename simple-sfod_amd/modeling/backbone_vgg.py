@@ -13,6 +13,8 @@ initialisation draw for draw; none of their forward methods is ever called.  Com
 Activations are NHWC internally; the NCHW tensors this module accepts/returns are zero-copy
 channels-last views, so the Detectron2 ``Backbone`` surface is kept without layout traffic.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -149,14 +151,39 @@ class vgg_backbone(nn.Module):
         return dict(zip(self._stage_names, outs))
 
     # ---- engine -------------------------------------------------------------------------------------
+    def _packed_weights(self, dt, cin0_pad, with_dgrad):
+        """Packed forward weights of all layers (+ the rotated dgrad weights of layers 1.. when a backward
+        follows), refreshed from the fp32 master weights by ONE launch per call."""
+        if os.environ.get("SFOD_NO_MULTIPACK"):   # A/B hook: one launch per layer
+            f = [native.pack_conv_weight(c.weight.detach(), cin0_pad if i == 0 else c.in_channels, dt)
+                 for i, (c, _, _, _) in enumerate(self._plan)]
+            r = ([None] + [native.pack_conv_weight(c.weight.detach(), c.out_channels, dt, rot180=True)
+                           for c, _, _, _ in self._plan[1:]]) if with_dgrad else None
+            return f, r
+        key = (dt, cin0_pad, bool(with_dgrad))
+        packers = self.__dict__.setdefault("_packers", {})
+        pk = packers.get(key)
+        if pk is None:
+            specs = []
+            for li, (conv, _, _, _) in enumerate(self._plan):
+                specs.append((conv.weight, cin0_pad if li == 0 else conv.in_channels, False))
+            if with_dgrad:
+                for conv, _, _, _ in self._plan[1:]:
+                    specs.append((conv.weight, conv.out_channels, True))
+            pk = packers[key] = native.ConvWeightPacker(specs, dt)
+        views = pk.pack()
+        n = len(self._plan)
+        return views[:n], ([None] + list(views[n:]) if with_dgrad else None)
+
     def _forward_impl(self, x, save=True):
         dt = native.dt_of(x)
         training = self.training
         saved, outs = [], []
-        for conv, bn, pool, stage_end in self._plan:
-            cin_pad = x.shape[-1]
+        fwd_w, rot_w = self._packed_weights(dt, x.shape[-1], save)
+        self._rot_w = rot_w
+        for li, (conv, bn, pool, stage_end) in enumerate(self._plan):
             cout = conv.out_channels
-            wp = native.pack_conv_weight(conv.weight.detach(), cin_pad, dt)
+            wp = fwd_w[li]
             B, H, W, _ = x.shape
             if training:
                 y, stats = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3, want_stats=True)
@@ -214,9 +241,8 @@ class vgg_backbone(nn.Module):
             db = None if native.grad_sink(conv.bias) is not None else torch.zeros_like(conv.bias)
             pgrads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
             if li > 0:
-                dt = native.dt_of(dy)
-                wr = native.pack_conv_weight(conv.weight.detach(), cout, dt, rot180=True)
-                dz = native.conv_fwd(dy, wr, None, cin, 3)
+                # rotated weights were packed together with the forward ones (same step, same values)
+                dz = native.conv_fwd(dy, self._rot_w[li], None, cin, 3)
             del saved[li]
         return pgrads
 

@@ -281,6 +281,51 @@ def grad_sink(param):
     return None
 
 
+class ConvWeightPacker:
+    """All conv weights of a module packed by ONE launch per call (the per-layer kernels are launch-bound:
+    ~8 us each for <= 9 MB).  ``specs``: list of (weight parameter OIHW, inner_pad, rot180).  The descriptor
+    table lives on the device and is rebuilt only when a parameter's storage moved."""
+
+    def __init__(self, specs, dt):
+        self.specs, self.dt = list(specs), dt
+        self._ptrs = None
+        self.views = None
+
+    def _build(self):
+        dev = self.specs[0][0].device
+        tdt = torch_dtype(self.dt)
+        sizes, blocks = [], []
+        for w, pad, rot in self.specs:
+            cout, cin, ks, _ = w.shape
+            rows = cin if rot else cout
+            sizes.append((rows, ks * ks, pad))
+            blocks.append(query("sfod_pack_conv_weights_blocks", cout, cin, ks, pad, int(rot)))
+        offs, tot = [], 0
+        for r, t, p_ in sizes:
+            offs.append(tot)
+            tot += (r * t * p_ + 127) // 128 * 128          # keep every packed tensor 256-byte aligned
+        self._buf = torch.empty(tot, dtype=tdt, device=dev)
+        self.views = [self._buf[o:o + r * t * p_].view(r, t, p_) for o, (r, t, p_) in zip(offs, sizes)]
+        rows, first = [], 0
+        for (w, pad, rot), v, nb in zip(self.specs, self.views, blocks):
+            cout, cin, ks, _ = w.shape
+            rows.append([w.data_ptr(), v.data_ptr(), cout, cin, ks, pad, int(rot), first])
+            first += nb
+        rows.append([0, 0, 0, 0, 0, 0, 0, first])
+        self._total = first
+        self._desc = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self._ptrs = tuple(w.data_ptr() for w, _, _ in self.specs)
+
+    def pack(self):
+        ptrs = tuple(w.data_ptr() for w, _, _ in self.specs)
+        if ptrs != self._ptrs:
+            for w, _, _ in self.specs:
+                assert w.is_contiguous() and w.dtype == torch.float32
+            self._build()
+        call("sfod_pack_conv_weights_multi", self._desc, len(self.specs), self._total, self.dt)
+        return self.views
+
+
 def unpack_conv_wgrad(dw_packed, dw_oihw, accumulate=False):
     cout, cin, ks, _ = dw_oihw.shape
     call("sfod_unpack_conv_wgrad", dw_packed, dw_oihw, cout, cin, ks, dw_packed.shape[-1], int(accumulate))
