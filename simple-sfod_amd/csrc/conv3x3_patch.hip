@@ -66,6 +66,7 @@ struct P3Args {
   int B, H, W, Cin, Cout, ldy, act;
   int TH, TW, PW;
   int tiles_x, tiles_y, tiles_n;
+  unsigned m_pw, m_tw, m_tn, m_tx, m_ty;   // fdiv magics of PW, TW, tiles_n, tiles_x, tiles_y
   int nbody;    // Cin / (32 * G)
   int ntiles;
   int nblk;
@@ -84,15 +85,19 @@ __device__ __forceinline__ void bufload16(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 // s_barrier; a read that is merely issued when its wave arrives at the barrier can still be in the LDS
 // queue when another wave's DMA (issued right after the barrier) overwrites that ring slot / patch
 // buffer -- nothing orders a ds_read against an incoming LDS-DMA (seen as rare wrong tiles under load).
+// x / d for small operands (x * d < 2^32) with a host-computed magic m = 2^32 / d + 1: the setup of a
+// workgroup sits on the critical path before its first DMA, and a runtime integer division is ~40 VALU ops
+__device__ __forceinline__ unsigned fdiv(unsigned x, unsigned d, unsigned m) { return d == 1 ? x : __umulhi(x, m); }
+
 template <int N> __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ float act_f(float v, int act) {
-  if (act == 1) return fmaxf(v, 0.f);
-  if (act == 2) return v > 0.f ? v : 0.2f * v;
-  return v;
-}
+// activation without per-element branches: act 0 identity, 1 ReLU, 2 LeakyReLU(0.2) == max(v, relu ? 0 : v * slope)
+// with slope 1 / - / 0.2 (a runtime `if (act == ..)` per element compiled to scalar branches around every value)
+struct ActP { float slope; bool relu; };
+__device__ __forceinline__ ActP act_params(int act) { return ActP{act == 2 ? 0.2f : 1.f, act == 1}; }
+__device__ __forceinline__ float act_f(float v, ActP p) { return fmaxf(v, p.relu ? 0.f : v * p.slope); }
 
 // vmcnt immediates per stage (steady state / last body), see header comment.  Derived by simulating the
 // per-wave DMA issue order (patch pieces, then the weights of stage j + D) of each variant.
@@ -137,12 +142,12 @@ k_conv3x3_patch(P3Args a) {
     const int q = a.ntiles / 8, r = a.ntiles % 8, xcd = bid % 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
   }
-  const int tn = bid % a.tiles_n;
-  int t = bid / a.tiles_n;
-  const int txi = t % a.tiles_x;
-  t /= a.tiles_x;
-  const int tyi = t % a.tiles_y;
-  const int b = t / a.tiles_y;
+  int t = (int)fdiv((unsigned)bid, (unsigned)a.tiles_n, a.m_tn);
+  const int tn = bid - t * a.tiles_n;
+  int t2 = (int)fdiv((unsigned)t, (unsigned)a.tiles_x, a.m_tx);
+  const int txi = t - t2 * a.tiles_x;
+  const int b = (int)fdiv((unsigned)t2, (unsigned)a.tiles_y, a.m_ty);
+  const int tyi = t2 - b * a.tiles_y;
   const int mtile = (b * a.tiles_y + tyi) * a.tiles_x + txi;
   const int x0 = txi * a.TW, y0 = tyi * a.TH, n0 = tn * BN;
   const int PW = a.PW;
@@ -150,19 +155,7 @@ k_conv3x3_patch(P3Args a) {
   const bf16_t* ximg = a.x + (int64_t)b * a.H * a.W * a.Cin;
   const int Ktot = 9 * a.Cin;
 
-  // ---- pixel table: tile pixel -> pixel index inside the image, -1 outside ------------------------
-  int* pixtab = reinterpret_cast<int*>(smem + PIXTAB_OFF);
-  {
-    const int p = threadIdx.x;
-    int v = -1;
-    if (p < npix) {
-      const int ty = p / a.TW, tx = p - ty * a.TW;
-      if (y0 + ty < a.H && x0 + tx < a.W) v = (y0 + ty) * a.W + (x0 + tx);
-    }
-    pixtab[p] = v;
-  }
-
-  // ---- DMA descriptors ---------------------------------------------------------------------------
+  // ---- DMA descriptors (first: the prologue's loads should leave as early as possible) --------------
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
       (void*)ximg, (short)0, a.H * a.W * a.Cin * 2, 0x00020000);
   const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc(
@@ -172,7 +165,7 @@ k_conv3x3_patch(P3Args a) {
   for (int k = 0; k < NPW; ++k) {
     const int row = (wave * NPW + k) * 16 + (lane >> 2);
     const int lc = (lane & 3) ^ ((row >> 2) & 3);
-    const int py = row / PW, px = row - py * PW;
+    const int py = (int)fdiv((unsigned)row, (unsigned)PW, a.m_pw), px = row - py * PW;
     const int iy = y0 - 1 + py, ix = x0 - 1 + px;
     const bool ok = (py < a.TH + 2) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     poff[k] = ok ? (unsigned)(((iy * a.W + ix) * a.Cin + lc * 8) * 2) : OOB_OFF;
@@ -196,12 +189,31 @@ k_conv3x3_patch(P3Args a) {
     bufload16(wres, boff, (unsigned)(tap * a.Cin + slice * 32) * 2u, smem + BRING_OFF + (sg % NBS) * BSLOT + wave * 1024);
   };
 
+  // ---- prologue: first patch + weights of the first D stages (in flight while the tables below are built) --
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) issue_patch(k, 0, 0);
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue_b(d);
+
+  // ---- pixel table: tile pixel -> pixel index inside the image, -1 outside (epilogue only) -----------
+  int* pixtab = reinterpret_cast<int*>(smem + PIXTAB_OFF);
+  {
+    const int p = threadIdx.x;
+    int v = -1;
+    if (p < npix) {
+      const int ty = (int)fdiv((unsigned)p, (unsigned)a.TW, a.m_tw), tx = p - ty * a.TW;
+      if (y0 + ty < a.H && x0 + tx < a.W) v = (y0 + ty) * a.W + (x0 + tx);
+    }
+    pixtab[p] = v;
+  }
+
   // ---- fragment addressing -------------------------------------------------------------------------
   int rowA[FM];
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
     const int p = wm * WROWS + i * 32 + (lane & 31);
-    rowA[i] = (p < npix) ? ((p / a.TW) * PW + (p % a.TW)) : 0;
+    const int ty = (int)fdiv((unsigned)p, (unsigned)a.TW, a.m_tw);
+    rowA[i] = (p < npix) ? (ty * PW + (p - ty * a.TW)) : 0;
   }
   int offB[FN];  // byte offset inside a (pair) slice of the B slot, k-step 0 (k-step 1 = ^32)
 #pragma unroll
@@ -245,11 +257,6 @@ k_conv3x3_patch(P3Args a) {
     }
   };
 
-  // ---- prologue: first patch + weights of the first D stages ---------------------------------------------
-#pragma unroll
-  for (int k = 0; k < NPW; ++k) issue_patch(k, 0, 0);
-#pragma unroll
-  for (int d = 0; d < D; ++d) issue_b(d);
 
   const int nstages = a.nbody * 9;
   for (int body = 0; body < a.nbody; ++body) {
@@ -305,15 +312,21 @@ k_conv3x3_patch(P3Args a) {
     bcol[j] = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
   }
   __syncthreads();  // every wave is done reading operands; LDS is reused below
+  const ActP actp = act_params(a.act);
   const int64_t ybase = (int64_t)b * a.H * a.W;
+  // interior tile (the common case): every row of every wave is a real pixel -> no row masks
+  const bool full = (npix == 8 / (G == 1 ? 2 : 1) * WROWS) && (y0 + a.TH <= a.H) && (x0 + a.TW <= a.W);
   unsigned vmask[FM];  // bit r: row (i, r) of this lane is a real output pixel
 #pragma unroll
   for (int i = 0; i < FM; ++i) {
-    unsigned m = 0;
+    unsigned m = 0xffffu;
+    if (!full) {
+      m = 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (pixtab[wm * WROWS + ml] >= 0) m |= (1u << r);
+      for (int r = 0; r < 16; ++r) {
+        const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (pixtab[wm * WROWS + ml] >= 0) m |= (1u << r);
+      }
     }
     vmask[i] = m;
   }
@@ -329,7 +342,7 @@ k_conv3x3_patch(P3Args a) {
           const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float v = acc[i][j][r] + bcol[j];
           acc[i][j][r] = v;
-          *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + nl * 2) = (bf16_t)act_f(v, a.act);
+          *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + nl * 2) = (bf16_t)act_f(v, actp);
         }
       }
     const bool vec_ok = (a.ldy % 8) == 0;
@@ -361,7 +374,7 @@ k_conv3x3_patch(P3Args a) {
           const int n = n0 + wn * 64 + j * 32 + (lane & 31);
           const float v = acc[i][j][r] + bcol[j];
           acc[i][j][r] = v;
-          if (pix >= 0 && n < a.Cout) yo[(ybase + pix) * a.ldy + n] = act_f(v, a.act);
+          if (pix >= 0 && n < a.Cout) yo[(ybase + pix) * a.ldy + n] = act_f(v, actp);
         }
       }
   }
@@ -377,21 +390,36 @@ k_conv3x3_patch(P3Args a) {
     const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      float s = 0.f;
+      float s = 0.f, q = 0.f, mean;
+      if (full) {
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s += ((vmask[i] >> r) & 1u) ? acc[i][j][r] : 0.f;
-      s += __shfl_xor(s, 32);
-      const float mean = s * inv;
-      float q = 0.f;
+          for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+        s += __shfl_xor(s, 32);
+        mean = s * inv;
 #pragma unroll
-      for (int i = 0; i < FM; ++i)
+        for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float d = acc[i][j][r] - mean;
-          q += ((vmask[i] >> r) & 1u) ? d * d : 0.f;
-        }
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[i][j][r] - mean;
+            q = fmaf(d, d, q);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) s += ((vmask[i] >> r) & 1u) ? acc[i][j][r] : 0.f;
+        s += __shfl_xor(s, 32);
+        mean = s * inv;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[i][j][r] - mean;
+            q += ((vmask[i] >> r) & 1u) ? d * d : 0.f;
+          }
+      }
       q += __shfl_xor(q, 32);
       if (h == 0) {
         sred[(wave * 64 + j * 32 + (lane & 31)) * 2 + 0] = s;
@@ -516,6 +544,9 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.act = act;
   a.TH = p.TH; a.TW = p.TW; a.PW = p.TW + 2;
   a.tiles_x = p.tiles_x; a.tiles_y = p.tiles_y; a.tiles_n = p.tiles_n;
+  auto magic = [](int d) { return (unsigned)((((unsigned long long)1) << 32) / (unsigned)d + 1ull); };
+  a.m_pw = magic(a.PW); a.m_tw = magic(a.TW); a.m_tn = magic(a.tiles_n); a.m_tx = magic(a.tiles_x);
+  a.m_ty = magic(a.tiles_y);
   a.nbody = Cin / (32 * p.G);
   a.ntiles = B * p.tiles_y * p.tiles_x * p.tiles_n;
   a.nblk = p.nblk;

@@ -53,6 +53,7 @@ k_conv_first(F1Args a) {
   float bcol[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) bcol[j] = a.bias ? a.bias[j * 32 + l31] : 0.f;
+  const bool relu = (a.act == 1);
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int t = tile;
@@ -116,7 +117,7 @@ k_conv_first(F1Args a) {
           const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
           const float v = acc[i][j][r] + bcol[j];
           acc[i][j][r] = v;
-          const float o = (a.act == 1) ? fmaxf(v, 0.f) : v;
+          const float o = fmaxf(v, relu ? 0.f : v);
           *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + (j * 32 + l31) * 2) = (bf16_t)o;
         }
     // same-wave readback (LDS is in order per wave): 8 rows x 128 B per instruction

@@ -50,10 +50,10 @@ __device__ __forceinline__ void chunk_to_tap(int gq, int ks, int cpt_shift, int&
   else { tap = gq >> cpt_shift; cc = gq & ((1 << cpt_shift) - 1); }
 }
 
+// branch-free: act 0 identity, 1 ReLU, 2 LeakyReLU(0.2) == max(v, relu ? 0 : v * slope), slope 1 / - / 0.2
 __device__ __forceinline__ float apply_act(float v, int act) {
-  if (act == 1) return fmaxf(v, 0.f);
-  if (act == 2) return v > 0.f ? v : 0.2f * v;
-  return v;
+  const float slope = (act == 2) ? 0.2f : 1.f;
+  return fmaxf(v, (act == 1) ? 0.f : v * slope);
 }
 
 // =============================================================================================
