@@ -367,6 +367,8 @@ def add_native_config(cfg):
     SFOD.EMA.KEEP_RATE    hard-coded 0.9996 in the reference (:584).
     SFOD.COMPUTE_DTYPE    "fp32" (parity mode, fp32 MFMA) or "bf16" (throughput mode).
     SFOD.ELIDE_DEAD_BRANCHES  skip the zero-weighted 2nd ROI pass / BPC / domain branch.
+    SFOD.OVERLAP_TEACHER  run the teacher's pseudo-labelling pass on a second HIP stream beside the
+                          student's backbone forward (they are independent until the student's RPN loss).
     """
     _C = cfg
     _C.SFOD = CN()
@@ -375,6 +377,7 @@ def add_native_config(cfg):
     _C.SFOD.EMA.KEEP_RATE = 0.9996
     _C.SFOD.COMPUTE_DTYPE = "fp32"
     _C.SFOD.ELIDE_DEAD_BRANCHES = True
+    _C.SFOD.OVERLAP_TEACHER = True
     _C.SFOD.SYNTHETIC = CN()
     _C.SFOD.SYNTHETIC.HEIGHT = 1024
     _C.SFOD.SYNTHETIC.WIDTH = 2048

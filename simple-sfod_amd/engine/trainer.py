@@ -302,20 +302,9 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             d["instances"] = label.view(i) if isinstance(label, BatchedGT) else label[i]
         return unlabeled_data
 
-    # ---- step (:335-581) ----------------------------------------------------------------------------
-    def run_step(self):
+    def _teacher_pass(self, unlabel_data_k):
+        """Steps 1-2 of run_step: train-mode teacher under no_grad, score threshold -> pseudo ground truth."""
         cfg = self.cfg
-        assert self.model.training, "[AdaptiveTeacherTrainer] model was changed to eval mode!"
-        start = time.perf_counter()
-        unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
-        if not cfg.WEAK_STRONG_AUGMENT:
-            unlabel_data_q = [dict(d) for d in unlabel_data_k]
-        data_time = time.perf_counter() - start
-        record_dict = {}
-        # 0. remove the labels of the target data (source-free)
-        unlabel_data_q = self.remove_label(unlabel_data_q)
-        unlabel_data_k = self.remove_label(unlabel_data_k)
-        # 1. pseudo-labels from the (train-mode) teacher
         with torch.no_grad():
             _, proposals_rpn_k, proposals_roih_k = self.model_teacher(unlabel_data_k, branch="unsup_data_weak",
                                                                       batched=True)
@@ -331,6 +320,39 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
                                 ((proposals_rpn_k.logits > cur_threshold) & rpn_live).sum().float() / B)
         pseudo = proposals_roih_k.pseudo_gt()
         self.storage.put_scalar("roi_head/num_pseudo_proposals", pseudo.count.float().mean())
+        return pseudo
+
+    # ---- step (:335-581) ----------------------------------------------------------------------------
+    def run_step(self):
+        cfg = self.cfg
+        assert self.model.training, "[AdaptiveTeacherTrainer] model was changed to eval mode!"
+        start = time.perf_counter()
+        unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
+        if not cfg.WEAK_STRONG_AUGMENT:
+            unlabel_data_q = [dict(d) for d in unlabel_data_k]
+        data_time = time.perf_counter() - start
+        record_dict = {}
+        # 0. remove the labels of the target data (source-free)
+        unlabel_data_q = self.remove_label(unlabel_data_q)
+        unlabel_data_k = self.remove_label(unlabel_data_k)
+        # 1. pseudo-labels from the (train-mode) teacher.  The student's backbone forward does not depend on
+        # them (only its heads' losses do), so with SFOD.OVERLAP_TEACHER the teacher pass runs on a second
+        # stream beside it: its low-occupancy tail (sort, NMS, ROIAlign, small GEMMs) fills the conv kernels' gaps.
+        ov = self.__dict__.get("overlap_teacher")      # None -> config; bench.py's roofline segment forces False
+        overlap = ((cfg.SFOD.OVERLAP_TEACHER if ov is None else ov) and self.model_teacher is not self.model
+                   and hasattr(self.model, "prefetch_features"))
+        if overlap:
+            main = torch.cuda.current_stream()
+            side = self.__dict__.get("_side_stream")
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)
+            side.wait_stream(main)       # EMA'd teacher weights, input frames, last step's readers of side buffers
+            with torch.cuda.stream(side):
+                pseudo = self._teacher_pass(unlabel_data_k)
+            self.model.prefetch_features(unlabel_data_q)
+            main.wait_stream(side)
+        else:
+            pseudo = self._teacher_pass(unlabel_data_k)
         # 3. attach the pseudo-labels
         unlabel_data_q = self.add_label(unlabel_data_q, pseudo)
         unlabel_data_k = self.add_label(unlabel_data_k, pseudo)

@@ -71,6 +71,20 @@ class GeneralizedRCNN(nn.Module):
     def _features(self, images):
         return self.backbone.forward_nhwc(images.tensor.permute(0, 2, 3, 1))
 
+    def prefetch_features(self, batched_inputs):
+        """Run preprocessing + the backbone for ``batched_inputs`` NOW; the next ``forward`` on the same list
+        object picks the result up instead of recomputing it.  Lets a trainer start the student's backbone
+        before the pseudo-labels (which only the heads' losses need) exist."""
+        images = self.preprocess_image(batched_inputs)
+        self._prefetched = (batched_inputs, images, self._features(images))
+
+    def _images_and_features(self, batched_inputs):
+        pf = self.__dict__.pop("_prefetched", None)
+        if pf is not None and pf[0] is batched_inputs:
+            return pf[1], pf[2]
+        images = self.preprocess_image(batched_inputs)
+        return images, self._features(images)
+
     def forward(self, batched_inputs):
         if not self.training:
             return self.inference(batched_inputs)
@@ -131,9 +145,8 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
             return self.inference(batched_inputs)
         if branch == "domain_classifier":
             return self._forward_domain_classifier(batched_inputs)
-        images = self.preprocess_image(batched_inputs)
+        images, features = self._images_and_features(batched_inputs)
         gt = gather_gt(batched_inputs, self.device)
-        features = self._features(images)
 
         if branch in ("supervised", "supervised_target"):
             proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt, as_instances=False)

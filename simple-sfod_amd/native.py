@@ -377,11 +377,12 @@ _ws_cache = {}
 
 
 def _workspace(dev, nbytes):
-    """Grow-only scratch buffer per device (stream-ordered reuse: every user runs on the current stream)."""
-    cur = _ws_cache.get(dev)
+    """Grow-only scratch buffer per (device, stream): reuse is stream-ordered, two streams never share one."""
+    key = (dev, _stream())
+    cur = _ws_cache.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
-        _ws_cache[dev] = cur
+        _ws_cache[key] = cur
     return cur
 
 

@@ -343,6 +343,33 @@ def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     assert "modelTeacher.backbone.vgg0.0.weight" in sd and "modelStudent.roi_heads.box_head.fc1.weight" in sd
 
 
+def test_teacher_on_second_stream_gives_the_same_step(sfod, native):
+    """SFOD.OVERLAP_TEACHER only changes WHEN the teacher pass and the student's backbone forward are
+    launched (two streams), never what they compute: first-step losses and the teacher's refreshed BN
+    statistics are bit-identical, and three steps stay finite with the streams interleaved."""
+    recs, bn = [], []
+    for overlap in ("False", "True"):
+        cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "fp32", "SOLVER.IMS_PER_BATCH_TARGET", "2",
+                                   "SFOD.SYNTHETIC.HEIGHT", "256", "SFOD.SYNTHETIC.WIDTH", "512",
+                                   "SFOD.SYNTHETIC.NUM_IMAGES", "4", "INPUT.MIN_SIZE_TRAIN", "(192,)",
+                                   "SOLVER.MAX_ITER", "3", "SOLVER.CHECKPOINT_PERIOD", "0",
+                                   "SFOD.OVERLAP_TEACHER", overlap])
+        torch.manual_seed(cfg.SEED)
+        tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+        tr.iter = 0
+        tr.run_step()
+        torch.cuda.synchronize()
+        recs.append({k: v for k, v in tr.storage.flush().items() if k.startswith("loss")})
+        bn.append(tr.teacher_flat.fbuf.clone())
+        for i in (1, 2):
+            tr.iter = i
+            tr.run_step()
+        torch.cuda.synchronize()
+        assert all(np.isfinite(v) for v in tr.storage.flush().values())
+    assert recs[0] == recs[1], (recs[0], recs[1])
+    assert torch.equal(bn[0], bn[1])
+
+
 def test_config1_source_training_step_matches_oracle(sfod, native):
     """BASELINE config #1 (faster_rcnn_VGG_cityscapes_source_new.yaml, 2 synthetic 512x1024 frames
     -> 600x1200 tensors, 1 SGD step): 4 finite losses, LR = 0.04 * 0.001, and the same numbers as
