@@ -147,6 +147,42 @@ extern "C" int sfod_rpn_gather_topk(const float* props, const float* sorted_scor
 // u64 per row), then a single-workgroup greedy reduce that resolves 64 boxes at a time with
 // ballot / cross-lane reads.
 // ---------------------------------------------------------------------------------------------
+// The IoU test of one row box against the 64 boxes of a column block.  The kernel is VALU-bound (n^2 / 2
+// tests), so the loop is uniform (every lane walks all 64 columns; diagonal / tail bits are masked afterwards)
+// and the division of `inter / union > thr` is replaced by the sign of fma(-thr, union, inter) whenever that
+// is outside a 2^-20 * union guard band; inside the band (about one pair in a million) the whole wave takes
+// the exact division, so the keep set stays bit-identical to torchvision's formula.
+template <bool CLASS_TEST>
+__device__ __forceinline__ uint32_t nms_row_half(Box bi, float sa, int ci, const float* __restrict__ cbx,
+                                                 const int* __restrict__ ccl, float thr) {
+  uint32_t word = 0;
+#pragma unroll
+  for (int j = 0; j < 32; ++j) {
+    const float4 c = *reinterpret_cast<const float4*>(cbx + j * 4);
+    const float w = fmaxf(fminf(bi.x2, c.z) - fmaxf(bi.x1, c.x), 0.f);
+    const float hgt = fmaxf(fminf(bi.y2, c.w) - fmaxf(bi.y1, c.y), 0.f);
+    const float inter = w * hgt;
+    const float sb = (c.z - c.x) * (c.w - c.y);
+    const float uni = (sa + sb) - inter;
+    const float r = __builtin_fmaf(-thr, uni, inter);
+    bool sup = r > 0.f;
+    if (__builtin_amdgcn_ballot_w64(!(fabsf(r) > 9.5367431640625e-07f * fabsf(uni))))   // also NaN / inf
+      sup = (inter / uni) > thr;
+    if (CLASS_TEST) sup = sup & (ccl[j] == ci);
+    word |= sup ? (1u << j) : 0u;
+  }
+  return word;
+}
+
+template <bool CLASS_TEST>
+__device__ __forceinline__ uint64_t nms_row_word(Box bi, int ci, const float* __restrict__ cbx,
+                                                 const int* __restrict__ ccl, float thr) {
+  const float sa = (bi.x2 - bi.x1) * (bi.y2 - bi.y1);
+  const uint32_t lo = nms_row_half<CLASS_TEST>(bi, sa, ci, cbx, ccl, thr);
+  const uint32_t hi = nms_row_half<CLASS_TEST>(bi, sa, ci, cbx + 128, ccl + 32, thr);
+  return ((uint64_t)hi << 32) | lo;
+}
+
 __global__ void __launch_bounds__(64)
 k_nms_mask(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
            const int32_t* __restrict__ classes, const int32_t* __restrict__ mode,
@@ -160,28 +196,30 @@ k_nms_mask(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
   const bool use_alt = (mode != nullptr) && (mode[b] != 0) && (alt_boxes != nullptr);
   const float* src = (use_alt ? alt_boxes : boxes) + (int64_t)b * n * 4;
   const bool class_test = (classes != nullptr) && !use_alt;
-  __shared__ float cbox[64 * 4];
+  __shared__ __attribute__((aligned(16))) float cbox[64 * 4];
   __shared__ int ccls[64];
   const int cj = cb * 64 + lane;
-  if (cj < live) {
-    *reinterpret_cast<float4*>(&cbox[lane * 4]) = *reinterpret_cast<const float4*>(src + (int64_t)cj * 4);
-    ccls[lane] = class_test ? classes[(int64_t)b * n + cj] : 0;
+  {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // columns past the live prefix: empty boxes, masked below
+    int c = 0;
+    if (cj < live) {
+      v = *reinterpret_cast<const float4*>(src + (int64_t)cj * 4);
+      c = class_test ? classes[(int64_t)b * n + cj] : 0;
+    }
+    *reinterpret_cast<float4*>(&cbox[lane * 4]) = v;
+    ccls[lane] = c;
   }
   __syncthreads();
   const int i = rb * 64 + lane;
   if (i >= n) return;
   uint64_t bits = 0;
   if (i < live) {
-    Box bi = load_box(src + (int64_t)i * 4);
+    const Box bi = load_box(src + (int64_t)i * 4);
     const int ci = class_test ? classes[(int64_t)b * n + i] : 0;
+    bits = class_test ? nms_row_word<true>(bi, ci, cbox, ccls, thr) : nms_row_word<false>(bi, ci, cbox, ccls, thr);
     const int jmax = min(64, live - cb * 64);
-    const int jstart = (rb == cb) ? lane + 1 : 0;
-    for (int j = jstart; j < jmax; ++j) {
-      Box bj = Box{cbox[j * 4 + 0], cbox[j * 4 + 1], cbox[j * 4 + 2], cbox[j * 4 + 3]};
-      bool s = nms_suppresses(bi, bj, thr);
-      if (class_test) s = s && (ccls[j] == ci);
-      if (s) bits |= (1ull << j);
-    }
+    if (jmax < 64) bits &= (1ull << jmax) - 1ull;
+    if (rb == cb) bits &= ~((2ull << lane) - 1ull);   // keep j > lane only
   }
   mask[((int64_t)b * n + i) * CB + cb] = bits;
 }

@@ -587,7 +587,7 @@ def nms(boxes, thr, max_keep, valid=None, n_per_image=None, alt_boxes=None, clas
     B, n, _ = boxes.shape
     dev = boxes.device
     nbytes = max(8, query("sfod_nms_mask_bytes", B, n))
-    k = (dev, nbytes)
+    k = (dev, _stream(), nbytes)      # per stream: two streams may run NMS at once
     if k not in _mask_ws:
         _mask_ws[k] = torch.empty(nbytes // 8, dtype=torch.int64, device=dev)
     mask = _mask_ws[k]
