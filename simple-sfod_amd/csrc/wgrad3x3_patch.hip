@@ -162,35 +162,89 @@ k_wgrad3x3_patch(W3Args a) {
     dy_col[i] = (c + 8 <= a.lddy && c < a.Cout) ? c : -1;
   }
 
-  auto tile_origin = [&](int t, int& b, int& y0, int& x0) {
-    const int per = a.tiles_y * a.tiles_x;
-    b = t / per;
-    const int r = t - b * per;
-    const int tyi = r / a.tiles_x;
-    y0 = tyi * a.TH;
-    x0 = (r - tyi * a.tiles_x) * a.TW;
-  };
-  auto issue_patch = [&](int k, int t, int buf) {
-    int b, y0, x0;
-    tile_origin(t, b, y0, x0);
+  // Interior tiles (no image border inside the halo / the tile): every DMA offset is a per-tile scalar base plus a
+  // per-lane constant; lanes that never load (table padding, channel tails) carry 0x80000000, which lands
+  // beyond num_records for any base (< 2^31) -> zeros.  Border tiles take the general path below.
+  unsigned pr_rel[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
     const int py = pr_pack[k] >> 8, px = pr_pack[k] & 255;
-    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-    const bool ok = pr_pack[k] != 0xffff && pr_col[k] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-    const unsigned off = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + pr_col[k]) * 2) : OOB_OFF;
-    bufload16(xres, off, 0u, smem + buf * XBUF + (wave * 6 + k) * 1024);
-  };
-  // dy chunk c of tile t into ring slot
-  auto issue_dy = [&](int t, int c, int slot) {
-    int b, y0, x0;
-    tile_origin(t, b, y0, x0);
+    pr_rel[k] = (pr_pack[k] != 0xffff && pr_col[k] >= 0)
+                    ? (unsigned)((((py - 1) * a.W + (px - 1)) * a.Cin + pr_col[k]) * 2) : OOB_OFF;
+  }
+  unsigned dy_rel[4][ND];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int q = wave * ND + i;
       const int row = (q & 3) * 16 + (lane >> 2);
       const int tt = tabT[c * 64 + row];
-      const int ty = tt >> 8, tx = tt & 255;
-      const bool ok = tt != 0xffff && dy_col[i] >= 0 && y0 + ty < a.H && x0 + tx < a.W;
-      const unsigned off = ok ? (unsigned)((((b * a.H + y0 + ty) * a.W + x0 + tx) * a.lddy + dy_col[i]) * 2) : OOB_OFF;
+      dy_rel[c][i] = (tt != 0xffff && dy_col[i] >= 0)
+                         ? (unsigned)((((tt >> 8) * a.W + (tt & 255)) * a.lddy + dy_col[i]) * 2) : OOB_OFF;
+    }
+
+  // Tile origins (image, y0, x0) of the current and the next tile are carried in scalar registers and advanced
+  // once per tile: decoding them with two runtime integer divisions at every DMA issue (~10 per tile) cost
+  // about as many VALU cycles per stage as the stage's MFMAs.
+  struct Org { int b, y0, x0; unsigned base_x, base_dy; bool in_x, in_dy; };
+  auto finish = [&](Org o) {
+    const int pix = (o.b * a.H + o.y0) * a.W + o.x0;
+    o.base_dy = (unsigned)(pix * a.lddy * 2);
+    o.base_x = (unsigned)(pix * a.Cin * 2);       // offset of the tile's first pixel; the halo starts one row / column before
+    o.in_dy = (o.y0 + a.TH <= a.H) && (o.x0 + a.TW <= a.W);
+    o.in_x = o.in_dy && o.y0 >= 1 && o.x0 >= 1 && (o.y0 + a.TH + 1 <= a.H) && (o.x0 + a.TW + 1 <= a.W);
+    return o;
+  };
+  auto tile_origin = [&](int t) {
+    const int per = a.tiles_y * a.tiles_x;
+    Org o;
+    o.b = t / per;
+    const int r = t - o.b * per;
+    const int tyi = r / a.tiles_x;
+    o.y0 = tyi * a.TH;
+    o.x0 = (r - tyi * a.tiles_x) * a.TW;
+    return finish(o);
+  };
+  auto advance = [&](Org o) {
+    o.x0 += a.TW;
+    if (o.x0 >= a.tiles_x * a.TW) {
+      o.x0 = 0;
+      o.y0 += a.TH;
+      if (o.y0 >= a.tiles_y * a.TH) { o.y0 = 0; ++o.b; }
+    }
+    return finish(o);
+  };
+  auto issue_patch = [&](int k, Org o, int buf) {
+    unsigned off;
+    if (o.in_x) {
+      off = o.base_x + pr_rel[k];
+    } else {
+      const int b = o.b, y0 = o.y0, x0 = o.x0;
+      const int py = pr_pack[k] >> 8, px = pr_pack[k] & 255;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      const bool ok = pr_pack[k] != 0xffff && pr_col[k] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      off = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + pr_col[k]) * 2) : OOB_OFF;
+    }
+    bufload16(xres, off, 0u, smem + buf * XBUF + (wave * 6 + k) * 1024);
+  };
+  // dy chunk c of tile t into ring slot
+  auto issue_dy = [&](Org o, auto cc, int slot) {
+    constexpr int c = decltype(cc)::value;
+    const int b = o.b, y0 = o.y0, x0 = o.x0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i) {
+      const int q = wave * ND + i;
+      unsigned off;
+      if (o.in_dy) {
+        off = o.base_dy + dy_rel[c][i];
+      } else {
+        const int row = (q & 3) * 16 + (lane >> 2);
+        const int tt = tabT[c * 64 + row];
+        const int ty = tt >> 8, tx = tt & 255;
+        const bool ok = tt != 0xffff && dy_col[i] >= 0 && y0 + ty < a.H && x0 + tx < a.W;
+        off = ok ? (unsigned)((((b * a.H + y0 + ty) * a.W + x0 + tx) * a.lddy + dy_col[i]) * 2) : OOB_OFF;
+      }
       bufload16(dres, off, 0u, smem + DY_OFF + slot * DYSLOT + q * 1024);
     }
   };
@@ -245,12 +299,14 @@ k_wgrad3x3_patch(W3Args a) {
 
   if (t_begin < t_end) {
     // ---- prologue: patch of the first tile, dy chunks 0 and 1 ---------------------------------------
+    Org cur = tile_origin(t_begin);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) issue_patch(k, t_begin, 0);
-    issue_dy(t_begin, 0, 0);
-    issue_dy(t_begin, 1, 1);
+    for (int k = 0; k < 6; ++k) issue_patch(k, cur, 0);
+    issue_dy(cur, IC<0>{}, 0);
+    issue_dy(cur, IC<1>{}, 1);
     int gc = 0;  // global chunk counter (ring slot = gc % 3)
-    for (int t = t_begin; t < t_end; ++t) {
+    for (int t = t_begin; t < t_end; ++t, cur = advance(cur)) {
+      const Org nxt = advance(cur);
       const bool last = (t == t_end - 1);
       const int xbuf = (t - t_begin) & 1;
       auto stage = [&](auto cc) {
@@ -261,10 +317,10 @@ k_wgrad3x3_patch(W3Args a) {
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (!last) {
-          if constexpr (c == 0) { issue_patch(0, t + 1, xbuf ^ 1); issue_patch(1, t + 1, xbuf ^ 1); }
-          else if constexpr (c == 1) { issue_patch(2, t + 1, xbuf ^ 1); issue_patch(3, t + 1, xbuf ^ 1); }
-          else if constexpr (c == 2) issue_patch(4, t + 1, xbuf ^ 1);
-          else issue_patch(5, t + 1, xbuf ^ 1);
+          if constexpr (c == 0) { issue_patch(0, nxt, xbuf ^ 1); issue_patch(1, nxt, xbuf ^ 1); }
+          else if constexpr (c == 1) { issue_patch(2, nxt, xbuf ^ 1); issue_patch(3, nxt, xbuf ^ 1); }
+          else if constexpr (c == 2) issue_patch(4, nxt, xbuf ^ 1);
+          else issue_patch(5, nxt, xbuf ^ 1);
         }
         {
           // dy chunk two stages ahead
@@ -273,7 +329,7 @@ k_wgrad3x3_patch(W3Args a) {
           int slot = gc + 2;
           slot -= (slot >= 3) ? 3 : 0;
           slot -= (slot >= 3) ? 3 : 0;
-          if (t2 < t_end) issue_dy(t2, c2, slot);
+          if (t2 < t_end) issue_dy((c >= 2) ? nxt : cur, IC<c2>{}, slot);
         }
         compute_chunk(c, xbuf * XBUF, DY_OFF + gc * DYSLOT);
         gc = (gc == 2) ? 0 : gc + 1;
