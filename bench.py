@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-planted", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--opts", nargs="*", default=[], help="extra KEY VALUE config overrides (A/B runs)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="teacher pass on the main stream (SFOD.OVERLAP_TEACHER False)")
     ap.add_argument("--kernel-table", action="store_true", help="stderr: per-shape table of the MFMA kernels")
@@ -133,7 +134,7 @@ def main():
         opts += ["SFOD.OVERLAP_TEACHER", "False"]
     if args.res == "full":
         opts += ["INPUT.MIN_SIZE_TRAIN", "(1024,)", "INPUT.MAX_SIZE_TRAIN", "2048"]
-    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs", YAML[args.model]), opts)
+    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs", YAML[args.model]), opts + list(args.opts))
     torch.manual_seed(cfg.SEED + rank)
     trainer = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
     if not args.no_planted:
@@ -214,7 +215,11 @@ def main():
                         "(teacher fwd + NMS pseudo-labels + student fwd/bwd + SGD + EMA), synthetic 1024x2048 8-class "
                         f"frames -> {h}x{w} network tensors ({'INPUT.MIN_SIZE_TRAIN=600 of the config' if args.res == 'r600' else 'MIN_SIZE_TRAIN overridden to 1024'})",
             "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-            "ema": bool(cfg.SFOD.EMA.ENABLED), "teacher_on_second_stream": overlapped, "elide_zero_weight_branches": bool(cfg.SFOD.ELIDE_DEAD_BRANCHES),
+            "ema": bool(cfg.SFOD.EMA.ENABLED), "teacher_on_second_stream": overlapped,
+            "input_pipeline": ("uint8 1024x2048 frames resident in HBM; ResizeShortestEdge (Pillow-exact bilinear) + "
+                               "RandomFlip on the device every step, prefetched one batch ahead on a loader stream"
+                               if bool(cfg.SFOD.SYNTHETIC.DEVICE_RESIZE) else
+                               "frames resized once at start-up (Pillow), RandomFlip on the device every step"), "elide_zero_weight_branches": bool(cfg.SFOD.ELIDE_DEAD_BRANCHES),
             "planted_labels": not args.no_planted,
             "algorithmic_tflop_per_image": round(step_flops(args.res, args.model) / 1e12, 3),
         },

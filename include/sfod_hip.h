@@ -43,6 +43,17 @@ int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes, int B, in
  * (d2 build_augmentation; daod/data/mappers/two_crop_augmentation_mapper.py:73-157), on device */
 int sfod_hflip_u8(const void* src, void* dst, int C, int H, int W, void* stream);
 
+/* ResizeShortestEdge on a uint8 [C,H,W] frame -> [C,h,w], bit-exact with Pillow's Image.resize(..., BILINEAR)
+ * (what d2's ResizeTransform calls for uint8 images; detection_utils / two_crop_augmentation_mapper.py:73-157):
+ * separable support-scaled triangle filter, 22-bit fixed-point coefficients, uint8 clip between the passes.
+ * hbounds/vbounds: int32 [out][2] = (first source index, tap count); hcoef/vcoef: int32 [out][ksize] fixed-point
+ * weights -- built on the host like Pillow's precompute_coeffs + normalize_coeffs_8bpc.  flip != 0 also mirrors
+ * the result horizontally (RandomFlip follows the resize). */
+int sfod_resize_bilinear_u8(const void* src, void* dst, int C, int H, int W, int h, int w,
+                            const int32_t* hbounds, const int32_t* hcoef, int ksize_h,
+                            const int32_t* vbounds, const int32_t* vcoef, int ksize_v, int flip,
+                            void* stream);
+
 /* ---- K2/K5/K14/K18: implicit-GEMM convolution / linear layer on MFMA.
  * y[m, n] = act( sum_{tap, c} x[pix(m) + tap][c] * w[n][tap][c] + bias[n] ),  m = (b, oy, ox)
  * x: [B,H,W,Cin] NHWC, w: packed [Cout][KH*KW][Cin] (K contiguous), y: [B,H,W,ldy] with ldy >=

@@ -114,6 +114,58 @@ extern "C" int sfod_hflip_u8(const void* src, void* dst, int C, int H, int W, vo
 }
 
 // ---------------------------------------------------------------------------------------------
+// ResizeShortestEdge on uint8 frames, bit-exact with Pillow's ImagingResample (BILINEAR, 8 bits per
+// channel): two separable passes with a support-scaled triangle filter, fixed-point coefficients
+// (22 fractional bits) and a uint8 clip BETWEEN the passes.  Fused here: every output pixel recomputes
+// the <= KS horizontally filtered values of its KS source rows (each rounded and clipped exactly like
+// Pillow's temporary image), then filters them vertically.  The coefficient tables are built on the host
+// (float64, same operation order as Pillow's precompute_coeffs / normalize_coeffs_8bpc).  flip != 0
+// additionally mirrors the output (RandomFlip comes after the resize in the mapper's augmentation list).
+// ---------------------------------------------------------------------------------------------
+#define RS_PREC 22
+__device__ __forceinline__ int rs_clip8(int v) {
+  v >>= RS_PREC;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+
+__global__ void __launch_bounds__(256)
+k_resize_bilinear_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int C, int H, int W,
+                     int h, int w, const int32_t* __restrict__ hb, const int32_t* __restrict__ hk, int ksh,
+                     const int32_t* __restrict__ vb, const int32_t* __restrict__ vk, int ksv, int flip) {
+  const int64_t total = (int64_t)C * h * w;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int x = (int)(t % w);
+    const int y = (int)((t / w) % h);
+    const int c = (int)(t / ((int64_t)w * h));
+    const int xmin = hb[2 * x], xn = hb[2 * x + 1];
+    const int ymin = vb[2 * y], yn = vb[2 * y + 1];
+    const uint8_t* plane = src + (int64_t)c * H * W;
+    int acc = 1 << (RS_PREC - 1);
+    for (int j = 0; j < yn; ++j) {
+      const uint8_t* row = plane + (int64_t)(ymin + j) * W + xmin;
+      int sh = 1 << (RS_PREC - 1);
+      for (int i = 0; i < xn; ++i) sh += (int)row[i] * hk[x * ksh + i];
+      acc += rs_clip8(sh) * vk[y * ksv + j];
+    }
+    const int xo = flip ? (w - 1 - x) : x;
+    dst[((int64_t)c * h + y) * w + xo] = (uint8_t)rs_clip8(acc);
+  }
+}
+
+extern "C" int sfod_resize_bilinear_u8(const void* src, void* dst, int C, int H, int W, int h, int w,
+                                       const int32_t* hbounds, const int32_t* hcoef, int ksize_h,
+                                       const int32_t* vbounds, const int32_t* vcoef, int ksize_v, int flip,
+                                       void* stream) {
+  if ((int64_t)C * h * w == 0) return 0;
+  SFOD_REQUIRE(ksize_h >= 1 && ksize_v >= 1 && H >= 1 && W >= 1, "resize: bad sizes");
+  hipLaunchKernelGGL(k_resize_bilinear_u8, dim3(ew_grid((int64_t)C * h * w)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint8_t*)src, (uint8_t*)dst, C, H, W, h, w, hbounds, hcoef, ksize_h, vbounds, vcoef,
+                     ksize_v, flip);
+  return sfod_check_launch("resize_bilinear_u8");
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3 BatchNorm statistics finalize.  stats[blk][0][c] = sum over the block's rows, stats[blk][1][c]
 // = sum of squared deviations from the block mean, counts[blk] (behind the sums) = rows of the block
 // (all written by the conv epilogue).  Combined in

@@ -9,9 +9,11 @@ synthetic 8-class Cityscapes-shape frames (there is no dataset / network in the 
 environment); real COCO-json loading and the strong augmentation are "next" rows
 (SURVEY.md section 8f).
 
-Frames are generated once, resized by the mapper's rule (shortest edge 600, max
-1333, PIL bilinear on uint8) and kept resident on the device; the per-iteration work is the
-random horizontal flip.
+Frames are generated once and kept resident on the device at their native size (1024x2048 by
+default); every iteration the mapper's ResizeShortestEdge (shortest edge 600, max 1333,
+Pillow bilinear on uint8) and RandomFlip run on the device in one launch per frame
+(``native.resize_bilinear_u8``, bit-exact with Pillow; SFOD.SYNTHETIC.DEVICE_RESIZE).  On a CPU device
+(host-logic tests) or with DEVICE_RESIZE off the frames are resized once with Pillow at start-up.
 """
 import numpy as np
 import torch
@@ -75,11 +77,15 @@ class SyntheticTargetDataset:
         short = cfg.INPUT.MIN_SIZE_TRAIN[0] if train else cfg.INPUT.MIN_SIZE_TEST
         max_size = cfg.INPUT.MAX_SIZE_TRAIN if train else cfg.INPUT.MAX_SIZE_TEST
         newh, neww = resize_shortest_edge_shape(s.HEIGHT, s.WIDTH, short, max_size)
+        resize = (newh, neww) != (s.HEIGHT, s.WIDTH)
+        # resize per iteration on the device (the mapper's job), or once here with Pillow
+        self.device_resize = bool(resize and s.DEVICE_RESIZE and torch.device(device).type == "cuda")
         self.items = []
         for i in range(n):
             img, boxes, classes = make_frame(i, s.HEIGHT, s.WIDTH, s.BOXES_PER_IMAGE, seed=max(cfg.SEED, 0))
-            if (newh, neww) != (s.HEIGHT, s.WIDTH):
-                img = _resize_u8(img, newh, neww)
+            if resize:
+                if not self.device_resize:
+                    img = _resize_u8(img, newh, neww)
                 boxes = boxes * torch.tensor([neww / s.WIDTH, newh / s.HEIGHT] * 2)
             self.items.append({"image": img.to(device), "boxes": boxes.to(device), "classes": classes.to(device),
                                "height": s.HEIGHT, "width": s.WIDTH, "image_id": i,
@@ -127,8 +133,13 @@ class TwoCropLoader:
 
     def _map(self, item):
         img, boxes = item["image"], item["boxes"]
-        if self.flip and torch.rand(1, generator=self.gen).item() < 0.5:
+        do_flip = bool(self.flip and torch.rand(1, generator=self.gen).item() < 0.5)
+        if getattr(self.dataset, "device_resize", False):
+            newh, neww = self.dataset.size
+            img = native.resize_bilinear_u8(img, newh, neww, flip=do_flip)     # resize (+ flip) in one launch
+        elif do_flip:
             img = native.hflip_u8(img) if img.is_cuda else torch.flip(img, dims=[2])
+        if do_flip:
             w = img.shape[2]
             boxes = torch.stack([w - boxes[:, 2], boxes[:, 1], w - boxes[:, 0], boxes[:, 3]], dim=1)
         inst = Instances((int(img.shape[1]), int(img.shape[2])))
@@ -140,9 +151,37 @@ class TwoCropLoader:
     def __iter__(self):
         return self
 
-    def __next__(self):
+    def _produce(self):
         weak = [self._map(self.dataset.items[next(self.sampler)]) for _ in range(self.batch)]
         if self.labeled:
             return weak
         strong = [dict(d) for d in weak]
         return strong, weak
+
+    def __next__(self):
+        """One batch.  On a GPU the mapper's device work (resize + flip launches) for batch t+1 is enqueued on
+        a separate low-priority stream while step t runs -- what the reference's loader worker processes do
+        on the host -- and the consumer's stream waits for its event."""
+        if not getattr(self.dataset, "device_resize", False):
+            return self._produce()
+        main = torch.cuda.current_stream()
+        st = self.__dict__.get("_stream")
+        if st is None:
+            st = self._stream = torch.cuda.Stream(priority=0)
+            self._ahead = None
+        if self._ahead is None:
+            self._ahead = self._enqueue(st)
+        batch, ev = self._ahead
+        main.wait_event(ev)
+        for lst in (batch if isinstance(batch, tuple) else (batch,)):
+            for d in lst:
+                d["image"].record_stream(main)     # allocated on the loader stream, consumed elsewhere
+        self._ahead = self._enqueue(st)            # next batch: overlaps the step that consumes this one
+        return batch
+
+    def _enqueue(self, st):
+        with torch.cuda.stream(st):
+            batch = self._produce()
+            ev = torch.cuda.Event()
+            ev.record(st)
+        return batch, ev

@@ -254,6 +254,66 @@ def preprocess(images_u8, Hp, Wp, cpad, mean, std, dt):
     return out, sizes
 
 
+def pil_bilinear_coeffs(in_size, out_size):
+    """Pillow's precompute_coeffs (BILINEAR, box = the whole axis) + normalize_coeffs_8bpc, same float64
+    operation order: -> (bounds int32 [out,2] = (first index, count), coeffs int32 [out,ksize], ksize)."""
+    import math
+    import numpy as np
+    scale = float(in_size) / float(out_size)
+    filterscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)          # C double -> int: truncation (operand is > -1 here)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [0.0] * ksize
+        ww = 0.0
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w = 1.0 - a if a < 1.0 else 0.0
+            k[x] = w
+            ww += w
+        for x in range(xmax):
+            if ww != 0.0:
+                k[x] /= ww
+        bounds[xx] = (xmin, xmax)
+        for x in range(ksize):
+            v = k[x] * (1 << 22)
+            kk[xx, x] = int(v - 0.5) if k[x] < 0 else int(v + 0.5)
+    return bounds, kk, ksize
+
+
+_resize_tabs = {}
+
+
+def resize_bilinear_u8(img, newh, neww, flip=False):
+    """uint8 [C,H,W] device frame -> [C,newh,neww], bit-exact with PIL ``Image.resize((neww, newh), BILINEAR)``
+    (optionally followed by a horizontal flip), in one launch."""
+    assert img.dtype == torch.uint8 and img.dim() == 3
+    img = img.contiguous()
+    C, H, W = img.shape
+    key = (img.device, H, W, newh, neww)
+    tabs = _resize_tabs.get(key)
+    if tabs is None:
+        hb, hk, ksh = pil_bilinear_coeffs(W, neww)
+        vb, vk, ksv = pil_bilinear_coeffs(H, newh)
+        tabs = tuple(torch.from_numpy(a).to(img.device) for a in (hb, hk, vb, vk)) + (ksh, ksv)
+        _resize_tabs[key] = tabs
+    hb, hk, vb, vk, ksh, ksv = tabs
+    out = torch.empty(C, newh, neww, dtype=torch.uint8, device=img.device)
+    call("sfod_resize_bilinear_u8", img, out, C, H, W, newh, neww, hb, hk, ksh, vb, vk, ksv, int(flip))
+    return out
+
+
 def hflip_u8(img):
     """uint8 [C,H,W] device image -> horizontally flipped copy."""
     assert img.dtype == torch.uint8 and img.dim() == 3

@@ -777,3 +777,22 @@ def test_sgd_ema_fused(native):
     torch.testing.assert_close(pd.cpu(), sd["w"], rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(md.cpu(), bufs["w"], rtol=1e-6, atol=1e-7)
     torch.testing.assert_close(td.cpu(), tref["w"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(64, 128, 38, 75), (100, 50, 37, 19), (33, 77, 66, 154), (512, 1024, 300, 600)])
+@pytest.mark.parametrize("flip", [False, True])
+def test_resize_bilinear_u8_equals_pillow(native, shape, flip):
+    """sfod_resize_bilinear_u8 (the mapper's ResizeShortestEdge [+ RandomFlip] on device) is bit-exact with
+    Pillow's Image.resize(BILINEAR) -- and with oracle/resize.py, its restatement."""
+    from PIL import Image
+    from oracle.resize import resize_bilinear_u8
+    H, W, h, w = shape
+    g = torch.Generator().manual_seed(H + W)
+    img = torch.randint(0, 256, (3, H, W), generator=g, dtype=torch.uint8)
+    ref = np.asarray(Image.fromarray(img.permute(1, 2, 0).numpy()).resize((w, h), Image.BILINEAR)).transpose(2, 0, 1)
+    if H * W <= 64 * 128:
+        assert np.array_equal(resize_bilinear_u8(img.numpy(), h, w), ref)
+    if flip:
+        ref = ref[:, :, ::-1]
+    got = native.resize_bilinear_u8(img.to(DEV), h, w, flip=flip).cpu().numpy()
+    assert np.array_equal(got, ref)

@@ -200,3 +200,27 @@ def test_sgd_zero_grad_still_decays():
     bufs = {}
     om.sgd_step(sd, {"w": torch.zeros(1)}, bufs, lr=0.1, weight_decay=1e-4)
     np.testing.assert_allclose(sd["w"].item(), 0.99999, rtol=1e-7)
+
+
+@pytest.mark.parametrize("shape", [(64, 128, 38, 75), (100, 50, 37, 19), (33, 77, 66, 154), (97, 203, 97, 60)])
+def test_resize_restatement_equals_pillow(shape):
+    """oracle/resize.py against Pillow itself (the library d2's ResizeTransform calls for uint8 frames):
+    bit equality for down-scaling, up-scaling, odd sizes and one unchanged axis."""
+    from PIL import Image
+    from oracle.resize import resize_bilinear_u8
+    H, W, h, w = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    img = rng.integers(0, 256, (3, H, W), dtype=np.uint8)
+    ref = np.asarray(Image.fromarray(img.transpose(1, 2, 0)).resize((w, h), Image.BILINEAR)).transpose(2, 0, 1)
+    assert np.array_equal(resize_bilinear_u8(img, h, w), ref)
+
+
+def test_host_coefficient_tables_equal_the_oracle():
+    """native.pil_bilinear_coeffs (what the HIP kernel consumes) == oracle/resize.precompute_coeffs."""
+    import importlib
+    native = importlib.import_module("simple-sfod_amd.native")
+    from oracle.resize import precompute_coeffs
+    for n_in, n_out in [(1024, 600), (2048, 1200), (75, 38), (50, 133)]:
+        b0, k0 = precompute_coeffs(n_in, n_out)
+        b1, k1, ks = native.pil_bilinear_coeffs(n_in, n_out)
+        assert ks == k0.shape[1] and np.array_equal(b0, b1) and np.array_equal(k0, k1)
