@@ -732,6 +732,34 @@ extern "C" int sfod_add_inplace(void* a, const void* b, int64_t n, int dt, void*
   return sfod_check_launch("add_inplace");
 }
 
+// a *= mask * scale  (dropout forward / backward: mask is a 0/1 byte per element, scale = 1 / (1 - p))
+template <typename T>
+__global__ void k_mul_mask(T* __restrict__ a, const uint8_t* __restrict__ m, int64_t nvec, float scale) {
+  constexpr int V = VecT<T>::N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float x[V];
+    load_vec<T>(a + t * V, x);
+#pragma unroll
+    for (int i = 0; i < V; ++i) x[i] = m[t * V + i] ? x[i] * scale : 0.f;
+    store_vec<T>(a + t * V, x);
+  }
+}
+
+extern "C" int sfod_mul_mask(void* a, const uint8_t* mask, int64_t n, float scale, int dt, void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(n % V == 0, "mul_mask: n not a multiple of the vector width");
+  const int64_t nvec = n / V;
+  if (nvec == 0) return 0;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_mul_mask<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (float*)a, mask,
+                       nvec, scale);
+  else
+    hipLaunchKernelGGL(k_mul_mask<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a, mask,
+                       nvec, scale);
+  return sfod_check_launch("mul_mask");
+}
+
 // ---------------------------------------------------------------------------------------------
 // ResNet-C4 helpers (d2 build_resnet_backbone: BasicStem + BottleneckBlock)
 // ---------------------------------------------------------------------------------------------

@@ -8,7 +8,9 @@ weighted by zero (``DOMAIN_CLASSIFIER.IMAGE/INSTANCE: False``); with SFOD.ELIDE_
 domain branch is not executed.  Forward passes run on the HIP conv / GEMM kernels; the image-level
 discriminator also has a hand-written backward (``dc_img_loss``: BCE-with-logits against a constant
 domain label, ``source_free_adaptive_teacher_rcnn.py:145-155``), so ``DOMAIN_CLASSIFIER.IMAGE: True``
-trains.  The instance-level head is forward-only (its loss is reported, not differentiated).
+trains; the instance-level head has one too (``dc_ins_loss``: ROIAlign -> box head -> GRL -> DAInsHead with
+dropout -> BCE, ``source_free_adaptive_teacher_rcnn.py:157-201,341-349``), gradients reach the box head and,
+through ROIAlign, the backbone.
 """
 import torch
 import torch.nn as nn
@@ -145,3 +147,92 @@ class DAInsHead(nn.Module):
         h = native.conv_fwd(h, native.pack_fc_weight(fc2.weight, dt), fc2.bias, 1024, 1, act=1)
         y = native.conv_fwd(h, native.pack_fc_weight(fc3.weight, dt), fc3.bias, 1, 1, out_dtype=torch.float32, ldy=8)
         return y[:, :1]
+
+
+class _DCInsLossFn(torch.autograd.Function):
+    """feature map (+ sampled rois) -> mean BCE-with-logits of the instance-level discriminator on the box
+    head's features behind a gradient-reversal layer (``instance_dc_loss``, rcnn.py:341-349).  The mean runs
+    over the live rois (padding rows of the fixed-capacity roi array carry batch index -1).  ``masks``: the two
+    dropout masks (uint8, [R,1024]) or None in eval mode."""
+
+    @staticmethod
+    def forward(ctx, heads, head, feat_nchw, rois, label, masks, *params):
+        dtype = heads.compute_dtype
+        dt = native.F32 if dtype == torch.float32 else native.BF16
+        st = heads._box_forward(feat_nchw, rois)
+        fc1 = getattr(head, head.da_ins_fc1_layers[0])
+        fc2 = getattr(head, head.da_ins_fc2_layers[0])
+        fc3 = getattr(head, head.da_ins_fc3_layers[0])
+        r1 = native.conv_fwd(st["h2"], native.pack_fc_weight(fc1.weight.detach(), dt), fc1.bias.detach(), 1024, 1, act=1)
+        z1 = r1
+        if masks is not None:
+            z1 = native.mul_mask_(r1.clone(), masks[0], 2.0)
+        r2 = native.conv_fwd(z1, native.pack_fc_weight(fc2.weight.detach(), dt), fc2.bias.detach(), 1024, 1, act=1)
+        z2 = r2
+        if masks is not None:
+            z2 = native.mul_mask_(r2.clone(), masks[1], 2.0)
+        y = native.conv_fwd(z2, native.pack_fc_weight(fc3.weight.detach(), dt), fc3.bias.detach(), 1, 1,
+                            out_dtype=torch.float32, ldy=8)
+        z = y[:, 0]
+        live = (rois[:, 0] >= 0).float()
+        n_live = live.sum().clamp(min=1)
+        # scalar glue on R logits: F.binary_cross_entropy_with_logits(z, label) over the live rows
+        bce = torch.clamp(z, min=0) - z * label + torch.log1p(torch.exp(-z.abs()))
+        loss = (bce * live).sum() / n_live
+        ctx.heads, ctx.head, ctx.st, ctx.rois, ctx.masks = heads, head, st, rois, masks
+        ctx.acts = (r1, z1, r2, z2, z, live, n_live)
+        ctx.label = float(label)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        heads, head, st, rois, masks = ctx.heads, ctx.head, ctx.st, ctx.rois, ctx.masks
+        r1, z1, r2, z2, z, live, n_live = ctx.acts
+        dtype = heads.compute_dtype
+        dt = native.F32 if dtype == torch.float32 else native.BF16
+        E = native.chunk_elems(dt)
+        fc1 = getattr(head, head.da_ins_fc1_layers[0])
+        fc2 = getattr(head, head.da_ins_fc2_layers[0])
+        fc3 = getattr(head, head.da_ins_fc3_layers[0])
+        R = z.shape[0]
+        dz = torch.zeros(R, E, dtype=dtype, device=z.device)            # 1 logit padded to a chunk
+        dz[:, 0] = ((torch.sigmoid(z) - ctx.label) * live * (g / n_live)).to(dtype)
+        # fc3
+        dw3 = native.conv_wgrad(z2, dz, 1, 1).view(1, -1)
+        db3 = native.bias_grad(dz, 1)
+        d2 = native.conv_fwd(dz, native.pack_fc_weight(fc3.weight.detach(), dt, transpose=True, ld=E), None, 1024, 1)
+        if masks is not None:
+            native.mul_mask_(d2, masks[1], 2.0)
+        native.act_bwd_(d2, r2, 1)
+        # fc2
+        dw2 = native.conv_wgrad(z1, d2, 1024, 1).view(1024, -1)
+        db2 = native.bias_grad(d2, 1024)
+        d1 = native.conv_fwd(d2, native.pack_fc_weight(fc2.weight.detach(), dt, transpose=True), None, 1024, 1)
+        if masks is not None:
+            native.mul_mask_(d1, masks[0], 2.0)
+        native.act_bwd_(d1, r1, 1)
+        # fc1
+        dw1 = native.conv_wgrad(st["h2"], d1, 1024, 1).view(1024, -1)
+        db1 = native.bias_grad(d1, 1024)
+        dh2 = native.conv_fwd(d1, native.pack_fc_weight(fc1.weight.detach(), dt, transpose=True), None,
+                              fc1.in_features, 1)
+        # gradient reversal (gradient_scalar(box_features, -1.0)), then the box head and ROIAlign
+        dh2 = dh2 * -1.0
+        dfeat, (bw1, bb1, bw2, bb2) = heads._box_head_backward(st, rois, dh2)
+        ctx.st = ctx.acts = None
+        return (None, None, dfeat, None, None, None, bw1, bb1, bw2, bb2, dw1, db1, dw2, db2, dw3, db3)
+
+
+def dc_ins_loss(roi_heads, head, feat_nchw, rois, domain_label, training=True):
+    """loss_DC_ins_{s,t}: box_features = box_head(ROIAlign(features, sampled proposals)) -> GRL(-1) -> DAInsHead
+    (dropout p = 0.5 in training mode, masks drawn with torch's generator) -> BCE-with-logits (mean)."""
+    assert len(head.da_ins_fc1_layers) == 1
+    bh = roi_heads.box_head
+    fc = [getattr(head, n[0]) for n in (head.da_ins_fc1_layers, head.da_ins_fc2_layers, head.da_ins_fc3_layers)]
+    masks = None
+    if training:
+        R = rois.shape[0]
+        masks = [(torch.rand(R, 1024, device=rois.device) >= 0.5).to(torch.uint8) for _ in range(2)]
+    params = [bh.fc1.weight, bh.fc1.bias, bh.fc2.weight, bh.fc2.bias,
+              fc[0].weight, fc[0].bias, fc[1].weight, fc[1].bias, fc[2].weight, fc[2].bias]
+    return _DCInsLossFn.apply(roi_heads, head, feat_nchw, rois, float(domain_label), masks, *params)

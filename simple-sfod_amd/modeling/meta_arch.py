@@ -20,7 +20,7 @@ from .. import native
 from ..registry import BACKBONE_REGISTRY, META_ARCH_REGISTRY, PROPOSAL_GENERATOR_REGISTRY, ROI_HEADS_REGISTRY
 from ..structures import Boxes, ImageList, Instances
 from .batched import BatchedGT, gather_gt
-from .dann import DAInsHead, FCDiscriminator_img, dc_img_loss
+from .dann import DAInsHead, FCDiscriminator_img, dc_img_loss, dc_ins_loss
 
 
 def build_model(cfg):
@@ -181,7 +181,7 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
     def _forward_domain_classifier(self, batched_inputs):
         """rcnn.py:137-210.  ``image`` is the source-side sample (label 0), ``image_unlabeled`` the target
         (label 1); both pass the backbone with gradients, the discriminator sees them through the
-        gradient-reversal layer.  Instance-level losses (INS_DC) are reported forward-only (dropout off)."""
+        gradient-reversal layer, and so do the box head's features for the instance-level losses (INS_DC)."""
         losses = {}
         feats = {}
         for key, label, tag in (("image", 0, "s"), ("image_unlabeled", 1, "t")):
@@ -190,22 +190,18 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
             feats[tag] = (images, features)
             losses["loss_DC_img_" + tag] = dc_img_loss(self.DC_img, features[self.dis_type], label)
         if self.ins_dc:
-            if self.cfg.DOMAIN_CLASSIFIER.INSTANCE:
-                raise NotImplementedError("DOMAIN_CLASSIFIER.INSTANCE=True: the instance-level discriminator has no "
-                                          "backward yet (its loss is zero-weighted in the named configs)")
+            # rcnn.py:157-201: RPN proposals (no loss) -> label & sample against the (pseudo-)GT when there is
+            # one -> box features with gradients -> instance-level discriminator behind the GRL
             rh = self.roi_heads
-            with torch.no_grad():
-                for tag, label, gkey in (("s", 0, "instances"), ("t", 1, "instances_unlabeled")):
-                    images, features = feats[tag]
+            for tag, label, gkey in (("s", 0, "instances"), ("t", 1, "instances_unlabeled")):
+                images, features = feats[tag]
+                with torch.no_grad():
                     gt = gather_gt(batched_inputs, self.device, key=gkey)
                     props, _ = self.proposal_generator(images, features, None, compute_loss=False, as_instances=False)
-                    feat = features[rh.in_features[0]]
                     if gt is not None:
                         rois = rh.label_and_sample_proposals(props, gt, branch="domain_classifier")["rois"]
                     else:
                         rois = native.make_rois(props.boxes, props.count)
-                    z = self.DC_ins(rh._box_forward(feat, rois)["h2"])[:, 0]
-                    live = (rois[:, 0] >= 0).float()
-                    bce = torch.clamp(z, min=0) - z * float(label) + torch.log1p(torch.exp(-z.abs()))
-                    losses["loss_DC_ins_" + tag] = (bce * live).sum() / live.sum().clamp(min=1)
+                losses["loss_DC_ins_" + tag] = dc_ins_loss(rh, self.DC_ins, features[rh.in_features[0]], rois, label,
+                                                           training=self.training)
         return losses, [], []

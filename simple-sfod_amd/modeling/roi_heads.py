@@ -169,8 +169,8 @@ class StandardROIHeads(nn.Module):
     def _box_backward(self, st, rois, d_pred, feat_shape_nchw):
         dtype = self.compute_dtype
         dt = native.F32 if dtype == torch.float32 else native.BF16
-        bh, bp = self.box_head, self.box_predictor
-        K, C = self.num_classes, self.channels
+        bh = self.box_head
+        K = self.num_classes
         NP = 5 * K + 1
         d_pred_c = native.cast(d_pred, dtype)
         # predictor
@@ -178,6 +178,18 @@ class StandardROIHeads(nn.Module):
         dbp = native.bias_grad(d_pred, NP)
         wpt = native.pack_fc_weight(st["wp"], dt, transpose=True, ld=self.pred_ld)
         dh2 = native.conv_fwd(d_pred_c, wpt, None, bh.fc2.out_features, 1)
+        dfeat, (dw1, db1, dw2, db2) = self._box_head_backward(st, rois, dh2)
+        pgrads = [dw1, db1, dw2, db2, dwp[: K + 1].contiguous(), dbp[: K + 1].contiguous(),
+                  dwp[K + 1:].contiguous(), dbp[K + 1:].contiguous()]
+        return dfeat, pgrads
+
+    def _box_head_backward(self, st, rois, dh2):
+        """grad wrt the box-head output (``box_features`` = relu(fc2), consumed in place) -> (grad wrt the feature
+        map as an NCHW view, [dw1, db1, dw2, db2]); dw1 is None when it went straight into the flat gradient."""
+        dtype = self.compute_dtype
+        dt = native.F32 if dtype == torch.float32 else native.BF16
+        bh = self.box_head
+        C = self.channels
         native.act_bwd_(dh2, st["h2"], 1)
         # fc2
         dw2 = native.conv_wgrad(st["h1"], dh2, bh.fc2.out_features, 1).view(bh.fc2.out_features, -1)
@@ -200,9 +212,7 @@ class StandardROIHeads(nn.Module):
         B, H, W, _ = st["feat_shape"]
         dfeat = native.roi_align_bwd(dx0.view(-1, self.pooled * self.pooled, C), rois, (B, H, W, C), self.pooled,
                                      self.box_pooler.scale)
-        pgrads = [dw1, db1, dw2, db2, dwp[: K + 1].contiguous(), dbp[: K + 1].contiguous(),
-                  dwp[K + 1:].contiguous(), dbp[K + 1:].contiguous()]
-        return dfeat.permute(0, 3, 1, 2), pgrads
+        return dfeat.permute(0, 3, 1, 2), [dw1, db1, dw2, db2]
 
     # ---- label_and_sample_proposals (roi_heads.py:165-215) ----------------------------------------
     @torch.no_grad()

@@ -559,6 +559,11 @@ def add_(a, b):
     return a
 
 
+def mul_mask_(a, mask_u8, scale):
+    call("sfod_mul_mask", a, mask_u8, a.numel(), float(scale), dt_of(a))
+    return a
+
+
 def add_act(a, b, act=1):
     out = torch.empty_like(a)
     call("sfod_add_act", a, b, out, a.numel(), int(act), dt_of(a))

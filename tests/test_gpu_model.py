@@ -149,6 +149,61 @@ def test_dc_img_loss_backward_matches_reference_golden(sfod, native):
         assert rel_err(p.grad, torch.from_numpy(fx["g/" + k])) < 1e-4, k
 
 
+def test_dc_ins_loss_backward_matches_a_torch_restatement(sfod, native):
+    """Instance-level discriminator (rcnn.py:157-201,341-349; dann.py:97-155): ROIAlign -> box head -> GRL(-1) ->
+    DAInsHead -> BCE-with-logits(mean), eval mode (no dropout), fp32, against the same chain written with torch
+    ops on the CPU (oracle ROIAlign): loss, feature-map gradient, box-head and discriminator gradients; a
+    padding roi (batch index -1) must not contribute.  Train mode: the dropout masks are applied in both
+    directions (loss changes, gradients stay finite and zero where both masks dropped)."""
+    from oracle.roi_align import roi_align
+    cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "fp32"])
+    torch.manual_seed(3)
+    model = sfod.modeling.build_model(cfg)
+    rh, head = model.roi_heads, model.DC_ins
+    with torch.no_grad():     # default init (std 0.01 / zero bias) gives a nearly input-independent logit
+        for p_ in head.parameters():
+            p_.normal_(0, 0.05)
+    g = torch.Generator().manual_seed(11)
+    B, C, Hf, Wf = 2, 512, 6, 9
+    feat = torch.randn(B, C, Hf, Wf, generator=g)
+    rois = torch.tensor([[0, 10.0, 20.0, 150.0, 120.0], [1, 0.0, 0.0, 287.0, 191.0], [0, 100.0, 40.0, 130.0, 90.0],
+                         [-1, 0.0, 0.0, 0.0, 0.0], [1, 33.0, 7.0, 250.0, 66.0]])
+    fd = feat.to(DEV).requires_grad_(True)
+    model.eval()
+    loss = sfod.modeling.dann.dc_ins_loss(rh, head, fd, rois.to(DEV), 1, training=False)
+    loss.backward()
+    # torch restatement on the CPU
+    fc = feat.clone().requires_grad_(True)
+    live = rois[:, 0] >= 0
+    pooled = roi_align(fc, rois[live], 7, rh.box_pooler.scale, 0, True)
+    bh = rh.box_head
+    cpu = lambda t: t.detach().cpu().clone().requires_grad_(True)
+    w = {n: cpu(p_) for n, p_ in list(bh.named_parameters()) + [("da." + n, p_) for n, p_ in head.named_parameters()]}
+    h = torch.relu(pooled.flatten(1) @ w["fc1.weight"].t() + w["fc1.bias"])
+    h = torch.relu(h @ w["fc2.weight"].t() + w["fc2.bias"])
+    h = sfod.modeling.dann.gradient_scalar(h, -1.0)
+    lv = "da.da_ins_fc{}_level_" + model.dis_type
+    for k in (1, 2):
+        h = torch.relu(h @ w[lv.format(k) + ".weight"].t() + w[lv.format(k) + ".bias"])
+    z = h @ w[lv.format(3) + ".weight"].t() + w[lv.format(3) + ".bias"]
+    ref = torch.nn.functional.binary_cross_entropy_with_logits(z, torch.ones_like(z))
+    ref.backward()
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    assert rel_err(fd.grad.cpu(), fc.grad) < 2e-4
+    for n, p_ in list(bh.named_parameters()) + [("da." + n, p_) for n, p_ in head.named_parameters()]:
+        assert rel_err(p_.grad.cpu(), w[n].grad) < 2e-4, n
+    # train mode: dropout on
+    model.train()
+    for p_ in model.parameters():
+        p_.grad = None
+    fd2 = feat.to(DEV).requires_grad_(True)
+    torch.manual_seed(5)
+    l2 = sfod.modeling.dann.dc_ins_loss(rh, head, fd2, rois.to(DEV), 1, training=True)
+    l2.backward()
+    assert np.isfinite(l2.item()) and abs(l2.item() - loss.item()) > 1e-7
+    assert torch.isfinite(fd2.grad).all() and fd2.grad.abs().sum() > 0
+
+
 def test_domain_classifier_branch_trains_with_image_level_loss(sfod, native):
     """rcnn.py:137-210 through the trainer with DOMAIN_CLASSIFIER.IMAGE on: both domain losses are
     ln 2-ish at initialisation, DC_img and (through the reversed gradient) the backbone receive gradients."""
@@ -167,6 +222,25 @@ def test_domain_classifier_branch_trains_with_image_level_loss(sfod, native):
     assert 0.0 < rec["loss_DC_img_s"] < 0.2 and 0.0 < rec["loss_DC_img_t"] < 0.2     # 0.1 * ~ln 2
     assert rec["loss_DC_ins_s"] == 0.0                                                 # zero-weighted
     assert not torch.equal(w0, tr.model.DC_img.conv1.weight.detach())
+
+
+def test_domain_classifier_branch_trains_with_instance_level_loss(sfod, native):
+    """DOMAIN_CLASSIFIER.INSTANCE on: loss_DC_ins_{s,t} are weighted in, the instance discriminator's
+    parameters move (they receive gradients only from this branch)."""
+    cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "fp32", "SOLVER.IMS_PER_BATCH_TARGET", "2",
+                               "SFOD.SYNTHETIC.HEIGHT", "256", "SFOD.SYNTHETIC.WIDTH", "512",
+                               "SFOD.SYNTHETIC.NUM_IMAGES", "4", "INPUT.MIN_SIZE_TRAIN", "(192,)",
+                               "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0",
+                               "DOMAIN_CLASSIFIER.INSTANCE", "True", "SEMISUPNET.DIS_LOSS_WEIGHT", "0.1"])
+    torch.manual_seed(cfg.SEED)
+    tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+    name = "da_ins_fc3_level_" + tr.model.dis_type
+    w0 = getattr(tr.model.DC_ins, name).weight.detach().clone()
+    tr.train()
+    rec = tr.storage.history[-1]
+    for k in ("loss_DC_ins_s", "loss_DC_ins_t"):
+        assert np.isfinite(rec[k]) and 0.0 < rec[k] < 0.2, (k, rec)                     # 0.1 * ~ln 2
+    assert not torch.equal(w0, getattr(tr.model.DC_ins, name).weight.detach())
 
 
 def _student_vs_oracle(sfod, B, H, W, ngt, dtype, seed):
