@@ -121,6 +121,9 @@ class BaseTrainer:
         self.device = torch.device(cfg.MODEL.DEVICE)
         self.model = self.build_model(cfg)
         self.optimizer = self.build_optimizer(cfg, self.model)
+        if cfg.MODEL.WEIGHTS:     # DetectionCheckpointer(model).resume_or_load(MODEL.WEIGHTS, resume=False), train_net_mt.py:75
+            from ..checkpoint import load_model_weights
+            load_model_weights(self.model, cfg.MODEL.WEIGHTS)
         self._attach_reducer()
         self.scheduler = WarmupMultiStepLR(self.optimizer, cfg)
         self.data_loader = data_loader or self.build_train_loader(cfg)
@@ -218,11 +221,19 @@ class BaseTrainer:
             self.after_step()
 
     def state_dict_for_checkpoint(self):
-        return {"model": self.model.state_dict(), "iteration": self.iter}
+        return {"model": self.model.state_dict(), "iteration": self.iter, "optimizer": self.optimizer.state_dict(),
+                "scheduler": self.scheduler.state_dict()}
 
     def save_checkpoint(self, name):
-        os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
-        torch.save(self.state_dict_for_checkpoint(), os.path.join(self.cfg.OUTPUT_DIR, name + ".pth"))
+        """fvcore Checkpointer.save: ``<OUTPUT_DIR>/<name>.pth`` + the ``last_checkpoint`` pointer file."""
+        from ..checkpoint import DetectionTSCheckpointer
+        return DetectionTSCheckpointer(self, self.cfg.OUTPUT_DIR).save(name)
+
+    def resume_or_load(self, resume=True):
+        """DefaultTrainer.resume_or_load: continue from ``last_checkpoint`` in OUTPUT_DIR (model, optimizer,
+        scheduler, iteration) when ``resume`` and it exists, else (re)load ``MODEL.WEIGHTS``."""
+        from ..checkpoint import DetectionTSCheckpointer
+        return DetectionTSCheckpointer(self, self.cfg.OUTPUT_DIR).resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
 
 
 def threshold_bbox(proposal_bbox_inst, thres=0.7, proposal_type="roih"):
@@ -253,7 +264,14 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         self._attach_reducer()
         self.model_teacher = self.build_model(cfg)
         self.teacher_flat = FlatModelState(self.model_teacher, frozen_prefixes=self._frozen(cfg), with_grad=False)
-        self._copy_main_model()
+        # DetectionCheckpointer(model).resume_or_load(cfg.MODEL.WEIGHTS, resume=False) for the student and for the
+        # teacher (:51-64); loading is in place, so the flat buffers see it.  Without weights: teacher <- student.
+        if cfg.MODEL.WEIGHTS:
+            from ..checkpoint import load_model_weights
+            load_model_weights(self.model, cfg.MODEL.WEIGHTS)
+            load_model_weights(self.model_teacher, cfg.MODEL.WEIGHTS)
+        else:
+            self._copy_main_model()
         self.ema_enabled = bool(cfg.SFOD.EMA.ENABLED)
         if self.ema_enabled:
             self.optimizer.attach_teacher(self.teacher_flat, cfg.SFOD.EMA.KEEP_RATE)

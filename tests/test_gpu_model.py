@@ -444,6 +444,48 @@ def test_teacher_on_second_stream_gives_the_same_step(sfod, native):
     assert torch.equal(bn[0], bn[1])
 
 
+def test_checkpoint_round_trip_resume_and_model_weights(sfod, native, tmp_path):
+    """DetectionTSCheckpointer conventions (detection_ts_checkpointer.py, ts_ensemble.py): save -> one dict with
+    modelTeacher.* / modelStudent.* + optimizer / scheduler / iteration + last_checkpoint; resume continues with
+    identical state; a plain (source-trained) model given as MODEL.WEIGHTS initialises student AND teacher."""
+    base = ["SFOD.COMPUTE_DTYPE", "fp32", "SOLVER.IMS_PER_BATCH_TARGET", "2", "SFOD.SYNTHETIC.HEIGHT", "256",
+            "SFOD.SYNTHETIC.WIDTH", "512", "SFOD.SYNTHETIC.NUM_IMAGES", "4", "INPUT.MIN_SIZE_TRAIN", "(192,)",
+            "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0", "OUTPUT_DIR", str(tmp_path)]
+    cfg = make_cfg(sfod, opts=base)
+    torch.manual_seed(cfg.SEED)
+    tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+    tr.train()
+    path = tr.save_checkpoint("model_{:07d}".format(tr.iter))
+    assert os.path.exists(path) and open(os.path.join(str(tmp_path), "last_checkpoint")).read() == "model_0000001.pth"
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    assert sd["iteration"] == 1 and {"model", "optimizer", "scheduler"} <= set(sd)
+    assert "modelTeacher.backbone.vgg0.0.weight" in sd["model"] and "modelStudent.DC_img.conv1.weight" in sd["model"]
+    # resume in a fresh trainer: identical parameters, buffers, momentum, lr schedule position
+    torch.manual_seed(123)
+    tr2 = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+    assert not torch.equal(tr2.optimizer.flat.param, tr.optimizer.flat.param)
+    tr2.resume_or_load(resume=True)
+    assert tr2.start_iter == 2
+    assert torch.equal(tr2.optimizer.flat.param, tr.optimizer.flat.param)
+    assert torch.equal(tr2.teacher_flat.param, tr.teacher_flat.param)
+    assert torch.equal(tr2.teacher_flat.fbuf, tr.teacher_flat.fbuf) and torch.equal(tr2.optimizer.flat.ibuf, tr.optimizer.flat.ibuf)
+    assert torch.equal(tr2.optimizer.mom, tr.optimizer.mom)
+    assert tr2.scheduler.last_epoch == tr.scheduler.last_epoch
+    # a source-only checkpoint (plain keys, DDP "module." prefix) as MODEL.WEIGHTS: student and teacher both get it
+    plain = {"module." + k: v.cpu() for k, v in tr.model.state_dict().items()}
+    wpath = os.path.join(str(tmp_path), "source.pth")
+    torch.save({"model": plain, "iteration": 79999}, wpath)
+    cfg3 = make_cfg(sfod, opts=base + ["MODEL.WEIGHTS", wpath])
+    torch.manual_seed(7)
+    tr3 = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg3)
+    assert torch.equal(tr3.optimizer.flat.param, tr.optimizer.flat.param)
+    assert torch.equal(tr3.teacher_flat.param, tr.optimizer.flat.param)       # teacher == loaded student weights
+    assert torch.equal(tr3.teacher_flat.fbuf, tr.optimizer.flat.fbuf)
+    tr3.iter = 0
+    tr3.run_step()                                                             # and it trains from there
+    torch.cuda.synchronize()
+
+
 def test_config1_source_training_step_matches_oracle(sfod, native):
     """BASELINE config #1 (faster_rcnn_VGG_cityscapes_source_new.yaml, 2 synthetic 512x1024 frames
     -> 600x1200 tensors, 1 SGD step): 4 finite losses, LR = 0.04 * 0.001, and the same numbers as

@@ -143,3 +143,48 @@ def test_r101_config_and_resnet_module_surface(sfod):
     from oracle import resnet as ore
     y = ore.forward({"backbone." + k: v for k, v in sd.items()}, torch.randn(1, 3, 64, 96), depth=101, training=False)
     assert y.shape == (1, 1024, 4, 6)
+
+
+def test_checkpoint_key_matching_and_loading_semantics(tmp_path):
+    """simple-sfod_amd/checkpoint.py on a small CPU module: fvcore's module.-prefix stripping (only when every key
+    has it), shape filter, missing / unexpected reporting, in-place loading; Detectron2's longest-suffix matching
+    for ``matching_heuristics`` checkpoints; the .pkl format of convert_vgg_bn.py:156."""
+    import importlib
+    import pickle
+    import numpy as np
+    import torch
+    import torch.nn as nn
+    ck = importlib.import_module("simple-sfod_amd.checkpoint")
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4))
+            self.head = nn.Linear(4, 2)
+    torch.manual_seed(0)
+    src, dst = Net(), Net()
+    w_ptr = dst.backbone[0].weight.data_ptr()
+    sd = {"module." + k: v.clone() for k, v in src.state_dict().items()}
+    sd["module.head.weight"] = torch.zeros(3, 4)                 # wrong shape -> skipped, reported
+    sd["module.extra.bias"] = torch.zeros(1)                     # unexpected
+    del sd["module.backbone.1.running_var"]                      # missing
+    inc = ck.load_state_into(dst, sd)
+    assert inc.incorrect_shapes == [("head.weight", (3, 4), (2, 4))]
+    assert inc.unexpected_keys == ["extra.bias"] and set(inc.missing_keys) == {"backbone.1.running_var", "head.weight"}
+    assert torch.equal(dst.backbone[0].weight, src.backbone[0].weight) and dst.backbone[0].weight.data_ptr() == w_ptr
+    assert not torch.equal(dst.head.weight, src.head.weight)
+    # prefix kept when not every key carries it
+    assert set(ck.strip_prefix_if_present({"module.a": 1, "b": 2}, "module.")) == {"module.a", "b"}
+    # matching heuristics: checkpoint keys are suffixes of the model's
+    dst2 = Net()
+    heur = {"0.weight": src.backbone[0].weight.detach().numpy(), "1.running_mean": np.full(4, 7.0, dtype=np.float32),
+            "head.bias": src.head.bias.detach().numpy()}
+    path = tmp_path / "w.pkl"
+    with open(path, "wb") as f:
+        pickle.dump({"model": heur, "__author__": "torchvision", "matching_heuristics": True}, f)
+    inc = ck.load_model_weights(dst2, str(path))
+    assert torch.equal(dst2.backbone[0].weight, src.backbone[0].weight)
+    assert torch.equal(dst2.backbone[1].running_mean, torch.full((4,), 7.0)) and torch.equal(dst2.head.bias, src.head.bias)
+    assert inc.unexpected_keys == [] and "head.weight" in inc.missing_keys
+    with pytest.raises(FileNotFoundError):
+        ck.load_model_weights(dst2, str(tmp_path / "nope.pth"))

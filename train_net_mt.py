@@ -38,6 +38,8 @@ def main():
     Trainer = sfod.engine.get_trainer_class(cfg)
     if args.eval_only:
         model = Trainer.build_model(cfg)
+        # DetectionCheckpointer(model).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume) (train_net_mt.py:75-77)
+        sfod.checkpoint.load_model_weights(model, cfg.MODEL.WEIGHTS)
         loader = sfod.data.TwoCropLoader(cfg, torch.device(cfg.MODEL.DEVICE), rank, world, labeled=True)
         sfod.engine.adabn_refinement(cfg, model, loader)
         if rank == 0 and cfg.OUTPUT_DIR:
@@ -45,11 +47,13 @@ def main():
             torch.save({"model": model.state_dict()}, os.path.join(cfg.OUTPUT_DIR, "adabn.pth"))
         return
     trainer = Trainer(cfg)
-    if world > 1:
+    if world > 1 and not cfg.MODEL.WEIGHTS:      # same random initial weights on every rank (DDP constructor broadcast)
         dist.broadcast(trainer.optimizer.flat.param, 0)
         dist.broadcast(trainer.optimizer.flat.fbuf, 0)
         if hasattr(trainer, "_copy_main_model"):
             trainer._copy_main_model()
+    if args.resume:                              # the reference keeps this call commented out (train_net_mt.py:86)
+        trainer.resume_or_load(resume=True)
     trainer.train()
 
 
