@@ -354,30 +354,48 @@ k_wgrad3x3_patch(W3Args a) {
 // dw[i] (+)= sum_s slab[s][i], fixed order.  MODE 0: dw is the packed [Cout][9][Cin] gradient (accumulated into);
 // MODE 1 / 2: dw is the state-dict layout OIHW [Cout][Cin][3][3], overwritten (1) or accumulated into (2) -- the
 // unpack pass and the zero fill of a packed temporary are folded into this reduction.
-template <int MODE>
+// SG slab groups per workgroup: 256 threads = (256 / SG) float4 elements x SG groups, each group sums every
+// SG-th slab and the groups are combined through LDS in a fixed order (deterministic).  Small gradients
+// (conv1_2: 9216 float4 x 512 slabs = 75 MB) would otherwise be read by 36 workgroups.
+template <int MODE, int SG>
 __global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int nslab, int64_t stride4, int Cin) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+  constexpr int EPB = 256 / SG;                    // elements (float4) per workgroup
+  __shared__ float4 part[SG > 1 ? 256 : 1];
+  const int el = threadIdx.x % EPB, grp = threadIdx.x / EPB;
+  for (int64_t base = (int64_t)blockIdx.x * EPB; base < n4; base += (int64_t)gridDim.x * EPB) {
+    const int64_t i = base + el;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    int64_t o = 0;
+    if (i < n4) {
+      for (int k = grp; k < nslab; k += SG) {
+        const float4 v = reinterpret_cast<const float4*>(slab)[k * stride4 + i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    if constexpr (SG > 1) {
+      __syncthreads();                             // previous iteration's readers are done
+      part[threadIdx.x] = s;
+      __syncthreads();
+      if (grp != 0) continue;
+#pragma unroll
+      for (int g2 = 1; g2 < SG; ++g2) {
+        const float4 v = part[g2 * EPB + el];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    if (i >= n4) continue;
     if constexpr (MODE == 0) {
-      s = reinterpret_cast<const float4*>(dw)[i];
+      float4 o = reinterpret_cast<const float4*>(dw)[i];
+      o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+      reinterpret_cast<float4*>(dw)[i] = o;
     } else {
       const int64_t e = i * 4;                       // packed element (co, tap, ci .. ci+3)
       const int ci = (int)(e % Cin);
       const int64_t ct = e / Cin;
       const int tap = (int)(ct % 9);
       const int64_t co = ct / 9;
-      o = (co * Cin + ci) * 9 + tap;
-      if constexpr (MODE == 2) { s.x = dw[o]; s.y = dw[o + 9]; s.z = dw[o + 18]; s.w = dw[o + 27]; }
-    }
-    for (int k = 0; k < nslab; ++k) {
-      const float4 v = reinterpret_cast<const float4*>(slab)[k * stride4 + i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    if constexpr (MODE == 0) {
-      reinterpret_cast<float4*>(dw)[i] = s;
-    } else {
+      const int64_t o = (co * Cin + ci) * 9 + tap;
+      if constexpr (MODE == 2) { s.x += dw[o]; s.y += dw[o + 9]; s.z += dw[o + 18]; s.w += dw[o + 27]; }
       dw[o] = s.x; dw[o + 9] = s.y; dw[o + 18] = s.z; dw[o + 27] = s.w;
     }
   }
@@ -449,13 +467,21 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
   int rc = sfod_check_launch("wgrad3x3_patch");
   if (rc) return rc;
   const int64_t n = (int64_t)Cout * 9 * Cin;  // multiple of 4 (Cin % 32 == 0)
-  int g = (int)((n / 4 + 255) / 256);
-  if (g > 2048) g = 2048;
-  if (out_mode == 0)
-    hipLaunchKernelGGL(k_wgrad_reduce<0>, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4, Cin);
-  else if (out_mode == 1)
-    hipLaunchKernelGGL(k_wgrad_reduce<1>, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4, Cin);
-  else
-    hipLaunchKernelGGL(k_wgrad_reduce<2>, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n / 4, p.nslab, n / 4, Cin);
+  const int64_t n4 = n / 4;
+  const bool wide = true;                           // slabs spread over 8 groups per workgroup (more loads in flight)
+  const int epb = wide ? 32 : 256;
+  int g = (int)((n4 + epb - 1) / epb);
+  if (g > 8192) g = 8192;
+#define RED_LAUNCH(MODE_)                                                                                         \
+  do {                                                                                                            \
+    if (wide) hipLaunchKernelGGL((k_wgrad_reduce<MODE_, 8>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4,  \
+                                 p.nslab, n4, Cin);                                                               \
+    else hipLaunchKernelGGL((k_wgrad_reduce<MODE_, 1>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4,       \
+                            p.nslab, n4, Cin);                                                                    \
+  } while (0)
+  if (out_mode == 0) RED_LAUNCH(0);
+  else if (out_mode == 1) RED_LAUNCH(1);
+  else RED_LAUNCH(2);
+#undef RED_LAUNCH
   return sfod_check_launch("wgrad_reduce");
 }
