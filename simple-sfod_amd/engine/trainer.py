@@ -79,38 +79,63 @@ class EventStorage:
 
 
 class GradientReducer:
-    """Sum all-reduce of the flat gradient buffer in two phases so that communication overlaps the
-    backbone backward: ``launch_early()`` (called when the backbone's backward starts, i.e. when every
-    gradient of the heads is final) starts an asynchronous all-reduce of the contiguous heads slice
-    [lo, hi) on the collective's own stream; ``finish()`` waits for it and reduces the rest.  xGMI is
-    point-to-point, so one large message per phase (not 25 MB DDP buckets) keeps every link busy."""
+    """Sum all-reduce of the flat gradient buffer in phases so that communication overlaps the backbone
+    backward.  ``launch_early()`` (called when the backbone's backward starts, i.e. when every gradient of the
+    heads is final) starts an asynchronous all-reduce of the contiguous heads slice on the collective's own
+    stream; ``launch_mid()`` (called by the VGG backward once the gradients of stages vgg2..vgg4 are written:
+    96 % of the trunk's parameters, with the two most expensive stages of the backward still to run) does the
+    same for that slice; ``finish()`` waits for both and reduces what is left (vgg0/vgg1 + the norm parameters,
+    < 1 MB).  xGMI is point-to-point, so few large messages (not 25 MB DDP buckets) keep every link busy."""
 
-    def __init__(self, flat, prefixes=("proposal_generator.", "roi_heads.")):
+    def __init__(self, flat, prefixes=("proposal_generator.", "roi_heads."),
+                 mid_prefixes=("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4.")):
         self.flat = flat
-        self.work = None
-        inside = [(o, o + k) for n, (o, k, _) in flat.offsets.items() if n.startswith(tuple(prefixes))]
-        self.lo, self.hi = (min(a for a, _ in inside), max(b for _, b in inside)) if inside else (0, 0)
-        # the slice must contain nothing but head parameters (named_parameters order keeps modules together)
-        for n, (o, k, _) in flat.offsets.items():
-            if self.lo <= o < self.hi and not n.startswith(tuple(prefixes)):
-                self.lo = self.hi = 0
-        self.hi = min((self.hi + 3) // 4 * 4, flat.grad.numel())
+        self.work, self.work_mid = None, None
+        self.lo, self.hi = self._pure_run(prefixes)
+        self.mlo, self.mhi = self._pure_run(mid_prefixes) if mid_prefixes else (0, 0)
+        if self.mhi > self.mlo and self.hi > self.lo and not (self.mhi <= self.lo or self.hi <= self.mlo):
+            self.mlo = self.mhi = 0          # overlapping slices: keep the heads phase only
+
+    def _pure_run(self, prefixes):
+        """Longest run of consecutive parameters (in buffer order) that all match ``prefixes`` -> [lo, hi) in
+        elements, hi rounded up to the 16-byte padding of the last parameter; (0, 0) if there is none."""
+        prefixes = tuple(prefixes)
+        items = sorted(((o, o + k, n) for n, (o, k, _) in self.flat.offsets.items()), key=lambda t: t[0])
+        best, cur = (0, 0), None
+        for i, (o, e, n) in enumerate(items):
+            if n.startswith(prefixes):
+                nxt = items[i + 1][0] if i + 1 < len(items) else self.flat.grad.numel()
+                cur = (cur[0], nxt) if cur is not None else (o, nxt)      # up to the next parameter (padding)
+                if cur[1] - cur[0] > best[1] - best[0]:
+                    best = cur
+            else:
+                cur = None
+        return best
 
     def launch_early(self):
         if self.work is None and self.hi > self.lo and get_world_size() > 1:
             self.work = dist.all_reduce(self.flat.grad[self.lo:self.hi], async_op=True)
 
+    def launch_mid(self):
+        if self.work_mid is None and self.mhi > self.mlo and get_world_size() > 1:
+            self.work_mid = dist.all_reduce(self.flat.grad[self.mlo:self.mhi], async_op=True)
+
     def finish(self):
         g = self.flat.grad
-        if self.work is None:
+        done = sorted([(lo, hi) for lo, hi, w in ((self.lo, self.hi, self.work), (self.mlo, self.mhi, self.work_mid))
+                       if w is not None])
+        if not done:
             dist.all_reduce(g)
             return
-        if self.lo > 0:
-            dist.all_reduce(g[: self.lo])
-        if self.hi < g.numel():
-            dist.all_reduce(g[self.hi:])
-        self.work.wait()
-        self.work = None
+        pos = 0
+        for lo, hi in done + [(g.numel(), g.numel())]:
+            if lo > pos:
+                dist.all_reduce(g[pos:lo])
+            pos = max(pos, hi)
+        for w in (self.work, self.work_mid):
+            if w is not None:
+                w.wait()
+        self.work = self.work_mid = None
 
 
 class BaseTrainer:
@@ -144,6 +169,7 @@ class BaseTrainer:
         if get_world_size() > 1 and not dc_live:
             self._reducer = GradientReducer(self.optimizer.flat)
             self.model.backbone._pre_backward = self._reducer.launch_early
+            self.model.backbone._mid_backward = self._reducer.launch_mid      # VGG: after stage vgg2's gradients
 
     @classmethod
     def build_model(cls, cfg):

@@ -151,6 +151,17 @@ class vgg_backbone(nn.Module):
         return dict(zip(self._stage_names, outs))
 
     # ---- engine -------------------------------------------------------------------------------------
+    def _first_layer_of_stage(self, stage):
+        """index into ``_plan`` of the first conv of ``vgg<stage>``"""
+        s, first = 0, 0
+        for i, (_, _, _, stage_end) in enumerate(self._plan):
+            if s == stage:
+                return first
+            if stage_end:
+                s += 1
+                first = i + 1
+        return 0
+
     def _packed_weights(self, dt, cin0_pad, with_dgrad):
         """Packed forward weights of all layers (+ the rotated dgrad weights of layers 1.. when a backward
         follows), refreshed from the fp32 master weights by ONE launch per call."""
@@ -216,6 +227,8 @@ class vgg_backbone(nn.Module):
             if stage_end:
                 s += 1
         dz = None
+        mid_hook = getattr(self, "_mid_backward", None)
+        mid_layer = self._first_layer_of_stage(2) if mid_hook is not None else -1
         for li in range(len(self._plan) - 1, -1, -1):
             conv, bn, pool, stage_end = self._plan[li]
             x, y, mean, invstd = saved[li]
@@ -244,6 +257,8 @@ class vgg_backbone(nn.Module):
                 # rotated weights were packed together with the forward ones (same step, same values)
                 dz = native.conv_fwd(dy, self._rot_w[li], None, cin, 3)
             del saved[li]
+            if li == mid_layer and mid_hook is not None:
+                mid_hook()   # gradients of vgg2..vgg4 are in the flat buffer: GradientReducer.launch_mid
         return pgrads
 
 

@@ -50,9 +50,25 @@ def _worker(rank, world, port, q):
     tr2 = SimpleNamespace(optimizer=opt, _reducer=red)
     sfod.engine.trainer.BaseTrainer._reduce_gradients(tr2)
     ok_sum = ok_sum and torch.allclose(flat.grad, sum(gathered)) and red.work is None
-    # a slice that is not purely head parameters disables the early phase (plain single all-reduce)
-    red_bad = sfod.engine.trainer.GradientReducer(flat, prefixes=("0.weight", "2."))
-    ok_sum = ok_sum and red_bad.lo == red_bad.hi == 0
+    # three phases: module 2 early, module 0 (the "deep trunk" slice) mid-backward, the norm parameters at the end
+    flat.grad.copy_(local)
+    red3 = sfod.engine.trainer.GradientReducer(flat, prefixes=("2.",), mid_prefixes=("0.",))
+    assert red3.mlo == flat.offsets["0.weight"][0] and red3.mhi == flat.offsets["2.weight"][0]
+    red3.launch_early()
+    red3.launch_mid()
+    tr3 = SimpleNamespace(optimizer=opt, _reducer=red3)
+    sfod.engine.trainer.BaseTrainer._reduce_gradients(tr3)
+    ok_sum = ok_sum and torch.allclose(flat.grad, sum(gathered)) and red3.work is None and red3.work_mid is None
+    # only the mid phase was launched (e.g. no heads slice): the rest is reduced in finish()
+    flat.grad.copy_(local)
+    red4 = sfod.engine.trainer.GradientReducer(flat, prefixes=("nothing.",), mid_prefixes=("0.",))
+    red4.launch_early()
+    red4.launch_mid()
+    sfod.engine.trainer.BaseTrainer._reduce_gradients(SimpleNamespace(optimizer=opt, _reducer=red4))
+    ok_sum = ok_sum and torch.allclose(flat.grad, sum(gathered))
+    # prefixes that match scattered parameters: the longest pure run is used (0.weight, 108 elements, vs 2.*, 18)
+    red_run = sfod.engine.trainer.GradientReducer(flat, prefixes=("0.weight", "2."), mid_prefixes=())
+    ok_sum = ok_sum and red_run.lo == flat.offsets["0.weight"][0] and red_run.hi == flat.offsets["0.bias"][0]
     # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream
     s = iter(sfod.data.TrainingSampler(10, seed=7, rank=rank, world=world))
     mine = [next(s) for _ in range(10)]

@@ -556,13 +556,20 @@ def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native):
         assert red is not None and 0 < red.lo < red.hi <= tr.optimizer.flat.grad.numel()
         names = [n for n, (o, k, _) in tr.optimizer.flat.offsets.items() if red.lo <= o < red.hi]
         assert names and all(n.startswith(("proposal_generator.", "roi_heads.")) for n in names)
-        launched = []
-        orig_launch = red.launch_early
+        # mid-backward phase: conv weights + biases of stages vgg2..vgg4, adjacent to (not overlapping) the heads
+        mid = [n for n, (o, k, _) in tr.optimizer.flat.offsets.items() if red.mlo <= o < red.mhi]
+        assert mid and all(n.startswith(("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4.")) for n in mid)
+        assert "backbone.vgg2.0.weight" in mid and "backbone.vgg4.6.bias" in mid and red.mhi <= red.lo
+        assert (red.mhi - red.mlo) > 0.9 * sum(p_.numel() for n, p_ in tr.model.backbone.named_parameters() if p_.dim() == 4)
+        launched, mids = [], []
+        orig_launch, orig_mid = red.launch_early, red.launch_mid
         red.launch_early = lambda: (launched.append(1), orig_launch())[1]
+        red.launch_mid = lambda: (mids.append(1), orig_mid())[1]
         tr.model.backbone._pre_backward = red.launch_early
+        tr.model.backbone._mid_backward = red.launch_mid
         p0 = tr.optimizer.flat.param.clone()
         tr.train()
-        assert len(launched) == 2 and red.work is None
+        assert len(launched) == 2 and len(mids) == 2 and red.work is None and red.work_mid is None
         assert tr.optimizer.grad_scale == 0.5
         assert torch.isfinite(tr.optimizer.flat.param).all() and not torch.equal(p0, tr.optimizer.flat.param)
     finally:
