@@ -234,10 +234,37 @@ class ResNet(nn.Module):
         y = native.conv_fwd(cols.view(B * Ho * Wo, kpad), wp, shift.contiguous(), conv.out_channels, 1, act=1)
         return native.maxpool3s2(y.view(B, Ho, Wo, conv.out_channels))
 
+    def _pack_live_weights(self, dt, with_dgrad):
+        """Forward (and, for a backward, rotated) packed weights of every live conv in ONE launch per forward
+        (native.ConvWeightPacker) instead of two tiny launches per conv."""
+        key = (dt, bool(with_dgrad))
+        packers = self.__dict__.setdefault("_packers", {})
+        ent = packers.get(key)
+        if ent is None:
+            convs = []
+            for name in self.stage_names:
+                if name in self.frozen:
+                    continue
+                for blk in getattr(self, name):
+                    for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut):
+                        if c is not None:
+                            convs.append(c)
+            specs = [(c.weight, c.in_channels, False) for c in convs]
+            if with_dgrad:
+                specs += [(c.weight, c.out_channels, True) for c in convs]
+            ent = packers[key] = (native.ConvWeightPacker(specs, dt), convs)
+        pk, convs = ent
+        views = pk.pack()
+        n = len(convs)
+        self._wp = {id(c): views[i] for i, c in enumerate(convs)}
+        self._wr = {id(c): views[n + i] for i, c in enumerate(convs)} if with_dgrad else {}
+
     def _live_conv_bn(self, x, conv, relu, dt):
         bn = conv.norm
         k = conv.kernel_size[0]
-        wp = native.pack_conv_weight(conv.weight.detach(), x.shape[-1], dt)
+        wp = self.__dict__.get("_wp", {}).get(id(conv)) if x.shape[-1] == conv.in_channels else None
+        if wp is None:
+            wp = native.pack_conv_weight(conv.weight.detach(), x.shape[-1], dt)
         B, H, W, _ = x.shape
         if self.training:
             y, stats = native.conv_fwd(x, wp, None, conv.out_channels, k, want_stats=True)
@@ -273,6 +300,7 @@ class ResNet(nn.Module):
     def _forward_impl(self, x, save=True):
         dt = native.dt_of(x)
         saved, outs = [], {}
+        self._pack_live_weights(dt, with_dgrad=save)
         x = self._stem_forward(x, dt)
         for name in self.stage_names:
             live = name not in self.frozen
@@ -298,7 +326,9 @@ class ResNet(nn.Module):
         dw = native.conv_weight_grad(x_in, dy, conv.weight)
         dx = None
         if need_dx:
-            wr = native.pack_conv_weight(conv.weight.detach(), conv.out_channels, native.dt_of(dy), rot180=True)
+            wr = self.__dict__.get("_wr", {}).get(id(conv))      # packed with the forward weights (same step, same values)
+            if wr is None:
+                wr = native.pack_conv_weight(conv.weight.detach(), conv.out_channels, native.dt_of(dy), rot180=True)
             dx = native.conv_fwd(dy, wr, None, conv.in_channels, k)
         return dx, [dw, dgamma, dbeta]
 
