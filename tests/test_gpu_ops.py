@@ -796,3 +796,20 @@ def test_resize_bilinear_u8_equals_pillow(native, shape, flip):
         ref = ref[:, :, ::-1]
     got = native.resize_bilinear_u8(img.to(DEV), h, w, flip=flip).cpu().numpy()
     assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("dtype", _dtypes())
+def test_conv_weight_packer_equals_per_layer_packing(native, dtype):
+    """sfod_pack_conv_weights_multi (all layers in one launch, LDS-tiled transpose) == sfod_pack_conv_weight per
+    layer, bit for bit: forward and rotated layouts, channel padding (3 -> 8), ragged tiles, 1x1 kernels."""
+    dt = native.dt_of(torch.empty(0, dtype=dtype))
+    E = native.chunk_elems(dt)
+    g = torch.Generator().manual_seed(4)
+    shapes = [(64, 3, 3), (72, 40, 3), (128, 64, 3), (40, 96, 1), (257, 33, 3)]
+    ws = [torch.randn(co, ci, k, k, generator=g).to(DEV) for co, ci, k in shapes]
+    pad = lambda c: (c + E - 1) // E * E
+    specs = [(w, pad(w.shape[1]), False) for w in ws] + [(w, pad(w.shape[0]), True) for w in ws]
+    views = native.ConvWeightPacker(specs, dt).pack()
+    for (w, p_, rot), v in zip(specs, views):
+        ref = native.pack_conv_weight(w, p_, dt, rot180=rot)
+        assert v.shape == ref.shape and torch.equal(v, ref), (tuple(w.shape), rot)
