@@ -1,5 +1,5 @@
 import importlib, sys, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import resnet as ore
 sfod = importlib.import_module("simple-sfod_amd")
 rn = importlib.import_module("simple-sfod_amd.modeling.backbone_resnet")

@@ -1,6 +1,6 @@
 import importlib, sys, os, torch
 import torch.nn.functional as F
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import resnet as ore
 sfod = importlib.import_module("simple-sfod_amd")
 native = sfod.native

@@ -1,7 +1,7 @@
 """Diagnostic (not part of the product): per-parameter gradient error of the student step."""
 import importlib, os, sys
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 sfod = importlib.import_module("simple-sfod_amd")
 import test_gpu_model as T
