@@ -80,6 +80,17 @@ int sfod_set_conv3x3_variant(int variant);
  * kernel (Cin = one padded 8-channel chunk, Cout = 64, bf16) */
 int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
 
+/* First VGG layer (3 real channels in one 8-wide chunk -> 64, bf16) with the train-mode BatchNorm + ReLU folded in
+ * by recomputation -- the layer's K is 27, its cost is writing 64 channels per pixel: pass 1 (y = NULL) produces
+ * only the BatchNorm partial statistics (nothing stored), pass 2 (scale = gamma * invstd, shift = beta - mean *
+ * scale, act = 1) recomputes the convolution and stores z = relu(scale * (conv + bias) + shift) directly, so
+ * neither y nor a separate BatchNorm pass exist.  For forward-only use (the teacher: vgg.py:15-20 under no_grad;
+ * a backward needs y).  stats layout / count as sfod_conv_fwd for this shape (sfod_conv_stats_blocks). */
+int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, int ldy);
+int sfod_conv_first_fused(const void* x, const void* w, const float* bias, const float* scale,
+                          const float* shift, void* y, float* stats, int B, int H, int W, int ldy,
+                          int act, void* stream);
+
 /* weight gradient: dw[n][tap][c] += sum_m dy[m][n] * x[pix(m)+tap][c]  (fp32, packed layout, added
  * into the caller's (zero-initialised) buffer).  3x3 bf16 layers run the halo-patch kernel: pixel
  * splits write fp32 slabs into `ws` (sfod_conv_wgrad_ws_bytes, may be 0 -> ws unused) and are summed

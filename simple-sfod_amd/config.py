@@ -378,6 +378,9 @@ def add_native_config(cfg):
     _C.SFOD.COMPUTE_DTYPE = "fp32"
     _C.SFOD.ELIDE_DEAD_BRANCHES = True
     _C.SFOD.OVERLAP_TEACHER = True
+    # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass
+    # that stores the activated output directly; sfod_conv_first_fused)
+    _C.SFOD.FUSE_FIRST_LAYER = True
     _C.SFOD.SYNTHETIC = CN()
     _C.SFOD.SYNTHETIC.HEIGHT = 1024
     _C.SFOD.SYNTHETIC.WIDTH = 2048

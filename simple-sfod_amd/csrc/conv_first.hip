@@ -26,7 +26,9 @@ struct F1Args {
   const bf16_t* x;     // [B,H,W,8]
   const bf16_t* w;     // [64][9][8]
   const float* bias;
-  bf16_t* y;           // [B,H,W,ldy]
+  const float* scale;  // optional per-channel affine applied to (conv + bias) before the activation: the BatchNorm
+  const float* shift;  //   of a second pass whose statistics came from a first, store-free pass (teacher forward)
+  bf16_t* y;           // [B,H,W,ldy]; nullptr: statistics only, nothing is stored
   float* stats;
   int B, H, W, ldy, act;
   int tiles_y, tiles_x, ntiles;
@@ -50,10 +52,15 @@ k_conv_first(F1Args a) {
       if (tap < 9) v = *reinterpret_cast<const uint4*>(a.w + ((j * 32 + l31) * 9 + tap) * 8);
       bq[j][s] = __builtin_bit_cast(bf16x8, v);
     }
-  float bcol[2];
+  float bcol[2], scol[2], hcol[2];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) bcol[j] = a.bias ? a.bias[j * 32 + l31] : 0.f;
+  for (int j = 0; j < 2; ++j) {
+    bcol[j] = a.bias ? a.bias[j * 32 + l31] : 0.f;
+    scol[j] = a.scale ? a.scale[j * 32 + l31] : 1.f;
+    hcol[j] = a.shift ? a.shift[j * 32 + l31] : 0.f;
+  }
   const bool relu = (a.act == 1);
+  const bool affine = (a.scale != nullptr);
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int t = tile;
@@ -113,21 +120,29 @@ k_conv_first(F1Args a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const float v = acc[i][j][r] + bcol[j];
-          acc[i][j][r] = v;
-          const float o = fmaxf(v, relu ? 0.f : v);
-          *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + (j * 32 + l31) * 2) = (bf16_t)o;
-        }
-    // same-wave readback (LDS is in order per wave): 8 rows x 128 B per instruction
+        for (int r = 0; r < 16; ++r) acc[i][j][r] += bcol[j];
+    if (a.y != nullptr) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int row = it * 8 + (lane >> 3), ch = lane & 7;
-      const int iy = y0 + 2 * wave + (row >> 5), ix = x0 + (row & 31);
-      if (iy < a.H && ix < a.W) {
-        const uint4 v = *reinterpret_cast<const uint4*>(stg + row * STG_PITCH + ch * 16);
-        *reinterpret_cast<uint4*>(a.y + (((int64_t)b * a.H + iy) * a.W + ix) * a.ldy + ch * 8) = v;
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            float v = acc[i][j][r];
+            if (affine) v = __builtin_fmaf(v, scol[j], hcol[j]);
+            const float o = fmaxf(v, relu ? 0.f : v);
+            *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + (j * 32 + l31) * 2) = (bf16_t)o;
+          }
+      // same-wave readback (LDS is in order per wave): 8 rows x 128 B per instruction
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + (lane >> 3), ch = lane & 7;
+        const int iy = y0 + 2 * wave + (row >> 5), ix = x0 + (row & 31);
+        if (iy < a.H && ix < a.W) {
+          const uint4 v = *reinterpret_cast<const uint4*>(stg + row * STG_PITCH + ch * 16);
+          *reinterpret_cast<uint4*>(a.y + (((int64_t)b * a.H + iy) * a.W + ix) * a.ldy + ch * 8) = v;
+        }
       }
     }
     if (a.stats != nullptr) {
@@ -189,9 +204,10 @@ k_conv_first(F1Args a) {
 int sfod_f1_nblk(int B, int H, int W) { return B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
 
 int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int B, int H, int W,
-                   int ldy, int act, hipStream_t s) {
+                   int ldy, int act, hipStream_t s, const float* scale, const float* shift) {
   F1Args a;
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = (bf16_t*)y; a.stats = stats;
+  a.scale = scale; a.shift = shift;
   a.B = B; a.H = H; a.W = W; a.ldy = ldy; a.act = act;
   a.tiles_y = (H + TH - 1) / TH; a.tiles_x = (W + TW - 1) / TW;
   a.ntiles = B * a.tiles_y * a.tiles_x;

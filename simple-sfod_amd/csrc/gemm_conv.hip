@@ -487,6 +487,20 @@ static int launch_conv_fwd(const void* x, const void* w, const float* bias, void
   return launch_conv_fwd_ut<T, OutT, false>(x, w, bias, y, stats, a, s);
 }
 
+extern "C" int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, int ldy) {
+  return use_first_kernel(B, H, W, Cin, Cout, 3, dt, ldy, SFOD_BF16) ? 1 : 0;
+}
+
+extern "C" int sfod_conv_first_fused(const void* x, const void* w, const float* bias, const float* scale,
+                                     const float* shift, void* y, float* stats, int B, int H, int W, int ldy,
+                                     int act, void* stream) {
+  SFOD_REQUIRE(use_first_kernel(B, H, W, 8, 64, 3, SFOD_BF16, ldy, SFOD_BF16),
+               "conv_first_fused: shape not served by the first-layer kernel (sfod_conv_first_supported)");
+  SFOD_REQUIRE(y != nullptr || stats != nullptr, "conv_first_fused: nothing to produce");
+  SFOD_REQUIRE((scale == nullptr) == (shift == nullptr), "conv_first_fused: scale and shift come together");
+  return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, (hipStream_t)stream, scale, shift);
+}
+
 extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
                              int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
                              int out_dt, void* stream) {

@@ -95,6 +95,7 @@ class vgg_backbone(nn.Module):
         del self.vgg
         self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
         self.bn_momentum, self.bn_eps = 0.1, 1e-5
+        self.fuse_first = bool(cfg.SFOD.FUSE_FIRST_LAYER) if "SFOD" in cfg and "FUSE_FIRST_LAYER" in cfg.SFOD else True
         # execution plan: (conv, bn, pool_after, stage_end)
         self._plan = []
         for s, stage in enumerate(self.stages):
@@ -196,6 +197,19 @@ class vgg_backbone(nn.Module):
             cout = conv.out_channels
             wp = fwd_w[li]
             B, H, W, _ = x.shape
+            if (li == 0 and training and not save and not pool and not stage_end and self.fuse_first
+                    and native.conv_first_supported(x, cout)):
+                # forward-only (teacher): the first layer's K is 27 and its cost is its 64-channel output, so
+                # BatchNorm + ReLU are folded in by recomputation -- a store-free statistics pass, then a second
+                # pass that writes z directly; y (only a backward would need it) is never materialised
+                stats = native.conv_first_stats(x, wp, conv.bias.detach())
+                mean, invstd = native.bn_finalize(stats, B * H * W, cout, bn.running_mean, bn.running_var,
+                                                  self.bn_momentum, self.bn_eps, True,
+                                                  num_batches_tracked=bn.num_batches_tracked)
+                scale = bn.weight.detach() * invstd
+                shift = bn.bias.detach() - mean * scale
+                x = native.conv_first_apply(x, wp, conv.bias.detach(), scale, shift, relu=True)
+                continue
             if training:
                 y, stats = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3, want_stats=True)
                 mean, invstd = native.bn_finalize(stats, B * H * W, cout, bn.running_mean, bn.running_var,

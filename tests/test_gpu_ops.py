@@ -813,3 +813,34 @@ def test_conv_weight_packer_equals_per_layer_packing(native, dtype):
     for (w, p_, rot), v in zip(specs, views):
         ref = native.pack_conv_weight(w, p_, dt, rot180=rot)
         assert v.shape == ref.shape and torch.equal(v, ref), (tuple(w.shape), rot)
+
+
+def test_conv_first_recompute_fused_batchnorm(native):
+    """sfod_conv_first_fused: the store-free pass yields exactly the statistics of the storing pass, and the
+    second pass writes relu(bn(conv)) directly (checked against torch on bf16-rounded operands; it is slightly
+    MORE accurate than conv -> bf16 -> BatchNorm because the affine sees the fp32 accumulator)."""
+    B, H, W = 2, 70, 130
+    g = torch.Generator().manual_seed(8)
+    x = torch.zeros(B, H, W, 8)
+    x[..., :3] = torch.randn(B, H, W, 3, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) / math.sqrt(27)
+    bias = torch.randn(64, generator=g) * 0.1
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.2
+    xd = x.to(DEV).bfloat16()
+    wp = native.pack_conv_weight(w.to(DEV), 8, native.BF16)
+    assert native.conv_first_supported(xd, 64)
+    y, st_ref = native.conv_fwd(xd, wp, bias.to(DEV), 64, 3, want_stats=True)
+    st = native.conv_first_stats(xd, wp, bias.to(DEV))
+    assert st.nblk == st_ref.nblk and torch.equal(st, st_ref)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    mean, invstd = native.bn_finalize(st, B * H * W, 64, rm, rv, 0.1, 1e-5, False)
+    scale = gamma.to(DEV) * invstd
+    shift = beta.to(DEV) - mean * scale
+    z = native.conv_first_apply(xd, wp, bias.to(DEV), scale, shift, relu=True)
+    xr, wr = nchw(xd.float().cpu())[:, :3], w.bfloat16().float()
+    yc = F.conv2d(xr, wr, bias, padding=1)
+    ref = F.relu(F.batch_norm(yc, None, None, gamma, beta, True, 0.1, 1e-5))
+    assert rel_err(nchw(z.float().cpu()), ref) < 6e-3
+    # and it agrees with the unfused product path (conv -> bf16 -> BN kernel) to bf16 rounding
+    z2 = native.bn_relu_pool_fwd(y, mean, invstd, gamma.to(DEV), beta.to(DEV), False)
+    assert rel_err(z.float().cpu(), z2.float().cpu()) < 8e-3
