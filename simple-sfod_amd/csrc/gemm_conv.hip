@@ -422,9 +422,9 @@ extern "C" int sfod_set_conv_algo(int algo) { g_conv_algo = algo; return 0; }
 static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, int dt) {
   if (ksize != 3 || dt != SFOD_BF16 || !p.ok || g_conv_algo == 1) return false;
   if (g_conv_algo == 2) return true;
-  // small maps (e.g. the 18x37 RPN head): too few 512-pixel tiles to fill the chip, the 128-row
-  // generic tiles do better there
-  return (int64_t)B * p.tiles_y * p.tiles_x * p.tiles_n >= 128;
+  // with the 256-pixel shapes the halo-patch kernel also wins on small maps (batch 1: the 18x37 RPN head
+  // 0.042 vs 0.071 ms, conv5 0.046 vs 0.071); only degenerate problems stay on the generic kernel
+  return (int64_t)B * p.tiles_y * p.tiles_x * p.tiles_n >= 8;
 }
 
 // first VGG layer: 3 real channels in one 8-wide chunk, 64 outputs, bf16 in / bf16 out
@@ -739,7 +739,7 @@ static bool use_patch_wgrad(const W3Plan& p, int ksize, int dt) {
   if (ksize != 3 || dt != SFOD_BF16 || !p.ok || g_conv_algo == 1) return false;
   if (g_conv_algo == 2) return true;
   // tiny problems: not enough pixel tiles to give every (co, ci) block a few tiles per split
-  return p.nsplit * p.tiles_per_split >= 16;
+  return p.nsplit * p.tiles_per_split >= 3;
 }
 
 extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
