@@ -69,6 +69,27 @@ def _worker(rank, world, port, q):
     # prefixes that match scattered parameters: the longest pure run is used (0.weight, 108 elements, vs 2.*, 18)
     red_run = sfod.engine.trainer.GradientReducer(flat, prefixes=("0.weight", "2."), mid_prefixes=())
     ok_sum = ok_sum and red_run.lo == flat.offsets["0.weight"][0] and red_run.hi == flat.offsets["0.bias"][0]
+    # the real model's parameter layout (modules constructed on the CPU: no kernel runs at construction): the three
+    # phases cover disjoint slices, every element is reduced exactly once, result == plain all-reduce
+    cfg_m = sfod.config.setup_cfg(os.path.join(ROOT, "configs",
+                                               "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"), [])
+    torch.manual_seed(1)
+    big = sfod.registry.META_ARCH_REGISTRY.get(cfg_m.MODEL.META_ARCHITECTURE)(cfg_m)
+    bflat = sfod.engine.FlatModelState(big, frozen_prefixes=("DC_img.", "DC_ins."))
+    g = torch.Generator().manual_seed(100 + rank)
+    bflat.grad.copy_(torch.randn(bflat.grad.numel(), generator=g))
+    mine_g = bflat.grad.clone()
+    parts = [torch.zeros_like(mine_g) for _ in range(world)]
+    dist.all_gather(parts, mine_g)
+    redm = sfod.engine.trainer.GradientReducer(bflat)
+    n_heads, n_mid = redm.hi - redm.lo, redm.mhi - redm.mlo
+    ok_model = n_heads > 25_000_000 and n_mid > 14_000_000 and redm.mhi <= redm.lo
+    redm.launch_early()
+    redm.launch_mid()
+    sfod.engine.trainer.BaseTrainer._reduce_gradients(SimpleNamespace(optimizer=SimpleNamespace(flat=bflat, grad_scale=1.0),
+                                                                      _reducer=redm))
+    ok_sum = ok_sum and ok_model and torch.equal(bflat.grad, sum(parts))
+    del big, bflat, parts
     # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream
     s = iter(sfod.data.TrainingSampler(10, seed=7, rank=rank, world=world))
     mine = [next(s) for _ in range(10)]
