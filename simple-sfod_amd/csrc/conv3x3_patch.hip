@@ -481,6 +481,26 @@ extern "C" int sfod_set_conv3x3_variant(int variant) {
   return 0;
 }
 
+// tile shape for a BM-pixel workgroup: maximise covered-output efficiency under TH*TW <= BM and
+// (TH+2)*(TW+2) <= patch capacity; returns false if nothing fits
+static bool p3_best_tile(int H, int W, int BM, int cap, int& TH, int& TW, int& tiles_y, int& tiles_x) {
+  double best = -1.0;
+  for (int tw = 4; tw <= 128 && tw <= W + 3; ++tw) {
+    int th = BM / tw;
+    while (th > 1 && (th + 2) * (tw + 2) > cap) --th;
+    if (th > H) th = H;
+    if (th < 1 || (th + 2) * (tw + 2) > cap) continue;
+    const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+    // even out the rows so that the last tile row is not nearly empty
+    th = (H + ty - 1) / ty;
+    const double eff = (double)H * W / ((double)ty * tx * (double)BM);
+    // tie-break towards wide tiles (longer contiguous runs per patch row)
+    const double score = eff + 1e-6 * tw;
+    if (score > best) { best = score; TH = th; TW = tw; tiles_y = ty; tiles_x = tx; }
+  }
+  return best >= 0.0;
+}
+
 P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   P3Plan p;
   p.ok = 0;
@@ -494,6 +514,18 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
     const int64_t mt = ((int64_t)B * H * W + 255) / 256;          // 256-pixel tiles (lower bound)
     const int64_t wg128 = mt * ((Cout + 127) / 128);
     variant = (Cout > 64 && wg128 >= 512) ? 2 : 3;
+    // long-K layers whose 512 x 128 tiles fill whole rounds of the 256 CUs (one workgroup per CU): the big tile's
+    // 2x lower L2 -> LDS traffic wins by ~4 % there (1024x2048 frames: conv4_2 / conv5); with a ragged last
+    // round or tiles that overhang the map (600x1200 frames) the two-workgroups-per-CU shape stays ahead
+    if (variant == 2 && Cin >= 512 && Cout >= 512) {
+      int th, tw, ty, tx;
+      if (p3_best_tile(H, W, 512, PATCH_ROWS_BIG, th, tw, ty, tx)) {
+        const int64_t wgs = (int64_t)B * ty * tx * ((Cout + 127) / 128);
+        const int64_t rounds = (wgs + 255) / 256;
+        const double px_eff = (double)H * W / ((double)ty * tx * 512.0);     // 75x150 maps: 0.915 -> stays on 256 x 128
+        if (wgs >= 512 && (double)wgs / (double)(rounds * 256) >= 0.97 && px_eff >= 0.97) variant = 1;
+      }
+    }
   }
   if ((variant == 3 || variant == 4) && Cin % 64 != 0) variant = (variant == 3) ? 2 : 1;
   p.G = (variant <= 2) ? 1 : 2;
@@ -502,21 +534,7 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   if ((int64_t)H * W * Cin >= (int64_t)1 << 30 || (int64_t)Cout * 9 * Cin >= (int64_t)1 << 30) return p;  // 32-bit byte offsets
   const int BM = (p.G == 1 ? 4 : 8) * p.FM * 32;
   const int cap = (BM == 256) ? PATCH_ROWS_SMALL : PATCH_ROWS_BIG;
-  double best = -1.0;
-  for (int tw = 4; tw <= 128 && tw <= W + 3; ++tw) {
-    int th = BM / tw;
-    while (th > 1 && (th + 2) * (tw + 2) > cap) --th;
-    if (th > H) th = H;
-    if (th < 1 || (th + 2) * (tw + 2) > cap) continue;
-    const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
-    // even out the rows so that the last tile row is not nearly empty
-    th = (H + ty - 1) / ty;
-    const double eff = (double)H * W / ((double)ty * tx * (double)BM);
-    // tie-break towards wide tiles (longer contiguous runs per patch row)
-    const double score = eff + 1e-6 * tw;
-    if (score > best) { best = score; p.TH = th; p.TW = tw; p.tiles_y = ty; p.tiles_x = tx; }
-  }
-  if (best < 0.0) return p;
+  if (!p3_best_tile(H, W, BM, cap, p.TH, p.TW, p.tiles_y, p.tiles_x)) return p;
   p.tiles_n = (Cout + (128 / p.G) - 1) / (128 / p.G);
   p.nblk = B * p.tiles_y * p.tiles_x;
   p.ok = 1;
