@@ -138,6 +138,117 @@ k_roi_align_fwd(const T* __restrict__ feat, int H, int W, int C, const float* __
   }
 }
 
+// Separable forward (same factorisation as the backward below): out[ph][pw] = sum_py sum_px Ay[ph][py] *
+// Ax[pw][px] * F[py][px] / count.  Every footprint pixel is read ONCE per channel pair (the sample-by-sample form
+// reads 4 corners per sample: ~5x the L2 -> CU traffic, which bounded it), contracted first with Ay (7 partial
+// columns in registers) and then with Ax into the 7 x 7 outputs the thread keeps in registers.  fp32 sums in a
+// different order than torchvision's loop: equal within rounding (tests: 1e-5 relative in fp32).
+template <typename T> struct Pair;
+template <> struct Pair<float> {
+  static __device__ __forceinline__ void load(const float* p, float& a, float& b) {
+    const float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y;
+  }
+  static __device__ __forceinline__ void store(float* p, float a, float b) { *reinterpret_cast<float2*>(p) = make_float2(a, b); }
+};
+template <> struct Pair<bf16_t> {
+  static __device__ __forceinline__ void load(const bf16_t* p, float& a, float& b) {
+    const uint32_t w = *reinterpret_cast<const uint32_t*>(p);
+    a = __uint_as_float(w << 16); b = __uint_as_float(w & 0xffff0000u);
+  }
+  static __device__ __forceinline__ void store(bf16_t* p, float a, float b) {
+    union { bf16_t h[2]; uint32_t v; } u;
+    u.h[0] = (bf16_t)a; u.h[1] = (bf16_t)b;
+    *reinterpret_cast<uint32_t*>(p) = u.v;
+  }
+};
+
+template <typename T, int P>
+__global__ void __launch_bounds__(256)
+k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois, float scale,
+                    T* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sw[];   // Ay [P][H], Ax [P][W], then int lim[4]
+  const int r = blockIdx.x;
+  const float* roi = rois + (int64_t)r * 5;
+  const int tid = threadIdx.x;
+  T* orow = out + (int64_t)r * P * P * C;
+  if (roi[0] < 0.f) {  // padding row
+    for (int i = tid; i < P * P * C / 2; i += blockDim.x) Pair<T>::store(orow + 2 * i, 0.f, 0.f);
+    return;
+  }
+  const RoiGeom g = roi_geom(roi, scale, P);
+  float* Ay = sw;
+  float* Ax = sw + P * H;
+  int* lim = reinterpret_cast<int*>(Ax + P * W);            // ylo, yhi, xlo, xhi
+  for (int i = tid; i < P * (H + W); i += blockDim.x) sw[i] = 0.f;
+  if (tid == 0) { lim[0] = H; lim[1] = -1; lim[2] = W; lim[3] = -1; }
+  __syncthreads();
+  if (tid < 2 * P) {
+    const bool isy = tid < P;
+    const int p = isy ? tid : tid - P;
+    const int L = isy ? H : W;
+    const int gn = isy ? g.grid_h : g.grid_w;
+    const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
+    float* row = (isy ? Ay : Ax) + p * L;
+    int lo = L, hi = -1;
+    for (int i = 0; i < gn; ++i) {
+      float v = start + (float)p * bin + ((float)i + .5f) * bin / (float)gn;
+      if (v < -1.0f || v > (float)L) continue;
+      if (v <= 0.f) v = 0.f;
+      int l = (int)v, hgh;
+      if (l >= L - 1) { hgh = l = L - 1; v = (float)l; } else hgh = l + 1;
+      const float lw = v - (float)l, hw = 1.f - lw;
+      row[l] += hw;
+      row[hgh] += lw;
+      lo = min(lo, l);
+      hi = max(hi, hgh);
+    }
+    if (hi >= 0) {
+      atomicMin(&lim[isy ? 0 : 2], lo);
+      atomicMax(&lim[isy ? 1 : 3], hi);
+    }
+  }
+  __syncthreads();
+  const int ylo = lim[0], yhi = lim[1], xlo = lim[2], xhi = lim[3];
+  const float inv = 1.f / g.count;
+  const T* fb = feat + (int64_t)g.b * H * W * C;
+  for (int c2 = tid; c2 < C / 2; c2 += blockDim.x) {
+    float o[P][P][2];
+#pragma unroll
+    for (int ph = 0; ph < P; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < P; ++pw) o[ph][pw][0] = o[ph][pw][1] = 0.f;
+    for (int px = xlo; px <= xhi; ++px) {
+      float col[P][2];
+#pragma unroll
+      for (int ph = 0; ph < P; ++ph) col[ph][0] = col[ph][1] = 0.f;
+      for (int py = ylo; py <= yhi; ++py) {
+        float f0, f1;
+        Pair<T>::load(fb + ((int64_t)py * W + px) * C + 2 * c2, f0, f1);
+#pragma unroll
+        for (int ph = 0; ph < P; ++ph) {
+          const float a = Ay[ph * H + py];
+          col[ph][0] = __builtin_fmaf(a, f0, col[ph][0]);
+          col[ph][1] = __builtin_fmaf(a, f1, col[ph][1]);
+        }
+      }
+#pragma unroll
+      for (int pw = 0; pw < P; ++pw) {
+        const float ax = Ax[pw * W + px];
+#pragma unroll
+        for (int ph = 0; ph < P; ++ph) {
+          o[ph][pw][0] = __builtin_fmaf(ax, col[ph][0], o[ph][pw][0]);
+          o[ph][pw][1] = __builtin_fmaf(ax, col[ph][1], o[ph][pw][1]);
+        }
+      }
+    }
+#pragma unroll
+    for (int ph = 0; ph < P; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < P; ++pw)
+        Pair<T>::store(orow + (int64_t)(ph * P + pw) * C + 2 * c2, o[ph][pw][0] * inv, o[ph][pw][1] * inv);
+  }
+}
+
 // Backward.  The bilinear sampling of one ROI is separable: the weight of feature pixel (py, px)
 // in pooled bin (ph, pw) is Ay[ph][py] * Ax[pw][px] / count, with Ay / Ax the 1-D interpolation
 // weights of the bin's sample rows / columns summed over the adaptive grid (the validity test of a
@@ -242,6 +353,16 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
   if (R == 0) return 0;
   SFOD_REQUIRE(C % ((dt == SFOD_F32) ? 4 : 8) == 0, "roi_align: C must be a multiple of the 16-byte vector");
   hipStream_t s = (hipStream_t)stream;
+  const size_t lds = (size_t)pooled * (H + W) * 4 + 16;
+  if (pooled == 7 && lds <= 48 * 1024 && C % 2 == 0) {       // the configs' POOLER_RESOLUTION: separable form
+    if (dt == SFOD_F32)
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<float, 7>), dim3(R), dim3(256), lds, s, (const float*)feat, H, W, C,
+                         rois, scale, (float*)out);
+    else
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<bf16_t, 7>), dim3(R), dim3(256), lds, s, (const bf16_t*)feat, H, W, C,
+                         rois, scale, (bf16_t*)out);
+    return sfod_check_launch("roi_align_fwd_sep");
+  }
   if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_roi_align_fwd<float>, dim3(R), dim3(256), 0, s, (const float*)feat, H, W, C, rois,
                        pooled, scale, (float*)out);
