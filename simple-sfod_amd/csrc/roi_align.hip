@@ -166,7 +166,7 @@ template <typename T, int P>
 __global__ void __launch_bounds__(256)
 k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois, float scale,
                     T* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float sw[];   // Ay [P][H], Ax [P][W], then int lim[4]
+  extern __shared__ __attribute__((aligned(16))) float sw[];   // Ay [P][H], Ax [P][W], then int sup[2 * P][2]
   const int r = blockIdx.x;
   const float* roi = rois + (int64_t)r * 5;
   const int tid = threadIdx.x;
@@ -178,9 +178,8 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
   const RoiGeom g = roi_geom(roi, scale, P);
   float* Ay = sw;
   float* Ax = sw + P * H;
-  int* lim = reinterpret_cast<int*>(Ax + P * W);            // ylo, yhi, xlo, xhi
+  int* sup = reinterpret_cast<int*>(Ax + P * W);            // [ph] (ylo, yhi), then [pw] (xlo, xhi): support of each row
   for (int i = tid; i < P * (H + W); i += blockDim.x) sw[i] = 0.f;
-  if (tid == 0) { lim[0] = H; lim[1] = -1; lim[2] = W; lim[3] = -1; }
   __syncthreads();
   if (tid < 2 * P) {
     const bool isy = tid < P;
@@ -202,50 +201,58 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
       lo = min(lo, l);
       hi = max(hi, hgh);
     }
-    if (hi >= 0) {
-      atomicMin(&lim[isy ? 0 : 2], lo);
-      atomicMax(&lim[isy ? 1 : 3], hi);
-    }
+    sup[2 * tid] = lo;          // lo > hi: this bin row / column has no valid sample
+    sup[2 * tid + 1] = hi;
   }
   __syncthreads();
-  const int ylo = lim[0], yhi = lim[1], xlo = lim[2], xhi = lim[3];
+  int xlo = W, xhi = -1;
+#pragma unroll
+  for (int pw = 0; pw < P; ++pw) { xlo = min(xlo, sup[2 * (P + pw)]); xhi = max(xhi, sup[2 * (P + pw) + 1]); }
   const float inv = 1.f / g.count;
   const T* fb = feat + (int64_t)g.b * H * W * C;
-  for (int c2 = tid; c2 < C / 2; c2 += blockDim.x) {
-    float o[P][P][2];
+  // a lane owns one 16-byte channel vector (a wavefront reads 1 KiB per pixel); the bin rows are spread over the
+  // remaining thread groups like the bins of the sample-by-sample kernel
+  constexpr int V = RVec<T>::N;
+  const int cv = C / V;
+  const int clanes = min(cv, (int)blockDim.x);
+  const int groups = blockDim.x / clanes;
+  const int cl = tid % clanes, grp = tid / clanes;
+  if (grp >= groups) return;
+  for (int c = cl; c < cv; c += clanes) {
+    const T* fc = fb + c * V;
+    for (int ph = grp; ph < P; ph += groups) {
+      // a bin row only sees the few feature rows its samples touch: contract those with Ay, then spread over pw
+      const int ylo = sup[2 * ph], yhi = sup[2 * ph + 1];
+      float o[P][V];
 #pragma unroll
-    for (int ph = 0; ph < P; ++ph)
+      for (int pw = 0; pw < P; ++pw)
 #pragma unroll
-      for (int pw = 0; pw < P; ++pw) o[ph][pw][0] = o[ph][pw][1] = 0.f;
-    for (int px = xlo; px <= xhi; ++px) {
-      float col[P][2];
+        for (int i = 0; i < V; ++i) o[pw][i] = 0.f;
+      for (int px = xlo; px <= xhi; ++px) {
+        float col[V];
 #pragma unroll
-      for (int ph = 0; ph < P; ++ph) col[ph][0] = col[ph][1] = 0.f;
-      for (int py = ylo; py <= yhi; ++py) {
-        float f0, f1;
-        Pair<T>::load(fb + ((int64_t)py * W + px) * C + 2 * c2, f0, f1);
-#pragma unroll
-        for (int ph = 0; ph < P; ++ph) {
+        for (int i = 0; i < V; ++i) col[i] = 0.f;
+        for (int py = ylo; py <= yhi; ++py) {
+          float f[V];
+          RVec<T>::load(fc + ((int64_t)py * W + px) * C, f);
           const float a = Ay[ph * H + py];
-          col[ph][0] = __builtin_fmaf(a, f0, col[ph][0]);
-          col[ph][1] = __builtin_fmaf(a, f1, col[ph][1]);
+#pragma unroll
+          for (int i = 0; i < V; ++i) col[i] = __builtin_fmaf(a, f[i], col[i]);
+        }
+#pragma unroll
+        for (int pw = 0; pw < P; ++pw) {
+          const float ax = Ax[pw * W + px];
+#pragma unroll
+          for (int i = 0; i < V; ++i) o[pw][i] = __builtin_fmaf(ax, col[i], o[pw][i]);
         }
       }
 #pragma unroll
       for (int pw = 0; pw < P; ++pw) {
-        const float ax = Ax[pw * W + px];
 #pragma unroll
-        for (int ph = 0; ph < P; ++ph) {
-          o[ph][pw][0] = __builtin_fmaf(ax, col[ph][0], o[ph][pw][0]);
-          o[ph][pw][1] = __builtin_fmaf(ax, col[ph][1], o[ph][pw][1]);
-        }
+        for (int i = 0; i < V; ++i) o[pw][i] *= inv;
+        RVec<T>::store(orow + (int64_t)(ph * P + pw) * C + c * V, o[pw]);
       }
     }
-#pragma unroll
-    for (int ph = 0; ph < P; ++ph)
-#pragma unroll
-      for (int pw = 0; pw < P; ++pw)
-        Pair<T>::store(orow + (int64_t)(ph * P + pw) * C + 2 * c2, o[ph][pw][0] * inv, o[ph][pw][1] * inv);
   }
 }
 
@@ -353,8 +360,8 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
   if (R == 0) return 0;
   SFOD_REQUIRE(C % ((dt == SFOD_F32) ? 4 : 8) == 0, "roi_align: C must be a multiple of the 16-byte vector");
   hipStream_t s = (hipStream_t)stream;
-  const size_t lds = (size_t)pooled * (H + W) * 4 + 16;
-  if (pooled == 7 && lds <= 48 * 1024 && C % 2 == 0) {       // the configs' POOLER_RESOLUTION: separable form
+  const size_t lds = (size_t)pooled * (H + W) * 4 + 4 * pooled * 4;
+  if (pooled == 7 && lds <= 48 * 1024) {       // the configs' POOLER_RESOLUTION: separable form
     if (dt == SFOD_F32)
       hipLaunchKernelGGL((k_roi_align_fwd_sep<float, 7>), dim3(R), dim3(256), lds, s, (const float*)feat, H, W, C,
                          rois, scale, (float*)out);
