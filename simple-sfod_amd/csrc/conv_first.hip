@@ -59,8 +59,7 @@ k_conv_first(F1Args a) {
     scol[j] = a.scale ? a.scale[j * 32 + l31] : 1.f;
     hcol[j] = a.shift ? a.shift[j * 32 + l31] : 0.f;
   }
-  const bool relu = (a.act == 1);
-  const bool affine = (a.scale != nullptr);
+  const float lo = (a.act == 1) ? 0.f : -__builtin_inff();
 
   for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
     int t = tile;
@@ -103,15 +102,19 @@ k_conv_first(F1Args a) {
     }
     // ---- epilogue: rows of M-fragment i are the 32 pixels of image row y0 + 2*wave + i
     unsigned char* stg = smem + STG_OFF + wave * (64 * STG_PITCH);
+    const bool full = (y0 + TH <= a.H) && (x0 + TW <= a.W);   // interior tile: no row masks
     unsigned vmask[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      unsigned m = 0;
-      const int iy = y0 + 2 * wave + i;
+      unsigned m = 0xffffu;
+      if (!full) {
+        m = 0;
+        const int iy = y0 + 2 * wave + i;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (iy < a.H && x0 + px < a.W) m |= (1u << r);
+        for (int r = 0; r < 16; ++r) {
+          const int px = (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (iy < a.H && x0 + px < a.W) m |= (1u << r);
+        }
       }
       vmask[i] = m;
     }
@@ -129,9 +132,9 @@ k_conv_first(F1Args a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float v = acc[i][j][r];
-            if (affine) v = __builtin_fmaf(v, scol[j], hcol[j]);
-            const float o = fmaxf(v, relu ? 0.f : v);
+            // scol / hcol are (1, 0) without an affine and lo is -inf without a ReLU: two VALU ops per element,
+            // no per-element select on the (uniform) mode
+            const float o = fmaxf(__builtin_fmaf(acc[i][j][r], scol[j], hcol[j]), lo);
             *reinterpret_cast<bf16_t*>(stg + ml * STG_PITCH + (j * 32 + l31) * 2) = (bf16_t)o;
           }
       // same-wave readback (LDS is in order per wave): 8 rows x 128 B per instruction
@@ -153,21 +156,36 @@ k_conv_first(F1Args a) {
       const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        float sm = 0.f;
+        float sm = 0.f, q = 0.f, mean;
+        if (full) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) sm += ((vmask[i] >> r) & 1u) ? acc[i][j][r] : 0.f;
-        sm += __shfl_xor(sm, 32);
-        const float mean = sm * inv;
-        float q = 0.f;
+            for (int r = 0; r < 16; ++r) sm += acc[i][j][r];
+          sm += __shfl_xor(sm, 32);
+          mean = sm * inv;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+          for (int i = 0; i < 2; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const float d = acc[i][j][r] - mean;
-            q += ((vmask[i] >> r) & 1u) ? d * d : 0.f;
-          }
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[i][j][r] - mean;
+              q = __builtin_fmaf(d, d, q);
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sm += ((vmask[i] >> r) & 1u) ? acc[i][j][r] : 0.f;
+          sm += __shfl_xor(sm, 32);
+          mean = sm * inv;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float d = acc[i][j][r] - mean;
+              q += ((vmask[i] >> r) & 1u) ? d * d : 0.f;
+            }
+        }
         q += __shfl_xor(q, 32);
         if (h == 0) {
           sred[(wave * 64 + j * 32 + l31) * 2 + 0] = sm;
