@@ -183,21 +183,23 @@ __device__ __forceinline__ uint64_t nms_row_word(Box bi, int ci, const float* __
   return ((uint64_t)hi << 32) | lo;
 }
 
-__global__ void __launch_bounds__(64)
-k_nms_mask(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
-           const int32_t* __restrict__ classes, const int32_t* __restrict__ mode,
-           const int32_t* __restrict__ n_per_image, int n, float thr, uint64_t* __restrict__ mask) {
-  const int b = blockIdx.z;
-  const int rb = blockIdx.y, cb = blockIdx.x;
+__device__ __forceinline__ void nms_mask_tile(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
+                                              const int32_t* __restrict__ classes, const int32_t* __restrict__ mode,
+                                              const int32_t* __restrict__ n_per_image, int n, float thr,
+                                              uint64_t* __restrict__ mask, int lo_blk, const int32_t* __restrict__ done,
+                                              int b, int rb, int cb, float* cbox, int* ccls) {
+  // progressive NMS (see sfod_nms): a phase covers the blocks that an earlier phase has not computed (both block
+  // indices < lo_blk); images whose keep list is already final are skipped
   if (cb < rb) return;  // only j > i matters
+  if (cb < lo_blk) return;                       // rb <= cb < lo_blk: computed by an earlier phase
+  if (lo_blk > 0 && done[b]) return;
   const int live = n_per_image ? min(n_per_image[b], n) : n;
+  if (rb * 64 >= live) return;                   // rows past the live prefix are never read
   const int CB = (n + 63) / 64;
   const int lane = threadIdx.x;
   const bool use_alt = (mode != nullptr) && (mode[b] != 0) && (alt_boxes != nullptr);
   const float* src = (use_alt ? alt_boxes : boxes) + (int64_t)b * n * 4;
   const bool class_test = (classes != nullptr) && !use_alt;
-  __shared__ __attribute__((aligned(16))) float cbox[64 * 4];
-  __shared__ int ccls[64];
   const int cj = cb * 64 + lane;
   {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);   // columns past the live prefix: empty boxes, masked below
@@ -224,16 +226,52 @@ k_nms_mask(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
   mask[((int64_t)b * n + i) * CB + cb] = bits;
 }
 
+__global__ void __launch_bounds__(64)
+k_nms_mask(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
+           const int32_t* __restrict__ classes, const int32_t* __restrict__ mode,
+           const int32_t* __restrict__ n_per_image, int n, float thr, uint64_t* __restrict__ mask) {
+  __shared__ __attribute__((aligned(16))) float cbox[64 * 4];
+  __shared__ int ccls[64];
+  nms_mask_tile(boxes, alt_boxes, classes, mode, n_per_image, n, thr, mask, 0, nullptr, blockIdx.z, blockIdx.y,
+                blockIdx.x, cbox, ccls);
+}
+
+// later phases: a fixed-size grid walks the phase's tiles, and returns at once when every image is finished (the
+// common case: launching the full 3-D grid just to have ~200 000 workgroups read a flag cost > 100 us)
+__global__ void __launch_bounds__(64)
+k_nms_mask_phase(const float* __restrict__ boxes, const float* __restrict__ alt_boxes,
+                 const int32_t* __restrict__ classes, const int32_t* __restrict__ mode,
+                 const int32_t* __restrict__ n_per_image, int n, float thr, uint64_t* __restrict__ mask,
+                 int lo_blk, const int32_t* __restrict__ done, int CBk, int B) {
+  __shared__ __attribute__((aligned(16))) float cbox[64 * 4];
+  __shared__ int ccls[64];
+  bool all = true;
+  for (int b = 0; b < B; ++b) all = all && (done[b] != 0);
+  if (all) return;
+  const int ncol = CBk - lo_blk;                 // only column blocks >= lo_blk are new
+  const int64_t total = (int64_t)B * CBk * ncol;
+  for (int64_t t = blockIdx.x; t < total; t += gridDim.x) {
+    const int cb = lo_blk + (int)(t % ncol);
+    const int rb = (int)((t / ncol) % CBk);
+    const int b = (int)(t / ((int64_t)ncol * CBk));
+    __syncthreads();                             // LDS tile of the previous iteration is no longer read
+    nms_mask_tile(boxes, alt_boxes, classes, mode, n_per_image, n, thr, mask, lo_blk, done, b, rb, cb, cbox, ccls);
+  }
+}
+
 __global__ void __launch_bounds__(256)
 k_nms_reduce(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ valid,
              const int32_t* __restrict__ n_per_image, int n, int max_keep,
-             int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+             int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count, int n_lim, int phase,
+             int32_t* __restrict__ done) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint64_t* remv = reinterpret_cast<uint64_t*>(smem_raw);  // [CB]
   __shared__ uint64_t s_kept;
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
-  const int live = n_per_image ? min(n_per_image[b], n) : n;
+  if (phase > 0 && done[b]) return;              // an earlier phase already produced the final keep list
+  const int live_all = n_per_image ? min(n_per_image[b], n) : n;
+  const int live = min(live_all, n_lim);         // this phase looks at the n_lim best boxes only
   const int CB = (n + 63) / 64;
   const int CBL = (live + 63) / 64;
   const uint64_t* M = mask + (int64_t)b * n * CB;
@@ -294,7 +332,10 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ vali
     }
     __syncthreads();
   }
-  if (tid == 0) keep_count[b] = nkept;
+  if (tid == 0) {
+    keep_count[b] = nkept;
+    done[b] = (nkept >= max_keep || n_lim >= live_all) ? 1 : 0;   // else a later phase redoes it on more boxes
+  }
 }
 
 // Wide greedy reduce for n <= 16384 (CB <= 256 column words): 16 wavefronts per image.  The
@@ -306,13 +347,16 @@ k_nms_reduce(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ vali
 __global__ void __launch_bounds__(1024)
 k_nms_reduce_wide(const uint64_t* __restrict__ mask, const uint8_t* __restrict__ valid,
                   const int32_t* __restrict__ n_per_image, int n, int max_keep,
-                  int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count) {
+                  int32_t* __restrict__ keep_idx, int32_t* __restrict__ keep_count, int n_lim, int phase,
+                  int32_t* __restrict__ done) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   unsigned long long* remv = reinterpret_cast<unsigned long long*>(smem_raw);  // [CB]
   __shared__ unsigned long long s_kept;
   const int b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int live = n_per_image ? min(n_per_image[b], n) : n;
+  if (phase > 0 && done[b]) return;              // an earlier phase already produced the final keep list
+  const int live_all = n_per_image ? min(n_per_image[b], n) : n;
+  const int live = min(live_all, n_lim);         // this phase looks at the n_lim best boxes only
   const int CB = (n + 63) / 64;
   const int CBL = (live + 63) / 64;
   const uint64_t* M = mask + (int64_t)b * n * CB;
@@ -346,7 +390,7 @@ k_nms_reduce_wide(const uint64_t* __restrict__ mask, const uint8_t* __restrict__
     }
   };
   int nkept = 0;
-  bool done = false;
+  bool full_list = false;
   auto step = [&](int blk, uint64_t (&pre)[4][4], uint64_t diag) {
     if (wave == 0) {
       const int i = blk * 64 + lane;
@@ -374,7 +418,7 @@ k_nms_reduce_wide(const uint64_t* __restrict__ mask, const uint8_t* __restrict__
     __syncthreads();
     const unsigned long long kept = s_kept;
     nkept += __builtin_popcountll(kept);
-    if (nkept >= max_keep) { done = true; return; }
+    if (nkept >= max_keep) { full_list = true; return; }
     if (kept != 0ull) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -388,20 +432,31 @@ k_nms_reduce_wide(const uint64_t* __restrict__ mask, const uint8_t* __restrict__
     __syncthreads();
   };
   if (CBL > 0) prefetch(0, preA, diagA);
-  for (int blk = 0; blk < CBL && !done; blk += 2) {
+  for (int blk = 0; blk < CBL && !full_list; blk += 2) {
     if (blk + 1 < CBL) prefetch(blk + 1, preB, diagB);
     step(blk, preA, diagA);
-    if (done || blk + 1 >= CBL) break;
+    if (full_list || blk + 1 >= CBL) break;
     if (blk + 2 < CBL) prefetch(blk + 2, preA, diagA);
     step(blk + 1, preB, diagB);
   }
-  if (tid == 0) keep_count[b] = nkept;
+  if (tid == 0) {
+    keep_count[b] = nkept;
+    done[b] = (nkept >= max_keep || n_lim >= live_all) ? 1 : 0;   // else a later phase redoes it on more boxes
+  }
 }
 
 extern "C" int64_t sfod_nms_mask_bytes(int B, int n) {
-  return (int64_t)B * n * ((n + 63) / 64) * 8;
+  // bit mask + one "keep list final" flag per image (progressive phases)
+  return (int64_t)B * n * ((n + 63) / 64) * 8 + (((int64_t)B * 4 + 255) / 256) * 256;
 }
 
+// Progressive greedy NMS.  The keep list is final as soon as max_keep boxes are kept, and a box can only be
+// suppressed by a better-scored one, so the result depends only on the best N boxes for the smallest N at which
+// the count is reached (the RPN's 2000 of 9990 are complete after ~3300 boxes: 11 % of the pair tests; the 100
+// detections kept of 16000 class-wise candidates after ~105: 0.004 %).  Phase k computes the suppression bits
+// among the best N_k boxes that earlier phases have not covered and re-runs the greedy reduce on them; a per-image
+// flag written by the reduce makes every later launch return at once for images that are finished.  Results are
+// identical to the one-shot form by construction.
 extern "C" int sfod_nms(const float* boxes, const float* alt_boxes, const int32_t* classes,
                         const int32_t* mode, const uint8_t* valid, const int32_t* n_per_image, int B,
                         int n, float thr, int max_keep, uint64_t* mask, int32_t* keep_idx,
@@ -414,18 +469,45 @@ extern "C" int sfod_nms(const float* boxes, const float* alt_boxes, const int32_
   }
   const int CB = (n + 63) / 64;
   SFOD_REQUIRE(CB * 8 <= 64 * 1024, "nms: n too large for the LDS removal set");
-  dim3 grid(CB, CB, B);
-  hipLaunchKernelGGL(k_nms_mask, grid, dim3(64), 0, s, boxes, alt_boxes, classes, mode, n_per_image, n,
-                     thr, mask);
-  int rc = sfod_check_launch("nms_mask");
-  if (rc) return rc;
-  if (CB <= 256)
-    hipLaunchKernelGGL(k_nms_reduce_wide, dim3(B), dim3(1024), CB * 8, s, mask, valid, n_per_image, n, max_keep,
-                       keep_idx, keep_count);
-  else
-    hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(256), CB * 8, s, mask, valid, n_per_image, n, max_keep,
-                       keep_idx, keep_count);
-  return sfod_check_launch("nms_reduce");
+  int32_t* done = reinterpret_cast<int32_t*>(reinterpret_cast<char*>(mask) + (int64_t)B * n * CB * 8);
+  // phase sizes: ~2x max_keep first (at least 512), then 3x that, then everything
+  int lims[3], nph = 0;
+  int64_t l0 = ((int64_t)2 * max_keep + 96 + 63) / 64 * 64;
+  if (l0 < 512) l0 = 512;
+  if (l0 * 5 / 4 >= n) {
+    lims[nph++] = n;
+  } else {
+    lims[nph++] = (int)l0;
+    if (l0 * 3 * 5 / 4 < n) lims[nph++] = (int)(l0 * 3);
+    lims[nph++] = n;
+  }
+  int lo_blk = 0;
+  for (int ph = 0; ph < nph; ++ph) {
+    const int n_lim = lims[ph];
+    const int CBk = (n_lim + 63) / 64;
+    if (ph == 0) {
+      dim3 grid(CBk, CBk, B);
+      hipLaunchKernelGGL(k_nms_mask, grid, dim3(64), 0, s, boxes, alt_boxes, classes, mode, n_per_image, n, thr,
+                         mask);
+    } else {
+      const int64_t total = (int64_t)B * CBk * (CBk - lo_blk);
+      const int g = (int)(total < 16384 ? total : 16384);
+      hipLaunchKernelGGL(k_nms_mask_phase, dim3(g), dim3(64), 0, s, boxes, alt_boxes, classes, mode, n_per_image, n,
+                         thr, mask, lo_blk, done, CBk, B);
+    }
+    int rc = sfod_check_launch("nms_mask");
+    if (rc) return rc;
+    if (CB <= 256)
+      hipLaunchKernelGGL(k_nms_reduce_wide, dim3(B), dim3(1024), CB * 8, s, mask, valid, n_per_image, n, max_keep,
+                         keep_idx, keep_count, n_lim, ph, done);
+    else
+      hipLaunchKernelGGL(k_nms_reduce, dim3(B), dim3(256), CB * 8, s, mask, valid, n_per_image, n, max_keep,
+                         keep_idx, keep_count, n_lim, ph, done);
+    rc = sfod_check_launch("nms_reduce");
+    if (rc) return rc;
+    lo_blk = CBk;
+  }
+  return 0;
 }
 
 __global__ void k_gather_kept(const float* __restrict__ cboxes, const float* __restrict__ cscores,

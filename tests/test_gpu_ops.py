@@ -498,6 +498,28 @@ def test_nms_large_bit_exact(native, n, max_keep, dense):
         assert keep_idx[b, :c].cpu().long().tolist() == ref.tolist()
 
 
+def test_nms_progressive_phases_mixed_images(native):
+    """Progressive NMS: image 0 (sparse boxes) reaches max_keep inside the first phase's 4096 boxes and is skipped by
+    the later launches, image 1 (dense boxes) does not and is redone on more boxes, image 2 has a short live prefix.
+    All three must equal the one-shot greedy result."""
+    g = torch.Generator().manual_seed(77)
+    n, max_keep = 9990, 2000
+    base = _rand_boxes(300, g, span=1100.0, size=220.0)       # image 1: 300 clusters of near-duplicates
+    dup = base[torch.randint(0, 300, (n,), generator=g)] + torch.rand(n, 4, generator=g)
+    boxes = torch.stack([_rand_boxes(n, g, span=1100.0, size=220.0), dup, _rand_boxes(n, g, span=1100.0, size=220.0)])
+    npi = torch.tensor([n, n, 700], dtype=torch.int32)
+    keep_idx, keep_cnt = native.nms(boxes.to(DEV), 0.7, max_keep, n_per_image=npi.to(DEV))
+    counts = []
+    for b in range(3):
+        m = int(npi[b])
+        ref = OB.nms(boxes[b, :m], torch.arange(m, 0, -1).float(), 0.7)[:max_keep]
+        c = keep_cnt[b].item()
+        counts.append(c)
+        assert c == len(ref)
+        assert keep_idx[b, :c].cpu().long().tolist() == ref.tolist()
+    assert counts[0] == max_keep and counts[1] < max_keep      # the two regimes the phases distinguish
+
+
 @pytest.mark.parametrize("n", [2, 100, 9990, 16000, 16384, 20000])
 def test_segmented_sort_stable_descending_with_ties(native, n):
     """LDS bitonic sort (n <= 16384) and the radix fallback: order identical to
