@@ -3,8 +3,8 @@
 // (box_pooler = d2 ROIPooler -> ROIAlign(7, 1/stride, 0, aligned=True)); SURVEY A.11.
 //
 // Forward: one workgroup per ROI, 16-byte channel vectors across the lanes; the feature map of the
-// hot config is 18x37x512 (<= 1.4 MB) and stays L2-resident, so the [R,49,C] output writes are the
-// HBM traffic.  Backward: separable weights, one atomic per footprint pixel and channel.
+// hot config is 37x75x512 (2.8 MB in bf16) and stays L2-resident, so the [R,49,C] output writes are the
+// HBM traffic.  Backward: tiled gather (one owner per gradient element, no atomics) for pooled == 7.
 #include "common.h"
 
 struct Sample {
@@ -343,10 +343,180 @@ k_roi_align_bwd(const T* __restrict__ dout, int H, int W, int C, const float* __
   }
 }
 
+// Backward, gather form (pooled == 7).  One workgroup owns an 8x8-pixel tile of one image's gradient map
+// for a 256-channel slice: it lists the ROIs whose footprint touches the tile (in ROI order: ballot +
+// prefix, so the fp32 summation order is fixed), then for each of them forms the tile-restricted
+// separable weights Ay [7][8] / Ax [7][8] (14 threads, double-buffered in LDS) and every thread (one
+// channel) accumulates  acc[py][px] += sum_ph Ay[ph][py] * (sum_pw Ax[pw][px] * g[ph][pw])  in
+// registers.  Each gradient element has exactly one owner: no atomics, one read-modify-write of the
+// tile at the end, and the result is bit-reproducible.  Bin rows / columns whose weights are all zero
+// inside the tile are skipped (wave-uniform masks).
+constexpr int RT = 8;            // tile edge in feature pixels
+constexpr int RT_LIST = 4096;    // ROI ids listed per pass
+
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_roi_align_bwd_tiled(const T* __restrict__ dout, int H, int W, int C, const float* __restrict__ rois, int R,
+                      float scale, float* __restrict__ dfeat) {
+  constexpr int P = 7;
+  __shared__ int list[RT_LIST];
+  __shared__ __attribute__((aligned(16))) float wts[2][2][P][RT];   // [buffer][y|x][bin][pixel]
+  __shared__ int masks[2][2];
+  __shared__ int wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int ntx = (W + RT - 1) / RT;
+  const int y0 = (blockIdx.x / ntx) * RT, x0 = (blockIdx.x % ntx) * RT;
+  const int b = blockIdx.z;
+  const int c = blockIdx.y * 256 + tid;
+  const bool cok = c < C;
+  float acc[RT][RT];
+#pragma unroll
+  for (int i = 0; i < RT; ++i)
+#pragma unroll
+    for (int j = 0; j < RT; ++j) acc[i][j] = 0.f;
+
+  // weights of ROI r restricted to the tile -> buffer `buf`; run by threads 0 .. 2P-1
+  auto build = [&](int r, int buf) {
+    const RoiGeom g = roi_geom(rois + (int64_t)r * 5, scale, P);
+    const bool isy = tid < P;
+    const int p = isy ? tid : tid - P;
+    const int L = isy ? H : W, o = isy ? y0 : x0;
+    const int gn = isy ? g.grid_h : g.grid_w;
+    const float start = isy ? g.start_h : g.start_w, bin = isy ? g.bin_h : g.bin_w;
+    float row[RT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i) row[i] = 0.f;
+    for (int i = 0; i < gn; ++i) {
+      float v = start + (float)p * bin + ((float)i + .5f) * bin / (float)gn;
+      if (v < -1.0f || v > (float)L) continue;
+      if (v <= 0.f) v = 0.f;
+      int l = (int)v, hgh;
+      if (l >= L - 1) { hgh = l = L - 1; v = (float)l; } else hgh = l + 1;
+      const float lw = v - (float)l, hw = 1.f - lw;
+#pragma unroll
+      for (int k = 0; k < RT; ++k) {
+        if (l - o == k) row[k] += hw;
+        if (hgh - o == k) row[k] += lw;
+      }
+    }
+    bool nz = false;
+#pragma unroll
+    for (int k = 0; k < RT; ++k) {
+      wts[buf][isy ? 0 : 1][p][k] = row[k];
+      nz |= row[k] != 0.f;
+    }
+    if (nz) atomicOr(&masks[buf][isy ? 0 : 1], 1 << p);
+  };
+
+  for (int r0 = 0; r0 < R; r0 += RT_LIST) {
+    // ---- ROIs of image b touching the tile, in ROI order -----------------------------------------
+    int n = 0;
+    const int rend = min(R, r0 + RT_LIST);
+    for (int rb = r0; rb < rend; rb += 256) {
+      const int r = rb + tid;
+      bool hit = false;
+      if (r < rend) {
+        const float* roi = rois + (int64_t)r * 5;
+        if (roi[0] >= 0.f && (int)roi[0] == b) {
+          const RoiGeom g = roi_geom(roi, scale, P);
+          if (g.grid_h > 0 && g.grid_w > 0) {
+            // footprint bound: samples lie in [start, start + P*bin], a sample touches floor(v), floor(v)+1
+            const float eh = g.start_h + (float)P * g.bin_h, ew = g.start_w + (float)P * g.bin_w;
+            const int ylo = (int)fmaxf(g.start_h, 0.f), yhi = min((int)fmaxf(eh, 0.f) + 1, H - 1);
+            const int xlo = (int)fmaxf(g.start_w, 0.f), xhi = min((int)fmaxf(ew, 0.f) + 1, W - 1);
+            hit = eh >= -1.f && ew >= -1.f && g.start_h <= (float)H && g.start_w <= (float)W &&
+                  ylo < y0 + RT && yhi >= y0 && xlo < x0 + RT && xhi >= x0;
+          }
+        }
+      }
+      const uint64_t bal = __ballot(hit);
+      if (lane == 0) wtot[wv] = __popcll(bal);
+      __syncthreads();
+      int base = n;
+      for (int k = 0; k < wv; ++k) base += wtot[k];
+      if (hit) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = r;
+      n += wtot[0] + wtot[1] + wtot[2] + wtot[3];
+      __syncthreads();
+    }
+    if (n == 0) continue;
+
+    // ---- accumulate ------------------------------------------------------------------------------
+    if (tid < 4) masks[tid >> 1][tid & 1] = 0;
+    __syncthreads();
+    if (tid < 2 * P) build(list[0], 0);
+    __syncthreads();
+    for (int i = 0; i < n; ++i) {
+      const int buf = i & 1;
+      const int ym = masks[buf][0], xm = masks[buf][1];
+      if (i + 1 < n && tid < 2 * P) build(list[i + 1], buf ^ 1);
+      if (ym != 0 && xm != 0 && cok) {
+        const int r = list[i];
+        const float* roi = rois + (int64_t)r * 5;
+        const RoiGeom g = roi_geom(roi, scale, P);
+        const float inv = 1.f / g.count;
+        const T* grow = dout + (int64_t)r * (P * P) * C + c;
+        float gv[P][P];
+#pragma unroll
+        for (int ph = 0; ph < P; ++ph)
+#pragma unroll
+          for (int pw = 0; pw < P; ++pw)
+            gv[ph][pw] = to_f32(grow[(int64_t)(ph * P + pw) * C]);   // unconditional: all 49 in flight
+        float ax[P][RT];
+#pragma unroll
+        for (int pw = 0; pw < P; ++pw) {
+          const float4 a0 = *reinterpret_cast<const float4*>(&wts[buf][1][pw][0]);
+          const float4 a1 = *reinterpret_cast<const float4*>(&wts[buf][1][pw][4]);
+          ax[pw][0] = a0.x * inv; ax[pw][1] = a0.y * inv; ax[pw][2] = a0.z * inv; ax[pw][3] = a0.w * inv;
+          ax[pw][4] = a1.x * inv; ax[pw][5] = a1.y * inv; ax[pw][6] = a1.z * inv; ax[pw][7] = a1.w * inv;
+        }
+#pragma unroll
+        for (int ph = 0; ph < P; ++ph) {
+          if (!((ym >> ph) & 1)) continue;
+          float t[RT];
+#pragma unroll
+          for (int px = 0; px < RT; ++px) {
+            float a = 0.f;
+#pragma unroll
+            for (int pw = 0; pw < P; ++pw) a = fmaf(ax[pw][px], gv[ph][pw], a);
+            t[px] = a;
+          }
+          const float4 b0 = *reinterpret_cast<const float4*>(&wts[buf][0][ph][0]);
+          const float4 b1 = *reinterpret_cast<const float4*>(&wts[buf][0][ph][4]);
+          const float ay[RT] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+          for (int py = 0; py < RT; ++py)
+#pragma unroll
+            for (int px = 0; px < RT; ++px) acc[py][px] = fmaf(ay[py], t[px], acc[py][px]);
+        }
+      }
+      __syncthreads();
+      if (tid < 2) masks[buf][tid] = 0;      // buffer `buf` is rebuilt for ROI i+2 after the next barrier
+    }
+    __syncthreads();
+  }
+  if (!cok) return;
+  float* fb = dfeat + (int64_t)b * H * W * C + c;
+#pragma unroll
+  for (int py = 0; py < RT; ++py)
+#pragma unroll
+    for (int px = 0; px < RT; ++px) {
+      const int y = y0 + py, x = x0 + px;
+      if (y < H && x < W && acc[py][px] != 0.f) fb[((int64_t)y * W + x) * C] += acc[py][px];
+    }
+}
+
+// SFOD_ROI_BWD_ATOMIC=1 selects the scatter (atomic) form for A/B measurements.
+static const bool g_roi_bwd_tiled = []() { const char* e = getenv("SFOD_ROI_BWD_ATOMIC"); return !(e && e[0] == '1'); }();
+
 template <typename T>
 static int dispatch_roi_bwd(const void* dout, int B, int H, int W, int C, const float* rois, int R, int pooled,
                             float scale, float* dfeat, hipStream_t s) {
-  (void)B;
+  if (pooled == 7 && g_roi_bwd_tiled) {
+    const dim3 grid(((H + RT - 1) / RT) * ((W + RT - 1) / RT), (C + 255) / 256, B);
+    hipLaunchKernelGGL(k_roi_align_bwd_tiled<T>, grid, dim3(256), 0, s, (const T*)dout, H, W, C, rois, R, scale,
+                       dfeat);
+    return sfod_check_launch("roi_align_bwd_tiled");
+  }
   const size_t lds = (size_t)pooled * (H + W) * 4 + 16;
   SFOD_REQUIRE(lds <= 64 * 1024, "roi_align_bwd: feature map too large");
   hipLaunchKernelGGL(k_roi_align_bwd<T>, dim3(R), dim3(256), lds, s, (const T*)dout, H, W, C, rois, pooled, scale,

@@ -444,6 +444,31 @@ def test_roi_align_many_rois_unordered_images(native):
     assert rel_err(dfeat2.cpu(), 2 * dfeat.cpu()) < 1e-5
 
 
+def test_roi_align_bwd_tiled_gather_reproducible_and_chunked(native):
+    """The pooled-7 backward is a gather (one owner per gradient element): two runs are bit-equal, more
+    ROIs than one list pass holds (4096) are processed in chunks, maps whose sides are not multiples of the
+    8-pixel tile and ROIs hanging over every border are handled; checked against the oracle's autograd."""
+    g = torch.Generator().manual_seed(33)
+    B, C, H, W = 2, 40, 21, 30
+    n = 4500
+    xy = torch.rand(n, 2, generator=g) * torch.tensor([W * 16.0 + 60, H * 16.0 + 60]) - 60
+    wh = torch.rand(n, 2, generator=g) * torch.tensor([260.0, 200.0]) + 0.5
+    rois = torch.cat([torch.randint(0, B, (n, 1), generator=g).float(), xy, xy + wh], 1)
+    rois[::211, 0] = -1
+    rois[3] = torch.tensor([1, -500.0, -500.0, -400.0, -450.0])      # entirely outside: no samples
+    rois[4] = torch.tensor([0, 10.0, 10.0, 10.0, 10.0])              # zero-sized
+    live = rois[:, 0] >= 0
+    fr = torch.zeros(B, C, H, W, requires_grad=True)
+    ref = oracle_roi_align(fr, rois[live], 7, 1 / 16.0, 0, True)
+    dout = torch.randn(n, C, 7, 7, generator=g)
+    ref.backward(dout[live])
+    dd = dout.permute(0, 2, 3, 1).reshape(n, 49, C).contiguous().to(DEV)
+    d1 = native.roi_align_bwd(dd, rois.to(DEV), (B, H, W, C), 7, 1 / 16.0)
+    d2 = native.roi_align_bwd(dd, rois.to(DEV), (B, H, W, C), 7, 1 / 16.0)
+    assert torch.equal(d1, d2)
+    assert rel_err(nchw(d1.cpu()), fr.grad) < 1e-5
+
+
 # -------------------------------------------------------------------------------------------------
 # NMS / sort / matcher / sampling: bit-exact
 # -------------------------------------------------------------------------------------------------
