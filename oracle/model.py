@@ -371,6 +371,29 @@ def teacher_forward(sd, images_u8, cfg):
     return props, dets
 
 
+def eval_inference(sd, images_u8, cfg, out_sizes=None):
+    """d2 ``GeneralizedRCNN.inference`` in eval mode (BN on running statistics, TEST top-k 6000 / 1000) +
+    ``detector_postprocess``: rescale the boxes to ``out_sizes`` [(h, w)], clip, drop empty (reached from
+    ``source_free_adaptive_teacher_rcnn.py:129-130`` and ``DefaultTrainer.test``)."""
+    with torch.no_grad():
+        x, sizes = preprocess(images_u8)
+        feat = vgg_forward(sd, x, cfg, training=False)
+        logits, deltas = rpn_head(sd, feat)
+        anchors = anchors_for(feat.shape[-2:], cfg)
+        props = rpn_proposals(anchors, logits, deltas, sizes, cfg, training=False)
+        scores, bdeltas, _ = box_head(sd, feat, [p[0] for p in props], cfg)
+        dets = fast_rcnn_inference(scores, bdeltas, [p[0] for p in props], sizes, cfg)
+        out = []
+        for n, det in enumerate(dets):
+            oh, ow = out_sizes[n] if out_sizes is not None else sizes[n]
+            sx, sy = ow / sizes[n][1], oh / sizes[n][0]
+            bx = det["boxes"] * torch.tensor([sx, sy, sx, sy])
+            bx = B.clip_boxes(bx, (oh, ow))
+            keep = B.nonempty(bx, 0.0)
+            out.append({"boxes": bx[keep], "scores": det["scores"][keep], "classes": det["classes"][keep]})
+    return out
+
+
 def student_losses(sd, images_u8, gt_boxes_list, gt_classes_list, rpn_keys, roi_keys, cfg,
                    return_aux=False, proposals=None):
     """branch='supervised_target' (rcnn.py:259-312) without the dead 2nd ROI pass / BPC.

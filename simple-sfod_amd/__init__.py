@@ -10,4 +10,4 @@ The directory name is not a Python identifier; import it with
 __version__ = "0.1.0"
 
 from . import config, structures, native, registry  # noqa: F401
-from . import modeling, engine, data, checkpoint  # noqa: F401  (registers the architectures by import)
+from . import modeling, engine, data, checkpoint, evaluation  # noqa: F401  (registers the architectures by import)

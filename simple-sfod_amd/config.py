@@ -385,6 +385,7 @@ def add_native_config(cfg):
     _C.SFOD.SYNTHETIC.HEIGHT = 1024
     _C.SFOD.SYNTHETIC.WIDTH = 2048
     _C.SFOD.SYNTHETIC.NUM_IMAGES = 64
+    _C.SFOD.SYNTHETIC.NUM_TEST_IMAGES = 16    # size of the synthetic evaluation set (Trainer.test)
     _C.SFOD.SYNTHETIC.BOXES_PER_IMAGE = 12
     # keep the full-size frames on the device and run the mapper's ResizeShortestEdge (+ flip) there every
     # iteration (sfod_resize_bilinear_u8, bit-exact with Pillow); False: resize once with Pillow at start-up

@@ -1,1 +1,2 @@
-from .synthetic import SyntheticTargetDataset, TwoCropLoader, TrainingSampler  # noqa: F401
+from .synthetic import (SyntheticTargetDataset, TwoCropLoader, TrainingSampler, InferenceSampler,  # noqa: F401
+                        TestLoader, CITYSCAPES_CLASSES)

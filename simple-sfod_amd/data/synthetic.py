@@ -95,6 +95,69 @@ class SyntheticTargetDataset:
     def __len__(self):
         return len(self.items)
 
+    def dataset_dicts(self, cfg):
+        """d2 dataset records (annotations at the frames' native size) -- the evaluator's ground truth."""
+        s = cfg.SFOD.SYNTHETIC
+        out = []
+        for i in range(len(self.items)):
+            _, boxes, classes = make_frame(i, s.HEIGHT, s.WIDTH, s.BOXES_PER_IMAGE, seed=max(cfg.SEED, 0))
+            out.append(coco_record(i, s.HEIGHT, s.WIDTH, boxes, classes))
+        return out
+
+
+class InferenceSampler:
+    """d2 InferenceSampler: rank r takes one contiguous share of range(size) (shares differ by at most 1)."""
+
+    def __init__(self, size, rank=0, world=1):
+        shard = size // world
+        left = size % world
+        sizes = [shard + int(r < left) for r in range(world)]
+        begin = sum(sizes[:rank])
+        self.indices = range(begin, min(begin + sizes[rank], size))
+
+    def __iter__(self):
+        return iter(self.indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+
+class TestLoader:
+    """``build_detection_test_loader(cfg, name, batch_size=TEST.IMS_PER_BATCH, mapper=DatasetMapperAnnotation(
+    cfg, is_train=False))`` (``base.py:163-171``): dataset order, ResizeShortestEdge(MIN_SIZE_TEST,
+    MAX_SIZE_TEST), no flip; ``height`` / ``width`` are the frame's native size (what ``detector_postprocess``
+    rescales the detections to)."""
+
+    def __init__(self, cfg, device, rank=0, world=1, dataset=None):
+        self.dataset = dataset or SyntheticTargetDataset(cfg, device, num_images=cfg.SFOD.SYNTHETIC.NUM_TEST_IMAGES,
+                                                         train=False)
+        self.batch = max(int(cfg.TEST.IMS_PER_BATCH), 1)
+        self.sampler = InferenceSampler(len(self.dataset), rank, world)
+
+    def __len__(self):
+        return (len(self.sampler) + self.batch - 1) // self.batch
+
+    def _map(self, item):
+        img = item["image"]
+        if getattr(self.dataset, "device_resize", False):
+            newh, neww = self.dataset.size
+            img = native.resize_bilinear_u8(img, newh, neww, flip=False)
+        inst = Instances((int(img.shape[1]), int(img.shape[2])))
+        inst.gt_boxes = Boxes(item["boxes"])
+        inst.gt_classes = item["classes"]
+        return {"image": img, "instances": inst, "height": item["height"], "width": item["width"],
+                "image_id": item["image_id"], "file_name": item["file_name"]}
+
+    def __iter__(self):
+        batch = []
+        for idx in self.sampler:
+            batch.append(self._map(self.dataset.items[idx]))
+            if len(batch) == self.batch:
+                yield batch
+                batch = []
+        if batch:
+            yield batch
+
 
 class TrainingSampler:
     """d2 TrainingSampler: one shared-seed infinite permutation stream, rank r takes r, r+W, ..."""

@@ -1,3 +1,3 @@
 from .trainer import (BaseTrainer, SourceFreeAdaptiveTeacherTrainer,  # noqa: F401
-                      SourceFreeAdaptiveTeacherSingleTrainer, adabn_refinement, get_trainer_class)
+                      SourceFreeAdaptiveTeacherSingleTrainer, adabn_refinement, test_refinement, get_trainer_class)
 from .solver import FusedSGD, FlatModelState, WarmupMultiStepLR, build_optimizer  # noqa: F401

@@ -182,6 +182,50 @@ class BaseTrainer:
     def build_train_loader(self, cfg):
         return TwoCropLoader(cfg, self.device, get_rank(), get_world_size(), labeled=True)
 
+    # ---- evaluation (d2 DefaultTrainer.test; base.py:125-171) ------------------------------------------
+    @classmethod
+    def build_test_loader(cls, cfg, dataset_name):
+        from ..data import TestLoader
+        return TestLoader(cfg, torch.device(cfg.MODEL.DEVICE), get_rank(), get_world_size())
+
+    @classmethod
+    def build_evaluator(cls, cfg, dataset_name, output_folder=None, data_loader=None):
+        """``NewCOCOEvaluator`` for the "coco" evaluator type (base.py:133-142); the synthetic target set
+        stands in for the registered datasets (no dataset files in the build environment)."""
+        from ..data import CITYSCAPES_CLASSES, TestLoader
+        from ..evaluation import NewCOCOEvaluator
+        loader = data_loader or TestLoader(cfg, torch.device("cpu"))
+        names = CITYSCAPES_CLASSES[: cfg.MODEL.ROI_HEADS.NUM_CLASSES]
+        if len(names) < cfg.MODEL.ROI_HEADS.NUM_CLASSES:
+            names = [str(i) for i in range(cfg.MODEL.ROI_HEADS.NUM_CLASSES)]
+        return NewCOCOEvaluator(dataset_name, loader.dataset.dataset_dicts(cfg), names, output_dir=output_folder)
+
+    @classmethod
+    def test(cls, cfg, model, evaluators=None):
+        """``DefaultTrainer.test``: one ``inference_on_dataset`` per ``DATASETS.TEST`` entry ->
+        ``OrderedDict{dataset: results}``, flattened when there is a single dataset."""
+        from collections import OrderedDict
+        from ..evaluation import inference_on_dataset, print_csv_format
+        if evaluators is not None and not isinstance(evaluators, (list, tuple)):
+            evaluators = [evaluators]
+        names = list(cfg.DATASETS.TEST) or ["synthetic_test"]
+        if evaluators is not None:
+            assert len(names) == len(evaluators), "{} != {}".format(len(names), len(evaluators))
+        results = OrderedDict()
+        for idx, dataset_name in enumerate(names):
+            data_loader = cls.build_test_loader(cfg, dataset_name)
+            evaluator = evaluators[idx] if evaluators is not None else \
+                cls.build_evaluator(cfg, dataset_name, data_loader=data_loader)
+            results_i = inference_on_dataset(model, data_loader, evaluator)
+            results[dataset_name] = results_i
+            if get_rank() == 0:
+                assert isinstance(results_i, dict), \
+                    "Evaluator must return a dict on the main process. Got {} instead.".format(results_i)
+                print_csv_format(results_i)
+        if len(results) == 1:
+            results = list(results.values())[0]
+        return results
+
     # ---- step ----------------------------------------------------------------------------------------
     def run_step(self):
         assert self.model.training, "[BaseTrainer] model was changed to eval mode!"
@@ -490,6 +534,17 @@ def adabn_refinement(cfg, model, data_loader, max_iters=1400):
         images = model.preprocess_image(data)
         model._features(images)
     return model
+
+
+def test_refinement(cfg, model, data_loader, max_iters=1400, trainer_cls=None):
+    """``base.py:270-315`` as called from ``adabn_refinement`` (:330-337): the statistics passes, then
+    ``trainer.test(cfg, model)`` and a ``adabn.pth`` checkpoint in ``OUTPUT_DIR``.  -> test results."""
+    adabn_refinement(cfg, model, data_loader, max_iters)
+    results = (trainer_cls or BaseTrainer).test(cfg, model)
+    if get_rank() == 0 and cfg.OUTPUT_DIR:
+        os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
+        torch.save({"model": model.state_dict()}, os.path.join(cfg.OUTPUT_DIR, "adabn.pth"))
+    return results
 
 
 TRAINERS = {

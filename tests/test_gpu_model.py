@@ -388,6 +388,77 @@ def test_teacher_pseudo_label_pipeline_matches_oracle(sfod, native):
             torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6)
 
 
+def test_eval_mode_inference_and_trainer_test_match_oracle(sfod, native, tmp_path):
+    """Evaluation path: eval-mode ``model(inputs)`` (BN on running statistics, TEST top-k,
+    detector_postprocess to the native frame size) against the oracle, detection by detection; then
+    ``Trainer.test`` on the synthetic evaluation set: the AP table from the device detections equals the
+    table computed from the oracle's detections through the same evaluator."""
+    opts = ["SFOD.COMPUTE_DTYPE", "fp32", "SFOD.SYNTHETIC.HEIGHT", "192", "SFOD.SYNTHETIC.WIDTH", "384",
+            "SFOD.SYNTHETIC.NUM_TEST_IMAGES", "3", "SFOD.SYNTHETIC.BOXES_PER_IMAGE", "4", "INPUT.MIN_SIZE_TEST", "128",
+            "TEST.IMS_PER_BATCH", "2", "DATASETS.TEST", "('synthetic_cityscapes_foggy_val',)"]
+    cfg = make_cfg(sfod, opts=opts)
+    torch.manual_seed(17)
+    model = sfod.modeling.build_model(cfg).train()
+    with torch.no_grad():     # planted scores: some detections clear TEST.SCORE_THRESH with distinct scores
+        model.roi_heads.box_predictor.cls_score.weight.mul_(60.0)
+        model.roi_heads.box_predictor.bbox_pred.weight.mul_(20.0)
+        for name, buf in model.named_buffers():
+            if name.endswith("running_mean"):
+                buf.normal_(0.0, 0.05)
+            if name.endswith("running_var"):
+                buf.uniform_(0.5, 1.5)
+    sd = oracle_state(model)
+    loader = sfod.engine.BaseTrainer.build_test_loader(cfg, "synthetic_cityscapes_foggy_val")
+    batches = list(loader)
+    assert [len(b) for b in batches] == [2, 1]
+    model.eval()
+    ev_dev = sfod.engine.BaseTrainer.build_evaluator(cfg, "x", data_loader=loader)
+    ev_ref = sfod.engine.BaseTrainer.build_evaluator(cfg, "x", data_loader=loader)
+    S = sfod.structures
+    ndet = 0
+    for batch in batches:
+        outs = model(batch)
+        ref = om.eval_inference(sd, [d["image"].cpu() for d in batch], om.Cfg(),
+                                [(d["height"], d["width"]) for d in batch])
+        ev_dev.process(batch, outs)
+        ref_outs = []
+        for o, r, d in zip(outs, ref, batch):
+            inst = o["instances"]
+            assert inst.image_size == (d["height"], d["width"]) == (192, 384)
+            nd, ndr = len(inst), len(r["scores"])
+            assert abs(nd - ndr) <= 2 and ndr > 0
+            db, ds, dc = inst.pred_boxes.tensor.cpu(), inst.scores.cpu(), inst.pred_classes.cpu().long()
+            assert (ds[:-1] >= ds[1:]).all()
+            hit = 0
+            for j in range(ndr):
+                m = (dc == r["classes"][j]) & ((db - r["boxes"][j]).abs().max(1).values < 0.5) \
+                    & ((ds - r["scores"][j]).abs() < 1e-3)
+                hit += bool(m.any())
+            assert hit >= 0.95 * ndr
+            ndet += ndr
+            ri = S.Instances((d["height"], d["width"]))
+            ri.pred_boxes, ri.scores, ri.pred_classes = S.Boxes(r["boxes"]), r["scores"], r["classes"]
+            ref_outs.append({"instances": ri})
+        ev_ref.process(batch, ref_outs)
+    assert ndet > 10
+    r_dev, r_ref = ev_dev.evaluate()["bbox"], ev_ref.evaluate()["bbox"]
+    assert list(r_dev.keys()) == list(r_ref.keys())
+    for k in r_ref:
+        a, b = r_dev[k], r_ref[k]
+        assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 1.0, (k, a, b)
+    # Trainer.test: same loader / evaluator construction, model restored to its mode, flattened single dataset
+    model.train()
+    res = sfod.engine.BaseTrainer.test(cfg, model)
+    assert model.training and list(res.keys()) == ["bbox"]
+    for k in r_dev:
+        assert (np.isnan(res["bbox"][k]) and np.isnan(r_dev[k])) or abs(res["bbox"][k] - r_dev[k]) < 1e-9
+    # --eval-only: AdaBN passes, then the test, then the "adabn" checkpoint (base.py:270-337)
+    cfg2 = make_cfg(sfod, opts=opts + ["OUTPUT_DIR", str(tmp_path)])
+    data = [[dict(d) for d in b] for b in batches]
+    res2 = sfod.engine.test_refinement(cfg2, model, data, max_iters=2)
+    assert "bbox" in res2 and os.path.isfile(os.path.join(str(tmp_path), "adabn.pth"))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", dtype, "SOLVER.IMS_PER_BATCH_TARGET", "2",

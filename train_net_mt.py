@@ -17,7 +17,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config-file", default="", metavar="FILE")
     ap.add_argument("--num-gpus", type=int, default=1)
-    ap.add_argument("--eval-only", action="store_true", help="AdaBN refinement (train_net_mt.py:73-82)")
+    ap.add_argument("--eval-only", action="store_true", help="AdaBN refinement + evaluation (train_net_mt.py:73-82)")
+    ap.add_argument("--adabn-iters", type=int, default=1400, help="statistics passes of the refinement (base.py:300)")
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
     args = ap.parse_args()
@@ -41,11 +42,11 @@ def main():
         # DetectionCheckpointer(model).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume) (train_net_mt.py:75-77)
         sfod.checkpoint.load_model_weights(model, cfg.MODEL.WEIGHTS)
         loader = sfod.data.TwoCropLoader(cfg, torch.device(cfg.MODEL.DEVICE), rank, world, labeled=True)
-        sfod.engine.adabn_refinement(cfg, model, loader)
-        if rank == 0 and cfg.OUTPUT_DIR:
-            os.makedirs(cfg.OUTPUT_DIR, exist_ok=True)
-            torch.save({"model": model.state_dict()}, os.path.join(cfg.OUTPUT_DIR, "adabn.pth"))
-        return
+        # base.adabn_refinement(cfg, model): reset BN statistics, <= 1400 forward passes, Trainer.test, save "adabn"
+        results = sfod.engine.test_refinement(cfg, model, loader, max_iters=args.adabn_iters, trainer_cls=Trainer)
+        if rank == 0:
+            print(results)
+        return results
     trainer = Trainer(cfg)
     if world > 1 and not cfg.MODEL.WEIGHTS:      # same random initial weights on every rank (DDP constructor broadcast)
         dist.broadcast(trainer.optimizer.flat.param, 0)
