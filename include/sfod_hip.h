@@ -300,6 +300,21 @@ int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_scores, const 
                         int32_t* det_classes, int32_t* det_count, float* gt_boxes,
                         int32_t* gt_classes, int32_t* gt_count, void* stream);
 
+/* Class-wise adaptive pseudo-label threshold: AdaptiveConfidenceBasedSelfTrainingLoss
+ * (daod/modeling/adaptive_thresh/adaptive_confidence.py:6-34, "convex" curve) with the trainer's bookkeeping
+ * (daod/engine/trainers/source_free_adaptive_teacher.py:282-295 count_label_prediction, :297-309
+ * update_adaptive_threshold, :393-404 per-step update, :461-466 selection).  Over the det_* arrays of
+ * sfod_frcnn_finalize [B,max_det]: writes the per-class counts of score > thr into reserve[row] ([R][K] fp32
+ * ring, caller-owned state), class_acc[K] = counter / max(max(counter), 1) with classes 0 and 2 excluded from
+ * the counter and pinned to 1, and, when `select` != 0, replaces the pseudo ground truth of every image by the
+ * stable subset score >= thr * (acc[c] / (2 - acc[c])) (gt_boxes/gt_classes/gt_scores [B,max_det], gt_count [B]).
+ * K <= 64. */
+int sfod_adaptive_pseudo_labels(const float* det_boxes, const float* det_scores,
+                                const int32_t* det_classes, const int32_t* det_count, int B,
+                                int max_det, int K, float thr, float* reserve, int R, int row,
+                                float* class_acc, int select, float* gt_boxes, int32_t* gt_classes,
+                                float* gt_scores, int32_t* gt_count, void* stream);
+
 /* ---- K20/K21: fused SGD(momentum, weight decay) + EMA teacher update over flat fp32 arrays.
  * d2 build_optimizer + torch SGD (Appendix A.15) and _update_teacher_model
  * (source_free_adaptive_teacher.py:583-603).  lr is a device scalar (no host sync on schedule).

@@ -11,6 +11,8 @@ Pinned against the real reference here:
   * ``daod/modeling/dann/dann.py`` (pure torch, imported directly by file path):
     ``FCDiscriminator_img`` forward + gradient through ``gradient_scalar(x, -1.0)``;
     ``DAInsHead`` eval-mode forward.
+  * ``daod/modeling/adaptive_thresh/adaptive_confidence.py`` (pure torch; ``Tensor.cuda`` neutralised while it
+    runs): the class-wise confidence mask and ``update``.
 Weights are not stored for the big modules: they are reproduced from the recorded seed by
 constructing the same torch.nn containers in the same order (checked via checksums).
 """
@@ -109,7 +111,59 @@ def gen_dann():
     print("dann_ref.npz: loss", float(loss))
 
 
+def gen_adaptive():
+    """``AdaptiveConfidenceBasedSelfTrainingLoss`` (adaptive_thresh/adaptive_confidence.py:6-34) is pure torch
+    but its constructor calls ``.cuda()`` (:13); with ``Tensor.cuda`` neutralised for the duration of this
+    function the class runs on the CPU unchanged.  Recorded: the mask for several per-class accuracy vectors
+    (the trainer assigns ``classwise_acc`` directly, source_free_adaptive_teacher.py:306-309) and ``update``."""
+    mod_path = os.path.join(REF, "daod/modeling/adaptive_thresh/adaptive_confidence.py")
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        ada = _load_by_path("ref_adaptive", mod_path)
+        K = 8
+        crit = ada.AdaptiveConfidenceBasedSelfTrainingLoss(threshold=0.8, num_classes=K)
+        g = torch.Generator().manual_seed(5)
+        conf = torch.rand(400, generator=g) * 0.95 + 0.05
+        labels = torch.randint(0, K, (400,), generator=g)
+        out = {"threshold": np.float64(0.8), "confidence": conf.numpy(), "labels": labels.numpy(),
+               "mask_init": crit(conf, labels).numpy(), "torch_version": np.array(torch.__version__)}
+        accs = []
+        for i in range(6):
+            counter = torch.randint(0, 40, (K,), generator=g).float()
+            if i == 0:
+                counter.zero_()
+            counter[0] = 0
+            counter[2] = 0
+            acc = counter / max(counter.max(), 1)          # trainer :306-309
+            acc[0] = 1
+            acc[2] = 1
+            crit.classwise_acc = acc
+            # confidences exactly on a class threshold exercise the '>='
+            c2 = conf.clone()
+            c2[:K] = 0.8 * (acc / (2. - acc))
+            l2 = labels.clone()
+            l2[:K] = torch.arange(K)
+            accs.append(acc.numpy())
+            out[f"conf_{i}"] = c2.numpy()
+            out[f"labels_{i}"] = l2.numpy()
+            out[f"mask_{i}"] = crit(c2, l2).numpy()
+        out["accs"] = np.stack(accs)
+        sel = torch.randint(0, K, (57,), generator=g)
+        crit.update(sel)
+        out["update_labels"] = sel.numpy()
+        out["update_acc"] = crit.classwise_acc.numpy()
+    finally:
+        torch.Tensor.cuda = orig
+    np.savez_compressed(os.path.join(OUT, "adaptive_ref.npz"), **out)
+    print("adaptive_ref.npz: kept", [int(out[f"mask_{i}"].sum()) for i in range(6)])
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "adaptive":
+        gen_adaptive()
+        sys.exit(0)
     gen_vgg()
     gen_dann()
+    gen_adaptive()

@@ -355,6 +355,44 @@ def threshold_bbox(det, thr):
     return {"gt_boxes": det["boxes"][m], "gt_classes": det["classes"][m], "scores": det["scores"][m]}
 
 
+class AdaptiveThreshold:
+    """Class-wise adaptive confidence threshold: ``AdaptiveConfidenceBasedSelfTrainingLoss``
+    (adaptive_thresh/adaptive_confidence.py:6-34, the "convex" curve) + the trainer's bookkeeping
+    (source_free_adaptive_teacher.py:116-120 state, :282-295 ``count_label_prediction``, :297-309
+    ``update_adaptive_threshold``, :393-404 per-step update, :461-466 selection after WARM_UP)."""
+
+    def __init__(self, threshold, num_classes, reserve):
+        self.threshold, self.num_classes = threshold, num_classes
+        self.classwise_acc = torch.ones(num_classes)
+        self.reserve_matrix = torch.zeros(reserve, num_classes)
+
+    def mask(self, confidence, pseudo_labels):
+        a = self.classwise_acc[pseudo_labels]
+        return confidence >= self.threshold * (a / (2. - a))
+
+    def update(self, dets, it, fixed_thr):
+        """:393-400: detections passing the CURRENT mask ("prediction_thresholding", :230-254), of which
+        those with ``score > BBOX_THRESHOLD`` are counted per class into row ``it % RESERVE``; then :297-309."""
+        K = self.num_classes
+        count = torch.zeros(K)
+        for d in dets:
+            m = self.mask(d["scores"], d["classes"])
+            sc, cl = d["scores"][m], d["classes"][m]
+            count += cl[sc > fixed_thr].bincount(minlength=K)
+        self.reserve_matrix[it % len(self.reserve_matrix)] = count
+        counter = self.reserve_matrix.sum(dim=0)
+        counter[0] = 0
+        counter[2] = 0
+        self.classwise_acc = counter / max(counter.max(), 1)
+        self.classwise_acc[0] = 1
+        self.classwise_acc[2] = 1
+
+    def select(self, det):
+        """``adaptive_threshold_bbox`` 'roih' (:204-226)."""
+        idx = torch.nonzero(self.mask(det["scores"], det["classes"])).flatten()
+        return {"gt_boxes": det["boxes"][idx], "gt_classes": det["classes"][idx], "scores": det["scores"][idx]}
+
+
 # ---------------------------------------------------------------------------------------------
 # branches
 # ---------------------------------------------------------------------------------------------

@@ -1276,3 +1276,102 @@ extern "C" int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_sco
                      det_classes, det_count, gt_boxes, gt_classes, gt_count);
   return sfod_check_launch("frcnn_finalize");
 }
+
+// Class-wise adaptive pseudo-label threshold (adaptive_thresh/adaptive_confidence.py:6-34 and the trainer's
+// bookkeeping, source_free_adaptive_teacher.py:282-309,393-404,461-466), one launch per step, no host sync:
+//   1. per-class count of this step's detections with score > thr -> ring row `row` of reserve [R][K]
+//      (the reference's "prediction_thresholding" pre-filter never removes such a detection: its thresholds
+//      are <= thr);  2. counter = column sums with classes 0 and 2 zeroed (:303-304), acc = counter /
+//      max(max(counter), 1), acc[0] = acc[2] = 1;  3. with `select`: the pseudo ground truth of every image
+//      is the stable subset  score >= thr * (acc[c] / (2 - acc[c]))  (fp32, same operation order as torch).
+__global__ void __launch_bounds__(256)
+k_adaptive_pseudo_labels(const float* __restrict__ dboxes, const float* __restrict__ dscores,
+                         const int32_t* __restrict__ dcls, const int32_t* __restrict__ dcount, int B,
+                         int max_det, int K, float thr, float* __restrict__ reserve, int R, int row,
+                         float* __restrict__ class_acc, int select, float* __restrict__ gboxes,
+                         int32_t* __restrict__ gcls, float* __restrict__ gscores, int32_t* __restrict__ gcount) {
+  __shared__ float s_cnt[64], s_thr[64];
+  __shared__ int s_wtot[4];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid < 64) s_cnt[tid] = 0.f;
+  __syncthreads();
+  for (int i = tid; i < B * max_det; i += blockDim.x) {
+    const int b = i / max_det, j = i - b * max_det;
+    if (j < min(dcount[b], max_det) && dscores[i] > thr) {
+      const int c = dcls[i];
+      if (c >= 0 && c < K) atomicAdd(&s_cnt[c], 1.f);
+    }
+  }
+  __syncthreads();
+  if (tid < K) {
+    reserve[(int64_t)row * K + tid] = s_cnt[tid];
+    float sum = 0.f;                       // small integers: exact in fp32 in any order
+    for (int r = 0; r < R; ++r) sum += (r == row) ? s_cnt[tid] : reserve[(int64_t)r * K + tid];
+    if (tid == 0 || tid == 2) sum = 0.f;
+    s_thr[tid] = sum;
+  }
+  __syncthreads();
+  float m = 1.f;
+  for (int k = 0; k < K; ++k) m = fmaxf(m, s_thr[k]);
+  __syncthreads();
+  if (tid < K) {
+    float acc = s_thr[tid] / m;
+    if (tid == 0 || tid == 2) acc = 1.f;
+    class_acc[tid] = acc;
+    s_thr[tid] = thr * (acc / (2.f - acc));
+  }
+  __syncthreads();
+  if (!select) return;
+  for (int b = 0; b < B; ++b) {
+    const int nd = min(dcount[b], max_det);
+    int n = 0;
+    for (int j0 = 0; j0 < max_det; j0 += 256) {
+      const int j = j0 + tid;
+      const int64_t i = (int64_t)b * max_det + j;
+      bool keep = false;
+      float sc = 0.f;
+      int c = 0;
+      if (j < nd) {
+        sc = dscores[i];
+        c = dcls[i];
+        keep = (c >= 0 && c < K) && sc >= s_thr[c];
+      }
+      const uint64_t bal = __ballot(keep);
+      if (lane == 0) s_wtot[wv] = __popcll(bal);
+      __syncthreads();
+      int base = n;
+      for (int k = 0; k < wv; ++k) base += s_wtot[k];
+      if (keep) {
+        const int o = base + __popcll(bal & ((1ull << lane) - 1ull));
+        const int64_t d = (int64_t)b * max_det + o;
+        store_box(gboxes + d * 4, load_box(dboxes + i * 4));
+        gcls[d] = c;
+        gscores[d] = sc;
+      }
+      n += s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3];
+      __syncthreads();
+    }
+    for (int j = n + tid; j < max_det; j += 256) {      // unused tail: zeros, like sfod_frcnn_finalize
+      const int64_t d = (int64_t)b * max_det + j;
+      store_box(gboxes + d * 4, Box{0.f, 0.f, 0.f, 0.f});
+      gcls[d] = 0;
+      gscores[d] = 0.f;
+    }
+    if (tid == 0) gcount[b] = n;
+  }
+}
+
+extern "C" int sfod_adaptive_pseudo_labels(const float* det_boxes, const float* det_scores,
+                                           const int32_t* det_classes, const int32_t* det_count, int B,
+                                           int max_det, int K, float thr, float* reserve, int R, int row,
+                                           float* class_acc, int select, float* gt_boxes, int32_t* gt_classes,
+                                           float* gt_scores, int32_t* gt_count, void* stream) {
+  SFOD_REQUIRE(K >= 1 && K <= 64, "adaptive_pseudo_labels: 1 <= K <= 64");
+  SFOD_REQUIRE(R >= 1 && row >= 0 && row < R, "adaptive_pseudo_labels: row outside the reserve ring");
+  if (B == 0) return 0;
+  hipLaunchKernelGGL(k_adaptive_pseudo_labels, dim3(1), dim3(256), 0, (hipStream_t)stream, det_boxes, det_scores,
+                     det_classes, det_count, B, max_det, K, thr, reserve, R, row, class_acc, select, gt_boxes,
+                     gt_classes, gt_scores, gt_count);
+  return sfod_check_launch("adaptive_pseudo_labels");
+}
+

@@ -28,6 +28,7 @@ import time
 import torch
 import torch.distributed as dist
 
+from .. import native
 from ..data.synthetic import TwoCropLoader
 from ..modeling import build_model
 from ..modeling.batched import BatchedGT
@@ -373,10 +374,34 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
     # ---- pseudo-labelling -------------------------------------------------------------------------
     def process_pseudo_label(self, proposals, cur_threshold, proposal_type, pseudo_label_method=""):
         """Instances-level API twin of :256-280 (host side; the step itself uses the fused kernel)."""
-        if pseudo_label_method != "thresholding":
+        if pseudo_label_method == "thresholding":
+            out = [threshold_bbox(p, thres=cur_threshold, proposal_type=proposal_type) for p in proposals]
+        elif pseudo_label_method in ("adaptive_thresholding", "prediction_thresholding"):
+            # :185-254 -- both use the class-wise criterion (``cur_threshold`` is ignored by the reference);
+            # the former returns gt_* fields, the latter keeps pred_*
+            out = [self._adaptive_threshold_bbox(p, proposal_type, pseudo_label_method == "adaptive_thresholding")
+                   for p in proposals]
+        else:
             raise ValueError("Unkown pseudo label boxes methods")
-        out = [threshold_bbox(p, thres=cur_threshold, proposal_type=proposal_type) for p in proposals]
         return out, sum(len(p) for p in out) / max(len(out), 1)
+
+    def _adaptive_threshold_bbox(self, inst, proposal_type, as_gt):
+        if proposal_type != "roih":
+            return threshold_bbox(inst, thres=self.cfg.SEMISUPNET.BBOX_THRESHOLD, proposal_type=proposal_type)
+        acc = self.__dict__.get("classwise_acc")
+        if acc is None:
+            acc = torch.ones(self.cfg.MODEL.ROI_HEADS.NUM_CLASSES, device=inst.scores.device)
+        a = acc.to(inst.scores.device)[inst.pred_classes.long()]
+        idx = torch.nonzero(inst.scores >= self.cfg.SEMISUPNET.BBOX_THRESHOLD * (a / (2. - a))).flatten()
+        new = Instances(inst.image_size)
+        if as_gt:
+            new.gt_boxes = Boxes(inst.pred_boxes.tensor[idx, :])
+            new.gt_classes = inst.pred_classes[idx]
+        else:
+            new.pred_boxes = Boxes(inst.pred_boxes.tensor[idx, :])
+            new.pred_classes = inst.pred_classes[idx]
+        new.scores = inst.scores[idx]
+        return new
 
     @staticmethod
     def remove_label(label_data):
@@ -406,6 +431,19 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         rpn_live = torch.arange(proposals_rpn_k.logits.shape[1], device=self.device)[None, :] < proposals_rpn_k.count[:, None]
         self.storage.put_scalar("rpn/num_pseudo_proposals",
                                 ((proposals_rpn_k.logits > cur_threshold) & rpn_live).sum().float() / B)
+        if "ADAPTIVE_THRESHOLD" in cfg and cfg.ADAPTIVE_THRESHOLD.ENABLED:
+            # :393-404 ring of per-class counts -> class-wise accuracy; :461-466 after WARM_UP the pseudo labels
+            # are score >= thr * acc/(2-acc) per class instead of the fixed threshold (one launch, no sync)
+            K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+            if self.__dict__.get("reserve_matrix") is None:
+                self.reserve_matrix = torch.zeros(cfg.ADAPTIVE_THRESHOLD.RESERVE, K, device=self.device)
+                self.classwise_acc = torch.ones(K, device=self.device)
+            native.adaptive_pseudo_labels_(d, cur_threshold, self.reserve_matrix,
+                                           self.iter % cfg.ADAPTIVE_THRESHOLD.RESERVE, self.classwise_acc,
+                                           select=self.iter >= cfg.ADAPTIVE_THRESHOLD.WARM_UP)
+            acc = self.classwise_acc.clone()
+            for i in range(min(8, K)):
+                self.storage.put_scalar("acc_thres/class_" + str(i), acc[i])
         pseudo = proposals_roih_k.pseudo_gt()
         self.storage.put_scalar("roi_head/num_pseudo_proposals", pseudo.count.float().mean())
         return pseudo

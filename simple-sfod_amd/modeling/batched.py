@@ -124,5 +124,8 @@ class BatchedDetections:
 
     def pseudo_gt(self):
         """The ``scores > BBOX_THRESHOLD`` subset (threshold_bbox 'roih') as a BatchedGT."""
+        # fixed threshold: the labels are a prefix of the score-ordered detections; after the class-wise
+        # adaptive selection (native.adaptive_pseudo_labels_) they are a subset with their own score array
+        scores = self.d["gt_scores"] if self.d.get("gt_adaptive") else self.d["det_scores"]
         return BatchedGT(self.d["gt_boxes"], self.d["gt_classes"], self.d["gt_count"], self.image_sizes,
-                         scores=self.d["det_scores"])
+                         scores=scores)

@@ -839,6 +839,22 @@ def frcnn_inference(pred, K, props, prop_count, sizes, score_thresh, nms_thresh,
     return out
 
 
+def adaptive_pseudo_labels_(d, thr, reserve, row, class_acc, select):
+    """In place on the detection dict of ``frcnn_inference``: updates ``reserve[row]`` / ``class_acc`` and, with
+    ``select``, replaces ``gt_boxes`` / ``gt_classes`` / ``gt_count`` (adds ``gt_scores``) by the class-wise
+    adaptive selection."""
+    B, max_det = d["det_scores"].shape
+    R, K = reserve.shape
+    if "gt_scores" not in d:
+        d["gt_scores"] = torch.zeros(B, max_det, dtype=torch.float32, device=reserve.device)
+    call("sfod_adaptive_pseudo_labels", d["det_boxes"], d["det_scores"], d["det_classes"], d["det_count"], B, max_det,
+         K, float(thr), reserve, R, int(row), class_acc, int(bool(select)), d["gt_boxes"], d["gt_classes"],
+         d["gt_scores"], d["gt_count"])
+    if select:
+        d["gt_adaptive"] = True
+    return d
+
+
 def sgd_ema_(param, grad, mom, teacher, lr, momentum, weight_decay, grad_scale, ema_keep, first_step):
     call("sfod_sgd_ema", param, grad, mom, teacher, param.numel(), lr, float(momentum), float(weight_decay),
          float(grad_scale), float(ema_keep), int(first_step))

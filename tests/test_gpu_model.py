@@ -488,6 +488,92 @@ def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     assert "modelTeacher.backbone.vgg0.0.weight" in sd and "modelStudent.roi_heads.box_head.fc1.weight" in sd
 
 
+def test_adaptive_pseudo_label_threshold_matches_oracle_bit_exact(sfod, native):
+    """class-wise adaptive threshold.  The kernel against the oracle's restatement of
+    adaptive_confidence.py:6-34 + trainer :282-309,393-404,461-466 over 7 steps of a 3-row ring (wrap-around),
+    scores planted exactly on the fixed and on the class thresholds, a class that is never counted (threshold 0),
+    an image without detections; everything is bit-exact (ring, accuracies, selected boxes / classes / scores)."""
+    g = torch.Generator().manual_seed(41)
+    B, max_det, K, R, thr = 3, 100, 8, 3, 0.8
+    at = om.AdaptiveThreshold(thr, K, R)
+    reserve = torch.zeros(R, K, device=DEV)
+    acc = torch.ones(K, device=DEV)
+    for it in range(7):
+        dets, d = [], {k: [] for k in ("det_boxes", "det_scores", "det_classes", "det_count")}
+        for b in range(B):
+            n = 0 if (b == 1 and it == 2) else int(torch.randint(20, 101, (1,), generator=g))
+            sc = torch.sort(torch.rand(n, generator=g) * 0.95 + 0.05, descending=True)[0]
+            cl = torch.randint(0, K - 1, (n,), generator=g)          # class 7 never appears
+            cl[torch.rand(n, generator=g) < 0.3] = 1 + (it % 3)       # one dominant class per step
+            if n > 8:
+                sc[3] = 0.8                                          # == fixed threshold: not counted ('>')
+                a = at.classwise_acc[cl[5]]
+                sc[5] = thr * (a / (2. - a))                         # == class threshold: selected ('>=')
+            bx = torch.rand(n, 4, generator=g) * 100
+            dets.append({"boxes": bx, "scores": sc, "classes": cl})
+            pad = max_det - n
+            d["det_boxes"].append(torch.cat([bx, torch.zeros(pad, 4)]))
+            d["det_scores"].append(torch.cat([sc, torch.zeros(pad)]))
+            d["det_classes"].append(torch.cat([cl, torch.zeros(pad, dtype=torch.int64)]).int())
+            d["det_count"].append(n)
+        dd = {"det_boxes": torch.stack(d["det_boxes"]).to(DEV), "det_scores": torch.stack(d["det_scores"]).to(DEV),
+              "det_classes": torch.stack(d["det_classes"]).to(DEV),
+              "det_count": torch.tensor(d["det_count"], dtype=torch.int32, device=DEV),
+              "gt_boxes": torch.full((B, max_det, 4), -1.0, device=DEV),
+              "gt_classes": torch.full((B, max_det), -1, dtype=torch.int32, device=DEV),
+              "gt_count": torch.full((B,), -1, dtype=torch.int32, device=DEV)}
+        select = it >= 2
+        native.adaptive_pseudo_labels_(dd, thr, reserve, it % R, acc, select)
+        at.update(dets, it, thr)
+        assert torch.equal(reserve.cpu(), at.reserve_matrix), it
+        assert torch.equal(acc.cpu(), at.classwise_acc), it
+        if not select:
+            assert (dd["gt_count"] == -1).all() and "gt_adaptive" not in dd      # fixed-threshold labels untouched
+            continue
+        for b in range(B):
+            ref = at.select(dets[b])
+            n = dd["gt_count"][b].item()
+            assert n == len(ref["scores"]), (it, b)
+            assert torch.equal(dd["gt_boxes"][b, :n].cpu(), ref["gt_boxes"])
+            assert torch.equal(dd["gt_classes"][b, :n].cpu().long(), ref["gt_classes"])
+            assert torch.equal(dd["gt_scores"][b, :n].cpu(), ref["scores"])
+            assert (dd["gt_boxes"][b, n:] == 0).all() and (dd["gt_classes"][b, n:] == 0).all()
+    assert at.classwise_acc[7] == 0 and at.classwise_acc[0] == 1 and 0 < at.classwise_acc[4] < 1
+
+
+def test_trainer_with_adaptive_threshold_enabled(sfod, native):
+    """ADAPTIVE_THRESHOLD.ENABLED: the ring / accuracies are trainer state, the pseudo labels switch to the
+    class-wise selection after WARM_UP, the per-class accuracies are logged as acc_thres/class_i (:401-404)."""
+    cfg = make_cfg(sfod, opts=["SOLVER.IMS_PER_BATCH_TARGET", "2", "SFOD.SYNTHETIC.HEIGHT", "256",
+                               "SFOD.SYNTHETIC.WIDTH", "512", "SFOD.SYNTHETIC.NUM_IMAGES", "4",
+                               "INPUT.MIN_SIZE_TRAIN", "(192,)", "SOLVER.MAX_ITER", "3", "SOLVER.CHECKPOINT_PERIOD", "0",
+                               "ADAPTIVE_THRESHOLD.ENABLED", "True", "ADAPTIVE_THRESHOLD.WARM_UP", "1",
+                               "ADAPTIVE_THRESHOLD.RESERVE", "2"])
+    torch.manual_seed(cfg.SEED)
+    tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+    with torch.no_grad():     # planted scores so that the teacher has confident detections of several classes
+        tr.model_teacher.roi_heads.box_predictor.cls_score.weight.mul_(60.0)
+    tr.train()
+    rec = tr.storage.history[-1]
+    for k in ("loss_cls_pseudo", "loss_box_reg_pseudo", "loss_rpn_cls_pseudo", "loss_rpn_loc_pseudo", "total_loss"):
+        assert np.isfinite(rec[k]), (k, rec)
+    for i in range(8):
+        assert 0.0 <= rec["acc_thres/class_%d" % i] <= 1.0
+    assert rec["acc_thres/class_0"] == 1.0 and rec["acc_thres/class_2"] == 1.0
+    assert tr.reserve_matrix.shape == (2, 8) and (tr.reserve_matrix >= 0).all() and tr.reserve_matrix.sum() > 0
+    # host-side API twins of :185-254
+    inst = sfod.structures.Instances((10, 10))
+    inst.pred_boxes = sfod.structures.Boxes(torch.arange(12.).view(3, 4).to(DEV))
+    inst.scores = torch.tensor([0.9, 0.5, 0.1], device=DEV)
+    inst.pred_classes = torch.tensor([0, 0, 2], device=DEV)
+    out, n = tr.process_pseudo_label([inst], 0.8, "roih", "adaptive_thresholding")
+    assert n == 1 and out[0].gt_classes.tolist() == [0] and out[0].has("gt_boxes")
+    out, n = tr.process_pseudo_label([inst], 0.8, "roih", "prediction_thresholding")
+    assert n == 1 and out[0].has("pred_boxes") and abs(out[0].scores.item() - 0.9) < 1e-6
+    with pytest.raises(ValueError):
+        tr.process_pseudo_label([inst], 0.8, "roih", "nope")
+
+
 def test_teacher_on_second_stream_gives_the_same_step(sfod, native):
     """SFOD.OVERLAP_TEACHER only changes WHEN the teacher pass and the student's backbone forward are
     launched (two streams), never what they compute: first-step losses and the teacher's refreshed BN

@@ -65,3 +65,33 @@ def test_reference_dann_discriminator_fixture_is_a_plain_conv_stack():
     loss.backward()
     # gradient_scalar(x, -1.0) flips the sign of the gradient that reaches the features
     torch.testing.assert_close(-x.grad, torch.from_numpy(fx["input_grad"]), rtol=1e-4, atol=1e-8)
+
+
+def test_adaptive_threshold_restatement_matches_reference_class():
+    """adaptive_confidence.py:6-34 run on the CPU (oracle/gen_golden.py: gen_adaptive): the oracle's mask is
+    bit-identical for every recorded per-class accuracy vector, including confidences exactly on a threshold
+    ('>=') and classes with accuracy 0 (threshold 0: everything passes)."""
+    from oracle import model as om
+    fx = np.load(os.path.join(GOLDEN, "adaptive_ref.npz"), allow_pickle=False)
+    at = om.AdaptiveThreshold(float(fx["threshold"]), 8, reserve=4)
+    conf, labels = torch.from_numpy(fx["confidence"]), torch.from_numpy(fx["labels"])
+    assert np.array_equal(at.mask(conf, labels).float().numpy(), fx["mask_init"])
+    assert np.array_equal(fx["mask_init"], (fx["confidence"] >= np.float32(0.8)).astype(np.float32))
+    for i in range(6):
+        at.classwise_acc = torch.from_numpy(fx["accs"][i])
+        m = at.mask(torch.from_numpy(fx[f"conf_{i}"]), torch.from_numpy(fx[f"labels_{i}"]))
+        assert np.array_equal(m.float().numpy(), fx[f"mask_{i}"]), i
+        assert fx[f"mask_{i}"][:8].all()            # the planted on-threshold confidences pass
+    # bookkeeping (:282-309): counts of score > thr into the ring, classes 0 and 2 pinned to accuracy 1
+    at = om.AdaptiveThreshold(0.8, 8, reserve=2)
+    det = {"scores": torch.tensor([0.95, 0.9, 0.85, 0.81, 0.8, 0.3]), "classes": torch.tensor([1, 1, 3, 0, 1, 5]),
+           "boxes": torch.arange(24.).view(6, 4)}
+    at.update([det], 0, 0.8)
+    assert at.reserve_matrix[0].tolist() == [1, 2, 0, 1, 0, 0, 0, 0]        # 0.8 itself is not > 0.8
+    assert at.classwise_acc.tolist() == [1, 1, 1, 0.5, 0, 0, 0, 0]
+    sel = at.select(det)
+    # class 1: thr .8; class 3: .8*(.5/1.5); class 0: .8; class 5: 0
+    assert sel["gt_classes"].tolist() == [1, 1, 3, 0, 1, 5] and len(sel["scores"]) == 6
+    at.update([det], 1, 0.8)
+    at.update([{"scores": torch.zeros(0), "classes": torch.zeros(0, dtype=torch.int64), "boxes": torch.zeros(0, 4)}], 2, 0.8)
+    assert at.reserve_matrix[0].sum() == 0 and at.reserve_matrix[1].tolist() == [1, 2, 0, 1, 0, 0, 0, 0]
