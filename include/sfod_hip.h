@@ -300,6 +300,20 @@ int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_scores, const 
                         int32_t* det_classes, int32_t* det_count, float* gt_boxes,
                         int32_t* gt_classes, int32_t* gt_count, void* stream);
 
+/* BPC calibration metric of the student's training pass (SURVEY 8a row a6 + 8f rank 4), logged as
+ * calibration/bpc_loss and weighted by 0 (source_free_adaptive_teacher.py:549-550,566).  Fuses
+ * SourceFreeFastRCNNOutputLayers.convert_bbox_scores (daod/modeling/roi_heads/source_free_fast_rcnn.py:15-36,
+ * 82-147: softmax, per-class decode, non-finite rows dropped, clip, score > 0, no NMS) applied -- as the
+ * reference does -- to the sampled proposals AFTER their boxes were overwritten by
+ * predict_boxes_for_gt_classes (source_free_adaptive_teacher_roi_heads.py:136-143), with bpc_loss
+ * (daod/loss/bpc_loss.py:10-262) against the images' (pseudo) ground truth.
+ * pred [R,ld] fp32 = (K+1 logits | 4K deltas) per sampled row; rois [R,5] (image, x1,y1,x2,y2; image < 0:
+ * padding row); roi_cls [R] the rows' gt classes (K = background); image_sizes [B,2] (h,w);
+ * gt_boxes [B,G,4], gt_classes [B,G], gt_count [B].  ws: B*4 doubles.  loss: 1 float. */
+int sfod_bpc_loss(const float* pred, int ld, int R, int K, const float* rois, const int32_t* roi_cls,
+                  int B, const int32_t* image_sizes, const float* gt_boxes, const int32_t* gt_classes,
+                  const int32_t* gt_count, int G, float iou_thresh, float* loss, void* ws, void* stream);
+
 /* Class-wise adaptive pseudo-label threshold: AdaptiveConfidenceBasedSelfTrainingLoss
  * (daod/modeling/adaptive_thresh/adaptive_confidence.py:6-34, "convex" curve) with the trainer's bookkeeping
  * (daod/engine/trainers/source_free_adaptive_teacher.py:282-295 count_label_prediction, :297-309

@@ -13,6 +13,8 @@ Pinned against the real reference here:
     ``DAInsHead`` eval-mode forward.
   * ``daod/modeling/adaptive_thresh/adaptive_confidence.py`` (pure torch; ``Tensor.cuda`` neutralised while it
     runs): the class-wise confidence mask and ``update``.
+  * ``daod/loss/bpc_loss.py`` (loaded by file path behind ``oracle/ref_stub``, ``Tensor.cuda`` neutralised): the
+    BPC calibration scalar for recorded ground truth / detections.
 Weights are not stored for the big modules: they are reproduced from the recorded seed by
 constructing the same torch.nn containers in the same order (checked via checksums).
 """
@@ -159,11 +161,78 @@ def gen_adaptive():
     print("adaptive_ref.npz: kept", [int(out[f"mask_{i}"].sum()) for i in range(6)])
 
 
+def gen_bpc():
+    """``bpc_loss`` (daod/loss/bpc_loss.py:10-262) run on the CPU: loaded by file path behind the import stub
+    (it only needs a box container with ``.tensor``), ``Tensor.cuda`` neutralised.  Recorded: per-image ground
+    truth (boxes, classes), detections (boxes, scores, classes) and the scalar, for cases with classes without
+    ground truth, exact IoU ties between two ground-truth boxes (the detection's score counts twice), an image
+    without ground truth, an image whose detections are all below 0.5."""
+    if os.path.join(HERE, "ref_stub") not in sys.path:
+        sys.path.insert(0, os.path.join(HERE, "ref_stub"))
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        bpc = _load_by_path("ref_bpc", os.path.join(REF, "daod/loss/bpc_loss.py"))
+        from detectron2.structures import Boxes
+        K = 8
+        g = torch.Generator().manual_seed(23)
+        out = {"num_classes": np.int64(K), "torch_version": np.array(torch.__version__)}
+
+        def rand_boxes(n, span=300.0, size=120.0):
+            xy = torch.rand(n, 2, generator=g) * span
+            wh = torch.rand(n, 2, generator=g) * size + 4
+            return torch.cat([xy, xy + wh], 1)
+
+        cases = []
+        for ci in range(5):
+            gts, dts = [], []
+            B = 3
+            for b in range(B):
+                ng = 0 if (ci == 2 and b == 1) else int(torch.randint(1, 9, (1,), generator=g))
+                gb = rand_boxes(ng)
+                gc = torch.randint(0, K - 2, (ng,), generator=g)       # classes 6, 7 never have ground truth
+                if ci == 1 and ng >= 2:                                 # two identical boxes of one class: IoU tie
+                    gb[1] = gb[0]
+                    gc[1] = gc[0]
+                nd = 200
+                db = rand_boxes(nd)
+                jit = torch.randint(0, max(ng, 1), (nd,), generator=g)
+                near = torch.rand(nd, generator=g) < 0.5
+                if ng > 0:
+                    db[near] = gb[jit[near]] + torch.randn(int(near.sum()), 4, generator=g) * 4
+                dc = torch.randint(0, K, (nd,), generator=g)
+                if ng > 0:
+                    dc[near] = gc[jit[near]]
+                ds = torch.rand(nd, generator=g)
+                if ci == 3:
+                    ds = ds * 0.45
+                gts.append((gb, gc))
+                dts.append((db, ds, dc))
+            ins = [types.SimpleNamespace(gt_boxes=Boxes(gb), gt_classes=gc) for gb, gc in gts]
+            outs = [types.SimpleNamespace(pred_boxes=Boxes(db), scores=ds, pred_classes=dc) for db, ds, dc in dts]
+            val = bpc.bpc_loss(K, ins, outs)
+            for b in range(B):
+                out[f"c{ci}_gt_boxes_{b}"], out[f"c{ci}_gt_classes_{b}"] = gts[b][0].numpy(), gts[b][1].numpy()
+                out[f"c{ci}_dt_boxes_{b}"], out[f"c{ci}_dt_scores_{b}"] = dts[b][0].numpy(), dts[b][1].numpy()
+                out[f"c{ci}_dt_classes_{b}"] = dts[b][2].numpy()
+            out[f"c{ci}_loss"] = np.float64(float(val))
+            cases.append(float(val))
+        out["num_cases"] = np.int64(5)
+    finally:
+        torch.Tensor.cuda = orig
+    np.savez_compressed(os.path.join(OUT, "bpc_ref.npz"), **out)
+    print("bpc_ref.npz:", cases)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "adaptive":
         gen_adaptive()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "bpc":
+        gen_bpc()
+        sys.exit(0)
     gen_vgg()
     gen_dann()
     gen_adaptive()
+    gen_bpc()

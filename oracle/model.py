@@ -355,6 +355,82 @@ def threshold_bbox(det, thr):
     return {"gt_boxes": det["boxes"][m], "gt_classes": det["classes"][m], "scores": det["scores"][m]}
 
 
+def predict_boxes_for_gt_classes(deltas, boxes, gt_classes, cfg):
+    """d2 ``FastRCNNOutputLayers.predict_boxes_for_gt_classes`` (A.12): decode every row with the deltas of
+    its own gt class, background clamped to K-1; not clipped.  The reference overwrites the sampled proposals'
+    boxes with the result (source_free_adaptive_teacher_roi_heads.py:136-143)."""
+    K = cfg.num_classes
+    pb = B.apply_deltas(deltas, boxes, cfg.roi_bbox_weights).view(-1, K, 4)
+    return pb[torch.arange(len(boxes)), gt_classes.clamp(0, K - 1)]
+
+
+def convert_bbox_scores(scores, deltas, boxes_per_image, image_sizes, cfg):
+    """``SourceFreeFastRCNNOutputLayers.convert_bbox_scores`` (source_free_fast_rcnn.py:15-36,82-147): softmax,
+    per-class decode, non-finite rows dropped, background column dropped, clip, keep ``score > 0``, NO NMS;
+    row-major (roi, class) order.  -> list of dict(boxes, scores, classes, roi_idx)."""
+    K = cfg.num_classes
+    out, off = [], 0
+    with torch.no_grad():
+        for pb, size in zip(boxes_per_image, image_sizes):
+            n = len(pb)
+            sc = F.softmax(scores[off:off + n], dim=-1)
+            bx = B.apply_deltas(deltas[off:off + n], pb, cfg.roi_bbox_weights)
+            off += n
+            valid = torch.isfinite(bx).all(dim=1) & torch.isfinite(sc).all(dim=1)
+            if not valid.all():
+                bx, sc = bx[valid], sc[valid]
+            sc = sc[:, :-1]
+            bx = B.clip_boxes(bx.reshape(-1, 4), size).view(-1, K, 4)
+            mask = sc > 0
+            inds = mask.nonzero()
+            # roi_idx: ``filter_inds[:, 0]`` (:147) -- an index into the rows that survived the finite filter
+            out.append({"boxes": bx[mask], "scores": sc[mask], "classes": inds[:, 1], "roi_idx": inds[:, 0]})
+    return out
+
+
+def bpc_loss(class_number, gts, dets, iou_thresh=0.5):
+    """``bpc_loss`` (daod/loss/bpc_loss.py:10-262), vectorised.  ``gts``: list of (boxes [G,4], classes [G]);
+    ``dets``: list of dict(boxes, scores, classes).  Per class (``evaluate_output`` :137-196): no ground truth
+    of the class -> every detection of it is a false positive; otherwise (``count_confusions`` :87-134, IoU with
+    the legacy +1 extents :62-85) a detection is a true positive when its best IoU over the class's ground truth
+    is > 0.5 -- once per ground-truth box attaining that maximum (``np.where(mask)[1]`` repeats the column on
+    ties) -- else a false positive.  ``loss_forward`` :200-262: AC / AN over true positives with score >= / < 0.5,
+    IC / IN over false positives, per image log(1 + (AN + IC) / (AC + IN)) when the denominator is > 0, mean."""
+    per_image = []
+    for (gb, gc), d in zip(gts, dets):
+        db, ds, dc = d["boxes"], d["scores"], d["classes"]
+        nAC = nAN = nIC = nIN = torch.zeros(())
+        for k in range(class_number):
+            gk, dk = gc == k, dc == k
+            s = ds[dk]
+            if int(gk.sum()) == 0:
+                tp_s, fp_s = torch.zeros(1), s
+            elif int(dk.sum()) > 0:
+                e, o = gb[gk], db[dk]
+                ea = (e[:, 2] - e[:, 0] + 1) * (e[:, 3] - e[:, 1] + 1)
+                oa = (o[:, 2] - o[:, 0] + 1) * (o[:, 3] - o[:, 1] + 1)
+                w = (torch.min(e[:, None, 2], o[None, :, 2]) - torch.max(e[:, None, 0], o[None, :, 0]) + 1).clamp(min=0)
+                h = (torch.min(e[:, None, 3], o[None, :, 3]) - torch.max(e[:, None, 1], o[None, :, 1]) + 1).clamp(min=0)
+                inter = w * h
+                ious = inter / (ea[:, None] + oa[None, :] - inter)
+                tpm = (ious > iou_thresh) & (ious == ious.max(dim=0, keepdim=True).values)
+                tp_cols = tpm.nonzero()[:, 1]                 # row-major: a column appears once per tied row
+                fpm = torch.ones(len(o), dtype=torch.bool)
+                fpm[tp_cols] = False
+                tp_s, fp_s = s[tp_cols], s[fpm]
+            else:
+                continue
+            t = torch.tanh
+            nAC = nAC + (tp_s[tp_s >= 0.5] * t(tp_s[tp_s >= 0.5])).sum()
+            nAN = nAN + (tp_s[tp_s < 0.5] * (1 - t(tp_s[tp_s < 0.5]))).sum()
+            nIC = nIC + ((1 - fp_s[fp_s >= 0.5]) * t(fp_s[fp_s >= 0.5])).sum()
+            nIN = nIN + ((1 - fp_s[fp_s < 0.5]) * (1 - t(fp_s[fp_s < 0.5]))).sum()
+        numr, denom = nAN + nIC, nAC + nIN
+        if denom > 0.0:
+            per_image.append(torch.log(1 + numr / denom))
+    return torch.stack(per_image).mean() if per_image else torch.tensor(0.0)
+
+
 class AdaptiveThreshold:
     """Class-wise adaptive confidence threshold: ``AdaptiveConfidenceBasedSelfTrainingLoss``
     (adaptive_thresh/adaptive_confidence.py:6-34, the "convex" curve) + the trainer's bookkeeping
@@ -434,7 +510,7 @@ def eval_inference(sd, images_u8, cfg, out_sizes=None):
 
 def student_losses(sd, images_u8, gt_boxes_list, gt_classes_list, rpn_keys, roi_keys, cfg,
                    return_aux=False, proposals=None):
-    """branch='supervised_target' (rcnn.py:259-312) without the dead 2nd ROI pass / BPC.
+    """branch='supervised_target' (rcnn.py:259-312) without the dead 2nd ROI pass; ``loss_bpc`` included.
 
     ``proposals`` (list of (boxes, logits)) replaces the RPN's own proposals: parity tests use it
     to give both implementations the same discrete proposal set, because a 1e-7 difference in a
@@ -454,8 +530,17 @@ def student_losses(sd, images_u8, gt_boxes_list, gt_classes_list, rpn_keys, roi_
     losses.update(fast_rcnn_losses(
         scores, bdeltas, torch.cat([s["boxes"] for s in samp]),
         torch.cat([s["gt_classes"] for s in samp]), torch.cat([s["gt_boxes"] for s in samp]), cfg))
+    # rcnn.py:293: BPC of the training pass's per-class predictions (convert_bbox_scores on the sampled proposals
+    # AFTER their boxes were overwritten by predict_boxes_for_gt_classes, roi_heads.py:136-158) against the
+    # (pseudo) ground truth; logged, weighted by 0, no gradient
+    with torch.no_grad():
+        nb = predict_boxes_for_gt_classes(bdeltas, torch.cat([s["boxes"] for s in samp]),
+                                          torch.cat([s["gt_classes"] for s in samp]), cfg)
+        nb = list(nb.split([len(s["boxes"]) for s in samp]))
+        inst = convert_bbox_scores(scores, bdeltas, nb, sizes, cfg)
+        losses["loss_bpc"] = bpc_loss(cfg.num_classes, list(zip(gt_boxes_list, gt_classes_list)), inst)
     if return_aux:
-        return losses, {"feat": feat, "logits": logits, "deltas": deltas, "labels": labels,
+        return losses, {"feat": feat, "logits": logits, "deltas": deltas, "labels": labels, "inst": inst,
                         "props": props, "own_props": own_props, "samp": samp, "scores": scores, "bdeltas": bdeltas}
     return losses
 

@@ -58,8 +58,8 @@ __device__ __forceinline__ Box apply_deltas(Box b, float d0, float d1, float d2,
   float w = b.x2 - b.x1, h = b.y2 - b.y1;
   float cx = b.x1 + 0.5f * w, cy = b.y1 + 0.5f * h;
   float dx = d0 / wx, dy = d1 / wy, dw = d2 / ww, dh = d3 / wh;
-  dw = fminf(dw, SCALE_CLAMP);
-  dh = fminf(dh, SCALE_CLAMP);
+  dw = dw > SCALE_CLAMP ? SCALE_CLAMP : dw;      // torch.clamp(max=): NaN propagates (fminf would drop it)
+  dh = dh > SCALE_CLAMP ? SCALE_CLAMP : dh;
   float pcx = dx * w + cx, pcy = dy * h + cy;
   float pw = expf(dw) * w, ph = expf(dh) * h;
   return Box{pcx - 0.5f * pw, pcy - 0.5f * ph, pcx + 0.5f * pw, pcy + 0.5f * ph};
@@ -1275,6 +1275,113 @@ extern "C" int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_sco
                      s_classes, keep_idx, keep_count, n, max_det, pseudo_thr, det_boxes, det_scores,
                      det_classes, det_count, gt_boxes, gt_classes, gt_count);
   return sfod_check_launch("frcnn_finalize");
+}
+
+// BPC calibration metric of the student's training pass (daod/loss/bpc_loss.py:10-262 on the output of
+// convert_bbox_scores, source_free_fast_rcnn.py:15-36,82-147, called from
+// source_free_adaptive_teacher_roi_heads.py:136-158), fused: per sampled ROI row the softmax, the
+// gt-class decode that overwrites the proposal box (:136-143, background clamped to K-1, unclipped), the
+// K per-class decodes FROM THAT BOX, clip, score > 0, then per class the best legacy (+1) IoU over the
+// image's ground truth of that class: > thr -> true positive, counted once per ground-truth box attaining
+// the maximum (bpc_loss.py:108 repeats the column on ties), else false positive; no ground truth of the
+// class -> false positive.  One workgroup per image accumulates AC / AN / IC / IN (bpc_loss.py:222-230)
+// in double; k_bpc_final: mean over images with AC + IN > 0 of log(1 + (AN + IC) / (AC + IN)).
+__global__ void __launch_bounds__(256)
+k_bpc_sums(const float* __restrict__ pred, int ld, int R, int K, const float* __restrict__ rois,
+           const int32_t* __restrict__ roi_cls, const int32_t* __restrict__ sizes,
+           const float* __restrict__ gboxes, const int32_t* __restrict__ gcls,
+           const int32_t* __restrict__ gcount, int G, float iou_thr, double* __restrict__ sums) {
+  __shared__ double red[4][256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int ng = min(gcount[b], G);
+  const float h = (float)sizes[b * 2], w = (float)sizes[b * 2 + 1];
+  const float* gb = gboxes + (int64_t)b * G * 4;
+  const int32_t* gc = gcls + (int64_t)b * G;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};          // AC, AN, IC, IN
+  for (int r = tid; r < R; r += blockDim.x) {
+    const float* roi = rois + (int64_t)r * 5;
+    if (roi[0] < 0.f || (int)roi[0] != b) continue;
+    const float* row = pred + (int64_t)r * ld;
+    float prob[KMAX + 1];
+    float m = row[0];
+    for (int c = 1; c <= K; ++c) m = fmaxf(m, row[c]);
+    float ssum = 0.f;
+    for (int c = 0; c <= K; ++c) { prob[c] = expf(row[c] - m); ssum += prob[c]; }
+    bool fin = true;
+    for (int c = 0; c <= K; ++c) { prob[c] = prob[c] / ssum; fin = fin && isfinite(prob[c]); }
+    const int gtc = min(max(roi_cls[r], 0), K - 1);
+    const float* dg = row + K + 1 + gtc * 4;
+    const Box pb = apply_deltas(Box{roi[1], roi[2], roi[3], roi[4]}, dg[0], dg[1], dg[2], dg[3], 10.f, 10.f, 5.f, 5.f);
+    Box bx[KMAX];
+    for (int c = 0; c < K; ++c) {
+      const float* d = row + K + 1 + c * 4;
+      bx[c] = apply_deltas(pb, d[0], d[1], d[2], d[3], 10.f, 10.f, 5.f, 5.f);
+      fin = fin && isfinite(bx[c].x1) && isfinite(bx[c].y1) && isfinite(bx[c].x2) && isfinite(bx[c].y2);
+    }
+    if (!fin) continue;
+    for (int c = 0; c < K; ++c) {
+      const float sc = prob[c];
+      if (!(sc > 0.f)) continue;
+      const Box o = clip_box(bx[c], h, w);
+      const float oa = (o.x2 - o.x1 + 1.f) * (o.y2 - o.y1 + 1.f);
+      float best = -1.f;
+      int mult = 0, ngc = 0;
+      for (int g = 0; g < ng; ++g) {
+        if (gc[g] != c) continue;
+        ++ngc;
+        const Box e = load_box(gb + g * 4);
+        const float ea = (e.x2 - e.x1 + 1.f) * (e.y2 - e.y1 + 1.f);
+        const float iw = fmaxf(0.f, fminf(e.x2, o.x2) - fmaxf(e.x1, o.x1) + 1.f);
+        const float ih = fmaxf(0.f, fminf(e.y2, o.y2) - fmaxf(e.y1, o.y1) + 1.f);
+        const float inter = iw * ih;
+        const float iou = inter / (ea + oa - inter);
+        if (iou > best) { best = iou; mult = 1; } else if (iou == best) ++mult;
+      }
+      const float th = tanhf(sc);
+      if (ngc > 0 && best > iou_thr) {
+        if (sc >= 0.5f) acc[0] += (double)mult * (double)(sc * th);
+        else acc[1] += (double)mult * (double)(sc * (1.f - th));
+      } else {
+        if (sc >= 0.5f) acc[2] += (double)((1.f - sc) * th);
+        else acc[3] += (double)((1.f - sc) * (1.f - th));
+      }
+    }
+  }
+  for (int k = 0; k < 4; ++k) red[k][tid] = acc[k];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st)
+      for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + st];
+    __syncthreads();
+  }
+  if (tid < 4) sums[b * 4 + tid] = red[tid][0];
+}
+
+__global__ void k_bpc_final(const double* __restrict__ sums, int B, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float tot = 0.f;
+  int n = 0;
+  for (int b = 0; b < B; ++b) {
+    const float numr = (float)sums[b * 4 + 1] + (float)sums[b * 4 + 2];
+    const float denom = (float)sums[b * 4 + 0] + (float)sums[b * 4 + 3];
+    if (denom > 0.f) { tot += logf(1.f + numr / denom); ++n; }
+  }
+  out[0] = n ? tot / (float)n : 0.f;
+}
+
+extern "C" int sfod_bpc_loss(const float* pred, int ld, int R, int K, const float* rois, const int32_t* roi_cls,
+                             int B, const int32_t* image_sizes, const float* gt_boxes, const int32_t* gt_classes,
+                             const int32_t* gt_count, int G, float iou_thresh, float* loss, void* ws,
+                             void* stream) {
+  SFOD_REQUIRE(K >= 1 && K <= KMAX && ld >= 5 * K + 1, "bpc_loss K / ld");
+  hipStream_t s = (hipStream_t)stream;
+  if (B > 0)
+    hipLaunchKernelGGL(k_bpc_sums, dim3(B), dim3(256), 0, s, pred, ld, R, K, rois, roi_cls, image_sizes, gt_boxes,
+                       gt_classes, gt_count, G, iou_thresh, (double*)ws);
+  int rc = sfod_check_launch("bpc_sums");
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_bpc_final, dim3(1), dim3(64), 0, s, (const double*)ws, B, loss);
+  return sfod_check_launch("bpc_final");
 }
 
 // Class-wise adaptive pseudo-label threshold (adaptive_thresh/adaptive_confidence.py:6-34 and the trainer's

@@ -150,8 +150,8 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
 
         if branch in ("supervised", "supervised_target"):
             proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt, as_instances=False)
-            _, detector_losses, _, _ = self.roi_heads(images, features, proposals_rpn, compute_loss=True,
-                                                      targets=gt, branch=branch)
+            _, detector_losses, _, proposal_instances = self.roi_heads(images, features, proposals_rpn,
+                                                                       compute_loss=True, targets=gt, branch=branch)
             losses = {}
             losses.update(detector_losses)
             losses.update(proposal_losses)
@@ -163,9 +163,13 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
                 with torch.no_grad():
                     proposals_roih, _ = self.roi_heads(images, features, proposals_rpn, targets=None,
                                                        compute_loss=False, branch=branch, as_instances=not batched)
-            # BPC (bpc_loss.py) is weighted by 0 and only logged (trainer :549-550,566): logging-only
-            # "next" row; the key is kept because the reference trainer indexes it unconditionally.
-            losses["loss_bpc"] = torch.zeros((), device=self.device)
+            # BPC (rcnn.py:293, bpc_loss.py): calibration of the training pass's per-class predictions against
+            # the pseudo labels; weighted by 0 and logged (trainer :549-550,566).  One fused launch, no grad.
+            if proposal_instances is not None:
+                with torch.no_grad():
+                    losses["loss_bpc"] = proposal_instances.bpc_loss(gt)
+            else:
+                losses["loss_bpc"] = torch.zeros((), device=self.device)
             return losses, proposals_roih, [], []
 
         if branch == "unsup_data_weak":

@@ -14,10 +14,11 @@ import math
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from .. import native
 from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
-from ..structures import ShapeSpec
+from ..structures import Boxes, Instances, ShapeSpec
 from .batched import BatchedDetections, BatchedGT, BatchedProposals
 
 
@@ -81,9 +82,118 @@ class FastRCNNOutputLayers(nn.Module):
         self.test_topk_per_image = cfg.TEST.DETECTIONS_PER_IMAGE
 
 
+_SCALE_CLAMP = math.log(1000.0 / 16)
+
+
+def _apply_deltas(deltas, boxes, weights=(10.0, 10.0, 5.0, 5.0)):
+    """d2 Box2BoxTransform.apply_deltas (A.5) in torch ops: the Instances-level API twins below use it; the
+    step itself decodes inside the HIP kernels (detect.hip)."""
+    deltas, boxes = deltas.float(), boxes.float()
+    wx, wy, ww, wh = weights
+    widths, heights = boxes[:, 2] - boxes[:, 0], boxes[:, 3] - boxes[:, 1]
+    ctr_x, ctr_y = boxes[:, 0] + 0.5 * widths, boxes[:, 1] + 0.5 * heights
+    dx, dy = deltas[:, 0::4] / wx, deltas[:, 1::4] / wy
+    dw = torch.clamp(deltas[:, 2::4] / ww, max=_SCALE_CLAMP)
+    dh = torch.clamp(deltas[:, 3::4] / wh, max=_SCALE_CLAMP)
+    pcx, pcy = dx * widths[:, None] + ctr_x[:, None], dy * heights[:, None] + ctr_y[:, None]
+    pw, ph = torch.exp(dw) * widths[:, None], torch.exp(dh) * heights[:, None]
+    return torch.stack((pcx - 0.5 * pw, pcy - 0.5 * ph, pcx + 0.5 * pw, pcy + 0.5 * ph), dim=-1).reshape(deltas.shape)
+
+
+class _PredictorAPI:
+    """d2 ``FastRCNNOutputLayers.{predict_boxes, predict_probs, predict_boxes_for_gt_classes}`` on
+    ``predictions = (scores [R,K+1], proposal_deltas [R,4K])`` and ``list[Instances]`` proposals (A.12)."""
+
+    def predict_boxes(self, predictions, proposals):
+        _, deltas = predictions
+        if not len(proposals):
+            return []
+        pb = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        return _apply_deltas(deltas, pb).split([len(p) for p in proposals])
+
+    def predict_probs(self, predictions, proposals):
+        scores, _ = predictions
+        return F.softmax(scores.float(), dim=-1).split([len(p) for p in proposals], dim=0)
+
+    def predict_boxes_for_gt_classes(self, predictions, proposals):
+        if not len(proposals):
+            return []
+        _, deltas = predictions
+        pb = torch.cat([p.proposal_boxes.tensor for p in proposals], dim=0)
+        N, K = pb.shape[0], deltas.shape[1] // 4
+        boxes = _apply_deltas(deltas, pb)
+        if K > 1:
+            gt = torch.cat([p.gt_classes for p in proposals], dim=0).clamp(0, K - 1)
+            boxes = boxes.view(N, K, 4)[torch.arange(N, device=boxes.device), gt]
+        return boxes.split([len(p) for p in proposals])
+
+
+for _name in ("predict_boxes", "predict_probs", "predict_boxes_for_gt_classes"):
+    setattr(FastRCNNOutputLayers, _name, getattr(_PredictorAPI, _name))
+
+
 class SourceFreeFastRCNNOutputLayers(FastRCNNOutputLayers):
-    """source_free_fast_rcnn.py:14 -- ``convert_bbox_scores`` only feeds the zero-weighted BPC loss
-    (quirk q6) and is a "next" row; the layers / losses / inference are the parent's."""
+    """source_free_fast_rcnn.py:14.  ``convert_bbox_scores`` (:15-36 -> ``fast_rcnn_inference_single_image_new``
+    :82-147) only feeds the zero-weighted, logged BPC loss; this is its Instances-level twin in torch ops --
+    the training step computes BPC from the same predictions in one fused kernel (``sfod_bpc_loss``)."""
+
+    def convert_bbox_scores(self, predictions, proposals):
+        boxes = self.predict_boxes(predictions, proposals)
+        scores = self.predict_probs(predictions, proposals)
+        results, kept = [], []
+        for bx, sc, prop in zip(boxes, scores, proposals):
+            valid = torch.isfinite(bx).all(dim=1) & torch.isfinite(sc).all(dim=1)
+            if not valid.all():
+                bx, sc = bx[valid], sc[valid]
+            sc = sc[:, :-1]
+            K = bx.shape[1] // 4
+            b = Boxes(bx.reshape(-1, 4))
+            b.clip(prop.image_size)
+            bx = b.tensor.view(-1, K, 4)
+            mask = sc > 0                     # "We do not filter out anything here"; NMS is commented out (:132-138)
+            inds = mask.nonzero()
+            res = Instances(prop.image_size)
+            res.pred_boxes = Boxes(bx[mask])
+            res.scores = sc[mask]
+            res.pred_classes = inds[:, 1]
+            results.append(res)
+            kept.append(inds[:, 0])
+        return results, kept
+
+
+class InstanceProposals:
+    """4th value of the training-mode ROI heads (``instance_proposals``,
+    source_free_adaptive_teacher_roi_heads.py:101,158): the per-class decoded predictions of the sampled
+    proposals, kept as references to the pass's prediction matrix and sample arrays.  ``bpc_loss(gt)`` runs the
+    fused kernel; ``to_instances()`` materialises the reference's ``list[Instances]`` (host API, syncs)."""
+
+    def __init__(self, heads, pred, samples):
+        self.heads, self.pred, self.samples = heads, pred, samples
+
+    def bpc_loss(self, targets, iou_thresh=0.5):
+        h, sm = self.heads, self.samples
+        sizes = native.dev_const(tuple((int(s[0]), int(s[1])) for s in sm["image_sizes"]), torch.int32,
+                                 self.pred.device)
+        return native.bpc_loss(self.pred, h.num_classes, sm["rois"], sm["gt_cls"], sizes, targets.boxes,
+                               targets.classes, targets.count, iou_thresh)
+
+    def to_instances(self):
+        h, sm = self.heads, self.samples
+        K = h.num_classes
+        rois, cls = sm["rois"], sm["gt_cls"]
+        props = []
+        for b, size in enumerate(sm["image_sizes"]):
+            m = rois[:, 0] == b
+            p = Instances(size)
+            p.proposal_boxes = Boxes(rois[m, 1:5])
+            p.gt_classes = cls[m].long()
+            props.append(p)
+        order = torch.cat([torch.nonzero(rois[:, 0] == b).flatten() for b in range(len(props))])
+        predictions = (self.pred[order, : K + 1], self.pred[order, K + 1: 5 * K + 1])
+        bp = h.box_predictor
+        for p, nb in zip(props, bp.predict_boxes_for_gt_classes(predictions, props)):     # :136-143
+            p.proposal_boxes = Boxes(nb)
+        return bp.convert_bbox_scores(predictions, props)[0]
 
 
 class _ROILossFn(torch.autograd.Function):
@@ -96,6 +206,7 @@ class _ROILossFn(torch.autograd.Function):
                                     samples["gt_box"], samples["n_valid"])
         ctx.heads, ctx.st, ctx.samples = heads, st, samples
         ctx.feat_shape = feat_nchw.shape
+        heads._last_pred = st["pred"]          # for InstanceProposals (BPC); alive until the backward anyway
         return loss[0].clone(), loss[1].clone()
 
     @staticmethod
@@ -266,7 +377,11 @@ class StandardROIHeads(nn.Module):
             self.proposal_append_gt = append
             l_cls, l_box = _ROILossFn.apply(self, feat, samples, *self._params())
             losses = {"loss_cls": l_cls, "loss_box_reg": l_box}
-            return samples, losses, None, None
+            instance_proposals = None
+            if isinstance(self.box_predictor, SourceFreeFastRCNNOutputLayers):
+                instance_proposals = InstanceProposals(self, self._last_pred, samples)
+            self._last_pred = None
+            return samples, losses, None, instance_proposals
         pred_instances, predictions = self._inference(feat, proposals)
         return (pred_instances.to_instances() if as_instances else pred_instances), predictions
 

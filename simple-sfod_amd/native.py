@@ -839,6 +839,16 @@ def frcnn_inference(pred, K, props, prop_count, sizes, score_thresh, nms_thresh,
     return out
 
 
+def bpc_loss(pred, K, rois, roi_cls, sizes_dev, gt_boxes, gt_classes, gt_count, iou_thresh=0.5):
+    """BPC calibration scalar of one training pass (fused convert_bbox_scores + bpc_loss) -> 0-dim tensor."""
+    B, G = gt_classes.shape
+    loss = torch.empty(1, dtype=torch.float32, device=pred.device)
+    ws = torch.empty(max(B, 1) * 4, dtype=torch.float64, device=pred.device)
+    call("sfod_bpc_loss", pred, pred.shape[-1], pred.shape[0], K, rois, roi_cls, B, sizes_dev, gt_boxes, gt_classes,
+         gt_count, G, float(iou_thresh), loss, ws)
+    return loss[0]
+
+
 def adaptive_pseudo_labels_(d, thr, reserve, row, class_acc, select):
     """In place on the detection dict of ``frcnn_inference``: updates ``reserve[row]`` / ``class_acc`` and, with
     ``select``, replaces ``gt_boxes`` / ``gt_classes`` / ``gt_count`` (adds ``gt_scores``) by the class-wise

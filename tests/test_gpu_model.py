@@ -278,7 +278,7 @@ def _student_vs_oracle(sfod, B, H, W, ngt, dtype, seed):
                                         [d["instances"].gt_boxes.tensor for d in inputs],
                                         [d["instances"].gt_classes for d in inputs],
                                         list(rpn_keys), list(roi_keys), ocfg, return_aux=True, proposals=given)
-    sum(losses_ref.values()).backward()
+    sum(v for k, v in losses_ref.items() if k != "loss_bpc").backward()
     # the oracle's own proposals agree with the device ones up to rare near-tie flips
     for b in range(B):
         ob = aux["own_props"][b][0]
@@ -486,6 +486,124 @@ def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     assert all(int(v.item()) == 3 for v in nbt)
     sd = tr.state_dict_for_checkpoint()["model"]
     assert "modelTeacher.backbone.vgg0.0.weight" in sd and "modelStudent.roi_heads.box_head.fc1.weight" in sd
+
+
+def test_bpc_kernel_and_convert_bbox_scores_match_oracle(sfod, native):
+    """SURVEY 8a row a6 + 8f rank 4.  The fused kernel (softmax, gt-class decode overwriting the proposal box,
+    per-class decode from it, clip, score > 0, per-class legacy-IoU matching, AC/AN/IC/IN, log) against the oracle
+    chain predict_boxes_for_gt_classes -> convert_bbox_scores -> bpc_loss (pinned to the reference's bpc_loss by
+    tests/golden/bpc_ref.npz): duplicated ground-truth boxes (IoU ties), classes and an image without ground truth,
+    a row with a non-finite delta, padding rows; and the Instances-level ``convert_bbox_scores`` twin."""
+    g = torch.Generator().manual_seed(77)
+    B, per, K, G = 3, 60, 8, 100
+    ocfg = om.Cfg()
+    sizes = [(200, 320), (180, 300), (220, 260)]
+    R = B * per + 12
+    pred = torch.zeros(R, 48)
+    pred[:, : K + 1] = torch.randn(R, K + 1, generator=g) * 2.5
+    pred[:, K + 1: 5 * K + 1] = torch.randn(R, 4 * K, generator=g) * 0.6
+    rois = torch.full((R, 5), -1.0)
+    roi_cls = torch.full((R,), K, dtype=torch.int32)
+    gts = []
+    for b in range(B):
+        ng = 0 if b == 1 else 6
+        xy = torch.rand(ng, 2, generator=g) * torch.tensor([200.0, 120.0])
+        gb = torch.cat([xy, xy + torch.rand(ng, 2, generator=g) * 80 + 10], 1)
+        gc = torch.randint(0, K - 2, (ng,), generator=g)
+        if ng:
+            gb[1], gc[1] = gb[0], gc[0]                  # identical boxes of one class: tie
+        gts.append((gb, gc))
+        rows = slice(b * per, (b + 1) * per)
+        xy = torch.rand(per, 2, generator=g) * torch.tensor([220.0, 130.0])
+        pb = torch.cat([xy, xy + torch.rand(per, 2, generator=g) * 70 + 8], 1)
+        if ng:
+            pb[:20] = gb[torch.randint(0, ng, (20,), generator=g)] + torch.randn(20, 4, generator=g) * 3
+            pred[b * per: b * per + 20, K + 1: 5 * K + 1] *= 0.05   # near-identity decode: some true positives
+        rois[rows, 0] = b
+        rois[rows, 1:] = pb
+        roi_cls[rows] = torch.randint(0, K + 1, (per,), generator=g).int()
+    pred[7, K + 1] = float("inf")                       # a non-finite box: the whole row is dropped
+    pred[9, K + 3 + 4 * 2] = float("nan")               # NaN passes torch.clamp(max=): dropped as well
+    perm = torch.randperm(R, generator=g)               # rows of the images interleaved with the padding rows
+    pred, rois, roi_cls = pred[perm].contiguous(), rois[perm].contiguous(), roi_cls[perm].contiguous()
+    gtb = torch.zeros(B, G, 4)
+    gtc = torch.zeros(B, G, dtype=torch.int32)
+    gcnt = torch.zeros(B, dtype=torch.int32)
+    for b, (gb, gc) in enumerate(gts):
+        gtb[b, : len(gb)], gtc[b, : len(gb)], gcnt[b] = gb, gc.int(), len(gb)
+    sz = torch.tensor(sizes, dtype=torch.int32, device=DEV)
+    got = native.bpc_loss(pred.to(DEV), K, rois.to(DEV), roi_cls.to(DEV), sz, gtb.to(DEV), gtc.to(DEV), gcnt.to(DEV))
+    # oracle chain, image by image in row order
+    idx = [torch.nonzero(rois[:, 0] == b).flatten() for b in range(B)]
+    order = torch.cat(idx)
+    sc, dl = pred[order, : K + 1], pred[order, K + 1: 5 * K + 1]
+    nb = om.predict_boxes_for_gt_classes(dl, rois[order, 1:], roi_cls[order].long(), ocfg)
+    inst = om.convert_bbox_scores(sc, dl, list(nb.split([len(i) for i in idx])), sizes, ocfg)
+    ref = om.bpc_loss(K, gts, inst)
+    assert len(inst[0]["scores"]) == (per - 2) * K      # the non-finite rows are gone, nothing else is filtered
+    assert abs(got.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item())), (got.item(), ref.item())
+    assert ref.item() > 0.01
+    # Instances-level twin of a6 (+ the predictor API it rests on) against the oracle
+    S = sfod.structures
+    cfg = make_cfg(sfod)
+    bp = sfod.modeling.roi_heads.SourceFreeFastRCNNOutputLayers(cfg, S.ShapeSpec(channels=32))
+    props = []
+    for b in range(B):
+        p = S.Instances(sizes[b])
+        p.proposal_boxes = S.Boxes(nb.split([len(i) for i in idx])[b])
+        p.gt_classes = roi_cls[idx[b]].long()
+        props.append(p)
+    res, kept = bp.convert_bbox_scores((sc, dl), props)
+    for b in range(B):
+        torch.testing.assert_close(res[b].pred_boxes.tensor, inst[b]["boxes"], rtol=1e-6, atol=1e-5)
+        torch.testing.assert_close(res[b].scores, inst[b]["scores"], rtol=1e-6, atol=1e-7)
+        assert torch.equal(res[b].pred_classes, inst[b]["classes"]) and torch.equal(kept[b], inst[b]["roi_idx"])
+    p0 = [S.Instances(sizes[b]) for b in range(B)]
+    for b in range(B):
+        p0[b].proposal_boxes, p0[b].gt_classes = S.Boxes(rois[idx[b], 1:]), roi_cls[idx[b]].long()
+    nb2 = torch.cat(list(bp.predict_boxes_for_gt_classes((sc, dl), p0)))
+    fin = torch.isfinite(nb).all(1)
+    torch.testing.assert_close(nb2[fin], nb[fin], rtol=1e-6, atol=1e-5)
+    assert [tuple(t.shape) for t in bp.predict_probs((sc, dl), p0)] == [(per, K + 1)] * B
+    # no image has a positive denominator -> 0 (bpc_loss.py:251-252)
+    z = native.bpc_loss(pred.to(DEV), K, torch.full((R, 5), -1.0, device=DEV), roi_cls.to(DEV), sz, gtb.to(DEV),
+                        gtc.to(DEV), gcnt.to(DEV))
+    assert z.item() == 0.0
+
+
+def test_instance_proposals_of_the_training_pass(sfod, native):
+    """4th value of the training-mode ROI heads (roi_heads.py:101,158): materialised with the Instances-level
+    ``convert_bbox_scores`` it yields K detections per sampled proposal (nothing is filtered), and the oracle's
+    bpc_loss over them equals the ``loss_bpc`` the fused kernel put into the loss dict."""
+    cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "fp32"])
+    torch.manual_seed(5)
+    model = sfod.modeling.build_model(cfg).train()
+    inputs = make_inputs(2, 160, 224, [3, 4], seed=8)
+    for d in inputs:
+        d["image"] = d["image"].to(DEV)
+    captured = {}
+    orig = model.roi_heads.forward
+
+    def capture(*a, **k):
+        out = orig(*a, **k)
+        if len(out) == 4:
+            captured["inst"], captured["samples"] = out[3], out[0]
+        return out
+    model.roi_heads.forward = capture
+    losses, _, _, _ = model(inputs, branch="supervised_target", batched=True)
+    ip = captured["inst"]
+    assert isinstance(ip, sfod.modeling.roi_heads.InstanceProposals)
+    insts = ip.to_instances()
+    cnt = captured["samples"]["count"].tolist()
+    dets = []
+    for b, inst in enumerate(insts):
+        assert len(inst) == cnt[b] * 8 and inst.image_size == (160, 224)
+        assert inst.pred_classes[:8].tolist() == list(range(8))
+        dets.append({"boxes": inst.pred_boxes.tensor.cpu(), "scores": inst.scores.cpu(), "classes": inst.pred_classes.cpu()})
+    gts = [(d["instances"].gt_boxes.tensor.cpu(), d["instances"].gt_classes.cpu()) for d in inputs]
+    ref = om.bpc_loss(8, gts, dets)
+    assert abs(losses["loss_bpc"].item() - ref.item()) < 1e-5 and ref.item() > 0
+    assert not losses["loss_bpc"].requires_grad
 
 
 def test_adaptive_pseudo_label_threshold_matches_oracle_bit_exact(sfod, native):

@@ -95,3 +95,22 @@ def test_adaptive_threshold_restatement_matches_reference_class():
     at.update([det], 1, 0.8)
     at.update([{"scores": torch.zeros(0), "classes": torch.zeros(0, dtype=torch.int64), "boxes": torch.zeros(0, 4)}], 2, 0.8)
     assert at.reserve_matrix[0].sum() == 0 and at.reserve_matrix[1].tolist() == [1, 2, 0, 1, 0, 0, 0, 0]
+
+
+def test_bpc_restatement_matches_reference_function():
+    """daod/loss/bpc_loss.py run on the CPU (oracle/gen_golden.py: gen_bpc): classes without ground truth,
+    duplicated ground-truth boxes (IoU tie: the detection counts twice), an image without ground truth, a batch
+    whose scores are all below 0.5."""
+    from oracle import model as om
+    fx = np.load(os.path.join(GOLDEN, "bpc_ref.npz"), allow_pickle=False)
+    K = int(fx["num_classes"])
+    for ci in range(int(fx["num_cases"])):
+        gts, dts = [], []
+        for b in range(3):
+            gts.append((torch.from_numpy(fx[f"c{ci}_gt_boxes_{b}"]), torch.from_numpy(fx[f"c{ci}_gt_classes_{b}"])))
+            dts.append({"boxes": torch.from_numpy(fx[f"c{ci}_dt_boxes_{b}"]),
+                        "scores": torch.from_numpy(fx[f"c{ci}_dt_scores_{b}"]),
+                        "classes": torch.from_numpy(fx[f"c{ci}_dt_classes_{b}"])})
+        got = float(om.bpc_loss(K, gts, dts))
+        assert abs(got - float(fx[f"c{ci}_loss"])) < 2e-6, (ci, got, float(fx[f"c{ci}_loss"]))
+    assert float(om.bpc_loss(K, [], [])) == 0.0
