@@ -1284,46 +1284,50 @@ extern "C" int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_sco
 // K per-class decodes FROM THAT BOX, clip, score > 0, then per class the best legacy (+1) IoU over the
 // image's ground truth of that class: > thr -> true positive, counted once per ground-truth box attaining
 // the maximum (bpc_loss.py:108 repeats the column on ties), else false positive; no ground truth of the
-// class -> false positive.  One workgroup per image accumulates AC / AN / IC / IN (bpc_loss.py:222-230)
-// in double; k_bpc_final: mean over images with AC + IN > 0 of log(1 + (AN + IC) / (AC + IN)).
+// class -> false positive.  AC / AN / IC / IN (bpc_loss.py:222-230) are accumulated per image in double
+// (wavefront reduction + one atomic per sum); k_bpc_final: mean over images with AC + IN > 0 of log(1 + (AN + IC) / (AC + IN)).
 __global__ void __launch_bounds__(256)
 k_bpc_sums(const float* __restrict__ pred, int ld, int R, int K, const float* __restrict__ rois,
            const int32_t* __restrict__ roi_cls, const int32_t* __restrict__ sizes,
            const float* __restrict__ gboxes, const int32_t* __restrict__ gcls,
-           const int32_t* __restrict__ gcount, int G, float iou_thr, double* __restrict__ sums) {
-  __shared__ double red[4][256];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int ng = min(gcount[b], G);
-  const float h = (float)sizes[b * 2], w = (float)sizes[b * 2 + 1];
-  const float* gb = gboxes + (int64_t)b * G * 4;
-  const int32_t* gc = gcls + (int64_t)b * G;
+           const int32_t* __restrict__ gcount, int B, int G, float iou_thr, double* __restrict__ sums) {
+  // one thread per (sampled row, class); the row's softmax and finite test are recomputed by its K threads
+  // (registers only: no per-thread class arrays)
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = (int)(t / K), c = (int)(t - (int64_t)r * K);
+  int b = -1;
   double acc[4] = {0.0, 0.0, 0.0, 0.0};          // AC, AN, IC, IN
-  for (int r = tid; r < R; r += blockDim.x) {
+  if (r < R) {
     const float* roi = rois + (int64_t)r * 5;
-    if (roi[0] < 0.f || (int)roi[0] != b) continue;
+    if (roi[0] >= 0.f && (int)roi[0] < B) b = (int)roi[0];
+  }
+  if (b >= 0) {
+    const float* roi = rois + (int64_t)r * 5;
     const float* row = pred + (int64_t)r * ld;
-    float prob[KMAX + 1];
     float m = row[0];
-    for (int c = 1; c <= K; ++c) m = fmaxf(m, row[c]);
+    for (int k = 1; k <= K; ++k) m = fmaxf(m, row[k]);
     float ssum = 0.f;
-    for (int c = 0; c <= K; ++c) { prob[c] = expf(row[c] - m); ssum += prob[c]; }
+    for (int k = 0; k <= K; ++k) ssum += expf(row[k] - m);
     bool fin = true;
-    for (int c = 0; c <= K; ++c) { prob[c] = prob[c] / ssum; fin = fin && isfinite(prob[c]); }
+    for (int k = 0; k <= K; ++k) fin = fin && isfinite(expf(row[k] - m) / ssum);
+    const float sc = expf(row[c] - m) / ssum;
     const int gtc = min(max(roi_cls[r], 0), K - 1);
     const float* dg = row + K + 1 + gtc * 4;
     const Box pb = apply_deltas(Box{roi[1], roi[2], roi[3], roi[4]}, dg[0], dg[1], dg[2], dg[3], 10.f, 10.f, 5.f, 5.f);
-    Box bx[KMAX];
-    for (int c = 0; c < K; ++c) {
-      const float* d = row + K + 1 + c * 4;
-      bx[c] = apply_deltas(pb, d[0], d[1], d[2], d[3], 10.f, 10.f, 5.f, 5.f);
-      fin = fin && isfinite(bx[c].x1) && isfinite(bx[c].y1) && isfinite(bx[c].x2) && isfinite(bx[c].y2);
+    Box mine{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < K; ++k) {
+      const float* d = row + K + 1 + k * 4;
+      const Box x = apply_deltas(pb, d[0], d[1], d[2], d[3], 10.f, 10.f, 5.f, 5.f);
+      fin = fin && isfinite(x.x1) && isfinite(x.y1) && isfinite(x.x2) && isfinite(x.y2);
+      if (k == c) mine = x;
     }
-    if (!fin) continue;
-    for (int c = 0; c < K; ++c) {
-      const float sc = prob[c];
-      if (!(sc > 0.f)) continue;
-      const Box o = clip_box(bx[c], h, w);
+    if (fin && sc > 0.f) {
+      const float h = (float)sizes[b * 2], w = (float)sizes[b * 2 + 1];
+      const Box o = clip_box(mine, h, w);
       const float oa = (o.x2 - o.x1 + 1.f) * (o.y2 - o.y1 + 1.f);
+      const int ng = min(gcount[b], G);
+      const float* gb = gboxes + (int64_t)b * G * 4;
+      const int32_t* gc = gcls + (int64_t)b * G;
       float best = -1.f;
       int mult = 0, ngc = 0;
       for (int g = 0; g < ng; ++g) {
@@ -1339,22 +1343,27 @@ k_bpc_sums(const float* __restrict__ pred, int ld, int R, int K, const float* __
       }
       const float th = tanhf(sc);
       if (ngc > 0 && best > iou_thr) {
-        if (sc >= 0.5f) acc[0] += (double)mult * (double)(sc * th);
-        else acc[1] += (double)mult * (double)(sc * (1.f - th));
+        if (sc >= 0.5f) acc[0] = (double)mult * (double)(sc * th);
+        else acc[1] = (double)mult * (double)(sc * (1.f - th));
       } else {
-        if (sc >= 0.5f) acc[2] += (double)((1.f - sc) * th);
-        else acc[3] += (double)((1.f - sc) * (1.f - th));
+        if (sc >= 0.5f) acc[2] = (double)((1.f - sc) * th);
+        else acc[3] = (double)((1.f - sc) * (1.f - th));
       }
     }
   }
-  for (int k = 0; k < 4; ++k) red[k][tid] = acc[k];
-  __syncthreads();
-  for (int st = 128; st > 0; st >>= 1) {
-    if (tid < st)
-      for (int k = 0; k < 4; ++k) red[k][tid] += red[k][tid + st];
-    __syncthreads();
+  // a wavefront normally covers rows of one image: reduce across it, one atomic per sum; mixed -> per lane
+  const int b0 = __shfl(b, __ffsll((unsigned long long)__ballot(b >= 0)) - 1);
+  if (__all(b < 0 || b == b0)) {
+    if (__ballot(b >= 0) == 0) return;
+    for (int k = 0; k < 4; ++k) {
+      double v = acc[k];
+      for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+      if ((threadIdx.x & 63) == 0 && v != 0.0) atomicAdd(&sums[b0 * 4 + k], v);
+    }
+  } else if (b >= 0) {
+    for (int k = 0; k < 4; ++k)
+      if (acc[k] != 0.0) atomicAdd(&sums[b * 4 + k], acc[k]);
   }
-  if (tid < 4) sums[b * 4 + tid] = red[tid][0];
 }
 
 __global__ void k_bpc_final(const double* __restrict__ sums, int B, float* __restrict__ out) {
@@ -1375,9 +1384,11 @@ extern "C" int sfod_bpc_loss(const float* pred, int ld, int R, int K, const floa
                              void* stream) {
   SFOD_REQUIRE(K >= 1 && K <= KMAX && ld >= 5 * K + 1, "bpc_loss K / ld");
   hipStream_t s = (hipStream_t)stream;
-  if (B > 0)
-    hipLaunchKernelGGL(k_bpc_sums, dim3(B), dim3(256), 0, s, pred, ld, R, K, rois, roi_cls, image_sizes, gt_boxes,
-                       gt_classes, gt_count, G, iou_thresh, (double*)ws);
+  if (B > 0) (void)hipMemsetAsync(ws, 0, sizeof(double) * 4 * B, s);
+  if (B > 0 && R > 0) {
+    hipLaunchKernelGGL(k_bpc_sums, dim3(cdiv((int64_t)R * K, 256)), dim3(256), 0, s, pred, ld, R, K, rois, roi_cls,
+                       image_sizes, gt_boxes, gt_classes, gt_count, B, G, iou_thresh, (double*)ws);
+  }
   int rc = sfod_check_launch("bpc_sums");
   if (rc) return rc;
   hipLaunchKernelGGL(k_bpc_final, dim3(1), dim3(64), 0, s, (const double*)ws, B, loss);
