@@ -1,0 +1,107 @@
+"""Strong augmentation: the oracle's restatement (oracle/augment.py) pinned bit-exactly against
+Pillow, the library the reference's torchvision transforms run on (daod/data/detection_utils.py:7-36)."""
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageEnhance, ImageFilter
+
+from oracle import augment as A
+
+
+def _img(seed, h=61, w=47):
+    return np.random.default_rng(seed).integers(0, 256, (h, w, 3), dtype=np.uint8)
+
+
+def test_luma_and_enhance_ops_match_pillow():
+    rng = np.random.default_rng(0)
+    img = _img(1)
+    pil = Image.fromarray(img, "RGB")
+    assert np.array_equal(A.to_L(img), np.asarray(pil.convert("L")))
+    assert np.array_equal(A.rgb_to_grayscale3(img)[..., 2], np.asarray(pil.convert("L")))
+    for f in list(rng.uniform(0.6, 1.4, 25)) + [0.0, 0.5, 1.0, 0.6, 1.4, 2.5]:
+        f = float(f)
+        assert np.array_equal(A.adjust_brightness(img, f), np.asarray(ImageEnhance.Brightness(pil).enhance(f))), f
+        assert np.array_equal(A.adjust_contrast(img, f), np.asarray(ImageEnhance.Contrast(pil).enhance(f))), f
+        assert np.array_equal(A.adjust_saturation(img, f), np.asarray(ImageEnhance.Color(pil).enhance(f))), f
+    # a flat image: the contrast mean is the pixel's own luma, rounding at .5
+    flat = np.full((3, 5, 3), 77, np.uint8)
+    assert A.contrast_mean(flat) == 77
+
+
+def test_hsv_round_trip_matches_pillow_exhaustively():
+    """All 2^24 RGB triples through convert("HSV") and all 2^24 HSV triples back."""
+    v = np.arange(256, dtype=np.uint8)
+    a, b, c = np.meshgrid(v, v, v, indexing="ij")
+    cube = np.stack([a.ravel(), b.ravel(), c.ravel()], 1).reshape(4096, 4096, 3)
+    assert np.array_equal(A.rgb2hsv(cube), np.asarray(Image.fromarray(cube, "RGB").convert("HSV")))
+    assert np.array_equal(A.hsv2rgb(cube), np.asarray(Image.fromarray(cube, "HSV").convert("RGB")))
+
+
+def test_adjust_hue_matches_the_pillow_recipe():
+    """torchvision functional_pil.adjust_hue: split HSV, add uint8(hue_factor * 255) with wrap-around, merge."""
+    img = _img(2)
+    pil = Image.fromarray(img, "RGB")
+    for hf in (-0.1, -0.05, -0.003, 0.0, 0.02, 0.1, 0.5, -0.5):
+        h, s, v = pil.convert("HSV").split()
+        np_h = np.array(h, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            np_h += np.array(hf * 255).astype("uint8")
+        ref = np.asarray(Image.merge("HSV", (Image.fromarray(np_h, "L"), s, v)).convert("RGB"))
+        assert np.array_equal(A.adjust_hue(img, hf), ref), hf
+    assert A.hue_shift(-0.05) == 244 and A.hue_shift(0.05) == 12
+
+
+def test_gaussian_blur_matches_pillow():
+    rng = np.random.default_rng(3)
+    for (h, w) in [(37, 53), (64, 128), (5, 7), (1, 9), (9, 1), (2, 2)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        for sigma in [0.1, 0.3, 0.5, 0.77, 1.0, 1.3, 1.7, 2.0, 3.5]:
+            ref = np.asarray(Image.fromarray(img, "RGB").filter(ImageFilter.GaussianBlur(radius=sigma)))
+            assert np.array_equal(A.gaussian_blur(img, sigma), ref), (h, w, sigma)
+    for _ in range(60):
+        h, w = int(rng.integers(1, 60)), int(rng.integers(1, 80))
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        sigma = float(rng.uniform(0.1, 2.0))
+        ref = np.asarray(Image.fromarray(img, "RGB").filter(ImageFilter.GaussianBlur(radius=sigma)))
+        assert np.array_equal(A.gaussian_blur(img, sigma), ref), (h, w, sigma)
+    # the configured sigma range never needs more than the two fractional outer taps around 3 inner ones
+    assert A.box_weights(A.gaussian_box_radius(2.0))[0] == 1 and A.box_weights(A.gaussian_box_radius(0.1))[0] == 0
+
+
+def test_tensor_round_trip_and_noise_cast_match_torch():
+    """ToTensor -> ToPILImage: ``x / 255 * 255`` truncated is the identity on uint8; the N(0,1) fill of
+    RandomErasing(value="random") goes through ``mul(255).byte()`` (truncate, keep the low 8 bits)."""
+    k = torch.arange(256, dtype=torch.uint8)
+    assert torch.equal(k.float().div(255).mul(255).byte(), k)
+    g = torch.Generator().manual_seed(0)
+    v = torch.randn(3, 17, 23, generator=g) * 1.5
+    assert np.array_equal(A.noise_to_u8(v.numpy()), v.mul(255).byte().numpy())
+    img = _img(4, 40, 50)
+    out = A.erase(img, 5, 7, 17, 23, v.numpy())
+    t = torch.from_numpy(img).permute(2, 0, 1).float().div(255)
+    t[:, 5:22, 7:30] = v
+    assert np.array_equal(out, t.mul(255).byte().permute(1, 2, 0).numpy())
+
+
+def test_erasing_params_follow_get_params():
+    # first attempt too tall for the image -> second attempt used
+    p = A.erasing_params(100, 400, (0.05, 0.2), (0.3, 3.3), [(0.99, 0.999, 0.5, 0.5), (0.0, 0.5, 0.5, 0.25)] + [(0, 0, 0, 0)] * 8)
+    area = 100 * 400 * 0.05
+    ar = np.exp((np.log(0.3) + np.log(3.3)) / 2)
+    h, w = int(round(np.sqrt(area * ar))), int(round(np.sqrt(area / ar)))
+    assert p == (int(0.5 * (100 - h + 1)), int(0.25 * (400 - w + 1)), h, w)
+    assert A.erasing_params(10, 2000, (0.2, 0.2), (8.0, 8.0), [(0.5, 0.5, 0.5, 0.5)] * 10) is None
+
+
+def test_pipeline_order():
+    img = _img(5)
+    pil = Image.fromarray(img, "RGB")
+    ops = [(A.SATURATION, 1.3), (A.HUE, -0.07), (A.BRIGHTNESS, 0.8), (A.CONTRAST, 1.2), (A.GRAYSCALE, 0.0)]
+    ref = ImageEnhance.Color(pil).enhance(1.3)
+    ref = Image.fromarray(A.adjust_hue(np.asarray(ref), -0.07), "RGB")
+    ref = ImageEnhance.Contrast(ImageEnhance.Brightness(ref).enhance(0.8)).enhance(1.2)
+    ref = ref.convert("L")
+    ref = np.repeat(np.asarray(ref)[..., None], 3, -1)
+    ref = np.asarray(Image.fromarray(ref, "RGB").filter(ImageFilter.GaussianBlur(radius=1.1)))
+    got = A.strong_augment(img, {"ops": ops, "sigma": 1.1, "erase": []})
+    assert np.array_equal(got, ref)
