@@ -329,6 +329,27 @@ int sfod_adaptive_pseudo_labels(const float* det_boxes, const float* det_scores,
                                 float* class_acc, int select, float* gt_boxes, int32_t* gt_classes,
                                 float* gt_scores, int32_t* gt_count, void* stream);
 
+/* ---- Strong augmentation on the device: build_strong_augmentation
+ * (daod/data/detection_utils.py:7-36) as applied by DatasetMapperTwoCropSeparate
+ * (daod/data/mappers/two_crop_augmentation_mapper.py:141-146), on planar uint8 [3][H][W] frames; bit-exact
+ * with the torchvision-on-Pillow path (channels in stored order, as the reference hands its BGR array to
+ * Pillow as "RGB").
+ * sfod_aug_color: a sequence of <= 8 point operations: 0 brightness, 1 contrast (at most one per call), 2
+ * saturation (Pillow ImageEnhance = Image.blend with black / the mean-luma level / the luma image; factor =
+ * blend alpha), 3 hue (Pillow HSV round trip; the factor slot carries the wrapped uint8 shift
+ * np.uint8(hue_factor * 255)), 4 grayscale (convert("L") replicated; factor ignored).  codes / factors are HOST
+ * arrays.  ws: 8 bytes of device memory (the contrast op's luma sum).  in may equal out.
+ * sfod_aug_gaussian_blur: ImageFilter.GaussianBlur(radius=sigma) (daod/data/transforms/augmentations.py:6-21):
+ * Pillow's three extended-box passes along x then along y; in, out, tmp distinct, C*H*W bytes each.
+ * sfod_aug_erase: RandomErasing(value="random") followed by ToPILImage: rectangle (i, j, h, w) of every channel
+ * is overwritten by (uint8)(noise * 255) (truncation, low 8 bits); noise [C][h][w] fp32 on the device. */
+int sfod_aug_color(const uint8_t* in, uint8_t* out, int H, int W, int n_ops, const int32_t* codes,
+                   const float* factors, void* ws, void* stream);
+int sfod_aug_gaussian_blur(const uint8_t* in, uint8_t* out, uint8_t* tmp, int C, int H, int W, float sigma,
+                           void* stream);
+int sfod_aug_erase(uint8_t* img, int C, int H, int W, int i, int j, int h, int w, const float* noise,
+                   void* stream);
+
 /* ---- K20/K21: fused SGD(momentum, weight decay) + EMA teacher update over flat fp32 arrays.
  * d2 build_optimizer + torch SGD (Appendix A.15) and _update_teacher_model
  * (source_free_adaptive_teacher.py:583-603).  lr is a device scalar (no host sync on schedule).

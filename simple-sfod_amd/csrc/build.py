@@ -24,6 +24,7 @@ SOURCES = {
     "wgrad3x3_patch.hip": [],
     "conv_first.hip": [],
     "sort.hip": [],
+    "augment.hip": ["-ffp-contract=off"],
     "runtime.cpp": [],
 }
 HEADERS = ["common.h", "conv_internal.h", os.path.join("..", "..", "include", "sfod_hip.h")]

@@ -314,6 +314,49 @@ def resize_bilinear_u8(img, newh, neww, flip=False):
     return out
 
 
+AUG_BRIGHTNESS, AUG_CONTRAST, AUG_SATURATION, AUG_HUE, AUG_GRAYSCALE = 0, 1, 2, 3, 4
+_aug_ws = {}
+
+
+def aug_color(img, ops):
+    """Point operations of the strong augmentation on a uint8 [3,H,W] device frame, in order: ``ops`` =
+    [(code, factor)] with the factors torchvision draws (brightness / contrast / saturation factor, hue_factor in
+    [-0.5, 0.5]; grayscale ignores it).  Bit-exact with the torchvision-on-Pillow path.  -> new tensor."""
+    assert img.dtype == torch.uint8 and img.dim() == 3 and img.shape[0] == 3
+    img = img.contiguous()
+    if not ops:
+        return img.clone()
+    codes = torch.tensor([int(c) for c, _ in ops], dtype=torch.int32)
+    # hue: np.uint8(hue_factor * 255) -- double product, truncation toward zero, wrap-around
+    factors = torch.tensor([float(int(f * 255) & 255) if c == AUG_HUE else float(f) for c, f in ops],
+                           dtype=torch.float32)
+    key = (img.device, torch.cuda.current_stream(img.device).cuda_stream)
+    ws = _aug_ws.get(key)
+    if ws is None:
+        ws = _aug_ws[key] = torch.zeros(1, dtype=torch.int64, device=img.device)
+    out = torch.empty_like(img)
+    # codes / factors are HOST arrays (copied into the launch arguments before the call returns)
+    call("sfod_aug_color", img, out, img.shape[1], img.shape[2], len(ops), codes.data_ptr(), factors.data_ptr(), ws)
+    return out
+
+
+def aug_gaussian_blur(img, sigma):
+    """Pillow ``ImageFilter.GaussianBlur(radius=sigma)`` on a uint8 [C,H,W] device frame.  -> new tensor."""
+    assert img.dtype == torch.uint8 and img.dim() == 3
+    img = img.contiguous()
+    out, tmp = torch.empty_like(img), torch.empty_like(img)
+    call("sfod_aug_gaussian_blur", img, out, tmp, img.shape[0], img.shape[1], img.shape[2], float(sigma))
+    return out
+
+
+def aug_erase_(img, i, j, h, w, noise):
+    """In place: RandomErasing(value="random") + ToPILImage -- rectangle <- (uint8)(noise * 255), noise [C,h,w]."""
+    assert img.dtype == torch.uint8 and img.dim() == 3 and img.is_contiguous()
+    assert noise.dtype == torch.float32 and tuple(noise.shape) == (img.shape[0], h, w) and noise.is_contiguous()
+    call("sfod_aug_erase", img, img.shape[0], img.shape[1], img.shape[2], int(i), int(j), int(h), int(w), noise)
+    return img
+
+
 def hflip_u8(img):
     """uint8 [C,H,W] device image -> horizontally flipped copy."""
     assert img.dtype == torch.uint8 and img.dim() == 3

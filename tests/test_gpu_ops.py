@@ -891,3 +891,72 @@ def test_conv_first_recompute_fused_batchnorm(native):
     # and it agrees with the unfused product path (conv -> bf16 -> BN kernel) to bf16 rounding
     z2 = native.bn_relu_pool_fwd(y, mean, invstd, gamma.to(DEV), beta.to(DEV), False)
     assert rel_err(z.float().cpu(), z2.float().cpu()) < 8e-3
+
+
+# -------------------------------------------------------------------------------------------------
+# strong augmentation: bit-exact against the oracle (pinned to Pillow in tests/test_augment.py)
+# -------------------------------------------------------------------------------------------------
+def _aug_frame(seed, h=97, w=131):
+    g = torch.Generator().manual_seed(seed)
+    img = torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)
+    img[:, :8, :8] = 0                      # black, white, gray and saturated corners: HSV special cases
+    img[:, :8, 8:16] = 255
+    img[:, 8:16, :8] = 128
+    img[0, 8:16, 8:16], img[1, 8:16, 8:16], img[2, 8:16, 8:16] = 255, 0, 0
+    return img
+
+
+def _hwc(t):
+    return t.permute(1, 2, 0).contiguous().numpy()
+
+
+def test_aug_color_ops_bit_exact(native):
+    from oracle import augment as A
+    import itertools
+    img = _aug_frame(3)
+    ref_in = _hwc(img)
+    d = img.to(DEV)
+    rng = np.random.default_rng(7)
+    singles = [[(A.BRIGHTNESS, f)] for f in (0.6, 0.93, 1.0, 1.4)] + [[(A.CONTRAST, f)] for f in (0.6, 1.0, 1.37)] + \
+              [[(A.SATURATION, f)] for f in (0.6, 1.21, 1.4)] + [[(A.HUE, f)] for f in (-0.1, -0.037, 0.0, 0.02, 0.1)] + \
+              [[(A.GRAYSCALE, 0.0)]]
+    perms = []
+    for p in list(itertools.permutations(range(4)))[::3]:
+        f = {0: rng.uniform(0.6, 1.4), 1: rng.uniform(0.6, 1.4), 2: rng.uniform(0.6, 1.4), 3: rng.uniform(-0.1, 0.1)}
+        ops = [(c, float(f[c])) for c in p]
+        if rng.random() < 0.5:
+            ops.append((A.GRAYSCALE, 0.0))
+        perms.append(ops)
+    for ops in singles + perms:
+        got = native.aug_color(d, ops)
+        ref = A.apply_ops(ref_in, ops)
+        assert np.array_equal(_hwc(got.cpu()), ref), ops
+    assert torch.equal(native.aug_color(d, []), d)
+    # full-size frame: the contrast mean is a 720 000-pixel integer sum
+    big = torch.randint(0, 256, (3, 600, 1200), generator=torch.Generator().manual_seed(1), dtype=torch.uint8)
+    ops = [(A.BRIGHTNESS, 1.13), (A.CONTRAST, 0.71), (A.HUE, 0.06), (A.SATURATION, 1.33)]
+    assert np.array_equal(_hwc(native.aug_color(big.to(DEV), ops).cpu()), A.apply_ops(_hwc(big), ops))
+
+
+def test_aug_gaussian_blur_bit_exact(native):
+    from oracle import augment as A
+    for (h, w) in [(97, 131), (5, 7), (1, 40), (40, 1), (600, 1200)]:
+        img = torch.randint(0, 256, (3, h, w), generator=torch.Generator().manual_seed(h), dtype=torch.uint8)
+        for sigma in ([0.1, 0.3, 0.77, 1.0, 1.3, 1.7, 2.0, 3.5] if h < 600 else [1.234]):
+            got = native.aug_gaussian_blur(img.to(DEV), sigma)
+            assert np.array_equal(_hwc(got.cpu()), A.gaussian_blur(_hwc(img), sigma)), (h, w, sigma)
+
+
+def test_aug_erase_bit_exact(native):
+    from oracle import augment as A
+    img = _aug_frame(5)
+    g = torch.Generator().manual_seed(9)
+    d = img.to(DEV).clone()
+    ref = _hwc(img)
+    for (i, j, h, w) in [(0, 0, 10, 20), (50, 60, 47, 71), (96, 130, 1, 1), (3, 4, 0, 5)]:
+        noise = torch.randn(3, h, w, generator=g) * 1.7
+        native.aug_erase_(d, i, j, h, w, noise.to(DEV))
+        ref = A.erase(ref, i, j, h, w, noise.numpy())
+        assert np.array_equal(_hwc(d.cpu()), ref), (i, j, h, w)
+    with pytest.raises(native.NativeLibraryError):
+        native.aug_erase_(d, 90, 0, 10, 10, torch.zeros(3, 10, 10, device=DEV))
