@@ -390,6 +390,9 @@ def add_native_config(cfg):
     # keep the full-size frames on the device and run the mapper's ResizeShortestEdge (+ flip) there every
     # iteration (sfod_resize_bilinear_u8, bit-exact with Pillow); False: resize once with Pillow at start-up
     _C.SFOD.SYNTHETIC.DEVICE_RESIZE = True
+    # with WEAK_STRONG_AUGMENT: the mapper's strong augmentation (colour jitter, grayscale, blur, erasing) on the
+    # device (sfod_aug_*); False: the strong list repeats the weak frames
+    _C.SFOD.SYNTHETIC.STRONG_AUGMENT = True
 
 
 def setup_cfg(config_file=None, opts=()):

@@ -98,7 +98,10 @@ k_aug_luma_sum(const uint8_t* __restrict__ in, int64_t n, AugOps o, int upto, un
     acc += (unsigned long long)luma(p);
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-  if ((threadIdx.x & 63) == 0) atomicAdd(sum, acc);
+  __shared__ unsigned long long part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sum, part[0] + part[1] + part[2] + part[3]);   // one atomic per workgroup
 }
 
 __global__ void __launch_bounds__(256)
@@ -184,7 +187,7 @@ extern "C" int sfod_aug_color(const uint8_t* in, uint8_t* out, int H, int W, int
     SFOD_REQUIRE(ws != nullptr, "aug_color: contrast needs the 8-byte workspace");
     sum = (unsigned long long*)ws;
     (void)hipMemsetAsync(sum, 0, sizeof(unsigned long long), s);
-    const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+    const int blocks = (int)((n + 255) / 256 < 512 ? (n + 255) / 256 : 512);
     hipLaunchKernelGGL(k_aug_luma_sum, dim3(blocks), dim3(256), 0, s, in, n, o, contrast_at, sum);
     int rc = sfod_check_launch("aug_luma_sum");
     if (rc) return rc;

@@ -181,7 +181,8 @@ class TwoCropLoader:
 
     With ``WEAK_STRONG_AUGMENT: False`` (hot yaml) the trainer discards the strong copy
     (source_free_adaptive_teacher.py:351-352), so both lists reference the same weakly augmented
-    tensors; strong augmentation is a "next" row."""
+    tensors; with it on (the R101 yaml) the strong list carries ``StrongAugmentation`` of the weak frame,
+    computed on the device (data/augment.py)."""
 
     def __init__(self, cfg, device, rank=0, world=1, labeled=False, dataset=None):
         total = cfg.SOLVER.IMS_PER_BATCH if labeled else cfg.SOLVER.IMS_PER_BATCH_TARGET
@@ -193,6 +194,12 @@ class TwoCropLoader:
         self.flip = cfg.INPUT.RANDOM_FLIP == "horizontal"
         self.gen = torch.Generator().manual_seed(max(cfg.SEED, 0) + rank)
         self.labeled = labeled
+        # the strong copy of the two-crop mapper (two_crop_augmentation_mapper.py:141-146) when the config uses it
+        self.strong_aug = None
+        if not labeled and "WEAK_STRONG_AUGMENT" in cfg and cfg.WEAK_STRONG_AUGMENT and \
+                torch.device(device).type == "cuda" and cfg.SFOD.SYNTHETIC.STRONG_AUGMENT:
+            from .augment import StrongAugmentation
+            self.strong_aug = StrongAugmentation(torch.Generator().manual_seed(max(cfg.SEED, 0) + 7919 * (rank + 1)))
 
     def _map(self, item):
         img, boxes = item["image"], item["boxes"]
@@ -219,6 +226,9 @@ class TwoCropLoader:
         if self.labeled:
             return weak
         strong = [dict(d) for d in weak]
+        if self.strong_aug is not None:
+            for d in strong:
+                d["image"] = self.strong_aug(d["image"])
         return strong, weak
 
     def __next__(self):

@@ -105,3 +105,35 @@ def test_pipeline_order():
     ref = np.asarray(Image.fromarray(ref, "RGB").filter(ImageFilter.GaussianBlur(radius=1.1)))
     got = A.strong_augment(img, {"ops": ops, "sigma": 1.1, "erase": []})
     assert np.array_equal(got, ref)
+
+
+def test_sampler_follows_torchvision_get_params(sfod):
+    """Which values are drawn and their ranges (ColorJitter.get_params, RandomApply / RandomGrayscale /
+    RandomErasing probabilities); the rectangle logic equals the oracle's restatement."""
+    D = sfod.data
+    aug = D.StrongAugmentation(torch.Generator().manual_seed(3))
+    n, jit, gray, blur, er = 1500, 0, 0, 0, [0, 0, 0]
+    for _ in range(n):
+        p = aug.sample(600, 1200)
+        codes = [c for c, _ in p["ops"]]
+        if 0 in codes:
+            jit += 1
+            assert sorted(codes[:4]) == [0, 1, 2, 3]
+            f = dict(p["ops"][:4])
+            assert all(0.6 <= f[k] <= 1.4 for k in (0, 1, 2)) and -0.1 <= f[3] <= 0.1
+        gray += codes[-1:] == [4]
+        if p["sigma"] is not None:
+            blur += 1
+            assert 0.1 <= p["sigma"] <= 2.0
+        assert len(p["erase"]) <= 3
+        for (i, j, h, w) in p["erase"]:
+            assert 0 <= i and i + h <= 600 and 0 <= j and j + w <= 1200 and h < 600 and w < 1200
+            assert 0.02 * 0.9 <= h * w / 720000 <= 0.2 * 1.1
+        er[len(p["erase"]) - 1 if p["erase"] else 0] += bool(p["erase"])
+    assert abs(jit / n - 0.8) < 0.04 and abs(gray / n - 0.2) < 0.04 and abs(blur / n - 0.5) < 0.05
+    g = np.random.default_rng(0)
+    for _ in range(200):
+        draws = [tuple(g.random(4)) for _ in range(10)]
+        hh, ww = int(g.integers(5, 700)), int(g.integers(5, 1300))
+        sc, ra = ((0.05, 0.2), (0.3, 3.3)) if g.random() < 0.5 else ((0.02, 0.2), (0.05, 8.0))
+        assert D.augment.erasing_params(hh, ww, sc, ra, draws) == A.erasing_params(hh, ww, sc, ra, draws)

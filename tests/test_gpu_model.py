@@ -692,6 +692,49 @@ def test_trainer_with_adaptive_threshold_enabled(sfod, native):
         tr.process_pseudo_label([inst], 0.8, "roih", "nope")
 
 
+def test_strong_augmentation_pipeline_and_loader(sfod, native):
+    """sampled parameters replayed through the oracle (pinned to Pillow) give the same bytes as
+    the device pipeline; with WEAK_STRONG_AUGMENT the loader's strong list is the augmented weak list (same shape,
+    same labels) and the trainer steps on it."""
+    from oracle import augment as A
+    aug = sfod.data.StrongAugmentation(torch.Generator().manual_seed(11))
+    g = torch.Generator().manual_seed(2)
+    seen = set()
+    for t in range(12):
+        img = torch.randint(0, 256, (3, 120, 200), generator=g, dtype=torch.uint8)
+        p = aug.sample(120, 200)
+        noises = [torch.randn(3, h, w, generator=g) for (_, _, h, w) in p["erase"]]
+        got = aug.apply(img.to(DEV), p, [n.to(DEV) for n in noises])
+        ref = A.strong_augment(img.permute(1, 2, 0).contiguous().numpy(),
+                               {"ops": p["ops"], "sigma": p["sigma"],
+                                "erase": [r + (n.numpy(),) for r, n in zip(p["erase"], noises)]})
+        assert np.array_equal(got.cpu().permute(1, 2, 0).numpy(), ref), p
+        seen |= {c for c, _ in p["ops"]} | ({"blur"} if p["sigma"] is not None else set()) | \
+            ({"erase"} if p["erase"] else set())
+    assert {0, 1, 2, 3, "blur", "erase"} <= seen
+    opts = ["SOLVER.IMS_PER_BATCH_TARGET", "2", "SFOD.SYNTHETIC.HEIGHT", "256", "SFOD.SYNTHETIC.WIDTH", "512",
+            "SFOD.SYNTHETIC.NUM_IMAGES", "4", "INPUT.MIN_SIZE_TRAIN", "(192,)", "SOLVER.MAX_ITER", "2",
+            "SOLVER.CHECKPOINT_PERIOD", "0", "WEAK_STRONG_AUGMENT", "True"]
+    cfg = make_cfg(sfod, opts=opts)
+    loader = sfod.data.TwoCropLoader(cfg, torch.device(DEV))
+    strong, weak = next(loader)
+    torch.cuda.synchronize()
+    assert len(strong) == len(weak) == 2
+    for s_, w_ in zip(strong, weak):
+        assert s_["image"].shape == w_["image"].shape and s_["image"].dtype == torch.uint8
+        assert s_["image_id"] == w_["image_id"] and torch.equal(s_["instances"].gt_boxes.tensor, w_["instances"].gt_boxes.tensor)
+    assert any(not torch.equal(s_["image"], w_["image"]) for s_, w_ in zip(strong, weak))
+    off = sfod.data.TwoCropLoader(make_cfg(sfod, opts=opts + ["SFOD.SYNTHETIC.STRONG_AUGMENT", "False"]), torch.device(DEV))
+    s2, w2 = next(off)
+    assert all(torch.equal(a["image"], b["image"]) for a, b in zip(s2, w2))
+    torch.manual_seed(cfg.SEED)
+    tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+    tr.train()
+    rec = tr.storage.history[-1]
+    for k in ("loss_cls_pseudo", "loss_rpn_cls_pseudo", "total_loss"):
+        assert np.isfinite(rec[k]), (k, rec)
+
+
 def test_teacher_on_second_stream_gives_the_same_step(sfod, native):
     """SFOD.OVERLAP_TEACHER only changes WHEN the teacher pass and the student's backbone forward are
     launched (two streams), never what they compute: first-step losses and the teacher's refreshed BN
