@@ -139,3 +139,85 @@ def test_two_rank_gloo_sharding_and_gradient_allreduce():
     # the two ranks drew disjoint strided slices of the same permutation
     ids = res[0][6]
     assert len(set(ids[0]) & set(ids[1])) == 0 or len(set(ids[0] + ids[1])) <= 6
+
+
+def _eval_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sfod = importlib.import_module("simple-sfod_amd")
+    S = sfod.structures
+    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs",
+                                             "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"),
+                                ["MODEL.DEVICE", "cpu", "SFOD.SYNTHETIC.HEIGHT", "64", "SFOD.SYNTHETIC.WIDTH", "128",
+                                 "SFOD.SYNTHETIC.NUM_TEST_IMAGES", "5", "TEST.IMS_PER_BATCH", "2", "INPUT.MIN_SIZE_TEST",
+                                 "32", "SFOD.SYNTHETIC.BOXES_PER_IMAGE", "4",
+                                 "DATASETS.TEST", "('synthetic_cityscapes_foggy_val',)"])
+
+    class Echo(torch.nn.Module):
+        """Returns half of each image's ground truth (even indices) as detections: AP is < 100 and depends on
+        every image, so a rank that dropped or duplicated its share would change the table."""
+
+        def forward(self, batched_inputs):
+            outs = []
+            for d in batched_inputs:
+                inst = S.Instances((d["height"], d["width"]))
+                sx = d["width"] / d["image"].shape[2]
+                keep = torch.arange(0, len(d["instances"]), 2)
+                inst.pred_boxes = S.Boxes(d["instances"].gt_boxes.tensor[keep] * sx)
+                inst.scores = torch.linspace(0.9, 0.6, len(keep))
+                inst.pred_classes = d["instances"].gt_classes[keep]
+                outs.append({"instances": inst})
+            return outs
+
+    # rank-local share (InferenceSampler) + gather in evaluate(): rank 0 gets the table, the others {}
+    res = sfod.engine.BaseTrainer.test(cfg, Echo())
+    loader = sfod.data.TestLoader(cfg, torch.device("cpu"), rank, world)
+    ids = [d["image_id"] for b in loader for d in b]
+    q.put((rank, res, ids))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_evaluation_gathers_predictions_on_rank0(sfod):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_eval_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict()
+    for _ in range(world):
+        rank, r, ids = q.get(timeout=300)
+        res[rank] = (r, ids)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 1, 2] and res[1][1] == [3, 4]
+    assert res[1][0] == {}                                   # d2: only the main process evaluates
+    table = res[0][0]["bbox"]
+    # single-process reference over the whole set
+    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs",
+                                             "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"),
+                                ["MODEL.DEVICE", "cpu", "SFOD.SYNTHETIC.HEIGHT", "64", "SFOD.SYNTHETIC.WIDTH", "128",
+                                 "SFOD.SYNTHETIC.NUM_TEST_IMAGES", "5", "TEST.IMS_PER_BATCH", "2", "INPUT.MIN_SIZE_TEST",
+                                 "32", "SFOD.SYNTHETIC.BOXES_PER_IMAGE", "4"])
+    loader = sfod.data.TestLoader(cfg, torch.device("cpu"))
+    ev = sfod.engine.BaseTrainer.build_evaluator(cfg, "x", data_loader=loader)
+    S = sfod.structures
+    for batch in loader:
+        outs = []
+        for d in batch:
+            inst = S.Instances((d["height"], d["width"]))
+            keep = torch.arange(0, len(d["instances"]), 2)
+            inst.pred_boxes = S.Boxes(d["instances"].gt_boxes.tensor[keep] * (d["width"] / d["image"].shape[2]))
+            inst.scores = torch.linspace(0.9, 0.6, len(keep))
+            inst.pred_classes = d["instances"].gt_classes[keep]
+            outs.append({"instances": inst})
+        ev.process(batch, outs)
+    ref = ev.evaluate()["bbox"]
+    assert 0 < ref["AP"] < 100
+    for k, v in ref.items():
+        assert (v != v and table[k] != table[k]) or abs(table[k] - v) < 1e-9, k
