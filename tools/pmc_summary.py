@@ -4,7 +4,7 @@ import csv, glob, sys, collections, json
 
 def load(pattern, counter):
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-    for f in glob.glob(pattern):
+    for f in glob.glob(pattern) + glob.glob(pattern.replace("/*/*", "/*")):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
