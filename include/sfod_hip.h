@@ -155,6 +155,11 @@ int sfod_bn_finalize_ws_floats(int C);
 int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* z, int B, int H, int W,
                           int C, int pool, int dt, void* stream);
+/* Bottleneck tail of the ResNet path (d2 BottleneckBlock.forward, reached through build_resnet_backbone of the r101
+ * yaml): z = relu(bn(y) + residual) in one pass over [rows, C]; same statistics / affine inputs as above. */
+int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
+                         const float* beta, const void* residual, void* z, int64_t rows, int C, int dt,
+                         void* stream);
 /* backward of the block above.  dz: grad w.r.t. block output; y: saved conv output; returns dy
  * (grad w.r.t. conv output), dgamma, dbeta.  ws: fp32 workspace [nblk*2*C] (see ws query).
  * dgamma_acc / dbeta_acc (may be NULL): the parameters' gradient accumulators (+= this call's dgamma /

@@ -372,11 +372,51 @@ k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, cons
   }
 }
 
+// Bottleneck tail in one pass: z = relu(bn(y) + residual) (d2 BottleneckBlock.forward: out = conv3(out);
+// out += shortcut; relu) -- the normalised tensor is never written.
+template <typename T>
+__global__ void __launch_bounds__(256)
+k_bn_add_relu_fwd(const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                  const float* __restrict__ gamma, const float* __restrict__ beta, const T* __restrict__ res,
+                  T* __restrict__ z, int64_t rows, int C) {
+  constexpr int V = VecT<T>::N;
+  const int cv = C / V;
+  const int64_t total = rows * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * V;
+    float v[V], r[V];
+    load_vec<T>(y + t * V, v);
+    load_vec<T>(res + t * V, r);
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+      v[i] = fmaxf((v[i] - mean[c0 + i]) * (invstd[c0 + i] * gamma[c0 + i]) + beta[c0 + i] + r[i], 0.f);
+    store_vec<T>(z + t * V, v);
+  }
+}
+
 static inline int ew_grid(int64_t total) {
   int64_t g = (total + 255) / 256;
   if (g > 256 * 16) g = 256 * 16;
   if (g < 1) g = 1;
   return (int)g;
+}
+
+extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
+                                    const float* beta, const void* residual, void* z, int64_t rows, int C, int dt,
+                                    void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(C % V == 0, "bn_add_relu: C not a multiple of the vector width");
+  if (rows == 0) return 0;
+  const int grid = ew_grid(rows * (C / V));
+  hipStream_t s = (hipStream_t)stream;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_bn_add_relu_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
+                       beta, (const float*)residual, (float*)z, rows, C);
+  else
+    hipLaunchKernelGGL(k_bn_add_relu_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, mean, invstd, gamma,
+                       beta, (const bf16_t*)residual, (bf16_t*)z, rows, C);
+  return sfod_check_launch("bn_add_relu_fwd");
 }
 
 extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,

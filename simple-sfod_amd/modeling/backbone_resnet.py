@@ -25,6 +25,8 @@ parameters; compute:
                     residual join relu(a + b); hand-written backward (BN, wgrad, dgrad per conv)
   stride-2 1x1      even-pixel subsampling shared by conv1 and the shortcut, then plain GEMMs
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -166,6 +168,7 @@ class ResNet(nn.Module):
                 raise NotImplementedError("trainable stages need RESNETS.NORM=BN (the named r101 config)")
         self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
         self.bn_momentum = 0.1
+        self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
 
     # ---- Detectron2 Backbone surface -----------------------------------------------------------------
     @property
@@ -259,7 +262,7 @@ class ResNet(nn.Module):
         self._wp = {id(c): views[i] for i, c in enumerate(convs)}
         self._wr = {id(c): views[n + i] for i, c in enumerate(convs)} if with_dgrad else {}
 
-    def _live_conv_bn(self, x, conv, relu, dt):
+    def _live_conv_bn(self, x, conv, relu, dt, residual=None):
         bn = conv.norm
         k = conv.kernel_size[0]
         wp = self.__dict__.get("_wp", {}).get(id(conv)) if x.shape[-1] == conv.in_channels else None
@@ -274,7 +277,10 @@ class ResNet(nn.Module):
         else:
             y = native.conv_fwd(x, wp, None, conv.out_channels, k)
             mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
-        z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False, relu=relu)
+        if residual is not None:      # bottleneck tail: relu(bn(y) + shortcut) without materialising bn(y)
+            z = native.bn_add_relu_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual)
+        else:
+            z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False, relu=relu)
         return y, mean, invstd, z
 
     def _block_forward(self, blk, x, live, dt):
@@ -288,13 +294,16 @@ class ResNet(nn.Module):
             return native.add_act(o, sc, 1), None
         y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt)
         y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt)
-        y3, m3, i3, t3 = self._live_conv_bn(a2, blk.conv3, False, dt)
         if blk.shortcut is not None:
             ys, ms, is_, ts = self._live_conv_bn(xs, blk.shortcut, False, dt)
         else:
             ys = ms = is_ = None
             ts = x
-        out = native.add_act(t3, ts, 1)
+        if self.fuse_residual:
+            y3, m3, i3, out = self._live_conv_bn(a2, blk.conv3, False, dt, residual=ts)
+        else:
+            y3, m3, i3, t3 = self._live_conv_bn(a2, blk.conv3, False, dt)
+            out = native.add_act(t3, ts, 1)
         return out, (x.shape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out)
 
     def _forward_impl(self, x, save=True):

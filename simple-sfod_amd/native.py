@@ -601,6 +601,15 @@ def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True):
     return z
 
 
+def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual):
+    """relu(bn(y) + residual) in one pass (bottleneck tail)."""
+    assert residual.shape == y.shape and residual.dtype == y.dtype
+    z = torch.empty_like(y)
+    C = y.shape[-1]
+    call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, y.numel() // C, C, dt_of(y))
+    return z
+
+
 def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None, relu=True,
                      dgamma_acc=None, dbeta_acc=None):
     """``dgamma_acc`` / ``dbeta_acc``: gradient accumulators (see ``grad_sink``) updated in the same launch."""

@@ -960,3 +960,27 @@ def test_aug_erase_bit_exact(native):
         assert np.array_equal(_hwc(d.cpu()), ref), (i, j, h, w)
     with pytest.raises(native.NativeLibraryError):
         native.aug_erase_(d, 90, 0, 10, 10, torch.zeros(3, 10, 10, device=DEV))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bn_add_relu_fwd_equals_the_two_pass_form(native, dtype):
+    """Bottleneck tail relu(bn(y) + shortcut) in one pass: identical to BN-apply followed by add + ReLU in fp32;
+    in bf16 it skips the rounding of the intermediate, so it is compared against the fp32 result."""
+    g = torch.Generator().manual_seed(4)
+    B, H, W, C = 2, 19, 23, 64
+    y = torch.randn(B, H, W, C, generator=g)
+    res = torch.randn(B, H, W, C, generator=g)
+    mean, invstd = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.1
+    ref = torch.relu((y - mean) * (invstd * gamma) + beta + res)
+    args = [t.to(DEV) for t in (mean, invstd, gamma, beta)]
+    yd, rd = y.to(DEV).to(dtype), res.to(DEV).to(dtype)
+    got = native.bn_add_relu_fwd(yd, *args, rd)
+    if dtype == torch.float32:
+        two = native.add_act(native.bn_relu_pool_fwd(yd, *args, False, relu=False), rd, 1)
+        assert torch.equal(got, two)
+        torch.testing.assert_close(got.cpu(), ref, rtol=1e-6, atol=1e-6)
+    else:
+        ref16 = torch.relu((yd.float().cpu() - mean) * (invstd * gamma) + beta + rd.float().cpu())
+        torch.testing.assert_close(got.float().cpu(), ref16, rtol=1e-2, atol=1e-2)
+        assert (got.float().cpu() - ref16).abs().max() <= (ref16.abs().max() / 128)
