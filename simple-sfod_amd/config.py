@@ -381,6 +381,8 @@ def add_native_config(cfg):
     # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass
     # that stores the activated output directly; sfod_conv_first_fused)
     _C.SFOD.FUSE_FIRST_LAYER = True
+    # d2's EvalHook inside Trainer.train(): Trainer.test every TEST.EVAL_PERIOD iterations and after the last one
+    _C.SFOD.EVAL_HOOK = True
     _C.SFOD.SYNTHETIC = CN()
     _C.SFOD.SYNTHETIC.HEIGHT = 1024
     _C.SFOD.SYNTHETIC.WIDTH = 2048

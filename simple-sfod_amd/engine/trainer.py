@@ -273,6 +273,31 @@ class BaseTrainer:
         p = self.cfg.SOLVER.CHECKPOINT_PERIOD
         if p > 0 and (self.iter + 1) % p == 0 and get_rank() == 0 and self.cfg.OUTPUT_DIR:
             self.save_checkpoint("model_{:07d}".format(self.iter))
+        # d2 hooks.EvalHook(cfg.TEST.EVAL_PERIOD, ...): every EVAL_PERIOD iterations, and once after the last one
+        ep = self.cfg.TEST.EVAL_PERIOD
+        nxt = self.iter + 1
+        if self.cfg.SFOD.EVAL_HOOK and ((ep > 0 and nxt % ep == 0 and nxt != self.max_iter) or nxt >= self.max_iter):
+            self._do_eval()
+
+    def _eval_targets(self):
+        """[(attribute suffix, result-key suffix, model)]: what the trainer's EvalHooks evaluate (base.py:254-258)."""
+        return [("", "", self.model)]
+
+    def _do_eval(self):
+        for attr, suffix, model in self._eval_targets():
+            results = self.test(self.cfg, model)
+            setattr(self, "_last_eval_results" + attr, results)
+            if isinstance(results, dict):          # EvalHook._do_eval: flattened scalars into the storage
+                flat = {}
+
+                def walk(prefix, d):
+                    for k, v in d.items():
+                        if isinstance(v, dict):
+                            walk(prefix + k + "/", v)
+                        else:
+                            flat[prefix + k] = float(v)
+                walk("", {k + suffix: v for k, v in results.items()} if suffix else results)
+                self.storage.put_scalars(**flat)
 
     def _flush_metrics(self):
         rpn = getattr(self.model, "proposal_generator", None)
@@ -370,6 +395,14 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         self.teacher_flat.param.copy_(s.param)
         self.teacher_flat.fbuf.copy_(s.fbuf)
         self.teacher_flat.ibuf.copy_(s.ibuf)
+
+    def _eval_targets(self):
+        """source_free_adaptive_teacher.py:648-662: two EvalHooks -- the student (result keys suffixed
+        ``_student``), then the teacher."""
+        out = [("_student", "_student", self.model)]
+        if self.model_teacher is not None and self.model_teacher is not self.model:
+            out.append(("_teacher", "", self.model_teacher))
+        return out
 
     # ---- pseudo-labelling -------------------------------------------------------------------------
     def process_pseudo_label(self, proposals, cur_threshold, proposal_type, pseudo_label_method=""):

@@ -486,6 +486,10 @@ def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     assert all(int(v.item()) == 3 for v in nbt)
     sd = tr.state_dict_for_checkpoint()["model"]
     assert "modelTeacher.backbone.vgg0.0.weight" in sd and "modelStudent.roi_heads.box_head.fc1.weight" in sd
+    # EvalHooks (source_free_adaptive_teacher.py:648-662): after the last iteration the student and the teacher were
+    # evaluated on every DATASETS.TEST entry; both models are back in training mode
+    for res in (tr._last_eval_results_student, tr._last_eval_results_teacher):
+        assert list(res.keys()) == list(cfg.DATASETS.TEST) and "AP50" in res[cfg.DATASETS.TEST[0]]["bbox"]
 
 
 def test_bpc_kernel_and_convert_bbox_scores_match_oracle(sfod, native):
