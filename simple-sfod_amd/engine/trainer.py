@@ -278,10 +278,44 @@ class BaseTrainer:
         nxt = self.iter + 1
         if self.cfg.SFOD.EVAL_HOOK and ((ep > 0 and nxt % ep == 0 and nxt != self.max_iter) or nxt >= self.max_iter):
             self._do_eval()
+        # ValLossHook(cfg.TEST.EVAL_PERIOD, ...) when TEST.VAL_LOSS (val_loss.py:89-93: final iteration or period)
+        if self.cfg.SFOD.EVAL_HOOK and self.cfg.TEST.VAL_LOSS and (nxt == self.max_iter or (ep > 0 and nxt % ep == 0)):
+            self._do_val_loss()
 
     def _eval_targets(self):
         """[(attribute suffix, result-key suffix, model)]: what the trainer's EvalHooks evaluate (base.py:254-258)."""
         return [("", "", self.model)]
+
+    def _val_loss_targets(self):
+        """[(model_name, model)] of the ValLossHooks (base.py:259-265)."""
+        return [("", self.model)]
+
+    @torch.no_grad()
+    def _do_val_loss(self):
+        """``ValLossHook._do_loss_eval`` (daod/engine/hooks/val_loss.py:15-78): the model AS IT IS (training mode, so
+        BatchNorm statistics move, as in the reference) on ``DATASETS.TEST[0]`` with ground truth, one image per
+        batch, under no_grad; per-key mean over the batches -> ``<key><model_name>_val`` and
+        ``total_loss<model_name>_val`` (sum of the ``loss*`` keys)."""
+        from ..data import TestLoader
+        for name, model in self._val_loss_targets():
+            loader = TestLoader(self.cfg, self.device, get_rank(), get_world_size())
+            loader.batch = 1
+            acc, nb = {}, 0
+            for inputs in loader:
+                rec = model(inputs)
+                if isinstance(rec, tuple):
+                    rec = rec[0]
+                if isinstance(rec, list):
+                    rec = {}
+                for k, v in rec.items():
+                    v = v.detach().float() if isinstance(v, torch.Tensor) else torch.tensor(float(v), device=self.device)
+                    acc[k] = acc[k] + v if k in acc else v
+                nb += 1
+            losses = {k: v / max(nb, 1) for k, v in acc.items() if k[:4] == "loss"}
+            if get_rank() == 0 and losses:
+                self.storage.put_scalar("total_loss" + name + "_val", sum(losses.values()))
+                if len(losses) > 1:
+                    self.storage.put_scalars(**{k + name + "_val": v for k, v in losses.items()})
 
     def _do_eval(self):
         for attr, suffix, model in self._eval_targets():
@@ -395,6 +429,13 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         self.teacher_flat.param.copy_(s.param)
         self.teacher_flat.fbuf.copy_(s.fbuf)
         self.teacher_flat.ibuf.copy_(s.ibuf)
+
+    def _val_loss_targets(self):
+        """source_free_adaptive_teacher.py:663-675: the student (``_student``), then the teacher."""
+        out = [("_student", self.model)]
+        if self.model_teacher is not None and self.model_teacher is not self.model:
+            out.append(("", self.model_teacher))
+        return out
 
     def _eval_targets(self):
         """source_free_adaptive_teacher.py:648-662: two EvalHooks -- the student (result keys suffixed

@@ -483,13 +483,20 @@ def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     assert 0.0 < moved.item() < 0.01
     assert tr.model_teacher.training and tr.model.training
     nbt = [v for k, v in tr.model_teacher.state_dict().items() if "num_batches_tracked" in k]
-    assert all(int(v.item()) == 3 for v in nbt)
+    # 3 training steps + the ValLossHook's train-mode passes over the test set after the last one (the reference's
+    # hook runs ``model(data)`` on the model as it is, so BatchNorm statistics move there too)
+    assert all(int(v.item()) == 3 + cfg.SFOD.SYNTHETIC.NUM_TEST_IMAGES for v in nbt)
     sd = tr.state_dict_for_checkpoint()["model"]
     assert "modelTeacher.backbone.vgg0.0.weight" in sd and "modelStudent.roi_heads.box_head.fc1.weight" in sd
     # EvalHooks (source_free_adaptive_teacher.py:648-662): after the last iteration the student and the teacher were
     # evaluated on every DATASETS.TEST entry; both models are back in training mode
     for res in (tr._last_eval_results_student, tr._last_eval_results_teacher):
         assert list(res.keys()) == list(cfg.DATASETS.TEST) and "AP50" in res[cfg.DATASETS.TEST[0]]["bbox"]
+    # ValLossHooks (TEST.VAL_LOSS; val_loss.py): mean supervised losses of the student and of the teacher on the test set
+    tr._flush_metrics()
+    rec = tr.storage.history[-1]
+    for k in ("loss_cls_student_val", "loss_rpn_loc_student_val", "total_loss_student_val", "loss_cls_val", "total_loss_val"):
+        assert np.isfinite(rec[k]), (k, sorted(rec))
 
 
 def test_bpc_kernel_and_convert_bbox_scores_match_oracle(sfod, native):

@@ -177,7 +177,8 @@ def test_r101_c4_teacher_student_trainer_steps(native):
     assert not torch.equal(sd0["backbone.res3.0.conv1.weight"], sd1["backbone.res3.0.conv1.weight"])
     assert not torch.equal(sd0["backbone.res4.22.conv3.norm.weight"], sd1["backbone.res4.22.conv3.norm.weight"])
     tsd = tr.model_teacher.state_dict()
-    assert int(tsd["backbone.res4.0.conv1.norm.num_batches_tracked"]) == 3
+    # 3 training steps + the ValLossHook's train-mode passes over the 16 test images after the last iteration
+    assert int(tsd["backbone.res4.0.conv1.norm.num_batches_tracked"]) == 3 + cfg.SFOD.SYNTHETIC.NUM_TEST_IMAGES
     assert not torch.equal(tsd["backbone.res4.0.conv1.norm.running_mean"], sd0["backbone.res4.0.conv1.norm.running_mean"])
     d_t = (tsd["backbone.res3.0.conv1.weight"] - sd0["backbone.res3.0.conv1.weight"]).norm()
     d_s = (sd1["backbone.res3.0.conv1.weight"] - sd0["backbone.res3.0.conv1.weight"]).norm()
