@@ -110,7 +110,12 @@ class FusedSGD:
         self.grad_scale = 1.0
 
     def attach_teacher(self, teacher_flat, keep_rate):
-        """Fuse the teacher EMA (``_update_teacher_model``) into the parameter update."""
+        """Fuse the teacher EMA (``_update_teacher_model``) into the parameter update.  A teacher key the student
+        lacks is the reference's error (source_free_adaptive_teacher.py:600-601), raised once here instead of at
+        every update."""
+        for key in teacher_flat.offsets:
+            if key not in self.flat.offsets:
+                raise Exception("{} is not found in student model".format(key))
         assert list(teacher_flat.offsets.items()) == list(self.flat.offsets.items()), \
             "teacher and student must have identical parameter layouts"
         self.teacher, self.ema_keep = teacher_flat, float(keep_rate)

@@ -188,3 +188,18 @@ def test_checkpoint_key_matching_and_loading_semantics(tmp_path):
     assert inc.unexpected_keys == [] and "head.weight" in inc.missing_keys
     with pytest.raises(FileNotFoundError):
         ck.load_model_weights(dst2, str(tmp_path / "nope.pth"))
+
+
+def test_ema_attach_raises_the_reference_error_for_a_key_the_student_lacks(sfod):
+    """source_free_adaptive_teacher.py:600-601: ``Exception("{} is not found in student model")``."""
+    E = sfod.engine
+    student = torch.nn.Sequential(torch.nn.Linear(3, 2))
+    teacher = torch.nn.Sequential(torch.nn.Linear(3, 2), torch.nn.Linear(2, 1))
+    fs, ft = E.FlatModelState(student), E.FlatModelState(teacher, with_grad=False)
+    opt = E.solver.FusedSGD.__new__(E.solver.FusedSGD)
+    opt.flat, opt.teacher, opt.ema_keep = fs, None, 0.0
+    with pytest.raises(Exception, match="1.weight is not found in student model"):
+        opt.attach_teacher(ft, 0.9996)
+    ok = E.FlatModelState(torch.nn.Sequential(torch.nn.Linear(3, 2)), with_grad=False)
+    opt.attach_teacher(ok, 0.9996)
+    assert opt.teacher is ok and opt.ema_keep == 0.9996
