@@ -383,6 +383,9 @@ def add_native_config(cfg):
     _C.SFOD.FUSE_FIRST_LAYER = True
     # d2's EvalHook inside Trainer.train(): Trainer.test every TEST.EVAL_PERIOD iterations and after the last one
     _C.SFOD.EVAL_HOOK = True
+    # json file {"<dataset name>": {"json_file": ..., "image_root": ...}}: COCO-format datasets for the names in
+    # DATASETS.*; names that are not registered fall back to the synthetic set (data/coco.py)
+    _C.SFOD.DATASETS_FILE = ""
     _C.SFOD.SYNTHETIC = CN()
     _C.SFOD.SYNTHETIC.HEIGHT = 1024
     _C.SFOD.SYNTHETIC.WIDTH = 2048

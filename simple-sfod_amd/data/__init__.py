@@ -1,3 +1,4 @@
 from .synthetic import (SyntheticTargetDataset, TwoCropLoader, TrainingSampler, InferenceSampler,  # noqa: F401
                         TestLoader, CITYSCAPES_CLASSES)
 from .augment import StrongAugmentation  # noqa: F401
+from .coco import CocoTargetDataset, load_coco_json, register_coco_instances, build_dataset  # noqa: F401

@@ -1,0 +1,123 @@
+"""COCO-json datasets behind the loader contract.
+
+The reference registers its datasets in code (``register_all_datasets(cfg)``, ``train_net_mt.py:71``; the
+Cityscapes-to-COCO converter writes the json files) and reads them with Detectron2's
+``load_coco_json`` / ``utils.read_image(file_name, format="BGR")``.  This module is the same thing without
+Detectron2 / pycocotools: ``register_coco_instances(name, json_file, image_root)``, ``load_coco_json`` with d2's
+conventions (category ids sorted and mapped to contiguous 0..K-1, ``bbox`` kept XYWH_ABS in the records,
+``iscrowd`` carried, images without annotations kept), and ``CocoTargetDataset``: frames decoded once with Pillow,
+kept resident on the device as uint8 CHW BGR tensors at their native size (288 GB of HBM hold the Cityscapes
+training set ~15 times), resized / flipped / augmented per iteration by the same device mapper as the
+synthetic set.  Frames of different sizes are handled per item; the loaders group batches by aspect ratio like
+``AspectRatioGroupedSemiSupDatasetTwoCropSourceFree`` (``daod/data/common.py:199-228``).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from .synthetic import _resize_u8, resize_shortest_edge_shape
+
+DATASETS = {}      # name -> (json_file, image_root)
+
+
+def register_coco_instances(name, json_file, image_root):
+    """d2 ``register_coco_instances`` (metadata-free): make ``name`` resolvable from ``DATASETS.*``."""
+    DATASETS[name] = (json_file, image_root)
+
+
+def register_from_file(path):
+    """``{"name": {"json_file": ..., "image_root": ...}, ...}`` -> registrations (``SFOD.DATASETS_FILE``)."""
+    with open(path) as f:
+        for name, d in json.load(f).items():
+            register_coco_instances(name, d["json_file"], d["image_root"])
+
+
+def load_coco_json(json_file, image_root):
+    """d2 ``load_coco_json`` for boxes -> (dataset dicts, class names).  Category ids are sorted and mapped to
+    0..K-1; every annotation keeps ``bbox`` (XYWH_ABS, ``bbox_mode`` 1), ``category_id`` (contiguous) and
+    ``iscrowd``; an annotation with ``ignore`` != 0 is rejected like in d2."""
+    with open(json_file) as f:
+        data = json.load(f)
+    cats = sorted(data["categories"], key=lambda c: c["id"])
+    id_map = {c["id"]: i for i, c in enumerate(cats)}
+    names = [c["name"] for c in cats]
+    anns = {}
+    seen = set()
+    for a in data.get("annotations", []):
+        assert a["id"] not in seen, "Annotation ids in '{}' are not unique!".format(json_file)
+        seen.add(a["id"])
+        assert a.get("ignore", 0) == 0, '"ignore" in COCO json file is not supported.'
+        anns.setdefault(a["image_id"], []).append(a)
+    dicts = []
+    for img in sorted(data["images"], key=lambda i: i["id"]):
+        rec = {"file_name": os.path.join(image_root, img["file_name"]), "height": img["height"],
+               "width": img["width"], "image_id": img["id"], "annotations": []}
+        for a in anns.get(img["id"], []):
+            obj = {"bbox": [float(v) for v in a["bbox"]], "bbox_mode": 1, "category_id": id_map[a["category_id"]],
+                   "iscrowd": int(a.get("iscrowd", 0))}
+            if "area" in a:
+                obj["area"] = float(a["area"])
+            rec["annotations"].append(obj)
+        dicts.append(rec)
+    return dicts, names
+
+
+def read_image_bgr(path):
+    """d2 ``utils.read_image(path, format="BGR")``: EXIF-oriented RGB decode, channels reversed.  -> uint8 HWC."""
+    from PIL import Image, ImageOps
+    with Image.open(path) as im:
+        im = ImageOps.exif_transpose(im).convert("RGB")
+        return np.asarray(im)[:, :, ::-1].copy()
+
+
+class CocoTargetDataset:
+    """Same item layout as ``SyntheticTargetDataset`` (image / boxes at the mapper's output scale / classes /
+    native height, width / ids) plus a per-item output ``size``; ``dataset_dicts`` are the loaded records."""
+
+    def __init__(self, cfg, device, names, train=True):
+        short = cfg.INPUT.MIN_SIZE_TRAIN[0] if train else cfg.INPUT.MIN_SIZE_TEST
+        max_size = cfg.INPUT.MAX_SIZE_TRAIN if train else cfg.INPUT.MAX_SIZE_TEST
+        self.device_resize = bool(cfg.SFOD.SYNTHETIC.DEVICE_RESIZE and torch.device(device).type == "cuda")
+        self.items, self._dicts, self.class_names = [], [], None
+        for name in names:
+            dicts, cls = load_coco_json(*DATASETS[name])
+            assert self.class_names in (None, cls), "datasets of one loader must share their categories"
+            self.class_names = cls
+            self._dicts += dicts
+        for rec in self._dicts:
+            img = torch.from_numpy(read_image_bgr(rec["file_name"])).permute(2, 0, 1).contiguous()
+            h, w = int(img.shape[1]), int(img.shape[2])
+            newh, neww = resize_shortest_edge_shape(h, w, short, max_size)
+            if (newh, neww) != (h, w) and not self.device_resize:
+                img = _resize_u8(img, newh, neww)
+            # the train mapper drops crowd annotations (two_crop_augmentation_mapper.py:124-131)
+            keep = [a for a in rec["annotations"] if a.get("iscrowd", 0) == 0]
+            b = torch.tensor([a["bbox"] for a in keep], dtype=torch.float32).reshape(-1, 4)
+            boxes = torch.cat([b[:, :2], b[:, :2] + b[:, 2:]], 1) * torch.tensor([neww / w, newh / h] * 2)
+            boxes[:, 0::2].clamp_(0, neww)          # transform_instance_annotations clips to the image
+            boxes[:, 1::2].clamp_(0, newh)
+            classes = torch.tensor([a["category_id"] for a in keep], dtype=torch.int64)
+            nonempty = ((boxes[:, 2] - boxes[:, 0]) > 1e-5) & ((boxes[:, 3] - boxes[:, 1]) > 1e-5)   # filter_empty_instances
+            self.items.append({"image": img.to(device), "boxes": boxes[nonempty].to(device),
+                               "classes": classes[nonempty].to(device), "height": h, "width": w,
+                               "image_id": rec["image_id"], "file_name": rec["file_name"], "size": (newh, neww)})
+        self.size = self.items[0]["size"] if self.items else (0, 0)
+
+    def __len__(self):
+        return len(self.items)
+
+    def dataset_dicts(self, cfg=None):
+        return self._dicts
+
+
+def build_dataset(cfg, device, names, train=True, num_images=None):
+    """The registered COCO-json datasets named in the config, else the synthetic stand-in."""
+    from .synthetic import SyntheticTargetDataset
+    if "DATASETS_FILE" in cfg.SFOD and cfg.SFOD.DATASETS_FILE:
+        register_from_file(cfg.SFOD.DATASETS_FILE)
+    real = [n for n in names if n in DATASETS]
+    if real:
+        return CocoTargetDataset(cfg, device, real, train=train)
+    return SyntheticTargetDataset(cfg, device, num_images=num_images, train=train)

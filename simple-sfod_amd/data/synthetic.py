@@ -6,8 +6,8 @@ The reference's loader (``daod/data/build.py:289-367``, ``daod/data/common.py:19
 ``image`` (uint8 ``3xHxW`` BGR tensor, post ResizeShortestEdge + RandomFlip), ``instances``,
 ``height``, ``width``, ``file_name``, ``image_id``.  This module reproduces that contract on
 synthetic 8-class Cityscapes-shape frames (there is no dataset / network in the build
-environment); real COCO-json loading and the strong augmentation are "next" rows
-(SURVEY.md section 8f).
+environment); registered COCO-json datasets take their place through ``data/coco.py``, the strong
+augmentation is ``data/augment.py``.
 
 Frames are generated once and kept resident on the device at their native size (1024x2048 by
 default); every iteration the mapper's ResizeShortestEdge (shortest edge 600, max 1333,
@@ -128,9 +128,12 @@ class TestLoader:
     MAX_SIZE_TEST), no flip; ``height`` / ``width`` are the frame's native size (what ``detector_postprocess``
     rescales the detections to)."""
 
-    def __init__(self, cfg, device, rank=0, world=1, dataset=None):
-        self.dataset = dataset or SyntheticTargetDataset(cfg, device, num_images=cfg.SFOD.SYNTHETIC.NUM_TEST_IMAGES,
-                                                         train=False)
+    def __init__(self, cfg, device, rank=0, world=1, dataset=None, dataset_name=None):
+        if dataset is None:
+            from .coco import build_dataset
+            dataset = build_dataset(cfg, device, [dataset_name] if dataset_name else list(cfg.DATASETS.TEST),
+                                    train=False, num_images=cfg.SFOD.SYNTHETIC.NUM_TEST_IMAGES)
+        self.dataset = dataset
         self.batch = max(int(cfg.TEST.IMS_PER_BATCH), 1)
         self.sampler = InferenceSampler(len(self.dataset), rank, world)
 
@@ -139,8 +142,8 @@ class TestLoader:
 
     def _map(self, item):
         img = item["image"]
-        if getattr(self.dataset, "device_resize", False):
-            newh, neww = self.dataset.size
+        newh, neww = item.get("size", self.dataset.size)
+        if getattr(self.dataset, "device_resize", False) and (newh, neww) != tuple(img.shape[1:]):
             img = native.resize_bilinear_u8(img, newh, neww, flip=False)
         inst = Instances((int(img.shape[1]), int(img.shape[2])))
         inst.gt_boxes = Boxes(item["boxes"])
@@ -189,8 +192,14 @@ class TwoCropLoader:
         assert total > 0 and total % world == 0, \
             "Total target batch size ({}) must be divisible by the number of gpus ({}).".format(total, world)
         self.batch = total // world
-        self.dataset = dataset or SyntheticTargetDataset(cfg, device)
+        if dataset is None:
+            from .coco import build_dataset
+            names = cfg.DATASETS.TRAIN if labeled else (cfg.DATASETS.TRAIN_TARGET if "TRAIN_TARGET" in cfg.DATASETS
+                                                        else cfg.DATASETS.TRAIN)
+            dataset = build_dataset(cfg, device, list(names), train=True)
+        self.dataset = dataset
         self.sampler = iter(TrainingSampler(len(self.dataset), max(cfg.SEED, 0), rank, world))
+        self._buckets = [[], []]       # aspect-ratio grouping (daod/data/common.py:199-228): w > h | otherwise
         self.flip = cfg.INPUT.RANDOM_FLIP == "horizontal"
         self.gen = torch.Generator().manual_seed(max(cfg.SEED, 0) + rank)
         self.labeled = labeled
@@ -204,8 +213,8 @@ class TwoCropLoader:
     def _map(self, item):
         img, boxes = item["image"], item["boxes"]
         do_flip = bool(self.flip and torch.rand(1, generator=self.gen).item() < 0.5)
-        if getattr(self.dataset, "device_resize", False):
-            newh, neww = self.dataset.size
+        newh, neww = item.get("size", self.dataset.size)
+        if getattr(self.dataset, "device_resize", False) and (newh, neww) != tuple(img.shape[1:]):
             img = native.resize_bilinear_u8(img, newh, neww, flip=do_flip)     # resize (+ flip) in one launch
         elif do_flip:
             img = native.hflip_u8(img) if img.is_cuda else torch.flip(img, dims=[2])
@@ -222,7 +231,15 @@ class TwoCropLoader:
         return self
 
     def _produce(self):
-        weak = [self._map(self.dataset.items[next(self.sampler)]) for _ in range(self.batch)]
+        # a batch holds images of ONE aspect class; the other bucket keeps what it has for a later batch
+        while True:
+            d = self._map(self.dataset.items[next(self.sampler)])
+            bucket = self._buckets[0 if d["width"] > d["height"] else 1]
+            bucket.append(d)
+            if len(bucket) == self.batch:
+                weak = bucket[:]
+                del bucket[:]
+                break
         if self.labeled:
             return weak
         strong = [dict(d) for d in weak]

@@ -187,7 +187,7 @@ class BaseTrainer:
     @classmethod
     def build_test_loader(cls, cfg, dataset_name):
         from ..data import TestLoader
-        return TestLoader(cfg, torch.device(cfg.MODEL.DEVICE), get_rank(), get_world_size())
+        return TestLoader(cfg, torch.device(cfg.MODEL.DEVICE), get_rank(), get_world_size(), dataset_name=dataset_name)
 
     @classmethod
     def build_evaluator(cls, cfg, dataset_name, output_folder=None, data_loader=None):
@@ -195,8 +195,8 @@ class BaseTrainer:
         stands in for the registered datasets (no dataset files in the build environment)."""
         from ..data import CITYSCAPES_CLASSES, TestLoader
         from ..evaluation import NewCOCOEvaluator
-        loader = data_loader or TestLoader(cfg, torch.device("cpu"))
-        names = CITYSCAPES_CLASSES[: cfg.MODEL.ROI_HEADS.NUM_CLASSES]
+        loader = data_loader or TestLoader(cfg, torch.device("cpu"), dataset_name=dataset_name)
+        names = getattr(loader.dataset, "class_names", None) or CITYSCAPES_CLASSES[: cfg.MODEL.ROI_HEADS.NUM_CLASSES]
         if len(names) < cfg.MODEL.ROI_HEADS.NUM_CLASSES:
             names = [str(i) for i in range(cfg.MODEL.ROI_HEADS.NUM_CLASSES)]
         return NewCOCOEvaluator(dataset_name, loader.dataset.dataset_dicts(cfg), names, output_dir=output_folder)
