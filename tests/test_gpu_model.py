@@ -746,6 +746,40 @@ def test_strong_augmentation_pipeline_and_loader(sfod, native):
         assert np.isfinite(rec[k]), (k, rec)
 
 
+def test_trainer_on_a_registered_coco_json_dataset(sfod, native, tmp_path):
+    """Loader contract on real files: frames of different sizes decoded from disk, resized per image
+    on the device (bit-exact with the Pillow path of the CPU loader), aspect-grouped ragged batches through two
+    trainer steps, evaluation hooks on the same dataset."""
+    from test_coco_dataset import _make_dataset
+    sizes = [(160, 320), (200, 120), (192, 384), (260, 150), (128, 256), (256, 128)]
+    jf, _ = _make_dataset(tmp_path, sizes)
+    sfod.data.register_coco_instances("tiny_gpu", jf, str(tmp_path))
+    opts = ["DATASETS.TRAIN_TARGET", "('tiny_gpu',)", "DATASETS.TEST", "('tiny_gpu',)", "INPUT.MIN_SIZE_TRAIN", "(128,)",
+            "INPUT.MAX_SIZE_TRAIN", "300", "INPUT.MIN_SIZE_TEST", "128", "INPUT.MAX_SIZE_TEST", "300",
+            "SOLVER.IMS_PER_BATCH_TARGET", "2", "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0",
+            "MODEL.ROI_HEADS.NUM_CLASSES", "3", "TEST.IMS_PER_BATCH", "2"]
+    cfg = make_cfg(sfod, opts=opts)
+    dev_loader = sfod.data.TwoCropLoader(cfg, torch.device(DEV))
+    cpu_loader = sfod.data.TwoCropLoader(make_cfg(sfod, opts=opts + ["MODEL.DEVICE", "cpu"]), torch.device("cpu"))
+    assert dev_loader.dataset.device_resize and not cpu_loader.dataset.device_resize
+    for _ in range(4):
+        (_, wd), (_, wc) = next(dev_loader), next(cpu_loader)
+        torch.cuda.synchronize()
+        assert [d["image_id"] for d in wd] == [d["image_id"] for d in wc]
+        for a, b in zip(wd, wc):
+            assert torch.equal(a["image"].cpu(), b["image"])                     # device resize (+ flip) == Pillow
+            torch.testing.assert_close(a["instances"].gt_boxes.tensor.cpu(), b["instances"].gt_boxes.tensor)
+    torch.manual_seed(cfg.SEED)
+    tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+    tr.train()
+    rec = tr.storage.history[-1]
+    for k in ("loss_cls_pseudo", "loss_rpn_cls_pseudo", "total_loss"):
+        assert np.isfinite(rec[k]), (k, rec)
+    tr._flush_metrics()                       # the hooks' scalars land after the step's own flush
+    assert np.isfinite(tr.storage.history[-1]["total_loss_student_val"])
+    assert "bbox" in tr._last_eval_results_teacher and "AP-person" in tr._last_eval_results_teacher["bbox"]
+
+
 def test_teacher_on_second_stream_gives_the_same_step(sfod, native):
     """SFOD.OVERLAP_TEACHER only changes WHEN the teacher pass and the student's backbone forward are
     launched (two streams), never what they compute: first-step losses and the teacher's refreshed BN
