@@ -34,6 +34,47 @@ def register_from_file(path):
             register_coco_instances(name, d["json_file"], d["image_root"])
 
 
+def register_datasets(datasets, root=None):
+    """``daod/data/datasets.py:41-108`` for its COCO-format families: the reference's dataset NAMES resolve to the
+    same files under ``$DETECTRON2_DATASETS`` (foggy Cityscapes ``cityscapes_instancesonly_foggy_<split>_<fog>``,
+    Cityscapes ``cityscapes_instancesonly_<split>``, ``sim10k_<split>``, ``kitti_<split>``).  A name whose json file
+    is absent stays unregistered (-> synthetic stand-in); the Pascal-VOC style sets (clipart / comic / watercolor)
+    are not supported."""
+    import re
+    root = root or os.getenv("DETECTRON2_DATASETS", "/scratch/username/datasets")
+    for name in datasets:
+        if name in DATASETS:
+            continue
+        if name.startswith("cityscapes_instancesonly_foggy_"):
+            m = re.match(r"cityscapes_instancesonly_foggy_(.*)_(.*)", name)
+            if m is None:
+                raise ValueError(f"Error parsing dataset {name}.")
+            split, fog = m.groups()
+            base = os.path.join(root, "cityscapes_foggy")
+            jf = os.path.join(base, "annotations", f"instancesonly_filtered_gtFine_{split}_{fog}.json")
+        elif name.startswith("cityscapes_instancesonly"):
+            split = re.match(r"cityscapes_instancesonly_(.*)", name).groups()[0]
+            base = os.path.join(root, "cityscapes")
+            jf = os.path.join(base, "annotations", f"instancesonly_filtered_gtFine_{split}.json")
+        elif name.startswith("sim10k") or name.startswith("kitti"):
+            m = re.match(r"(.*)_(.*)", name)
+            if m is None:
+                raise ValueError(f"Error parsing dataset {name}.")
+            ds, split = m.groups()
+            base = os.path.join(root, ds)
+            jf = os.path.join(base, f"sim10k_coco_{split}.json" if ds == "sim10k" else f"kitti_{split}_coco_format.json")
+        else:
+            continue
+        if os.path.isfile(jf):
+            register_coco_instances(name, jf, base)
+
+
+def register_all_datasets(cfg):
+    """``register_all_datasets(cfg)`` (``daod/data/datasets.py:17-23``, called at ``train_net_mt.py:71``)."""
+    for d in (cfg.DATASETS.TRAIN, cfg.DATASETS.TEST, cfg.DATASETS.get("TRAIN_TARGET", ())):
+        register_datasets(d)
+
+
 def load_coco_json(json_file, image_root):
     """d2 ``load_coco_json`` for boxes -> (dataset dicts, class names).  Category ids are sorted and mapped to
     0..K-1; every annotation keeps ``bbox`` (XYWH_ABS, ``bbox_mode`` 1), ``category_id`` (contiguous) and
@@ -117,6 +158,7 @@ def build_dataset(cfg, device, names, train=True, num_images=None):
     from .synthetic import SyntheticTargetDataset
     if "DATASETS_FILE" in cfg.SFOD and cfg.SFOD.DATASETS_FILE:
         register_from_file(cfg.SFOD.DATASETS_FILE)
+    register_datasets(names)
     real = [n for n in names if n in DATASETS]
     if real:
         return CocoTargetDataset(cfg, device, real, train=train)

@@ -88,3 +88,28 @@ def test_coco_json_dataset_loader_and_evaluator(sfod, tmp_path):
                                        "SFOD.SYNTHETIC.NUM_IMAGES", "2", "INPUT.MIN_SIZE_TRAIN", "(32,)",
                                        "SOLVER.IMS_PER_BATCH_TARGET", "1"])
     assert isinstance(D.TwoCropLoader(cfg2, torch.device("cpu")).dataset, D.SyntheticTargetDataset)
+
+
+def test_reference_dataset_names_resolve_under_the_datasets_root(sfod, tmp_path, monkeypatch):
+    """daod/data/datasets.py:41-108: name -> files under $DETECTRON2_DATASETS; absent files leave the name unregistered."""
+    D = sfod.data
+    root = tmp_path / "ds"
+    (root / "cityscapes_foggy" / "annotations").mkdir(parents=True)
+    (root / "kitti").mkdir()
+    jf, _ = _make_dataset(root / "cityscapes_foggy", [(20, 40), (30, 20)])
+    os.replace(jf, root / "cityscapes_foggy" / "annotations" / "instancesonly_filtered_gtFine_train_foggy_beta_0.02.json")
+    (root / "kitti" / "kitti_train_coco_format.json").write_text(json.dumps({"images": [], "annotations": [], "categories": []}))
+    monkeypatch.setenv("DETECTRON2_DATASETS", str(root))
+    names = ["cityscapes_instancesonly_foggy_train_foggy_beta_0.02", "cityscapes_instancesonly_val", "kitti_train",
+             "sim10k_train", "something_else"]
+    D.register_datasets(names)
+    reg = D.coco.DATASETS
+    assert reg[names[0]] == (str(root / "cityscapes_foggy" / "annotations" / "instancesonly_filtered_gtFine_train_foggy_beta_0.02.json"),
+                             str(root / "cityscapes_foggy"))
+    assert reg["kitti_train"][0].endswith("kitti/kitti_train_coco_format.json")
+    assert "cityscapes_instancesonly_val" not in reg and "sim10k_train" not in reg and "something_else" not in reg
+    cfg = sfod.config.setup_cfg(HOT, ["MODEL.DEVICE", "cpu", "DATASETS.TRAIN_TARGET", "('%s',)" % names[0],
+                                      "INPUT.MIN_SIZE_TRAIN", "(16,)", "SOLVER.IMS_PER_BATCH_TARGET", "1"])
+    D.register_all_datasets(cfg)
+    ds = D.TwoCropLoader(cfg, torch.device("cpu")).dataset
+    assert isinstance(ds, D.CocoTargetDataset) and len(ds) == 2

@@ -37,6 +37,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     torch.manual_seed(max(cfg.SEED, 0) + rank)           # d2 default_setup: seed_all_rng(SEED + rank)
     Trainer = sfod.engine.get_trainer_class(cfg)
+    sfod.data.register_all_datasets(cfg)                 # train_net_mt.py:71 (names without files -> synthetic stand-in)
     if args.eval_only:
         model = Trainer.build_model(cfg)
         # DetectionCheckpointer(model).resume_or_load(cfg.MODEL.WEIGHTS, resume=args.resume) (train_net_mt.py:75-77)
