@@ -472,6 +472,13 @@ template <typename T, typename OutT, bool UT>
 static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
                               const ConvArgs& a, hipStream_t s) {
   if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2>(x, w, bias, y, stats, a, s);
+  // long-K linear layers with few rows (the student's fc1: 4096 x 25088 -> 1024): 256 x 64 tiles, 8 waves, 3-stage
+  // pipeline -- one 8-wave workgroup per CU instead of one 4-wave one (0.35 -> 0.30 ms; SFOD_GEMM_TALL=0 disables)
+  static const int tall = []() { const char* e = getenv("SFOD_GEMM_TALL"); return e ? atoi(e) : 300; }();
+  if constexpr (UT) {
+    if (tall > 0 && a.ks == 1 && a.Cin >= 4096 && (int64_t)((a.M + 255) / 256) * ((a.Cout + 63) / 64) <= tall)
+      return launch_one<T, OutT, 1, UT, 4, 3>(x, w, bias, y, stats, a, s);
+  }
   // 256 x 128 tiles with a 3-stage DMA pipeline once the grid still fills the chip (>= 2 tiles / CU)
   const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
   if (UT && big_tiles >= 384) return launch_one<T, OutT, 2, UT, 4, 3>(x, w, bias, y, stats, a, s);
