@@ -12,8 +12,15 @@
  *     nothing synchronises.
  *   - return value: 0 on success, negative hipError_t otherwise, -1000 for bad arguments.
  *   - activations are NHWC ("pixel-major rows, channels contiguous"); `dt` selects the storage /
- *     MFMA input type: SFOD_F32 (parity mode, v_mfma_f32_32x32x2_f32) or SFOD_BF16 (throughput
- *     mode, v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+ *     MFMA input type: SFOD_F32 (v_mfma_f32_32x32x2_f32), SFOD_BF16 (reduced precision:
+ *     v_mfma_f32_32x32x16_bf16, fp32 accumulate) or SFOD_BF16X3 (fp32-equivalent arithmetic on the
+ *     bf16 matrix pipe, the default mode): every MFMA operand element v is stored as the pair
+ *     hi = bf16(v), lo = bf16(v - hi) (|v - hi - lo| <= 2^-16 |v|) and a product is accumulated in fp32 as
+ *     hi*hi + hi*lo + lo*hi (three v_mfma_f32_32x32x16_bf16; the dropped lo*lo term is <= 2^-16 relative).
+ *     Storage of a SFOD_BF16X3 tensor [.., C] (C a multiple of 8): 4 bytes per logical element, every group
+ *     of 8 consecutive channels is 32 bytes = 8 x bf16 hi followed by 8 x bf16 lo.  Convolutions / GEMMs take
+ *     SFOD_BF16X3 operands and write fp32; the elementwise producers (preprocess, BatchNorm apply, BatchNorm
+ *     backward, ROIAlign, cast) write the pairs.
  *   - per-image variable-length results live in fixed-capacity arrays plus an int32 count per
  *     image, so that no entry point needs a host round trip.
  */
@@ -26,6 +33,7 @@ extern "C" {
 
 #define SFOD_F32 0
 #define SFOD_BF16 1
+#define SFOD_BF16X3 2
 
 int sfod_version(void);
 /* last error text of the calling thread ("" if none) */
@@ -154,7 +162,7 @@ int sfod_bn_finalize_ws_floats(int C);
  * (floor), bit 1 drops the ReLU (d2 BottleneckBlock conv3 / shortcut norms, no activation) */
 int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* z, int B, int H, int W,
-                          int C, int pool, int dt, void* stream);
+                          int C, int pool, int dt, int out_dt, void* stream);
 /* Bottleneck tail of the ResNet path (d2 BottleneckBlock.forward, reached through build_resnet_backbone of the r101
  * yaml): z = relu(bn(y) + residual) in one pass over [rows, C]; same statistics / affine inputs as above. */
 int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
@@ -167,7 +175,7 @@ int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, 
 int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* dy, float* dgamma,
                           float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
-                          int W, int C, int pool, int dt, void* stream);
+                          int W, int C, int pool, int dt, int out_dt, void* stream);
 int sfod_bn_bwd_ws_floats(int M, int C);
 /* ---- ResNet-101-C4 backbone helpers (d2 build_resnet_backbone selected by the r101 yaml's missing
  * BACKBONE.NAME, configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28) ----

@@ -35,6 +35,48 @@ template <typename T> __device__ __forceinline__ T from_f32(float v);
 template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
 template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }
 
+// ---- SFOD_BF16X3 storage ("split" tensors, include/sfod_hip.h): a logical fp32 element is the pair
+// hi = bf16(v), lo = bf16(v - hi); a group of 8 consecutive channels occupies 32 bytes = 8 hi then 8 lo.
+// split_t is a 4-byte tag type: pointer arithmetic on split_t* counts LOGICAL elements, and a pointer to
+// the first element of an 8-group addresses the group's 32 bytes.  hi + lo is exact in fp32.
+struct split_t { uint32_t raw; };
+
+__device__ __forceinline__ void split_load8(const split_t* p, float* out) {   // p: 32-byte aligned group
+  const uint4 hv = reinterpret_cast<const uint4*>(p)[0], lv = reinterpret_cast<const uint4*>(p)[1];
+  const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w}, lw[4] = {lv.x, lv.y, lv.z, lv.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    out[2 * i] = __uint_as_float(hw[i] << 16) + __uint_as_float(lw[i] << 16);
+    out[2 * i + 1] = __uint_as_float(hw[i] & 0xffff0000u) + __uint_as_float(lw[i] & 0xffff0000u);
+  }
+}
+__device__ __forceinline__ void split_store8(split_t* p, const float* in) {
+  union { bf16_t h[8]; uint4 v; } hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    hi.h[i] = (bf16_t)in[i];
+    lo.h[i] = (bf16_t)(in[i] - (float)hi.h[i]);
+  }
+  reinterpret_cast<uint4*>(p)[0] = hi.v;
+  reinterpret_cast<uint4*>(p)[1] = lo.v;
+}
+// scalar access to logical element idx of a split tensor whose 8-groups start at `base`
+__device__ __forceinline__ void split_put(split_t* base, int64_t idx, float v) {
+  bf16_t* b = reinterpret_cast<bf16_t*>(base) + (idx >> 3) * 16 + (idx & 7);
+  const bf16_t h = (bf16_t)v;
+  b[0] = h;
+  b[8] = (bf16_t)(v - (float)h);
+}
+__device__ __forceinline__ float split_get(const split_t* base, int64_t idx) {
+  const bf16_t* b = reinterpret_cast<const bf16_t*>(base) + (idx >> 3) * 16 + (idx & 7);
+  return (float)b[0] + (float)b[8];
+}
+// out[idx] = v for any storage type (fp32 / bf16: plain element; split: the (hi, lo) pair)
+template <typename T> __device__ __forceinline__ void put_elem(T* base, int64_t idx, float v) { base[idx] = from_f32<T>(v); }
+template <> __device__ __forceinline__ void put_elem<split_t>(split_t* base, int64_t idx, float v) { split_put(base, idx, v); }
+template <typename T> __device__ __forceinline__ float get_elem(const T* base, int64_t idx) { return to_f32(base[idx]); }
+template <> __device__ __forceinline__ float get_elem<split_t>(const split_t* base, int64_t idx) { return split_get(base, idx); }
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // 64-lane wave reductions

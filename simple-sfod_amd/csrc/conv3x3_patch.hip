@@ -119,7 +119,11 @@ template <> struct WaitTab<2, 1> {   // 3 patch pieces per slice (stages 0-2 / 5
   static constexpr int NL[9] = {1, 2, 2, 2, 1, 1, 1, 1, 0};
 };
 
-template <int G, int FM, typename OutT>
+// SPLIT (SFOD_BF16X3, fp32-equivalent): x and w hold (hi, lo) bf16 pairs -- per 8 logical channels 8 hi then 8 lo
+// values, so the kernel sees 2 * Cin "physical" bf16 channels and its DMA / LDS side is unchanged; a 64-byte patch
+// row is then 16 logical channels as chunks (hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15), ONE MFMA k-step, fed as
+// hi*lo + lo*hi + hi*hi: the same four fragment reads as two bf16 k-steps, three MFMAs instead of two.
+template <int G, int FM, typename OutT, bool SPLIT = false>
 __global__ void __launch_bounds__(512, (Lay<G, FM>::SMALL ? 4 : 2))   // 2nd arg: waves per SIMD (small tiles: 2 workgroups / CU)
 k_conv3x3_patch(P3Args a) {
   using L = Lay<G, FM>;
@@ -219,7 +223,7 @@ k_conv3x3_patch(P3Args a) {
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
     const int n = wn * 64 + j * 32 + (lane & 31);
-    offB[j] = n * 64 + ((h ^ ((n >> 2) & 3)) << 4);
+    offB[j] = n * 64 + (((SPLIT ? 2 * h : h) ^ ((n >> 2) & 3)) << 4);
   }
 
   f32x16 acc[FM][FN];
@@ -240,7 +244,36 @@ k_conv3x3_patch(P3Args a) {
       int ra = rowA[i];
       asm volatile("" : "+v"(ra));   // keeps the 9 x FM tap addresses from being hoisted out of the K loop (VGPRs)
       const int row = ra + dtap;
-      addrA[i] = row * 64 + ((h ^ ((row >> 2) & 3)) << 4);
+      addrA[i] = row * 64 + (((SPLIT ? 2 * h : h) ^ ((row >> 2) & 3)) << 4);
+    }
+    if constexpr (SPLIT) {
+      bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        ah[i] = *reinterpret_cast<const bf16x8*>(patch + addrA[i]);
+        al[i] = *reinterpret_cast<const bf16x8*>(patch + (addrA[i] ^ 16));
+      }
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        bh[j] = *reinterpret_cast<const bf16x8*>(bsl + offB[j]);
+        bl[j] = *reinterpret_cast<const bf16x8*>(bsl + (offB[j] ^ 16));
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      return;
     }
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -541,9 +574,9 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   return p;
 }
 
-template <int G, int FM, typename OutT>
+template <int G, int FM, typename OutT, bool SPLIT = false>
 static int p3_launch_one(const P3Args& a, hipStream_t s) {
-  auto kern = k_conv3x3_patch<G, FM, OutT>;
+  auto kern = k_conv3x3_patch<G, FM, OutT, SPLIT>;
   constexpr int LDS = Lay<G, FM>::TOTAL;
   static bool attr_set = false;
   if (!attr_set) {
@@ -555,8 +588,9 @@ static int p3_launch_one(const P3Args& a, hipStream_t s) {
   return sfod_check_launch("conv3x3_patch");
 }
 
+// split != 0: SFOD_BF16X3 operands; Cin is then the PHYSICAL bf16 channel count (2 x logical), the output is fp32
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
-                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s) {
+                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split) {
   P3Args a;
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = y; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.act = act;
@@ -568,6 +602,13 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
   a.nbody = Cin / (32 * p.G);
   a.ntiles = B * p.tiles_y * p.tiles_x * p.tiles_n;
   a.nblk = p.nblk;
+  if (split) {
+    if (!out_f32) { sfod_set_error("conv3x3_patch: bf16x3 operands write fp32"); return SFOD_EBADARG; }
+    if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, true>(a, s);
+    if (p.G == 1) return p3_launch_one<1, 4, float, true>(a, s);
+    if (p.FM == 2) return p3_launch_one<2, 2, float, true>(a, s);
+    return p3_launch_one<2, 1, float, true>(a, s);
+  }
   if (p.G == 1 && p.FM == 2) return out_f32 ? p3_launch_one<1, 2, float>(a, s) : p3_launch_one<1, 2, bf16_t>(a, s);
   if (p.G == 1) return out_f32 ? p3_launch_one<1, 4, float>(a, s) : p3_launch_one<1, 4, bf16_t>(a, s);
   if (p.FM == 2) return out_f32 ? p3_launch_one<2, 2, float>(a, s) : p3_launch_one<2, 2, bf16_t>(a, s);

@@ -16,7 +16,7 @@ struct P3Plan {
 };
 P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout);
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
-                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s);
+                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split = 0);
 
 // BatchNorm statistics buffer layout shared by every conv kernel:
 //   stats[blk][0][c] = sum over the block's valid rows, stats[blk][1][c] = sum of squared deviations
@@ -34,7 +34,7 @@ struct W3Plan {
 W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy);
 // out_mode 0: dw packed [Cout][9][Cin], accumulated into; 1 / 2: dw OIHW, overwritten / accumulated into
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
-                   int Cin, int Cout, int lddy, int out_mode, hipStream_t s);
+                   int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split = 0);
 
 // ---- first layer (Cin = one padded chunk of 8, Cout = 64), bf16 ------------------------------------------
 int sfod_f1_nblk(int B, int H, int W);

@@ -16,6 +16,11 @@ template <> struct VecT<bf16_t> {
   typedef uint4 raw;
 };
 
+template <> struct VecT<split_t> {
+  static constexpr int N = 8;
+  typedef uint4 raw;
+};
+
 template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* out);
 template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* out) {
   float4 v = *reinterpret_cast<const float4*>(p);
@@ -30,7 +35,9 @@ template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, fl
     out[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
   }
 }
+template <> __device__ __forceinline__ void load_vec<split_t>(const split_t* p, float* out) { split_load8(p, out); }
 template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* in);
+template <> __device__ __forceinline__ void store_vec<split_t>(split_t* p, const float* in) { split_store8(p, in); }
 template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* in) {
   *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
 }
@@ -40,6 +47,24 @@ template <> __device__ __forceinline__ void store_vec<bf16_t>(bf16_t* p, const f
   for (int i = 0; i < 8; ++i) u.h[i] = (bf16_t)in[i];
   *reinterpret_cast<uint4*>(p) = u.v;
 }
+
+// V-element forms (V a multiple of the type's native vector width): a kernel that reads fp32 and writes
+// SFOD_BF16X3 pairs handles 8 channels per thread (two float4 in, one 32-byte group out)
+template <typename T, int V> __device__ __forceinline__ void load_n(const T* p, float* out) {
+  constexpr int N = VecT<T>::N;
+  static_assert(V % N == 0, "vector width");
+#pragma unroll
+  for (int k = 0; k < V / N; ++k) load_vec<T>(p + k * N, out + k * N);
+}
+template <typename T, int V> __device__ __forceinline__ void store_n(T* p, const float* in) {
+  constexpr int N = VecT<T>::N;
+  static_assert(V % N == 0, "vector width");
+#pragma unroll
+  for (int k = 0; k < V / N; ++k) store_vec<T>(p + k * N, in + k * N);
+}
+template <typename TI, typename TO> struct VecW {
+  static constexpr int N = VecT<TI>::N > VecT<TO>::N ? VecT<TI>::N : VecT<TO>::N;
+};
 
 // ---------------------------------------------------------------------------------------------
 // K1 preprocess
@@ -62,7 +87,7 @@ __global__ void k_preprocess(const uint8_t* const* __restrict__ imgs, const int3
     v[1] = ((float)im[plane + (int64_t)y * w + x] - m1) / s1;
     v[2] = ((float)im[2 * plane + (int64_t)y * w + x] - m2) / s2;
   }
-  for (int c = 0; c < Cpad; ++c) o[c] = from_f32<T>(c < 3 ? v[c] : 0.f);
+  for (int c = 0; c < Cpad; ++c) put_elem<T>(o, c, c < 3 ? v[c] : 0.f);
 }
 
 extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes, int B, int Hp, int Wp,
@@ -71,9 +96,13 @@ extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes
   SFOD_REQUIRE(Cpad >= 3, "Cpad < 3");
   dim3 grid(cdiv(Wp, 256), Hp, B);
   hipStream_t s = (hipStream_t)stream;
+  if (dt == SFOD_BF16X3) SFOD_REQUIRE(Cpad % 8 == 0, "preprocess: bf16x3 output needs Cpad % 8 == 0");
   if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_preprocess<float>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
                        Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out);
+  else if (dt == SFOD_BF16X3)
+    hipLaunchKernelGGL(k_preprocess<split_t>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
+                       Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (split_t*)out);
   else
     hipLaunchKernelGGL(k_preprocess<bf16_t>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
                        Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16_t*)out);
@@ -298,12 +327,12 @@ extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
 // ---------------------------------------------------------------------------------------------
 // K3/K4 forward: z = relu(gamma * (y - mean) * invstd + beta), optional 2x2/2 max-pool
 // ---------------------------------------------------------------------------------------------
-template <typename T, int POOL, int RELU>
+template <typename T, int POOL, int RELU, typename TO = T>
 __global__ void __launch_bounds__(256)
 k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
-                   const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ z,
+                   const float* __restrict__ gamma, const float* __restrict__ beta, TO* __restrict__ z,
                    int B, int H, int W, int C) {
-  constexpr int V = VecT<T>::N;
+  constexpr int V = VecW<T, TO>::N;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const int cv = C / V;
   const int64_t total = (int64_t)B * Ho * Wo * cv;
@@ -325,16 +354,16 @@ k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, cons
       for (; t < total; t += 2 * stride) {
         float v0[V], v1[V];
         const bool two = t + stride < total;
-        load_vec<T>(y + t * V, v0);
-        if (two) load_vec<T>(y + (t + stride) * V, v1);
+        load_n<T, V>(y + t * V, v0);
+        if (two) load_n<T, V>(y + (t + stride) * V, v1);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           const float a = (v0[i] - mu[i]) * sc[i] + sh[i], b2 = (v1[i] - mu[i]) * sc[i] + sh[i];
           v0[i] = RELU ? fmaxf(a, 0.f) : a;
           v1[i] = RELU ? fmaxf(b2, 0.f) : b2;
         }
-        store_vec<T>(z + t * V, v0);
-        if (two) store_vec<T>(z + (t + stride) * V, v1);
+        store_n<TO, V>(z + t * V, v0);
+        if (two) store_n<TO, V>(z + (t + stride) * V, v1);
       }
       return;
     }
@@ -364,11 +393,11 @@ k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, cons
       for (int dx = 0; dx < win; ++dx) {
         const int iy = POOL ? oy * 2 + dy : oy, ix = POOL ? ox * 2 + dx : ox;
         float v[V];
-        load_vec<T>(y + (((int64_t)b * H + iy) * W + ix) * C + c0, v);
+        load_n<T, V>(y + (((int64_t)b * H + iy) * W + ix) * C + c0, v);
 #pragma unroll
         for (int i = 0; i < V; ++i) r[i] = fmaxf(r[i], (v[i] - mu[i]) * sc[i] + sh[i]);
       }
-    store_vec<T>(z + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, r);
+    store_n<TO, V>(z + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, r);
   }
 }
 
@@ -421,23 +450,28 @@ extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const floa
 
 extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, void* z, int B, int H, int W,
-                                     int C, int pool_flags, int dt, void* stream) {
+                                     int C, int pool_flags, int dt, int out_dt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
-  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && out_dt == SFOD_BF16X3),
+               "bn: output type must equal the input type, or fp32 -> bf16x3");
+  SFOD_REQUIRE(dt != SFOD_BF16X3, "bn: reads fp32 or bf16 (convolutions write fp32 in bf16x3 mode)");
+  const int V = (out_dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "bn: C not a multiple of the vector width");
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   const int grid = ew_grid((int64_t)B * Ho * Wo * (C / V));
-#define LAUNCH(T, P, R)                                                                                  \
-  hipLaunchKernelGGL((k_bn_relu_pool_fwd<T, P, R>), dim3(grid), dim3(256), 0, s, (const T*)y, mean, invstd, \
-                     gamma, beta, (T*)z, B, H, W, C)
-  if (dt == SFOD_F32) {
-    if (norelu) { if (pool) LAUNCH(float, 1, 0); else LAUNCH(float, 0, 0); }
-    else { if (pool) LAUNCH(float, 1, 1); else LAUNCH(float, 0, 1); }
-  } else {
-    if (norelu) { if (pool) LAUNCH(bf16_t, 1, 0); else LAUNCH(bf16_t, 0, 0); }
-    else { if (pool) LAUNCH(bf16_t, 1, 1); else LAUNCH(bf16_t, 0, 1); }
-  }
+#define LAUNCH(T, P, R, TO)                                                                                  \
+  hipLaunchKernelGGL((k_bn_relu_pool_fwd<T, P, R, TO>), dim3(grid), dim3(256), 0, s, (const T*)y, mean, invstd, \
+                     gamma, beta, (TO*)z, B, H, W, C)
+#define LAUNCH4(T, TO)                                                           \
+  do {                                                                           \
+    if (norelu) { if (pool) LAUNCH(T, 1, 0, TO); else LAUNCH(T, 0, 0, TO); }     \
+    else { if (pool) LAUNCH(T, 1, 1, TO); else LAUNCH(T, 0, 1, TO); }            \
+  } while (0)
+  if (out_dt == SFOD_BF16X3) LAUNCH4(float, split_t);
+  else if (dt == SFOD_F32) LAUNCH4(float, float);
+  else LAUNCH4(bf16_t, bf16_t);
+#undef LAUNCH4
 #undef LAUNCH
   return sfod_check_launch("bn_relu_pool_fwd");
 }
@@ -452,23 +486,22 @@ extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const flo
 // ---------------------------------------------------------------------------------------------
 #define BNB_ROWS 64  // units per workgroup in pass 1
 
-template <typename T, int POOL, int RELU>
+template <typename T, int POOL, int RELU, int V = VecT<T>::N>
 __device__ __forceinline__ void bn_unit_grad(const T* __restrict__ y, const T* __restrict__ dz, int b,
                                              int oy, int ox, int H, int W, int C, int c0,
                                              const float* mu, const float* sc, const float* sh,
-                                             float (*xhat_out)[VecT<T>::N], float (*g_out)[VecT<T>::N],
+                                             float (*xhat_out)[V], float (*g_out)[V],
                                              const float* invs) {
-  constexpr int V = VecT<T>::N;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   float gz[V];
-  load_vec<T>(dz + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, gz);
+  load_n<T, V>(dz + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, gz);
   constexpr int NW = POOL ? 4 : 1;
   float zp[NW][V];
 #pragma unroll
   for (int k = 0; k < NW; ++k) {
     const int iy = POOL ? oy * 2 + (k >> 1) : oy, ix = POOL ? ox * 2 + (k & 1) : ox;
     float v[V];
-    load_vec<T>(y + (((int64_t)b * H + iy) * W + ix) * C + c0, v);
+    load_n<T, V>(y + (((int64_t)b * H + iy) * W + ix) * C + c0, v);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       xhat_out[k][i] = (v[i] - mu[i]) * invs[i];
@@ -590,13 +623,13 @@ k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restri
   }
 }
 
-template <typename T, int POOL, int RELU>
+template <typename T, int POOL, int RELU, typename TO = T>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
                const float* __restrict__ invstd, const float* __restrict__ gamma,
                const float* __restrict__ beta, const float* __restrict__ dgamma,
-               const float* __restrict__ dbeta, T* __restrict__ dy, int B, int H, int W, int C) {
-  constexpr int V = VecT<T>::N;
+               const float* __restrict__ dbeta, TO* __restrict__ dy, int B, int H, int W, int C) {
+  constexpr int V = VecW<T, TO>::N;
   constexpr int NW = POOL ? 4 : 1;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const int cv = C / V;
@@ -619,8 +652,8 @@ k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* _
       }
       for (; t < total; t += stride) {
         float v[V], gz[V], o[V];
-        load_vec<T>(y + t * V, v);
-        load_vec<T>(dz + t * V, gz);
+        load_n<T, V>(y + t * V, v);
+        load_n<T, V>(dz + t * V, gz);
 #pragma unroll
         for (int i = 0; i < V; ++i) {
           const float xh = (v[i] - mu[i]) * invs[i];
@@ -628,7 +661,7 @@ k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* _
           const float g = (!RELU || zp > 0.f) ? gz[i] : 0.f;
           o[i] = sc[i] * (g - k1[i] - xh * k2[i]);
         }
-        store_vec<T>(dy + t * V, o);
+        store_n<TO, V>(dy + t * V, o);
       }
       return;
     }
@@ -652,25 +685,25 @@ k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* _
       k2[i] = dgamma[c0 + i] * invM;
     }
     float xh[NW][V], g[NW][V];
-    bn_unit_grad<T, POOL, RELU>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
+    bn_unit_grad<T, POOL, RELU, V>(y, dz, b, oy, ox, H, W, C, c0, mu, sc, sh, xh, g, invs);
 #pragma unroll
     for (int k = 0; k < NW; ++k) {
       const int iy = POOL ? oy * 2 + (k >> 1) : oy, ix = POOL ? ox * 2 + (k & 1) : ox;
       float o[V];
 #pragma unroll
       for (int i = 0; i < V; ++i) o[i] = sc[i] * (g[k][i] - k1[i] - xh[k][i] * k2[i]);
-      store_vec<T>(dy + (((int64_t)b * H + iy) * W + ix) * C + c0, o);
+      store_n<TO, V>(dy + (((int64_t)b * H + iy) * W + ix) * C + c0, o);
     }
   }
 }
 
 // pixels of an odd-sized map that no 2x2 window covers: zero upstream gradient
-template <typename T>
+template <typename T, typename TO = T>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_leftover(const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
                   const float* __restrict__ gamma, const float* __restrict__ dgamma,
-                  const float* __restrict__ dbeta, T* __restrict__ dy, int B, int H, int W, int C) {
-  constexpr int V = VecT<T>::N;
+                  const float* __restrict__ dbeta, TO* __restrict__ dy, int B, int H, int W, int C) {
+  constexpr int V = VecW<T, TO>::N;
   const int Ho = H / 2, Wo = W / 2;
   const int cv = C / V;
   const int la = 2 * Ho * (W - 2 * Wo);      // right column (x = W-1) for y < 2Ho
@@ -687,14 +720,14 @@ k_bn_bwd_leftover(const T* __restrict__ y, const float* __restrict__ mean, const
     if (l < la) { iy = l; ix = 2 * Wo; } else { iy = 2 * Ho; ix = l - la; }
     float v[V], o[V];
     const int64_t off = (((int64_t)b * H + iy) * W + ix) * C + c0;
-    load_vec<T>(y + off, v);
+    load_n<T, V>(y + off, v);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const float invs = invstd[c0 + i];
       const float xh = (v[i] - mean[c0 + i]) * invs;
       o[i] = invs * gamma[c0 + i] * (0.f - dbeta[c0 + i] * invM - xh * dgamma[c0 + i] * invM);
     }
-    store_vec<T>(dy + off, o);
+    store_n<TO, V>(dy + off, o);
   }
 }
 
@@ -706,11 +739,14 @@ extern "C" int sfod_bn_bwd_ws_floats(int M, int C) {
 extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, void* dy, float* dgamma,
                                      float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
-                                     int W, int C, int pool_flags, int dt, void* stream) {
+                                     int W, int C, int pool_flags, int dt, int dy_dt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
-  const int V = (dt == SFOD_F32) ? 4 : 8;
-  SFOD_REQUIRE(C % V == 0 && C / V <= 256, "bn_bwd: unsupported channel count");
+  SFOD_REQUIRE(dt != SFOD_BF16X3 && (dy_dt == dt || (dt == SFOD_F32 && dy_dt == SFOD_BF16X3)),
+               "bn_bwd: dz / y are fp32 or bf16; dy has the same type, or bf16x3 from fp32");
+  const int V = (dt == SFOD_F32) ? 4 : 8;            // reduce pass (reads only)
+  const int VO = (dy_dt == SFOD_F32) ? 4 : 8;        // apply pass
+  SFOD_REQUIRE(C % VO == 0 && C / V <= 256, "bn_bwd: unsupported channel count");
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   const int cv = C / V, UL = 256 / cv;
   const int64_t units = (int64_t)B * Ho * Wo;
@@ -718,34 +754,39 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
   if (grid1 > BNB_GRID_MAX) grid1 = BNB_GRID_MAX;
   if (grid1 < 1) grid1 = 1;
   const size_t lds = sizeof(float) * UL * 2 * C;
-  const int grid3 = ew_grid(units * cv);
-#define LAUNCH(T, P, R)                                                                                \
+  const int grid3 = ew_grid(units * (C / VO));
+#define LAUNCH(T, P, R, TO)                                                                            \
   do {                                                                                                 \
     hipLaunchKernelGGL((k_bn_bwd_reduce<T, P, R>), dim3(grid1), dim3(256), lds, s, (const T*)dz,       \
                        (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                        \
     hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws, grid1, C,      \
                        dgamma, dbeta, dgamma_acc, dbeta_acc);                                          \
-    hipLaunchKernelGGL((k_bn_bwd_apply<T, P, R>), dim3(grid3), dim3(256), 0, s, (const T*)dz,          \
-                       (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (T*)dy, B, H, W, C);     \
+    hipLaunchKernelGGL((k_bn_bwd_apply<T, P, R, TO>), dim3(grid3), dim3(256), 0, s, (const T*)dz,      \
+                       (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (TO*)dy, B, H, W, C);    \
   } while (0)
-  if (dt == SFOD_F32) {
-    if (norelu) { if (pool) LAUNCH(float, 1, 0); else LAUNCH(float, 0, 0); }
-    else { if (pool) LAUNCH(float, 1, 1); else LAUNCH(float, 0, 1); }
-  } else {
-    if (norelu) { if (pool) LAUNCH(bf16_t, 1, 0); else LAUNCH(bf16_t, 0, 0); }
-    else { if (pool) LAUNCH(bf16_t, 1, 1); else LAUNCH(bf16_t, 0, 1); }
-  }
+#define LAUNCH4(T, TO)                                                           \
+  do {                                                                           \
+    if (norelu) { if (pool) LAUNCH(T, 1, 0, TO); else LAUNCH(T, 0, 0, TO); }     \
+    else { if (pool) LAUNCH(T, 1, 1, TO); else LAUNCH(T, 0, 1, TO); }            \
+  } while (0)
+  if (dy_dt == SFOD_BF16X3) LAUNCH4(float, split_t);
+  else if (dt == SFOD_F32) LAUNCH4(float, float);
+  else LAUNCH4(bf16_t, bf16_t);
+#undef LAUNCH4
 #undef LAUNCH
   int rc = sfod_check_launch("bn_relu_pool_bwd");
   if (rc) return rc;
   if (pool && ((H & 1) || (W & 1))) {
     const int L = 2 * Ho * (W - 2 * Wo) + (H - 2 * Ho) * W;
-    const int grid = ew_grid((int64_t)B * L * cv);
-    if (dt == SFOD_F32)
-      hipLaunchKernelGGL(k_bn_bwd_leftover<float>, dim3(grid), dim3(256), 0, s, (const float*)y, mean,
+    const int grid = ew_grid((int64_t)B * L * (C / VO));
+    if (dy_dt == SFOD_BF16X3)
+      hipLaunchKernelGGL((k_bn_bwd_leftover<float, split_t>), dim3(grid), dim3(256), 0, s, (const float*)y, mean,
+                         invstd, gamma, dgamma, dbeta, (split_t*)dy, B, H, W, C);
+    else if (dt == SFOD_F32)
+      hipLaunchKernelGGL((k_bn_bwd_leftover<float, float>), dim3(grid), dim3(256), 0, s, (const float*)y, mean,
                          invstd, gamma, dgamma, dbeta, (float*)dy, B, H, W, C);
     else
-      hipLaunchKernelGGL(k_bn_bwd_leftover<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)y, mean,
+      hipLaunchKernelGGL((k_bn_bwd_leftover<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)y, mean,
                          invstd, gamma, dgamma, dbeta, (bf16_t*)dy, B, H, W, C);
     rc = sfod_check_launch("bn_bwd_leftover");
   }
@@ -1041,7 +1082,7 @@ __global__ void k_pack_conv_weight(const float* __restrict__ w, T* __restrict__ 
       const int st = rot180 ? (taps - 1 - tap) : tap;
       v = w[((int64_t)co * Cin + ci) * taps + st];
     }
-    out[t] = from_f32<T>(v);
+    put_elem<T>(out, t, v);
   }
 }
 
@@ -1049,7 +1090,11 @@ extern "C" int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Co
                                      int CinPad, int rot180, int dt, void* stream) {
   const int rows = rot180 ? Cin : Cout;
   const int64_t total = (int64_t)rows * ksize * ksize * CinPad;
-  if (dt == SFOD_F32)
+  if (dt == SFOD_BF16X3) {
+    SFOD_REQUIRE(CinPad % 8 == 0, "pack_conv_weight: bf16x3 needs an inner size that is a multiple of 8");
+    hipLaunchKernelGGL(k_pack_conv_weight<split_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, (split_t*)w_packed, Cout, Cin, ksize, CinPad, rot180);
+  } else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_pack_conv_weight<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
                        w_oihw, (float*)w_packed, Cout, Cin, ksize, CinPad, rot180);
   else
@@ -1100,7 +1145,7 @@ k_pack_conv_weights_multi(const long long* __restrict__ desc, int n) {
       if (row >= rowsN || inner >= innerPad) continue;
       const int col = rot180 ? il : rl, cl = rot180 ? rl : il;
       const int st = rot180 ? (taps - 1 - tap) : tap;
-      out[((int64_t)row * taps + tap) * innerPad + inner] = from_f32<T>(tile[col][cl * taps + st]);
+      put_elem<T>(out, ((int64_t)row * taps + tap) * innerPad + inner, tile[col][cl * taps + st]);
     }
   };
   if (ks == 3) body(std::integral_constant<int, 9>{});
@@ -1115,7 +1160,10 @@ extern "C" int sfod_pack_conv_weights_blocks(int Cout, int Cin, int ksize, int i
 
 extern "C" int sfod_pack_conv_weights_multi(const int64_t* desc, int n, int total_blocks, int dt, void* stream) {
   SFOD_REQUIRE(n >= 1 && total_blocks >= 1, "pack_multi: empty table (kernel sizes 1 and 3 only)");
-  if (dt == SFOD_F32)
+  if (dt == SFOD_BF16X3)    // every innerPad of the table must be a multiple of 8 (caller's contract)
+    hipLaunchKernelGGL(k_pack_conv_weights_multi<split_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const long long*)desc, n);
+  else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_pack_conv_weights_multi<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                        (const long long*)desc, n);
   else
@@ -1165,7 +1213,7 @@ __global__ void k_pack_fc_weight(const float* __restrict__ w, T* __restrict__ ou
       if (chw_c > 0) { const int p = kp / chw_c, c = kp % chw_c; k = c * PP + p; }
       v = w[(int64_t)n * K + k];
     }
-    out[t] = from_f32<T>(v);
+    put_elem<T>(out, t, v);
   }
 }
 
@@ -1188,7 +1236,7 @@ k_pack_fc_chw(const float* __restrict__ w, T* __restrict__ out, int N, int C, in
   T* dst = out + (int64_t)n * ld;
   for (int j = threadIdx.x; j < PP * 64; j += 256) {
     const int p = j >> 6, cl = j & 63;
-    if (cl < cw) dst[(int64_t)p * C + c0 + cl] = from_f32<T>(tile[cl * PP + p]);
+    if (cl < cw) put_elem<T>(dst, (int64_t)p * C + c0 + cl, tile[cl * PP + p]);
   }
 }
 
@@ -1209,7 +1257,7 @@ k_pack_fc_chw_t(const float* __restrict__ w, T* __restrict__ out, int N, int C, 
     const int r = j >> 6, nl = j & 63;          // r = cl * PP + p
     if (nl < nw) {
       const int cl = r / PP, p = r - cl * PP;
-      out[((int64_t)p * C + c0 + cl) * ld + n0 + nl] = from_f32<T>(tile[nl * pitch + r]);
+      put_elem<T>(out, ((int64_t)p * C + c0 + cl) * ld + n0 + nl, tile[nl * pitch + r]);
     }
   }
 }
@@ -1217,6 +1265,7 @@ k_pack_fc_chw_t(const float* __restrict__ w, T* __restrict__ out, int N, int C, 
 extern "C" int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose,
                                       int ld, int dt, void* stream) {
   SFOD_REQUIRE(ld >= (transpose ? N : K), "pack_fc_weight: ld too small");
+  SFOD_REQUIRE(dt != SFOD_BF16X3 || ld % 8 == 0, "pack_fc_weight: bf16x3 needs ld % 8 == 0");
   if (chw_c > 0 && K % chw_c == 0 && K / chw_c <= 64 && (int64_t)N * K >= (1 << 20) &&
       ld == (transpose ? N : K)) {
     const int C = chw_c, PP = K / chw_c;
@@ -1225,17 +1274,22 @@ extern "C" int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, i
       const dim3 grid(cdiv(C, 64), N);
       const size_t lds = (size_t)64 * PP * 4;
       if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld);
+      else if (dt == SFOD_BF16X3) hipLaunchKernelGGL(k_pack_fc_chw<split_t>, grid, dim3(256), lds, s, w, (split_t*)out, N, C, PP, ld);
       else hipLaunchKernelGGL(k_pack_fc_chw<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld);
     } else {
       const dim3 grid(cdiv(C, 4), cdiv(N, 64));
       const size_t lds = (size_t)64 * (4 * PP + 1) * 4;
       if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw_t<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld);
+      else if (dt == SFOD_BF16X3) hipLaunchKernelGGL(k_pack_fc_chw_t<split_t>, grid, dim3(256), lds, s, w, (split_t*)out, N, C, PP, ld);
       else hipLaunchKernelGGL(k_pack_fc_chw_t<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld);
     }
     return sfod_check_launch("pack_fc_weight(chw)");
   }
   const int64_t total = (int64_t)(transpose ? K : N) * ld;
-  if (dt == SFOD_F32)
+  if (dt == SFOD_BF16X3)
+    hipLaunchKernelGGL(k_pack_fc_weight<split_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
+                       (split_t*)out, N, K, chw_c, transpose, ld);
+  else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_pack_fc_weight<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
                        (float*)out, N, K, chw_c, transpose, ld);
   else
@@ -1421,10 +1475,32 @@ __global__ void k_cast(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     d[i] = from_f32<D>(to_f32(s[i]));
 }
+// fp32 <-> SFOD_BF16X3 pairs, 8 elements per thread (n a multiple of 8)
+template <typename S, typename D>
+__global__ void k_cast8(const S* __restrict__ s, D* __restrict__ d, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load_n<S, 8>(s + i * 8, v);
+    store_n<D, 8>(d + i * 8, v);
+  }
+}
 extern "C" int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int dst_dt, void* stream) {
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 g(ew_grid(n)), b(256);
+  if (src_dt == SFOD_BF16X3 || dst_dt == SFOD_BF16X3) {
+    SFOD_REQUIRE(n % 8 == 0, "cast: bf16x3 tensors hold whole 8-element groups");
+    const dim3 g8(ew_grid(n / 8));
+    if (src_dt == SFOD_F32 && dst_dt == SFOD_BF16X3)
+      hipLaunchKernelGGL((k_cast8<float, split_t>), g8, b, 0, s, (const float*)src, (split_t*)dst, n / 8);
+    else if (src_dt == SFOD_BF16X3 && dst_dt == SFOD_F32)
+      hipLaunchKernelGGL((k_cast8<split_t, float>), g8, b, 0, s, (const split_t*)src, (float*)dst, n / 8);
+    else if (src_dt == SFOD_BF16X3 && dst_dt == SFOD_BF16X3)
+      hipLaunchKernelGGL((k_cast8<split_t, split_t>), g8, b, 0, s, (const split_t*)src, (split_t*)dst, n / 8);
+    else
+      SFOD_REQUIRE(false, "cast: bf16x3 converts from / to fp32 only");
+    return sfod_check_launch("cast");
+  }
   if (src_dt == SFOD_F32 && dst_dt == SFOD_BF16)
     hipLaunchKernelGGL((k_cast<float, bf16_t>), g, b, 0, s, (const float*)src, (bf16_t*)dst, n);
   else if (src_dt == SFOD_BF16 && dst_dt == SFOD_F32)

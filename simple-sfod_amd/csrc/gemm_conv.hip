@@ -66,7 +66,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // NST = LDS stages: 2 = load(t+1) || compute(t) with a full drain per K tile; 3 = two K tiles in
 // flight across raw s_barriers with a counted s_waitcnt vmcnt (the DMA queue is never drained
 // inside the loop).
-template <typename T, typename OutT, int WM, int WN, bool UT, int WR, int NST>
+// SPLIT (SFOD_BF16X3): T = bf16 over 2 * Cin physical channels holding (8 hi | 8 lo) groups; a 128-byte LDS row is
+// then 32 logical channels = two k-steps, each fed as hi*lo + lo*hi + hi*hi (fp32-equivalent product, see sfod_hip.h).
+template <typename T, typename OutT, int WM, int WN, bool UT, int WR, int NST, bool SPLIT = false>
 __global__ void __launch_bounds__(WR * 128)
 k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
            OutT* __restrict__ y, float* __restrict__ stats, ConvArgs a, int tiles_n, int ntiles) {
@@ -225,7 +227,37 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   auto stage_compute = [&](int buf) {
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + BM * 128;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) {
+          ah[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + (((4 * t + 2 * h) ^ swzA[i]) << 4));
+          al[i] = *reinterpret_cast<const bf16x8*>(sA + offA[i] + (((4 * t + 2 * h + 1) ^ swzA[i]) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < WN; ++j) {
+          bh[j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + (((4 * t + 2 * h) ^ swzB[j]) << 4));
+          bl[j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + (((4 * t + 2 * h + 1) ^ swzB[j]) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+          for (int j = 0; j < WN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+      }
+    } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         bf16x8 af[WM], bfr[WN];
@@ -419,8 +451,13 @@ static int ilog2_exact(int v) {
 static int g_conv_algo = 0;  // 0 auto, 1 generic implicit GEMM only, 2 halo-patch kernel whenever the shape allows
 extern "C" int sfod_set_conv_algo(int algo) { g_conv_algo = algo; return 0; }
 
+// SFOD_BF16X3 tensors are bf16 tensors with twice the channels (8 hi | 8 lo groups) as far as DMA, LDS layout and
+// tile plans are concerned: the kernels below are planned / launched on the PHYSICAL channel count.
+static inline bool is_bf16_storage(int dt) { return dt == SFOD_BF16 || dt == SFOD_BF16X3; }
+static inline int phys_ch(int dt, int c) { return dt == SFOD_BF16X3 ? 2 * c : c; }
+
 static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, int dt) {
-  if (ksize != 3 || dt != SFOD_BF16 || !p.ok || g_conv_algo == 1) return false;
+  if (ksize != 3 || !is_bf16_storage(dt) || !p.ok || g_conv_algo == 1) return false;
   if (g_conv_algo == 2) return true;
   // with the 256-pixel shapes the halo-patch kernel also wins on small maps (batch 1: the 18x37 RPN head
   // 0.042 vs 0.071 ms, conv5 0.046 vs 0.071); only degenerate problems stay on the generic kernel
@@ -435,25 +472,25 @@ static bool use_first_kernel(int B, int H, int W, int Cin, int Cout, int ksize, 
 
 extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, SFOD_BF16)) return 3;
-  const P3Plan p = (ksize == 3 && dt == SFOD_BF16) ? sfod_p3_plan(B, H, W, Cin, Cout) : P3Plan{};
+  const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
   return use_patch_kernel(p, B, H, W, ksize, dt) ? 2 : 1;
 }
 
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, SFOD_BF16)) return sfod_f1_nblk(B, H, W);
-  const P3Plan p = (ksize == 3 && dt == SFOD_BF16) ? sfod_p3_plan(B, H, W, Cin, Cout) : P3Plan{};
+  const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;
   return (B * H * W + 127) / 128;
 }
 
-template <typename T, typename OutT, int WN, bool UT, int WR, int NST>
+template <typename T, typename OutT, int WN, bool UT, int WR, int NST, bool SPLIT = false>
 static int launch_one(const void* x, const void* w, const float* bias, void* y, float* stats,
                       const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WR * 64, BN = 64 * WN;
   constexpr int OPER = NST * (BM + BN) * 128;
   constexpr int EPI = BM * (BN * 2 + 16) + WR * BN * 4;  // staged C tile + BN partial scratch
   constexpr int LDS = OPER > EPI ? OPER : EPI;
-  auto kern = k_conv_fwd<T, OutT, 2, WN, UT, WR, NST>;
+  auto kern = k_conv_fwd<T, OutT, 2, WN, UT, WR, NST, SPLIT>;
   static bool attr_set = false;
   if (!attr_set && LDS > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -468,30 +505,30 @@ static int launch_one(const void* x, const void* w, const float* bias, void* y, 
   return sfod_check_launch("conv_fwd");
 }
 
-template <typename T, typename OutT, bool UT>
+template <typename T, typename OutT, bool UT, bool SPLIT = false>
 static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
                               const ConvArgs& a, hipStream_t s) {
-  if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2>(x, w, bias, y, stats, a, s);
+  if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
   // long-K linear layers with few rows (the student's fc1: 4096 x 25088 -> 1024): 256 x 64 tiles, 8 waves, 3-stage
   // pipeline -- one 8-wave workgroup per CU instead of one 4-wave one (0.35 -> 0.30 ms; SFOD_GEMM_TALL=0 disables)
   static const int tall = []() { const char* e = getenv("SFOD_GEMM_TALL"); return e ? atoi(e) : 300; }();
   if constexpr (UT) {
     if (tall > 0 && a.ks == 1 && a.Cin >= 4096 && (int64_t)((a.M + 255) / 256) * ((a.Cout + 63) / 64) <= tall)
-      return launch_one<T, OutT, 1, UT, 4, 3>(x, w, bias, y, stats, a, s);
+      return launch_one<T, OutT, 1, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);
   }
   // 256 x 128 tiles with a 3-stage DMA pipeline once the grid still fills the chip (>= 2 tiles / CU)
   const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
-  if (UT && big_tiles >= 384) return launch_one<T, OutT, 2, UT, 4, 3>(x, w, bias, y, stats, a, s);
-  return launch_one<T, OutT, 2, UT, 2, 2>(x, w, bias, y, stats, a, s);
+  if (UT && big_tiles >= 384) return launch_one<T, OutT, 2, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);
+  return launch_one<T, OutT, 2, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
 }
 
-template <typename T, typename OutT>
+template <typename T, typename OutT, bool SPLIT = false>
 static int launch_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
                            const ConvArgs& a, hipStream_t s) {
   const int cpt = a.Cin / Chunk<T>::E;
   const bool ut = (a.ks == 1) || (cpt % 8 == 0);
-  if (ut) return launch_conv_fwd_ut<T, OutT, true>(x, w, bias, y, stats, a, s);
-  return launch_conv_fwd_ut<T, OutT, false>(x, w, bias, y, stats, a, s);
+  if (ut) return launch_conv_fwd_ut<T, OutT, true, SPLIT>(x, w, bias, y, stats, a, s);
+  return launch_conv_fwd_ut<T, OutT, false, SPLIT>(x, w, bias, y, stats, a, s);
 }
 
 extern "C" int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, int ldy) {
@@ -514,15 +551,19 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
   SFOD_REQUIRE(ksize == 1 || ksize == 3, "conv: ksize must be 1 or 3");
   SFOD_REQUIRE(ldy >= Cout, "conv: ldy < Cout");
   const int E = (dt == SFOD_F32) ? 4 : 8;
-  SFOD_REQUIRE(Cin % E == 0, "conv: Cin must be a multiple of the 16-byte chunk");
+  SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || dt == SFOD_BF16X3, "conv: unknown dt");
+  SFOD_REQUIRE(Cin % E == 0, "conv: Cin must be a multiple of the 16-byte chunk (bf16x3: of 8)");
+  SFOD_REQUIRE(dt != SFOD_BF16X3 || out_dt == SFOD_F32, "conv: bf16x3 operands write fp32");
   if ((int64_t)B * H * W == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, ldy, out_dt))
     return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, s);
-  if (ksize == 3 && dt == SFOD_BF16) {
+  const int split = (dt == SFOD_BF16X3);
+  Cin = phys_ch(dt, Cin);           // from here on: bf16 channels as stored
+  if (ksize == 3 && is_bf16_storage(dt)) {
     const P3Plan p = sfod_p3_plan(B, H, W, Cin, Cout);
     if (use_patch_kernel(p, B, H, W, ksize, dt))
-      return sfod_p3_launch(p, x, w, bias, y, stats, B, H, W, Cin, Cout, ldy, act, out_dt == SFOD_F32, s);
+      return sfod_p3_launch(p, x, w, bias, y, stats, B, H, W, Cin, Cout, ldy, act, out_dt == SFOD_F32, s, split);
   }
   ConvArgs a;
   a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.ldy = ldy; a.act = act;
@@ -537,6 +578,7 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
     SFOD_REQUIRE(out_dt == SFOD_F32, "conv: fp32 compute writes fp32");
     return launch_conv_fwd<float, float>(x, w, bias, y, stats, a, s);
   }
+  if (split) return launch_conv_fwd<bf16_t, float, true>(x, w, bias, y, stats, a, s);
   if (out_dt == SFOD_F32) return launch_conv_fwd<bf16_t, float>(x, w, bias, y, stats, a, s);
   return launch_conv_fwd<bf16_t, bf16_t>(x, w, bias, y, stats, a, s);
 }
@@ -743,21 +785,47 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
 }
 
 static bool use_patch_wgrad(const W3Plan& p, int ksize, int dt) {
-  if (ksize != 3 || dt != SFOD_BF16 || !p.ok || g_conv_algo == 1) return false;
+  if (ksize != 3 || !is_bf16_storage(dt) || !p.ok || g_conv_algo == 1) return false;
   if (g_conv_algo == 2) return true;
   // tiny problems: not enough pixel tiles to give every (co, ci) block a few tiles per split
   return p.nsplit * p.tiles_per_split >= 3;
 }
 
+// SFOD_BF16X3 on the generic kernel: it runs on the physical channels into a [2 Cout][taps][2 Cin] fp32 temporary
+// (in `ws`), whose four (hi | lo) x (hi | lo) quadrants per logical (co, ci) are then summed into dw.
+__global__ void __launch_bounds__(256)
+k_wgrad_combine_split(const float* __restrict__ dwp, float* __restrict__ dw, int64_t n4, int taps, int Cin) {
+  const int CinP = 2 * Cin;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t e = i * 4;
+    const int ci = (int)(e % Cin);
+    const int64_t ct = e / Cin;
+    const int tap = (int)(ct % taps);
+    const int64_t co = ct / taps;
+    const int64_t rh = (co >> 3) * 16 + (co & 7);
+    const int ch = (ci >> 3) * 16 + (ci & 7);
+    const float4* src = reinterpret_cast<const float4*>(dwp);
+    const int64_t a_hh = ((rh * taps + tap) * CinP + ch) >> 2, a_lh = (((rh + 8) * taps + tap) * CinP + ch) >> 2;
+    const float4 v0 = src[a_hh], v1 = src[a_hh + 2], v2 = src[a_lh], v3 = src[a_lh + 2];
+    float4 o = reinterpret_cast<float4*>(dw)[i];
+    o.x += (v1.x + v2.x + v3.x) + v0.x; o.y += (v1.y + v2.y + v3.y) + v0.y;
+    o.z += (v1.z + v2.z + v3.z) + v0.z; o.w += (v1.w + v2.w + v3.w) + v0.w;
+    reinterpret_cast<float4*>(dw)[i] = o;
+  }
+}
+
 extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
-  if (ksize != 3 || dt != SFOD_BF16) return 0;
-  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
-  return use_patch_wgrad(p, ksize, dt) ? p.ws_bytes : 0;
+  if (dt == SFOD_F32) return 0;
+  if (ksize == 3) {
+    const W3Plan p = sfod_w3_plan(B, H, W, phys_ch(dt, Cin), phys_ch(dt, Cout), phys_ch(dt, lddy));
+    if (use_patch_wgrad(p, ksize, dt)) return p.ws_bytes;
+  }
+  return dt == SFOD_BF16X3 ? (int64_t)16 * Cout * ksize * ksize * Cin : 0;
 }
 
 extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
-  if (ksize != 3 || dt != SFOD_BF16 || (int64_t)B * H * W == 0) return 0;
-  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
+  if (ksize != 3 || !is_bf16_storage(dt) || (int64_t)B * H * W == 0) return 0;
+  const W3Plan p = sfod_w3_plan(B, H, W, phys_ch(dt, Cin), phys_ch(dt, Cout), phys_ch(dt, lddy));
   return use_patch_wgrad(p, ksize, dt) ? 1 : 0;
 }
 
@@ -766,24 +834,40 @@ extern "C" int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oih
                                     int64_t ws_bytes, void* stream) {
   SFOD_REQUIRE(sfod_conv_wgrad_oihw_supported(B, H, W, Cin, Cout, ksize, lddy, dt),
                "wgrad_oihw: shape not served by the halo-patch kernel (query sfod_conv_wgrad_oihw_supported)");
-  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
+  const int CinP = phys_ch(dt, Cin), CoutP = phys_ch(dt, Cout), lddyP = phys_ch(dt, lddy);
+  const W3Plan p = sfod_w3_plan(B, H, W, CinP, CoutP, lddyP);
   SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
-  return sfod_w3_launch(p, x, dy, dw_oihw, ws, B, H, W, Cin, Cout, lddy, accumulate ? 2 : 1, (hipStream_t)stream);
+  return sfod_w3_launch(p, x, dy, dw_oihw, ws, B, H, W, CinP, CoutP, lddyP, accumulate ? 2 : 1, (hipStream_t)stream,
+                        dt == SFOD_BF16X3);
 }
 
 extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
                                int Cout, int ksize, int lddy, int dt, void* ws, int64_t ws_bytes,
                                void* stream) {
   SFOD_REQUIRE(ksize == 1 || ksize == 3, "wgrad: ksize must be 1 or 3");
+  SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || dt == SFOD_BF16X3, "wgrad: unknown dt");
   const int E = (dt == SFOD_F32) ? 4 : 8;
-  SFOD_REQUIRE(Cin % E == 0 && lddy % E == 0, "wgrad: Cin / lddy must be multiples of the 16-byte chunk");
+  SFOD_REQUIRE(Cin % E == 0 && lddy % E == 0, "wgrad: Cin / lddy must be multiples of the 16-byte chunk (bf16x3: of 8)");
   if ((int64_t)B * H * W == 0) return 0;
-  if (ksize == 3 && dt == SFOD_BF16) {
+  const int split = (dt == SFOD_BF16X3);
+  SFOD_REQUIRE(!split || Cout % 8 == 0, "wgrad: bf16x3 needs Cout % 8 == 0");
+  const int CinL = Cin, CoutL = Cout;
+  Cin = phys_ch(dt, Cin); Cout = phys_ch(dt, Cout); lddy = phys_ch(dt, lddy);     // bf16 channels as stored
+  if (ksize == 3 && is_bf16_storage(dt)) {
     const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
     if (use_patch_wgrad(p, ksize, dt)) {
       SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
-      return sfod_w3_launch(p, x, dy, dw, ws, B, H, W, Cin, Cout, lddy, 0, (hipStream_t)stream);
+      return sfod_w3_launch(p, x, dy, dw, ws, B, H, W, Cin, Cout, lddy, 0, (hipStream_t)stream, split);
     }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float* dw_out = dw;
+  if (split) {
+    const int64_t need = (int64_t)4 * Cout * ksize * ksize * Cin;
+    SFOD_REQUIRE(ws != nullptr && ws_bytes >= need, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)need, s);
+    if (e != hipSuccess) { sfod_set_error("wgrad: memset: %s", hipGetErrorString(e)); return -(int)e; }
+    dw_out = (float*)ws;
   }
   WgradArgs a;
   a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.lddy = lddy;
@@ -810,12 +894,17 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   a.tiles_n = tiles_n;
   a.tiles_m = tiles_m;
   dim3 grid(tiles_n * tiles_m * splits);
-  hipStream_t s = (hipStream_t)stream;
   if (dt == SFOD_F32)
     hipLaunchKernelGGL((k_conv_wgrad<float, 2, 2>), grid, dim3(256), 2 * 2 * 32 * 512, s, (const float*)x,
-                       (const float*)dy, dw, a);
+                       (const float*)dy, dw_out, a);
   else
     hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
-                       (const bf16_t*)dy, dw, a);
-  return sfod_check_launch("conv_wgrad");
+                       (const bf16_t*)dy, dw_out, a);
+  int rc = sfod_check_launch("conv_wgrad");
+  if (rc || !split) return rc;
+  const int64_t n4 = (int64_t)CoutL * ksize * ksize * CinL / 4;
+  int g = (int)((n4 + 255) / 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(k_wgrad_combine_split, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, ksize * ksize, CinL);
+  return sfod_check_launch("wgrad_combine_split");
 }

@@ -82,6 +82,13 @@ template <> struct RVec<bf16_t> {
   }
 };
 
+// SFOD_BF16X3 features / pooled outputs: 8 logical channels per lane (one 32-byte (8 hi | 8 lo) group)
+template <> struct RVec<split_t> {
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const split_t* p, float* o) { split_load8(p, o); }
+  static __device__ __forceinline__ void store(split_t* p, const float* o) { split_store8(p, o); }
+};
+
 // Forward.  One workgroup per ROI; a lane owns one 16-byte channel vector (NHWC: a bilinear corner
 // is one contiguous row segment, so a wavefront reads 1 KiB per corner), the 49 bins are spread over
 // the remaining thread groups.  The sampling arithmetic is scalar per bin and identical, operation
@@ -160,6 +167,10 @@ template <> struct Pair<bf16_t> {
     u.h[0] = (bf16_t)a; u.h[1] = (bf16_t)b;
     *reinterpret_cast<uint32_t*>(p) = u.v;
   }
+};
+
+template <> struct Pair<split_t> {     // only used to zero-fill padding rows: two logical elements = 8 bytes
+  static __device__ __forceinline__ void store(split_t* p, float, float) { *reinterpret_cast<uint2*>(p) = make_uint2(0u, 0u); }
 };
 
 template <typename T, int P>
@@ -535,6 +546,9 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
     if (dt == SFOD_F32)
       hipLaunchKernelGGL((k_roi_align_fwd_sep<float, 7>), dim3(R), dim3(256), lds, s, (const float*)feat, H, W, C,
                          rois, scale, (float*)out);
+    else if (dt == SFOD_BF16X3)
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<split_t, 7>), dim3(R), dim3(256), lds, s, (const split_t*)feat, H, W, C,
+                         rois, scale, (split_t*)out);
     else
       hipLaunchKernelGGL((k_roi_align_fwd_sep<bf16_t, 7>), dim3(R), dim3(256), lds, s, (const bf16_t*)feat, H, W, C,
                          rois, scale, (bf16_t*)out);
@@ -543,6 +557,9 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
   if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_roi_align_fwd<float>, dim3(R), dim3(256), 0, s, (const float*)feat, H, W, C, rois,
                        pooled, scale, (float*)out);
+  else if (dt == SFOD_BF16X3)
+    hipLaunchKernelGGL(k_roi_align_fwd<split_t>, dim3(R), dim3(256), 0, s, (const split_t*)feat, H, W, C, rois,
+                       pooled, scale, (split_t*)out);
   else
     hipLaunchKernelGGL(k_roi_align_fwd<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)feat, H, W, C,
                        rois, pooled, scale, (bf16_t*)out);
@@ -555,6 +572,7 @@ extern "C" int sfod_roi_align_bwd(const void* dout, int B, int H, int W, int C, 
   SFOD_REQUIRE(C % 8 == 0, "roi_align_bwd: C must be a multiple of 8");
   SFOD_REQUIRE(pooled >= 1 && pooled <= ROI_MAXP, "roi_align_bwd: pooled size must be <= 8");
   hipStream_t s = (hipStream_t)stream;
+  SFOD_REQUIRE(dt != SFOD_BF16X3, "roi_align_bwd: the upstream gradient is fp32 in bf16x3 mode");
   if (dt == SFOD_F32) return dispatch_roi_bwd<float>(dout, B, H, W, C, rois, R, pooled, scale, dfeat, s);
   return dispatch_roi_bwd<bf16_t>(dout, B, H, W, C, rois, R, pooled, scale, dfeat, s);
 }

@@ -401,6 +401,63 @@ k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int64_t n
   }
 }
 
+// SFOD_BF16X3 operands: the main kernel ran on PHYSICAL channels (per 8 logical channels: 8 hi | 8 lo), so a slab is
+// [2 Cout][9][2 Cin] and holds, for every logical (co, ci), the four partial products hi*hi, hi*lo, lo*hi, lo*lo of the
+// split operands.  This reduction sums the slabs (fixed order) and the four quadrants into the logical gradient
+// (lo*lo comes for free here, so it is kept).  Same output modes and slab-group scheme as k_wgrad_reduce;
+// Cin / n4 are LOGICAL sizes.
+template <int MODE, int SG>
+__global__ void __launch_bounds__(256)
+k_wgrad_reduce_split(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int nslab, int64_t stride4,
+                     int Cin) {
+  constexpr int EPB = 256 / SG;
+  __shared__ float4 part[SG > 1 ? 256 : 1];
+  const int el = threadIdx.x % EPB, grp = threadIdx.x / EPB;
+  const int CinP = 2 * Cin;
+  for (int64_t base = (int64_t)blockIdx.x * EPB; base < n4; base += (int64_t)gridDim.x * EPB) {
+    const int64_t i = base + el;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t e = i * 4;                       // logical packed element (co, tap, ci .. ci+3)
+    const int ci = (int)(e % Cin);
+    const int64_t ct = e / Cin;
+    const int tap = (int)(ct % 9);
+    const int64_t co = ct / 9;
+    if (i < n4) {
+      const int64_t rh = (co >> 3) * 16 + (co & 7);
+      const int ch = (ci >> 3) * 16 + (ci & 7);
+      const int64_t a_hh = ((rh * 9 + tap) * CinP + ch) >> 2;            // float4 index; ci % 4 == 0
+      const int64_t a_lh = (((rh + 8) * 9 + tap) * CinP + ch) >> 2;
+      for (int k = grp; k < nslab; k += SG) {
+        const float4* sl = reinterpret_cast<const float4*>(slab) + k * stride4;
+        const float4 v0 = sl[a_hh], v1 = sl[a_hh + 2], v2 = sl[a_lh], v3 = sl[a_lh + 2];   // +8 columns = +2 float4
+        s.x += (v1.x + v2.x + v3.x) + v0.x; s.y += (v1.y + v2.y + v3.y) + v0.y;
+        s.z += (v1.z + v2.z + v3.z) + v0.z; s.w += (v1.w + v2.w + v3.w) + v0.w;
+      }
+    }
+    if constexpr (SG > 1) {
+      __syncthreads();
+      part[threadIdx.x] = s;
+      __syncthreads();
+      if (grp != 0) continue;
+#pragma unroll
+      for (int g2 = 1; g2 < SG; ++g2) {
+        const float4 v = part[g2 * EPB + el];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    if (i >= n4) continue;
+    if constexpr (MODE == 0) {
+      float4 o = reinterpret_cast<const float4*>(dw)[i];
+      o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
+      reinterpret_cast<float4*>(dw)[i] = o;
+    } else {
+      const int64_t o = (co * Cin + ci) * 9 + tap;
+      if constexpr (MODE == 2) { s.x += dw[o]; s.y += dw[o + 9]; s.z += dw[o + 18]; s.w += dw[o + 27]; }
+      dw[o] = s.x; dw[o + 9] = s.y; dw[o + 18] = s.z; dw[o + 27] = s.w;
+    }
+  }
+}
+
 }  // namespace
 
 W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy) {
@@ -442,8 +499,10 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy) {
   return p;
 }
 
+// split != 0 (SFOD_BF16X3): Cin / Cout / lddy are PHYSICAL bf16 channel counts (2 x logical) and the plan was made on
+// them; dw is the LOGICAL gradient
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
-                   int Cin, int Cout, int lddy, int out_mode, hipStream_t s) {
+                   int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split) {
   W3Args a;
   a.x = (const bf16_t*)x; a.dy = (const bf16_t*)dy; a.slab = (float*)ws;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.lddy = lddy;
@@ -466,6 +525,20 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
   else hipLaunchKernelGGL(k_wgrad3x3_patch<2>, grid, blk, LDS_TOTAL, s, a);
   int rc = sfod_check_launch("wgrad3x3_patch");
   if (rc) return rc;
+  if (split) {
+    const int CinL = Cin / 2, CoutL = Cout / 2;
+    const int64_t n4 = (int64_t)CoutL * 9 * CinL / 4;          // logical float4 groups (CinL % 16 == 0)
+    const int64_t stride4 = (int64_t)Cout * 9 * Cin / 4;       // physical slab
+    int g = (int)((n4 + 31) / 32);
+    if (g > 8192) g = 8192;
+    if (out_mode == 0)
+      hipLaunchKernelGGL((k_wgrad_reduce_split<0, 8>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, p.nslab, stride4, CinL);
+    else if (out_mode == 1)
+      hipLaunchKernelGGL((k_wgrad_reduce_split<1, 8>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, p.nslab, stride4, CinL);
+    else
+      hipLaunchKernelGGL((k_wgrad_reduce_split<2, 8>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, p.nslab, stride4, CinL);
+    return sfod_check_launch("wgrad_reduce_split");
+  }
   const int64_t n = (int64_t)Cout * 9 * Cin;  // multiple of 4 (Cin % 32 == 0)
   const int64_t n4 = n / 4;
   const bool wide = true;                           // slabs spread over 8 groups per workgroup (more loads in flight)

@@ -166,7 +166,7 @@ class ResNet(nn.Module):
         for n in self.stage_names:
             if n not in self.frozen and self.norm_kind != "BN":
                 raise NotImplementedError("trainable stages need RESNETS.NORM=BN (the named r101 config)")
-        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self.bn_momentum = 0.1
         self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
 
@@ -190,7 +190,7 @@ class ResNet(nn.Module):
         return ps
 
     def forward(self, x):
-        dt = native.F32 if self.compute_dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(self.compute_dtype)
         n, c, h, w = x.shape
         xn = torch.zeros(n, h, w, native.chunk_elems(dt), dtype=self.compute_dtype, device=x.device)
         xn[..., :c] = x.permute(0, 2, 3, 1)

@@ -93,7 +93,7 @@ class vgg_backbone(nn.Module):
             self._out_feature_strides[name] = strides[i]
         self._out_features = self._stage_names
         del self.vgg
-        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self.bn_momentum, self.bn_eps = 0.1, 1e-5
         self.fuse_first = bool(cfg.SFOD.FUSE_FIRST_LAYER) if "SFOD" in cfg and "FUSE_FIRST_LAYER" in cfg.SFOD else True
         # execution plan: (conv, bn, pool_after, stage_end)
@@ -141,8 +141,11 @@ class vgg_backbone(nn.Module):
     def forward(self, x):
         """x: [N,3,H,W] normalised image batch (NCHW logical) or an already NHWC-packed tensor
         tagged by ``forward_nhwc``.  Returns {"vgg0".."vgg4"} as NCHW (channels-last) views."""
-        dt = native.F32 if self.compute_dtype == torch.float32 else native.BF16
-        xn = nhwc_from_nchw_view(x, self.compute_dtype, native.chunk_elems(dt))
+        dt = native.dt_of_dtype(self.compute_dtype)
+        if dt == native.BF16X3:     # fp32 NHWC padded to one 8-channel group, then converted to (hi, lo) pairs
+            xn = native.cast(nhwc_from_nchw_view(x, torch.float32, native.chunk_elems(dt)), self.compute_dtype)
+        else:
+            xn = nhwc_from_nchw_view(x, self.compute_dtype, native.chunk_elems(dt))
         return self.forward_nhwc(xn)
 
     def forward_nhwc(self, x_nhwc):
@@ -219,7 +222,8 @@ class vgg_backbone(nn.Module):
                 y = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3)
                 mean = bn.running_mean
                 invstd = torch.rsqrt(bn.running_var + self.bn_eps)
-            z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool)
+            z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool,
+                                        out_dtype=x.dtype)       # bf16x3: y is fp32, z is written as (hi, lo) pairs
             if save:
                 saved.append((x, y, mean, invstd))
             x = z
@@ -247,7 +251,7 @@ class vgg_backbone(nn.Module):
             conv, bn, pool, stage_end = self._plan[li]
             x, y, mean, invstd = saved[li]
             if stage_end and out_grads[stage_of[li]] is not None:
-                g = out_grads[stage_of[li]].permute(0, 2, 3, 1).to(dtype).contiguous()
+                g = out_grads[stage_of[li]].permute(0, 2, 3, 1).to(native.out_dtype_of(dtype)).contiguous()
                 dz = g if dz is None else native.add_(dz, g)
             if dz is None:
                 continue
@@ -258,7 +262,8 @@ class vgg_backbone(nn.Module):
             dy, dgamma, dbeta = native.bn_relu_pool_bwd(dz, y, mean, invstd, bn.weight.detach(),
                                                         bn.bias.detach(), pool,
                                                         dgamma_acc=gsink if direct_bn else None,
-                                                        dbeta_acc=bsink if direct_bn else None)
+                                                        dbeta_acc=bsink if direct_bn else None,
+                                                        out_dtype=dtype)    # bf16x3: dz / y fp32 -> dy pairs
             if direct_bn:
                 dgamma = dbeta = None
             cout, cin = conv.out_channels, conv.in_channels

@@ -46,8 +46,8 @@ class FCDiscriminator_img(nn.Module):
     def forward(self, x):
         """x: [N,C,H,W] (NCHW logical) -> [N,1,H,W] fp32 logits.  Forward only (see module doc)."""
         dtype = self.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
-        h = x.permute(0, 2, 3, 1).to(dtype).contiguous()
+        dt = native.dt_of_dtype(dtype)
+        h = native.nhwc_operand(x, dtype)
         for conv, act in ((self.conv1, 2), (self.conv2, 2), (self.conv3, 2)):
             wp = native.pack_conv_weight(conv.weight, h.shape[-1], dt)
             h = native.conv_fwd(h, wp, conv.bias, conv.out_channels, 3, act=act)
@@ -63,8 +63,8 @@ class _DCImgLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dc, feat_nchw, label, *params):
         dtype = dc.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
-        h = feat_nchw.permute(0, 2, 3, 1).to(dtype).contiguous()
+        dt = native.dt_of_dtype(dtype)
+        h = native.nhwc_operand(feat_nchw, dtype)
         acts = [h]
         for conv in (dc.conv1, dc.conv2, dc.conv3):
             wp = native.pack_conv_weight(conv.weight.detach(), h.shape[-1], dt)
@@ -83,11 +83,12 @@ class _DCImgLossFn(torch.autograd.Function):
     def backward(ctx, g):
         dc, acts, logits = ctx.dc, ctx.acts, ctx.logits
         dtype = dc.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(dtype)
         E = native.chunk_elems(dt)
+        adt = native.out_dtype_of(dtype)       # dtype gradients flow in (fp32 in bf16x3 mode: converted at the MFMA)
         B, H, W = logits.shape
-        dz = torch.zeros(B, H, W, E, dtype=dtype, device=logits.device)     # 1 channel padded to a chunk
-        dz[..., 0] = ((torch.sigmoid(logits) - ctx.label) * (g / logits.numel())).to(dtype)
+        dz = torch.zeros(B, H, W, E, dtype=adt, device=logits.device)     # 1 channel padded to a chunk
+        dz[..., 0] = ((torch.sigmoid(logits) - ctx.label) * (g / logits.numel())).to(adt)
         pgrads = []
         dy = dz
         convs = [dc.conv1, dc.conv2, dc.conv3, dc.classifier]
@@ -96,14 +97,14 @@ class _DCImgLossFn(torch.autograd.Function):
             cout = conv.out_channels
             if li < 3:
                 dy = native.act_bwd_(dy, acts[li + 1], 2)              # LeakyReLU(0.2) of this layer's output
-            dwp = native.conv_wgrad(x_in, dy, cout, 3)
+            dwp = native.conv_wgrad(x_in, dy, cout, 3, operand=dtype)
             dw = torch.empty_like(conv.weight)
             native.unpack_conv_wgrad(dwp, dw)
             db = native.bias_grad(dy, cout)
             pgrads = [dw, db] + pgrads
             wr = native.pack_conv_weight(conv.weight.detach(), dy.shape[-1], dt, rot180=True)
             dy = native.conv_fwd(dy, wr, None, conv.in_channels, 3)
-        dfeat = dy.permute(0, 3, 1, 2).to(ctx.feat_dtype)
+        dfeat = dy.permute(0, 3, 1, 2).to(native.out_dtype_of(ctx.feat_dtype))
         ctx.acts = None
         return (None, dfeat, None) + tuple(pgrads)
 
@@ -138,11 +139,11 @@ class DAInsHead(nn.Module):
         """Eval-mode forward (dropout off) on the GEMM kernel; single level."""
         assert len(self.da_ins_fc1_layers) == 1
         dtype = self.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(dtype)
         fc1 = getattr(self, self.da_ins_fc1_layers[0])
         fc2 = getattr(self, self.da_ins_fc2_layers[0])
         fc3 = getattr(self, self.da_ins_fc3_layers[0])
-        h = x.to(dtype).contiguous()
+        h = native.as_operand(x.contiguous(), dtype)
         h = native.conv_fwd(h, native.pack_fc_weight(fc1.weight, dt), fc1.bias, 1024, 1, act=1)
         h = native.conv_fwd(h, native.pack_fc_weight(fc2.weight, dt), fc2.bias, 1024, 1, act=1)
         y = native.conv_fwd(h, native.pack_fc_weight(fc3.weight, dt), fc3.bias, 1, 1, out_dtype=torch.float32, ldy=8)
@@ -158,7 +159,7 @@ class _DCInsLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, heads, head, feat_nchw, rois, label, masks, *params):
         dtype = heads.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(dtype)
         st = heads._box_forward(feat_nchw, rois)
         fc1 = getattr(head, head.da_ins_fc1_layers[0])
         fc2 = getattr(head, head.da_ins_fc2_layers[0])
@@ -189,30 +190,31 @@ class _DCInsLossFn(torch.autograd.Function):
         heads, head, st, rois, masks = ctx.heads, ctx.head, ctx.st, ctx.rois, ctx.masks
         r1, z1, r2, z2, z, live, n_live = ctx.acts
         dtype = heads.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(dtype)
         E = native.chunk_elems(dt)
         fc1 = getattr(head, head.da_ins_fc1_layers[0])
         fc2 = getattr(head, head.da_ins_fc2_layers[0])
         fc3 = getattr(head, head.da_ins_fc3_layers[0])
         R = z.shape[0]
-        dz = torch.zeros(R, E, dtype=dtype, device=z.device)            # 1 logit padded to a chunk
-        dz[:, 0] = ((torch.sigmoid(z) - ctx.label) * live * (g / n_live)).to(dtype)
+        adt = native.out_dtype_of(dtype)
+        dz = torch.zeros(R, E, dtype=adt, device=z.device)              # 1 logit padded to a chunk
+        dz[:, 0] = ((torch.sigmoid(z) - ctx.label) * live * (g / n_live)).to(adt)
         # fc3
-        dw3 = native.conv_wgrad(z2, dz, 1, 1).view(1, -1)
+        dw3 = native.conv_wgrad(z2, dz, 1, 1, operand=dtype).view(1, -1)
         db3 = native.bias_grad(dz, 1)
         d2 = native.conv_fwd(dz, native.pack_fc_weight(fc3.weight.detach(), dt, transpose=True, ld=E), None, 1024, 1)
         if masks is not None:
             native.mul_mask_(d2, masks[1], 2.0)
         native.act_bwd_(d2, r2, 1)
         # fc2
-        dw2 = native.conv_wgrad(z1, d2, 1024, 1).view(1024, -1)
+        dw2 = native.conv_wgrad(z1, d2, 1024, 1, operand=dtype).view(1024, -1)
         db2 = native.bias_grad(d2, 1024)
         d1 = native.conv_fwd(d2, native.pack_fc_weight(fc2.weight.detach(), dt, transpose=True), None, 1024, 1)
         if masks is not None:
             native.mul_mask_(d1, masks[0], 2.0)
         native.act_bwd_(d1, r1, 1)
         # fc1
-        dw1 = native.conv_wgrad(st["h2"], d1, 1024, 1).view(1024, -1)
+        dw1 = native.conv_wgrad(st["h2"], d1, 1024, 1, operand=dtype).view(1024, -1)
         db1 = native.bias_grad(d1, 1024)
         dh2 = native.conv_fwd(d1, native.pack_fc_weight(fc1.weight.detach(), dt, transpose=True), None,
                               fc1.in_features, 1)

@@ -46,7 +46,7 @@ class GeneralizedRCNN(nn.Module):
         self.vis_period = cfg.VIS_PERIOD
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor(cfg.MODEL.PIXEL_STD).view(-1, 1, 1), False)
-        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self._mean = [float(v) for v in cfg.MODEL.PIXEL_MEAN]
         self._std = [float(v) for v in cfg.MODEL.PIXEL_STD]
 
@@ -63,7 +63,7 @@ class GeneralizedRCNN(nn.Module):
                 raise TypeError("images must be uint8 CHW tensors (the mapper's output format)")
         hm = max(int(im.shape[1]) for im in imgs)
         wm = max(int(im.shape[2]) for im in imgs)
-        dt = native.F32 if self.compute_dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(self.compute_dtype)
         x, _ = native.preprocess(imgs, hm, wm, native.chunk_elems(dt), self._mean, self._std, dt)
         sizes = [(int(im.shape[1]), int(im.shape[2])) for im in imgs]
         return ImageList(x.permute(0, 3, 1, 2), sizes)

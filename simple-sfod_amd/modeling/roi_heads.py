@@ -242,7 +242,7 @@ class StandardROIHeads(nn.Module):
         self.box_predictor = self._make_predictor(cfg, self.box_head.output_shape)
         self.pooled = res
         self.channels = shape.channels
-        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         K = self.num_classes
         self.pred_ld = (5 * K + 1 + 7) // 8 * 8
         self.bbox_threshold = cfg.SEMISUPNET.BBOX_THRESHOLD if "SEMISUPNET" in cfg else 0.7
@@ -260,8 +260,8 @@ class StandardROIHeads(nn.Module):
     # ---- box branch: ROIAlign -> fc1 -> fc2 -> fused (cls_score | bbox_pred) -------------------------
     def _box_forward(self, feat_nchw, rois):
         dtype = self.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
-        feat = feat_nchw.permute(0, 2, 3, 1).to(dtype).contiguous()
+        dt = native.dt_of_dtype(dtype)
+        feat = native.nhwc_operand(feat_nchw, dtype)
         bh, bp = self.box_head, self.box_predictor
         C, PP = self.channels, self.pooled * self.pooled
         pooled = native.roi_align_fwd(feat, rois, self.pooled, self.box_pooler.scale)
@@ -279,13 +279,13 @@ class StandardROIHeads(nn.Module):
 
     def _box_backward(self, st, rois, d_pred, feat_shape_nchw):
         dtype = self.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(dtype)
         bh = self.box_head
         K = self.num_classes
         NP = 5 * K + 1
         d_pred_c = native.cast(d_pred, dtype)
         # predictor
-        dwp = native.conv_wgrad(st["h2"], d_pred_c, NP, 1).view(NP, -1)
+        dwp = native.conv_wgrad(st["h2"], d_pred_c, NP, 1, operand=dtype).view(NP, -1)
         dbp = native.bias_grad(d_pred, NP)
         wpt = native.pack_fc_weight(st["wp"], dt, transpose=True, ld=self.pred_ld)
         dh2 = native.conv_fwd(d_pred_c, wpt, None, bh.fc2.out_features, 1)
@@ -298,18 +298,18 @@ class StandardROIHeads(nn.Module):
         """grad wrt the box-head output (``box_features`` = relu(fc2), consumed in place) -> (grad wrt the feature
         map as an NCHW view, [dw1, db1, dw2, db2]); dw1 is None when it went straight into the flat gradient."""
         dtype = self.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(dtype)
         bh = self.box_head
         C = self.channels
         native.act_bwd_(dh2, st["h2"], 1)
         # fc2
-        dw2 = native.conv_wgrad(st["h1"], dh2, bh.fc2.out_features, 1).view(bh.fc2.out_features, -1)
+        dw2 = native.conv_wgrad(st["h1"], dh2, bh.fc2.out_features, 1, operand=dtype).view(bh.fc2.out_features, -1)
         db2 = native.bias_grad(dh2, bh.fc2.out_features)
         w2t = native.pack_fc_weight(bh.fc2.weight.detach(), dt, transpose=True)
         dh1 = native.conv_fwd(dh2, w2t, None, bh.fc2.in_features, 1)
         native.act_bwd_(dh1, st["h1"], 1)
         # fc1 (K axis in (p, c) order inside the kernels, (c, p) in the state dict)
-        dw1p = native.conv_wgrad(st["x0"], dh1, bh.fc1.out_features, 1).view(bh.fc1.out_features, -1)
+        dw1p = native.conv_wgrad(st["x0"], dh1, bh.fc1.out_features, 1, operand=dtype).view(bh.fc1.out_features, -1)
         dw1 = native.grad_sink(bh.fc1.weight)
         if dw1 is not None:     # 103 MB: accumulate straight into the flat gradient, nothing for autograd to add
             native.unpack_fc_wgrad(dw1p, dw1, chw_c=C, accumulate=True)

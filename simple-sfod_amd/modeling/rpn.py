@@ -133,7 +133,7 @@ class RPN(nn.Module):
         self.post_nms_topk = {True: r.POST_NMS_TOPK_TRAIN, False: r.POST_NMS_TOPK_TEST}
         self.nms_thresh = r.NMS_THRESH
         self.loss_weight = {"loss_rpn_cls": r.LOSS_WEIGHT, "loss_rpn_loc": r.BBOX_REG_LOSS_WEIGHT * r.LOSS_WEIGHT}
-        self.compute_dtype = torch.float32 if cfg.SFOD.COMPUTE_DTYPE == "fp32" else torch.bfloat16
+        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self.ld = (5 * A + 7) // 8 * 8  # fused head output row stride (fp32), whole 16-byte chunks
         self._flags = None
         self._last_head_state = None
@@ -145,8 +145,8 @@ class RPN(nn.Module):
     def _head_forward(self, feat_nchw):
         """feat (NCHW view of NHWC memory) -> dict(feat, t, rpn_out)"""
         dtype = self.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
-        feat = feat_nchw.permute(0, 2, 3, 1).to(dtype).contiguous()
+        dt = native.dt_of_dtype(dtype)
+        feat = native.nhwc_operand(feat_nchw, dtype)
         h = self.rpn_head
         C, A = self.channels, self.num_anchors
         wp = native.pack_conv_weight(h.conv.weight.detach(), C, dt)
@@ -201,14 +201,14 @@ class RPN(nn.Module):
         cell = self._cell()
         C, A = self.channels, self.num_anchors
         dtype = self.compute_dtype
-        dt = native.F32 if dtype == torch.float32 else native.BF16
+        dt = native.dt_of_dtype(dtype)
         _, d_out = native.rpn_loss(st["rpn_out"], cell, B, Hf, Wf, self.stride, labels, matched, gt.boxes,
                                    gt.count, self.batch_size_per_image, grad_scale=grad_scale)
         M = B * Hf * Wf
         t2 = st["t"].view(M, C)
         d_out_c = native.cast(d_out, dtype)
         # 1x1 heads: weight / bias gradients, then data gradient into the hidden map
-        dw1 = native.conv_wgrad(t2, d_out_c, 5 * A, 1).view(5 * A, C)
+        dw1 = native.conv_wgrad(t2, d_out_c, 5 * A, 1, operand=dtype).view(5 * A, C)
         db1 = native.bias_grad(d_out, 5 * A)
         w1t = native.pack_fc_weight(st["w1"], dt, transpose=True, ld=self.ld)
         dt_ = native.conv_fwd(d_out_c, w1t, None, C, 1)
@@ -216,7 +216,7 @@ class RPN(nn.Module):
         # 3x3 conv
         h = self.rpn_head
         dt4 = dt_.view(B, Hf, Wf, C)
-        dw0 = native.conv_weight_grad(st["feat"], dt4, h.conv.weight)
+        dw0 = native.conv_weight_grad(st["feat"], dt4, h.conv.weight, operand=dtype)
         db0 = native.bias_grad(dt_, C)
         wr = native.pack_conv_weight(h.conv.weight.detach(), C, dt, rot180=True)
         dfeat = native.conv_fwd(dt4, wr, None, C, 3)

@@ -10,14 +10,45 @@ PyTorch is used here only as the owner of device memory and streams (``tensor.da
 import ctypes
 import os
 import re
+import warnings
 
 import torch
+
+# SFOD_BF16X3 tensors are tagged with torch.complex32 (see SPLIT_DTYPE below); torch only ever allocates / views them
+warnings.filterwarnings("ignore", message="ComplexHalf support is experimental")
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sfod_hip.h")
 SO_PATH = os.environ.get("SFOD_HIP_LIB", os.path.join(_HERE, "lib", "libsfod_hip.so"))   # override: kernel A/B builds
 
-F32, BF16 = 0, 1
+F32, BF16, BF16X3 = 0, 1, 2
+
+# Storage tag of SFOD_BF16X3 ("split") tensors (include/sfod_hip.h): 4 bytes per logical element -- a (hi, lo) bf16
+# pair, stored per 8 channels as 8 hi then 8 lo.  torch never does arithmetic on them (only empty / zeros / view /
+# permute); torch.complex32 is used purely as a 4-byte dtype that cannot be confused with fp32 data, so tensor
+# shapes stay the LOGICAL shapes and every wrapper below dispatches on ``dt_of(t)``.  Conversions go through
+# ``cast`` (sfod_cast), never through ``Tensor.to``.
+SPLIT_DTYPE = torch.complex32
+
+COMPUTE_MODES = {"fp32": F32, "bf16": BF16, "bf16x3": BF16X3}
+
+
+def mode_dt(name):
+    """cfg.SFOD.COMPUTE_DTYPE -> dt code of the MFMA operands."""
+    try:
+        return COMPUTE_MODES[str(name).lower()]
+    except KeyError:
+        raise ValueError(f"SFOD.COMPUTE_DTYPE must be one of {sorted(COMPUTE_MODES)}, got {name!r}") from None
+
+
+def mode_dtype(name):
+    """cfg.SFOD.COMPUTE_DTYPE -> torch dtype of the MFMA operand tensors (activations fed to conv / GEMM, weights)."""
+    return torch_dtype(mode_dt(name))
+
+
+def out_dtype_of(dtype):
+    """dtype convolutions / GEMMs write (and elementwise gradients flow in) for operands of ``dtype``."""
+    return torch.float32 if dtype == SPLIT_DTYPE else dtype
 
 
 class NativeLibraryError(RuntimeError):
@@ -112,15 +143,38 @@ def dt_of(t):
         return F32
     if t.dtype == torch.bfloat16:
         return BF16
+    if t.dtype == SPLIT_DTYPE:
+        return BF16X3
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
+def dt_of_dtype(dtype):
+    return {torch.float32: F32, torch.bfloat16: BF16, SPLIT_DTYPE: BF16X3}[dtype]
+
+
 def torch_dtype(dt):
-    return torch.float32 if dt == F32 else torch.bfloat16
+    return {F32: torch.float32, BF16: torch.bfloat16, BF16X3: SPLIT_DTYPE}[dt]
 
 
 def chunk_elems(dt):
+    """channel granularity of a tensor of storage type dt (one 16-byte chunk; bf16x3: one 32-byte (hi | lo) group)"""
     return 4 if dt == F32 else 8
+
+
+def nhwc_operand(x_nchw, dtype):
+    """NCHW-shaped view of NHWC memory (what the backbones return) -> contiguous NHWC MFMA operand of ``dtype``."""
+    p = x_nchw.permute(0, 2, 3, 1)
+    if p.dtype == dtype:
+        return p.contiguous()
+    if dtype == SPLIT_DTYPE or p.dtype == SPLIT_DTYPE:
+        return cast(p.contiguous(), dtype)
+    return p.to(dtype).contiguous()
+
+
+def as_operand(t, dtype):
+    """t as an MFMA operand of ``dtype``: unchanged if it already is, else converted by sfod_cast (fp32 -> bf16 /
+    bf16x3 pairs).  The trunk's producers write operand tensors directly; the heads' small fp32 tensors pass here."""
+    return t if t.dtype == dtype else cast(t, dtype)
 
 
 class KernelTimer:
@@ -450,6 +504,7 @@ def unpack_fc_wgrad(dw_packed, dw, chw_c=0, accumulate=False):
 
 def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, want_stats=False):
     """x [B,H,W,Cin] NHWC (or [R,K] with ksize=1) -> y [B,H,W,ldy]; optional BN partial stats."""
+    x = as_operand(x, w_packed.dtype)
     dt = dt_of(x)
     if x.dim() == 2:
         B, H, W, cin = x.shape[0], 1, 1, x.shape[1]
@@ -457,7 +512,7 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     else:
         B, H, W, cin = x.shape
         oshape = lambda ld: (B, H, W, ld)
-    out_dtype = out_dtype or x.dtype
+    out_dtype = out_dtype or out_dtype_of(x.dtype)
     ldy = ldy or cout
     alloc = torch.zeros if ldy != cout else torch.empty
     y = alloc(oshape(ldy), dtype=out_dtype, device=x.device)
@@ -471,7 +526,7 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     if _timer is not None:
         _pending_tag = ":patch3x3" if query("sfod_conv_fwd_algo", B, H, W, cin, cout, ksize, dt) == 2 else ":gemm"
     call("sfod_conv_fwd", x, w_packed, bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
-         F32 if out_dtype == torch.float32 else BF16)
+         dt_of_dtype(out_dtype))
     _pending_tag = ""
     return (y, stats) if want_stats else y
 
@@ -515,28 +570,37 @@ def _workspace(dev, nbytes):
     return cur
 
 
-def conv_wgrad(x, dy, cout, ksize, dw_packed=None):
-    """-> fp32 packed grad [Cout, taps, Cin] (accumulated into dw_packed if given)."""
+def conv_wgrad(x, dy, cout, ksize, dw_packed=None, operand=None):
+    """-> fp32 packed grad [Cout, taps, Cin] (accumulated into dw_packed if given).  ``operand``: MFMA operand dtype
+    (default: x's); fp32 inputs of a bf16x3 model are converted to pairs here."""
+    operand = operand or x.dtype
+    x, dy = as_operand(x, operand), as_operand(dy, operand)
     dt = dt_of(x)
     if x.dim() == 2:
         B, H, W, cin = x.shape[0], 1, 1, x.shape[1]
     else:
         B, H, W, cin = x.shape
     lddy = dy.shape[-1]
-    if dw_packed is None:
-        dw_packed = torch.zeros(cout, ksize * ksize, cin, dtype=torch.float32, device=x.device)
-    nbytes = query("sfod_conv_wgrad_ws_bytes", B, H, W, cin, cout, ksize, lddy, dt)
+    # bf16x3 rows come in whole 8-channel groups: compute ceil8(cout) rows (dy's padding columns are zero)
+    cout_k = (cout + 7) // 8 * 8 if dt == BF16X3 else cout
+    assert cout_k <= lddy, "dy narrower than the padded output-channel count"
+    if dw_packed is None or cout_k != cout:
+        assert dw_packed is None, "accumulating bf16x3 weight gradients needs Cout % 8 == 0"
+        dw_packed = torch.zeros(cout_k, ksize * ksize, cin, dtype=torch.float32, device=x.device)
+    nbytes = query("sfod_conv_wgrad_ws_bytes", B, H, W, cin, cout_k, ksize, lddy, dt)
     ws = _workspace(x.device, nbytes) if nbytes > 0 else None
     global _pending_flops
     _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
-    call("sfod_conv_wgrad", x, dy, dw_packed, B, H, W, cin, cout, ksize, lddy, dt, ws, nbytes)
-    return dw_packed
+    call("sfod_conv_wgrad", x, dy, dw_packed, B, H, W, cin, cout_k, ksize, lddy, dt, ws, nbytes)
+    return dw_packed if cout_k == cout else dw_packed[:cout]
 
 
 def conv_wgrad_oihw_supported(x, dy, cout, ksize):
     if x.dim() != 4:
         return False
     B, H, W, cin = x.shape
+    if dt_of(x) == BF16X3 and (cout % 8 or dy.shape[-1] % 8):
+        return False
     return bool(query("sfod_conv_wgrad_oihw_supported", B, H, W, cin, cout, ksize, dy.shape[-1], dt_of(x)))
 
 
@@ -545,6 +609,7 @@ def conv_wgrad_oihw(x, dy, dw_oihw, accumulate=False):
     cout, cin, ksize, _ = dw_oihw.shape
     B, H, W, cinp = x.shape
     assert cinp == cin and dw_oihw.is_contiguous() and dw_oihw.dtype == torch.float32
+    dy = as_operand(dy, x.dtype)
     lddy = dy.shape[-1]
     dt = dt_of(x)
     nbytes = query("sfod_conv_wgrad_ws_bytes", B, H, W, cin, cout, ksize, lddy, dt)
@@ -555,10 +620,12 @@ def conv_wgrad_oihw(x, dy, dw_oihw, accumulate=False):
     return dw_oihw
 
 
-def conv_weight_grad(x, dy, weight):
+def conv_weight_grad(x, dy, weight, operand=None):
     """dL/dweight of a conv whose state-dict weight is ``weight`` (OIHW).  Accumulated straight into
     ``grad_sink(weight)`` when the parameter has one (returns None: nothing for autograd to add), else
     returned as a new tensor."""
+    operand = operand or x.dtype
+    x, dy = as_operand(x, operand), as_operand(dy, operand)
     cout, cin, k, _ = weight.shape
     sink = grad_sink(weight)
     if sink is not None and k == 3 and x.shape[-1] == cin and conv_wgrad_oihw_supported(x, dy, cout, 3):
@@ -592,12 +659,13 @@ def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, 
     return mean, invstd
 
 
-def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True):
+def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True, out_dtype=None):
+    """``out_dtype``: y.dtype, or SPLIT_DTYPE from an fp32 y (the next convolution's operand, written directly)."""
     B, H, W, C = y.shape
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
-    z = torch.empty(B, Ho, Wo, C, dtype=y.dtype, device=y.device)
+    z = torch.empty(B, Ho, Wo, C, dtype=out_dtype or y.dtype, device=y.device)
     call("sfod_bn_relu_pool_fwd", y, mean, invstd, gamma, beta, z, B, H, W, C, int(pool) | (0 if relu else 2),
-         dt_of(y))
+         dt_of(y), dt_of(z))
     return z
 
 
@@ -611,11 +679,12 @@ def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual):
 
 
 def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None, relu=True,
-                     dgamma_acc=None, dbeta_acc=None):
-    """``dgamma_acc`` / ``dbeta_acc``: gradient accumulators (see ``grad_sink``) updated in the same launch."""
+                     dgamma_acc=None, dbeta_acc=None, out_dtype=None):
+    """``dgamma_acc`` / ``dbeta_acc``: gradient accumulators (see ``grad_sink``) updated in the same launch.
+    ``out_dtype``: dtype of dy (y.dtype, or SPLIT_DTYPE from fp32 inputs: dy only feeds the wgrad / dgrad MFMAs)."""
     B, H, W, C = y.shape
     if dy is None:
-        dy = torch.empty_like(y)
+        dy = torch.empty(y.shape, dtype=out_dtype or y.dtype, device=y.device)
     if dgamma is None:
         dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
     if dbeta is None:
@@ -623,7 +692,7 @@ def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=
     ws = torch.empty(query("sfod_bn_bwd_ws_floats", B * H * W, C), dtype=torch.float32, device=y.device)
     call("sfod_bn_relu_pool_bwd", dz, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, dgamma_acc, dbeta_acc, ws,
          B, H, W, C,
-         int(pool) | (0 if relu else 2), dt_of(y))
+         int(pool) | (0 if relu else 2), dt_of(y), dt_of(dy))
     return dy, dgamma, dbeta
 
 
@@ -680,7 +749,7 @@ def cast(src, dtype):
     if src.dtype == dtype:
         return src
     dst = torch.empty(src.shape, dtype=dtype, device=src.device)
-    call("sfod_cast", src, dst, src.numel(), dt_of(src), F32 if dtype == torch.float32 else BF16)
+    call("sfod_cast", src.contiguous(), dst, src.numel(), dt_of(src), dt_of_dtype(dtype))
     return dst
 
 

@@ -1,0 +1,291 @@
+"""GPU parity tests of the SFOD_BF16X3 mode (fp32-equivalent arithmetic on the bf16 matrix pipe).
+
+Every MFMA operand is the pair hi = bf16(v), lo = bf16(v - hi); a product is hi*hi + hi*lo + lo*hi accumulated in
+fp32.  Per-product error <= 3 * 2^-16 (worst case), ~4e-6 rms measured (tools/experiments/mfma_split_precision.hip),
+so every kernel here must agree with an fp64-accumulated reference on the UNROUNDED fp32 operands to ~1e-5 -- the
+tolerances below are 3e-5 relative (L2), 25x tighter than the 1e-4 of BASELINE.json's north_star and >100x tighter
+than what one bf16 pass achieves (2e-3).  The storage layout (8 hi | 8 lo per 8 channels) is checked bit for bit.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+TOL = 3e-5
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def split_ref(x):
+    """fp32 [..., C] -> bf16 [..., 2C] in the documented layout (per 8 channels: 8 hi then 8 lo)."""
+    hi = x.bfloat16()
+    lo = (x - hi.float()).bfloat16()
+    s = x.shape
+    hi = hi.reshape(*s[:-1], s[-1] // 8, 1, 8)
+    lo = lo.reshape(*s[:-1], s[-1] // 8, 1, 8)
+    return torch.cat([hi, lo], dim=-2).reshape(*s[:-1], 2 * s[-1])
+
+
+def to_split(native, x_dev):
+    return native.cast(x_dev.contiguous(), native.SPLIT_DTYPE)
+
+
+def conv_ref64(x, w, bias=None, padding=0):
+    return F.conv2d(x.double(), w.double(), None if bias is None else bias.double(), padding=padding)
+
+
+def test_cast_layout_and_round_trip(native):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 5, 64, generator=g) * torch.logspace(-6, 3, 64)
+    x[0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, 1e-30, -3e38, 65504.0, 2 ** -126, 1 + 2 ** -12])
+    s = to_split(native, x.to(DEV))
+    assert s.dtype == native.SPLIT_DTYPE and s.shape == x.shape
+    assert torch.equal(s.view(torch.bfloat16).cpu().view(torch.int16), split_ref(x).view(torch.int16))
+    back = native.cast(s, torch.float32).cpu()
+    assert torch.equal(back, split_ref(x).float().reshape(37, 5, 8, 2, 8).sum(-2).reshape(37, 5, 64))
+    err = ((back - x).abs() / x.abs().clamp_min(1e-37)).max().item()
+    assert err <= 2.0 ** -16
+    assert torch.equal(native.cast(native.cast(back.to(DEV), native.SPLIT_DTYPE), torch.float32).cpu(), back)
+
+
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout, ks
+    (2, 9, 13, 64, 64, 3),
+    (1, 18, 37, 64, 128, 3),
+    (2, 7, 5, 128, 256, 3),
+    (1, 5, 6, 512, 512, 3),
+    (3, 16, 16, 3, 64, 3),      # first layer: 3 channels in one 8-channel group
+    (1, 18, 37, 512, 75, 1),    # RPN 1x1 heads fused
+    (2, 1, 1, 256, 1024, 1),
+    (1, 10, 12, 24, 40, 3),     # channel counts that are multiples of 8 only (non power of two -> 1x1 below)
+])
+@pytest.mark.parametrize("act", [0, 1])
+def test_conv_fwd_generic_kernel(native, shape, act):
+    B, H, W, Cin, Cout, ks = shape
+    if Cin == 24:
+        ks = 1
+    g = torch.Generator().manual_seed(hash(shape) % 1000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)
+    bias = torch.randn(Cout, generator=g)
+    cin_pad = (Cin + 7) // 8 * 8
+    ref = conv_ref64(x, w, bias, padding=ks // 2)
+    ref = F.relu(ref) if act else ref
+    xd = torch.zeros(B, H, W, cin_pad, device=DEV)
+    xd[..., :Cin] = nhwc(x).to(DEV)
+    wp = native.pack_conv_weight(w.to(DEV), cin_pad, native.BF16X3)
+    assert wp.dtype == native.SPLIT_DTYPE
+    try:
+        native.set_conv_algo(1)
+        y = native.conv_fwd(to_split(native, xd), wp, bias.to(DEV), Cout, ks, act=act)
+        y2 = native.conv_fwd(xd, wp, bias.to(DEV), Cout, ks, act=act)     # fp32 input: converted by the wrapper
+    finally:
+        native.set_conv_algo(0)
+    assert y.dtype == torch.float32
+    assert rel_err(nchw(y.cpu()), ref) < TOL
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("shape", [
+    # B, H, W, Cin, Cout  -- halo-patch kernel on physical channels 2 * Cin
+    (2, 37, 75, 64, 128),
+    (1, 20, 50, 64, 64),
+    (1, 33, 40, 128, 64),
+    (2, 9, 13, 16, 200),      # a single 32-physical-channel slice, Cout tail
+    (1, 70, 150, 48, 136),    # several tiles per image, 3 slices
+    (3, 5, 6, 256, 256),
+])
+@pytest.mark.parametrize("variant", ["plain", "relu_stats", "ldy"])
+@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4])
+def test_conv3x3_patch_kernel(native, shape, variant, wg):
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(B, Cin, H, W, generator=g) + 0.3
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(Cin * 9)
+    bias = torch.randn(Cout, generator=g)
+    ref = conv_ref64(x, w, bias, padding=1)
+    xd = to_split(native, nhwc(x).to(DEV))
+    wp = native.pack_conv_weight(w.to(DEV), Cin, native.BF16X3)
+    try:
+        native.set_conv_algo(2)
+        native.set_conv3x3_variant(wg)
+        assert native.query("sfod_conv_fwd_algo", B, H, W, Cin, Cout, 3, native.BF16X3) == 2
+        if variant == "plain":
+            y = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
+            assert rel_err(nchw(y.cpu()), ref) < TOL
+        elif variant == "relu_stats":
+            y, stats = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3, act=1, want_stats=True)
+            assert rel_err(nchw(y.cpu()), F.relu(ref)) < TOL
+            rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+            mean, invstd = native.bn_finalize(stats, B * H * W, Cout, rm, rv, 0.1, 1e-5)
+            torch.testing.assert_close(mean.cpu().double(), ref.mean(dim=(0, 2, 3)), rtol=1e-4, atol=2e-5)
+            torch.testing.assert_close(invstd.cpu().double(), torch.rsqrt(ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5),
+                                       rtol=1e-4, atol=1e-5)
+        else:
+            y = native.conv_fwd(xd, wp, None, Cout, 3, ldy=Cout + 8)
+            assert rel_err(nchw(y[..., :Cout].cpu()), ref - bias.double().view(1, -1, 1, 1)) < TOL
+            assert (y[..., Cout:] == 0).all()
+    finally:
+        native.set_conv_algo(0)
+        native.set_conv3x3_variant(0)
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 13, 64, 64, 3), (1, 11, 7, 128, 256, 3), (1, 6, 5, 512, 75, 1),
+                                   (3, 8, 8, 3, 64, 3), (1, 40, 1, 1024, 41, 1)])
+@pytest.mark.parametrize("algo", [1, 0])
+def test_conv_dgrad_and_wgrad(native, shape, algo):
+    B, H, W, Cin, Cout, ks = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, Cin, H, W, generator=g).double().requires_grad_(True)
+    w = (torch.randn(Cout, Cin, ks, ks, generator=g) / math.sqrt(Cin * ks * ks)).double().requires_grad_(True)
+    dy = (torch.randn(B, Cout, H, W, generator=g) * 1e-5).double()       # gradient-sized values: no range issue in bf16 pairs
+    F.conv2d(x, w, None, padding=ks // 2).backward(dy)
+    cin_pad, cout_pad = (Cin + 7) // 8 * 8, (Cout + 7) // 8 * 8
+    xd = torch.zeros(B, H, W, cin_pad, device=DEV)
+    xd[..., :Cin] = nhwc(x.detach().float()).to(DEV)
+    dyd = torch.zeros(B, H, W, cout_pad, device=DEV)
+    dyd[..., :Cout] = nhwc(dy.float()).to(DEV)
+    xs, dys = to_split(native, xd), to_split(native, dyd)
+    try:
+        native.set_conv_algo(algo)
+        dwp = native.conv_wgrad(xs, dys, Cout, ks)
+        dwp_f = native.conv_wgrad(xd, dyd, Cout, ks, operand=native.SPLIT_DTYPE)    # fp32 inputs converted by the wrapper
+        dw = torch.empty(Cout, Cin, ks, ks, dtype=torch.float32, device=DEV)
+        native.unpack_conv_wgrad(dwp.contiguous(), dw)
+        assert rel_err(dw.cpu(), w.grad) < TOL
+        assert rel_err(dwp_f, dwp) < 1e-6        # atomics: order of the fp32 sums may differ
+        if Cin >= 8:
+            wr = native.pack_conv_weight(w.detach().float().to(DEV), cout_pad, native.BF16X3, rot180=True)
+            dx = native.conv_fwd(dys, wr, None, Cin, ks)
+            assert rel_err(nchw(dx.cpu()), x.grad) < TOL
+    finally:
+        native.set_conv_algo(0)
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 37, 75, 64, 128),
+    (1, 20, 50, 32, 32),      # CO=2 variant (64 physical output channels)
+    (1, 33, 40, 128, 64),
+    (2, 9, 13, 16, 96),
+    (1, 70, 150, 48, 80),
+    (3, 5, 6, 256, 256),
+])
+def test_conv3x3_patch_wgrad(native, shape):
+    """k_wgrad3x3_patch on the physical channels + the quadrant-summing slab reduction against fp64 autograd."""
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator().manual_seed(sum(shape) + 1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g) * 1e-4
+    w = torch.zeros(Cout, Cin, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), w, None, padding=1).backward(dy.double())
+    xd, dyd = to_split(native, nhwc(x).to(DEV)), to_split(native, nhwc(dy).to(DEV))
+    try:
+        native.set_conv_algo(2)
+        assert native.query("sfod_conv_wgrad_ws_bytes", B, H, W, Cin, Cout, 3, Cout, native.BF16X3) > 16 * Cout * 9 * Cin
+        dwp = native.conv_wgrad(xd, dyd, Cout, 3)
+        dwp2 = native.conv_wgrad(xd, dyd, Cout, 3)
+        assert native.conv_wgrad_oihw_supported(xd, dyd, Cout, 3)
+        direct = torch.full((Cout, Cin, 3, 3), float("nan"), dtype=torch.float32, device=DEV)
+        native.conv_wgrad_oihw(xd, dyd, direct, accumulate=False)
+        acc = torch.ones(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
+        native.conv_wgrad_oihw(xd, dyd, acc, accumulate=True)
+    finally:
+        native.set_conv_algo(0)
+    dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
+    native.unpack_conv_wgrad(dwp, dw)
+    assert rel_err(dw.cpu(), w.grad) < TOL
+    assert torch.equal(dwp, dwp2), "slab reduction must be deterministic"
+    assert torch.equal(direct, dw)
+    torch.testing.assert_close(acc, dw + 1.0, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("pool", [False, True])
+@pytest.mark.parametrize("hw", [(8, 12), (7, 9), (37, 75)])
+def test_bn_relu_pool_split_outputs_equal_fp32_kernels(native, pool, hw):
+    """BatchNorm apply / backward writing (hi, lo) pairs == the fp32 kernels' outputs converted afterwards (the two
+    instantiations may contract a*b+c differently: equal within one fp32 rounding + the 2^-16 of the pair format)."""
+    H, W = hw
+    B, C = 2, 64
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(B, H, W, C, generator=g).to(DEV)
+    mean, var = y.mean(dim=(0, 1, 2)), y.var(dim=(0, 1, 2), unbiased=False)
+    invstd = torch.rsqrt(var + 1e-5)
+    gamma, beta = torch.rand(C, generator=g).to(DEV) + 0.5, torch.randn(C, generator=g).to(DEV) * 0.1
+    z32 = native.bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool)
+    zs = native.bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, out_dtype=native.SPLIT_DTYPE)
+    assert zs.dtype == native.SPLIT_DTYPE and zs.shape == z32.shape
+    zb = native.cast(zs, torch.float32)
+    assert ((zb - z32).abs() <= z32.abs() * 2.0 ** -16 + 1e-6).all()
+    assert ((zb == 0) == (z32 == 0)).all()           # ReLU zeros stay exact zeros
+    dz = torch.randn(z32.shape, generator=g).to(DEV) * 1e-4
+    dy32, dg32, db32 = native.bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool)
+    dys, dgs, dbs = native.bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, out_dtype=native.SPLIT_DTYPE)
+    assert torch.equal(dg32, dgs) and torch.equal(db32, dbs)
+    assert ((native.cast(dys, torch.float32) - dy32).abs() <= dy32.abs() * 2.0 ** -16 + 1e-10).all()
+
+
+def test_roi_align_fwd_split(native):
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C, R = 2, 19, 38, 64, 200
+    feat = torch.randn(B, H, W, C, generator=g).to(DEV)
+    xy = torch.rand(R, 2, generator=g) * torch.tensor([W * 32.0, H * 32.0])
+    wh = torch.rand(R, 2, generator=g) * 300 + 4
+    rois = torch.cat([torch.randint(0, B, (R, 1), generator=g).float(), xy, xy + wh], dim=1)
+    rois[7, 0] = -1          # padding row
+    rois = rois.to(DEV)
+    # reference: the fp32 kernel on the values the pairs hold
+    fs = to_split(native, feat)
+    ref = native.roi_align_fwd(native.cast(fs, torch.float32), rois, 7, 1.0 / 32)
+    out = native.roi_align_fwd(fs, rois, 7, 1.0 / 32)
+    assert out.dtype == native.SPLIT_DTYPE and out.shape == ref.shape
+    got = native.cast(out, torch.float32)
+    assert (got[7] == 0).all()
+    assert rel_err(got.cpu(), ref.cpu()) < 2.0 ** -16
+
+
+def test_preprocess_split(native):
+    g = torch.Generator().manual_seed(1)
+    imgs = [torch.randint(0, 256, (3, 20, 31), dtype=torch.uint8, generator=g).to(DEV),
+            torch.randint(0, 256, (3, 17, 40), dtype=torch.uint8, generator=g).to(DEV)]
+    mean, std = [103.53, 116.28, 123.675], [1.0, 57.0, 2.5]
+    x32, _ = native.preprocess(imgs, 20, 40, 8, mean, std, native.F32)
+    xs, _ = native.preprocess(imgs, 20, 40, 8, mean, std, native.BF16X3)
+    assert xs.dtype == native.SPLIT_DTYPE and xs.shape == (2, 20, 40, 8)
+    assert torch.equal(xs.view(torch.bfloat16), to_split(native, x32).view(torch.bfloat16))
+
+
+def test_weight_packers_split(native):
+    g = torch.Generator().manual_seed(2)
+    w = torch.randn(40, 24, 3, 3, generator=g).to(DEV)
+    for rot in (False, True):
+        inner = 40 if rot else 24
+        p32 = native.pack_conv_weight(w, inner, native.F32, rot180=rot)
+        ps = native.pack_conv_weight(w, inner, native.BF16X3, rot180=rot)
+        assert torch.equal(ps.view(torch.bfloat16), to_split(native, p32).view(torch.bfloat16))
+    pk32 = native.ConvWeightPacker([(w, 24, False), (w, 40, True)], native.F32).pack()
+    pks = native.ConvWeightPacker([(w, 24, False), (w, 40, True)], native.BF16X3).pack()
+    for a, b in zip(pk32, pks):
+        assert torch.equal(b.view(torch.bfloat16), to_split(native, a.contiguous()).view(torch.bfloat16))
+    fc = torch.randn(1024, 512 * 49, generator=g).to(DEV)          # fc1-shaped: tiled (c, p) -> (p, c) path
+    for tr in (False, True):
+        a = native.pack_fc_weight(fc, native.F32, chw_c=512, transpose=tr)
+        b = native.pack_fc_weight(fc, native.BF16X3, chw_c=512, transpose=tr)
+        assert torch.equal(b.view(torch.bfloat16), to_split(native, a).view(torch.bfloat16))
+    small = torch.randn(41, 1024, generator=g).to(DEV)
+    a = native.pack_fc_weight(small, native.F32, transpose=True, ld=48)
+    b = native.pack_fc_weight(small, native.BF16X3, transpose=True, ld=48)
+    assert torch.equal(b.view(torch.bfloat16), to_split(native, a).view(torch.bfloat16))
