@@ -32,7 +32,9 @@ FLOPS_R101 = {
 }
 YAML = {"vgg": "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml",
         "r101": "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml"}
-PEAK = {"bf16": 2500.0, "fp32": 157.3}  # dense MFMA TFLOP/s, MI355X_MICROARCH.md
+# dense MFMA TFLOP/s (MI355X_MICROARCH.md) per ALGORITHMIC flop: bf16x3 issues three bf16 MFMAs per product
+# (hi*hi + hi*lo + lo*hi), so its ceiling for the convolution's own 2*M*N*K count is the bf16 peak / 3
+PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
 
 
 def step_flops(res, model="vgg"):
@@ -100,7 +102,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--dtype", choices=["bf16", "fp32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16x3", "fp32", "bf16"], default="bf16x3")
     ap.add_argument("--res", choices=["r600", "full"], default="r600")
     ap.add_argument("--model", choices=["vgg", "r101"], default="vgg",
                     help="vgg: the headline VGG16-BN config; r101: r101_c4_..._source_free.yaml (BASELINE config #5)")

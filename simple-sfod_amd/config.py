@@ -365,7 +365,12 @@ def add_native_config(cfg):
     SFOD.EMA.ENABLED      quirk q1: the dispatched reference trainer has the EMA call commented
                           out (source_free_adaptive_teacher.py:581); its twins have it on.
     SFOD.EMA.KEEP_RATE    hard-coded 0.9996 in the reference (:584).
-    SFOD.COMPUTE_DTYPE    "fp32" (parity mode, fp32 MFMA) or "bf16" (throughput mode).
+    SFOD.COMPUTE_DTYPE    arithmetic of the convolutions / GEMMs.  "bf16x3" (default): fp32-equivalent products on the
+                          bf16 matrix pipe (operands as (hi, lo) bf16 pairs, hi*hi + hi*lo + lo*hi in fp32: ~4e-6
+                          relative per dot product, fp32 activations / statistics / losses elsewhere; gated by the
+                          same 1e-4 oracle tests as "fp32");  "fp32": v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA
+                          chains, 1/16 of the bf16 rate);  "bf16": one bf16 pass, bf16 activations (reduced precision,
+                          NOT a parity mode: losses within a few % of the oracle).
     SFOD.ELIDE_DEAD_BRANCHES  skip the zero-weighted 2nd ROI pass / BPC / domain branch.
     SFOD.OVERLAP_TEACHER  run the teacher's pseudo-labelling pass on a second HIP stream beside the
                           student's backbone forward (they are independent until the student's RPN loss).
@@ -375,7 +380,7 @@ def add_native_config(cfg):
     _C.SFOD.EMA = CN()
     _C.SFOD.EMA.ENABLED = True
     _C.SFOD.EMA.KEEP_RATE = 0.9996
-    _C.SFOD.COMPUTE_DTYPE = "fp32"
+    _C.SFOD.COMPUTE_DTYPE = "bf16x3"
     _C.SFOD.ELIDE_DEAD_BRANCHES = True
     _C.SFOD.OVERLAP_TEACHER = True
     # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass

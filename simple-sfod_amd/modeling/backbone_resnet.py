@@ -166,7 +166,12 @@ class ResNet(nn.Module):
         for n in self.stage_names:
             if n not in self.frozen and self.norm_kind != "BN":
                 raise NotImplementedError("trainable stages need RESNETS.NORM=BN (the named r101 config)")
+        # MFMA operand dtype (packed weights) and the dtype activations are stored in between the kernels.  bf16x3:
+        # activations stay fp32 here (residual joins, stride-2 subsampling and the elementwise backward all work on
+        # them) and are converted to (hi, lo) operand pairs at each convolution's input (native.as_operand); the VGG
+        # trunk instead has its BatchNorm kernels write the pairs directly.
         self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
+        self.act_dtype = native.out_dtype_of(self.compute_dtype)
         self.bn_momentum = 0.1
         self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
 
@@ -192,7 +197,7 @@ class ResNet(nn.Module):
     def forward(self, x):
         dt = native.dt_of_dtype(self.compute_dtype)
         n, c, h, w = x.shape
-        xn = torch.zeros(n, h, w, native.chunk_elems(dt), dtype=self.compute_dtype, device=x.device)
+        xn = torch.zeros(n, h, w, native.chunk_elems(dt), dtype=self.act_dtype, device=x.device)
         xn[..., :c] = x.permute(0, 2, 3, 1)
         return self.forward_nhwc(xn)
 
@@ -307,7 +312,9 @@ class ResNet(nn.Module):
         return out, (x.shape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out)
 
     def _forward_impl(self, x, save=True):
-        dt = native.dt_of(x)
+        dt = native.dt_of_dtype(self.compute_dtype)
+        if x.dtype != self.act_dtype:        # bf16x3: the preprocess kernel's pair tensor (3 channels: tiny) -> fp32
+            x = native.cast(x, self.act_dtype)
         saved, outs = [], {}
         self._pack_live_weights(dt, with_dgrad=save)
         x = self._stem_forward(x, dt)
@@ -332,12 +339,13 @@ class ResNet(nn.Module):
                                                     dbeta_acc=bsink if direct_bn else None)
         if direct_bn:
             dgamma = dbeta = None
-        dw = native.conv_weight_grad(x_in, dy, conv.weight)
+        dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.compute_dtype)
         dx = None
         if need_dx:
             wr = self.__dict__.get("_wr", {}).get(id(conv))      # packed with the forward weights (same step, same values)
             if wr is None:
-                wr = native.pack_conv_weight(conv.weight.detach(), conv.out_channels, native.dt_of(dy), rot180=True)
+                wr = native.pack_conv_weight(conv.weight.detach(), conv.out_channels,
+                                             native.dt_of_dtype(self.compute_dtype), rot180=True)
             dx = native.conv_fwd(dy, wr, None, conv.in_channels, k)
         return dx, [dw, dgamma, dbeta]
 
@@ -377,7 +385,7 @@ class ResNet(nn.Module):
             blk = blocks[bi]
             name = block_stage[bi]
             if stage_last[name] == bi and name in gmap:
-                g_in = gmap[name].permute(0, 2, 3, 1).to(self.compute_dtype).contiguous()
+                g_in = gmap[name].permute(0, 2, 3, 1).to(self.act_dtype).contiguous()
                 dx = g_in if dx is None else native.add_(dx, g_in)
             if dx is None:
                 saved[bi] = None

@@ -63,6 +63,12 @@ class _VGGFn(torch.autograd.Function):
         ctx.module = module
         ctx.saved = saved
         ctx.need_dx = False
+        if module.compute_dtype == native.SPLIT_DTYPE:
+            # bf16x3: between the layers activations are (hi, lo) operand pairs; what leaves the trunk (and meets
+            # autograd, whose gradients are fp32) is fp32 -- converted for the stages somebody consumes only
+            # (``needed_features``; vgg4 is 1/1024 of vgg0's pixels), the others are not returned
+            return tuple(native.cast(o, torch.float32).permute(0, 3, 1, 2) if n in module.needed_features else None
+                         for n, o in zip(module._stage_names, outs))
         return tuple(o.permute(0, 3, 1, 2) for o in outs)
 
     @staticmethod
@@ -92,6 +98,9 @@ class vgg_backbone(nn.Module):
             self._out_feature_channels[name] = chans[i]
             self._out_feature_strides[name] = strides[i]
         self._out_features = self._stage_names
+        # stages whose output is materialised for consumers in bf16x3 mode (the meta-architecture narrows this to
+        # the heads' IN_FEATURES); the other modes return zero-copy views of all five
+        self.needed_features = set(self._stage_names)
         del self.vgg
         self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self.bn_momentum, self.bn_eps = 0.1, 1e-5
@@ -139,20 +148,20 @@ class vgg_backbone(nn.Module):
         return ps
 
     def forward(self, x):
-        """x: [N,3,H,W] normalised image batch (NCHW logical) or an already NHWC-packed tensor
-        tagged by ``forward_nhwc``.  Returns {"vgg0".."vgg4"} as NCHW (channels-last) views."""
+        """x: [N,3,H,W] normalised image batch (NCHW logical).  Returns {"vgg0".."vgg4"} as NCHW (channels-last)
+        views -- the Detectron2 Backbone surface (fp32 tensors in fp32 and bf16x3 mode)."""
         dt = native.dt_of_dtype(self.compute_dtype)
         if dt == native.BF16X3:     # fp32 NHWC padded to one 8-channel group, then converted to (hi, lo) pairs
             xn = native.cast(nhwc_from_nchw_view(x, torch.float32, native.chunk_elems(dt)), self.compute_dtype)
-        else:
-            xn = nhwc_from_nchw_view(x, self.compute_dtype, native.chunk_elems(dt))
+            return self.forward_nhwc(xn)
+        xn = nhwc_from_nchw_view(x, self.compute_dtype, native.chunk_elems(dt))
         return self.forward_nhwc(xn)
 
     def forward_nhwc(self, x_nhwc):
         params = self._param_list()
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         outs = _VGGFn.apply(self, save, x_nhwc, *params)
-        return dict(zip(self._stage_names, outs))
+        return {n: o for n, o in zip(self._stage_names, outs) if o is not None}
 
     # ---- engine -------------------------------------------------------------------------------------
     def _first_layer_of_stage(self, stage):

@@ -42,6 +42,8 @@ class GeneralizedRCNN(nn.Module):
         shape = self.backbone.output_shape()
         self.proposal_generator = PROPOSAL_GENERATOR_REGISTRY.get(cfg.MODEL.PROPOSAL_GENERATOR.NAME)(cfg, shape)
         self.roi_heads = ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, shape)
+        if hasattr(self.backbone, "needed_features"):   # stage outputs somebody consumes (see backbone_vgg._VGGFn)
+            self.backbone.needed_features = set(self.proposal_generator.in_features) | set(self.roi_heads.in_features)
         self.input_format = cfg.INPUT.FORMAT
         self.vis_period = cfg.VIS_PERIOD
         self.register_buffer("pixel_mean", torch.tensor(cfg.MODEL.PIXEL_MEAN).view(-1, 1, 1), False)
@@ -130,6 +132,8 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
     def __init__(self, cfg):
         super().__init__(cfg)
         self.dis_type = cfg.SEMISUPNET.DIS_TYPE
+        if hasattr(self.backbone, "needed_features"):
+            self.backbone.needed_features.add(self.dis_type)
         self.DC_img = FCDiscriminator_img(self.backbone._out_feature_channels[self.dis_type],
                                           compute_dtype=self.compute_dtype)
         self.ins_dc = cfg.SEMISUPNET.INS_DC

@@ -1,8 +1,9 @@
-"""Diagnostic: how much do the ORACLE gradients move when every weight is perturbed by 1e-6
-(relative)?  Backbone gradients move by ~1% because a 1e-5 forward difference flips a handful of
+"""Diagnostic: how much do the ORACLE gradients move when every weight is perturbed by EPS (argv[1], default 1e-6;
+relative)?  Backbone gradients move by ~1% because a 1e-5 forward difference flips a handful of
 ReLU masks / max-pool arg-maxes; this sets the tolerance of the end-to-end gradient parity test.
 Measured: feat 2.7e-5, backbone conv grads 0.6-1.5e-2, fc1/fc2 2e-4, RPN head 8e-6."""
 import sys, os, torch
+EPS = float(sys.argv[1]) if len(sys.argv) > 1 else 1e-6
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from oracle import model as om
 from util_weights import reference_vgg_state
@@ -23,9 +24,10 @@ def run(sd, props=None):
     return sd, l, aux
 sdA, lA, auxA = run(sd0)
 # perturb every weight by 1e-6 relative noise (emulates a different fp32 summation order)
-sd1 = {k: (v * (1 + 1e-6 * torch.randn(v.shape, generator=g)) if v.dtype == torch.float32 and 'running' not in k else v) for k, v in sd0.items()}
+sd1 = {k: (v * (1 + EPS * torch.randn(v.shape, generator=g)) if v.dtype == torch.float32 and 'running' not in k else v) for k, v in sd0.items()}
 sdB, lB, auxB = run(sd1, props=auxA["props"])
 def rel(a, b): return ((a.double()-b.double()).norm()/(b.double().norm()+1e-30)).item()
 print("feat rel", rel(auxB["feat"], auxA["feat"]))
-for k in ["backbone.vgg0.0.weight", "backbone.vgg2.3.weight", "backbone.vgg4.0.weight", "backbone.vgg4.6.weight", "backbone.vgg4.7.bias", "roi_heads.box_head.fc1.weight", "roi_heads.box_head.fc2.weight", "proposal_generator.rpn_head.conv.weight"]:
+for k in ["backbone.vgg0.0.weight", "backbone.vgg2.3.weight", "backbone.vgg4.0.weight", "backbone.vgg4.6.weight", "backbone.vgg4.7.bias", "roi_heads.box_head.fc1.weight", "roi_heads.box_head.fc2.weight", "proposal_generator.rpn_head.conv.weight", "proposal_generator.rpn_head.conv.bias",
+          "proposal_generator.rpn_head.anchor_deltas.weight", "roi_heads.box_predictor.cls_score.weight"]:
     print(k, "%.3e" % rel(sdB[k].grad, sdA[k].grad))

@@ -53,11 +53,12 @@ def make_inputs(B, H, W, ngt, seed=0, with_gt=True):
     return out
 
 
-def test_backbone_matches_reference_golden(sfod, native):
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+def test_backbone_matches_reference_golden(sfod, native, dtype):
     """build_vgg_backbone under the same seed reproduces the reference's weights draw for draw and,
     on the HIP kernels, its forward outputs and train-mode BN running statistics (vgg.py)."""
     fx = np.load(os.path.join(GOLDEN, "vgg_ref.npz"), allow_pickle=False)
-    cfg = make_cfg(sfod)
+    cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", dtype])
     torch.manual_seed(int(fx["seed"]))
     bb = sfod.modeling.backbone_vgg.build_vgg_backbone(cfg, None)
     assert list(bb.state_dict().keys()) == list(fx["keys"])
@@ -67,16 +68,20 @@ def test_backbone_matches_reference_golden(sfod, native):
     assert [bb._out_feature_channels[f"vgg{i}"] for i in range(5)] == list(fx["out_feature_channels"])
     assert [bb._out_feature_strides[f"vgg{i}"] for i in range(5)] == list(fx["out_feature_strides"])
     bb = bb.to(DEV).train()
-    feats = bb(torch.from_numpy(fx["input"]).to(DEV))
+    with torch.no_grad():
+        feats = bb(torch.from_numpy(fx["input"]).to(DEV))
     for i in range(5):
-        f = feats[f"vgg{i}"].float().cpu()
+        assert feats[f"vgg{i}"].dtype == torch.float32
+        f = feats[f"vgg{i}"].cpu()
         assert list(f.shape) == list(fx[f"vgg{i}_shape"])
         got = f if i >= 2 else f[:, ::8, ::4, ::4]
-        assert rel_err(got, torch.from_numpy(fx[f"vgg{i}"])) < 2e-5
+        # 13 conv + BatchNorm layers deep: fp32 MFMA 2e-5; bf16x3 (4e-6 per dot product, see test_gpu_bf16x3.py) 1e-4 (measured 5.5e-5 at vgg4)
+        assert rel_err(got, torch.from_numpy(fx[f"vgg{i}"])) < (2e-5 if dtype == "fp32" else 1e-4)
     sd = bb.state_dict()
     for k in fx.files:
         if k.startswith("after/"):
-            torch.testing.assert_close(sd[k[len("after/"):]].cpu(), torch.from_numpy(fx[k]), rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(sd[k[len("after/"):]].cpu(), torch.from_numpy(fx[k]), rtol=1e-4,
+                                       atol=1e-6 if dtype == "fp32" else 2e-5)
 
 
 def test_dann_modules_match_reference_golden(sfod, native):
@@ -284,14 +289,18 @@ def _student_vs_oracle(sfod, B, H, W, ngt, dtype, seed):
         ob = aux["own_props"][b][0]
         n = min(len(ob), len(given[b][0]))
         assert abs(len(ob) - len(given[b][0])) <= max(2, 0.02 * len(ob))
-        if dtype == "fp32":
-            same = ((ob[:n] - given[b][0][:n]).abs().max(1).values < 1e-2).float().mean().item()
+        if dtype in ("fp32", "bf16x3"):
+            # as SETS (a flipped rank / NMS decision shifts every position behind it): nearly every proposal of the
+            # oracle has a device proposal within 0.01 px
+            d = (ob[:, None, :] - given[b][0][None, :, :]).abs().amax(-1)
+            same = (d.amin(1) < 1e-2).float().mean().item()
             assert same > 0.9, same
     return model, sd, losses, losses_ref
 
 
-def test_student_losses_and_gradients_match_oracle_fp32(sfod, native):
-    model, sd, losses, losses_ref = _student_vs_oracle(sfod, 2, 160, 224, [3, 5], "fp32", 3)
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+def test_student_losses_and_gradients_match_oracle(sfod, native, dtype):
+    model, sd, losses, losses_ref = _student_vs_oracle(sfod, 2, 160, 224, [3, 5], dtype, 3)
     for k, v in losses_ref.items():
         np.testing.assert_allclose(losses[k].item(), v.item(), rtol=1e-4, err_msg=k)
     worst = {}
@@ -312,26 +321,33 @@ def test_student_losses_and_gradients_match_oracle_fp32(sfod, native):
     # features by ~3e-5, flips a handful of ReLU masks / max-pool arg-maxes and thereby moves the
     # backbone gradients by 0.6-1.5 %, fc1/fc2 by 2e-4 and the RPN head by 1e-5.  Kernel-level
     # backward parity is checked tightly (1e-5 .. 1e-4) in test_gpu_ops.py.
+    # bf16x3: its forward features differ from the oracle's by ~1e-4 (vs ~1e-5 for the fp32 kernels) = the oracle
+    # under a 4e-6 weight perturbation (`grad_sensitivity.py 4e-6`: feat 1.1e-4): backbone 1.6-2.7 %, fc 3-7e-4, and
+    # the RPN 3x3 conv -- few hidden units under sparse gradients, so a single flipped ReLU shows -- 1.3e-3.
     def tol(name):
+        x3 = dtype == "bf16x3"
         if name.startswith("backbone"):
-            return 4e-2
+            return 6e-2 if x3 else 4e-2
         if name.startswith("roi_heads"):
-            return 2e-3
+            return 4e-3 if x3 else 2e-3
+        if x3:
+            return 1e-2 if ".rpn_head.conv." in name else 1e-3
         return 1e-4
     bad = {k: v for k, v in worst.items() if v > tol(k)}
     assert not bad, bad
     # BN running statistics refreshed identically
     for name, buf in model.state_dict().items():
         if "running" in name:
-            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6 if dtype == "fp32" else 2e-5)
         if "num_batches_tracked" in name:
             assert buf.item() == sd[name].item() == 1
 
 
-def test_student_ragged_batch_and_image_without_gt_fp32(sfod, native):
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+def test_student_ragged_batch_and_image_without_gt(sfod, native, dtype):
     """Edge cases of the batch contract: images of different sizes (zero-padded to the batch maximum, boxes
     clipped to each image's own size) and an image with no (pseudo-)ground truth at all."""
-    model, sd, losses, losses_ref = _student_vs_oracle(sfod, 3, [160, 128, 96], [224, 256, 192], [3, 0, 1], "fp32", 5)
+    model, sd, losses, losses_ref = _student_vs_oracle(sfod, 3, [160, 128, 96], [224, 256, 192], [3, 0, 1], dtype, 5)
     for k, v in losses_ref.items():
         np.testing.assert_allclose(losses[k].item(), v.item(), rtol=1e-4, atol=1e-6, err_msg=k)
     for name in ("roi_heads.box_head.fc2.weight", "proposal_generator.rpn_head.conv.weight"):
@@ -340,6 +356,8 @@ def test_student_ragged_batch_and_image_without_gt_fp32(sfod, native):
 
 
 def test_student_bf16_mode_tracks_the_fp32_oracle(sfod, native):
+    """"bf16" is the reduced-precision mode (one bf16 pass, bf16 activations): NOT a parity mode -- this only checks
+    that it tracks the oracle to a few per cent and produces finite gradients.  The parity modes are the two above."""
     model, sd, losses, losses_ref = _student_vs_oracle(sfod, 2, 160, 224, [4, 2], "bf16", 5)
     for k, v in losses_ref.items():
         assert abs(losses[k].item() - v.item()) <= 0.05 * abs(v.item()) + 1e-3, k
@@ -349,8 +367,9 @@ def test_student_bf16_mode_tracks_the_fp32_oracle(sfod, native):
         assert torch.isfinite(p.grad).all(), name
 
 
-def test_teacher_pseudo_label_pipeline_matches_oracle(sfod, native):
-    cfg = make_cfg(sfod)
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+def test_teacher_pseudo_label_pipeline_matches_oracle(sfod, native, dtype):
+    cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", dtype])
     torch.manual_seed(11)
     model = sfod.modeling.build_model(cfg).train()
     # planted labels: bias the classifier so that some detections clear the 0.8 threshold
@@ -366,8 +385,14 @@ def test_teacher_pseudo_label_pipeline_matches_oracle(sfod, native):
         n = props.count[b].item()
         nr = len(props_ref[b][0])
         assert abs(n - nr) <= max(2, 0.02 * nr)
-        k = min(n, nr, 50)   # the best proposals agree (NMS decisions can flip on 1e-6 box noise later on)
-        torch.testing.assert_close(props.boxes[b, :k].cpu(), props_ref[b][0][:k], rtol=1e-4, atol=5e-2)
+        # the best proposals agree; an NMS / rank decision can flip on 1e-6 logit noise (any other fp32 summation
+        # order does it too), which shifts the positions behind it: every one of the oracle's best 50 must be
+        # among the device's best 60 (<= 2 casualties of such a flip), and the first ones in the same order
+        k = min(n, nr, 50)
+        dev = props.boxes[b, : min(n, 60)].cpu()
+        d = (props_ref[b][0][:k, None, :] - dev[None, :, :]).abs().amax(-1)              # [k, 60]
+        assert (d.amin(1) < 5e-2).sum().item() >= k - 2
+        torch.testing.assert_close(props.boxes[b, :5].cpu(), props_ref[b][0][:5], rtol=1e-4, atol=5e-2)
         nd, ndr = dets.d["det_count"][b].item(), len(dets_ref[b]["scores"])
         assert abs(nd - ndr) <= 3
         # detections: match each oracle detection to a device detection of the same class
@@ -383,9 +408,10 @@ def test_teacher_pseudo_label_pipeline_matches_oracle(sfod, native):
         pl = om.threshold_bbox(dets_ref[b], 0.8)
         assert abs(dets.d["gt_count"][b].item() - len(pl["scores"])) <= 2
     # running statistics of the train-mode teacher were refreshed (AdaBN), also under no_grad
+    # (bf16x3: a channel mean is a sum of cancelling terms; its error is ~1e-6 of the channel's standard deviation)
     for name, buf in model.state_dict().items():
         if "running" in name:
-            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6)
+            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6 if dtype == "fp32" else 2e-5)
 
 
 def test_eval_mode_inference_and_trainer_test_match_oracle(sfod, native, tmp_path):
