@@ -16,6 +16,7 @@ from the model's are skipped (reported), missing / unexpected keys are reported,
 ``matching_heuristics`` the checkpoint keys are matched to model keys by longest common suffix like
 Detectron2's ``align_and_update_state_dicts`` (restated from its documented behaviour: D2 is not vendored).
 """
+import logging
 import os
 import pickle
 from collections import namedtuple
@@ -24,6 +25,7 @@ import numpy as np
 import torch
 
 IncompatibleKeys = namedtuple("IncompatibleKeys", ["missing_keys", "unexpected_keys", "incorrect_shapes"])
+logger = logging.getLogger("sfod.checkpoint")
 
 
 def load_file(path):
@@ -33,10 +35,12 @@ def load_file(path):
             data = pickle.load(f, encoding="latin1")
         if "model" in data and "__author__" in data:
             return data
-        if "blobs" in data:          # Detectron (Caffe2) model zoo format
-            data = data["blobs"]
-        data = {k: v for k, v in data.items() if not k.endswith("_momentum")}
-        return {"model": data, "__author__": "Caffe2", "matching_heuristics": True}
+        # Detectron (Caffe2) model-zoo pickles ("blobs", or a bare name -> array dict) need d2's c2_model_loading
+        # name conversion (conv1_w -> stem.conv1.weight, res2_0_branch2a_bn_s -> ...norm.weight, ...), which is not
+        # restated here: suffix matching would find nothing and leave the model at its random initialisation
+        raise ValueError("{}: Caffe2 / Detectron model-zoo pickles are not supported (no c2 name conversion); convert "
+                         "the weights to a Detectron2-style checkpoint ({{'model': ..., '__author__': ...}}, e.g. with "
+                         "the reference's convert_pretrained_model/convert_vgg_bn.py) first".format(path))
     data = torch.load(path, map_location="cpu", weights_only=False)
     if "model" not in data:
         data = {"model": data}
@@ -98,8 +102,33 @@ def load_state_into(module, state_dict, heuristics=False):
     return IncompatibleKeys(missing, list(inc.unexpected_keys), incorrect)
 
 
-def load_model_weights(model, path):
-    """``DetectionCheckpointer(model).resume_or_load(path, resume=False)``; ``""`` is a no-op."""
+def report_incompatible(inc, n_model_keys, path, who="model", require_backbone=True, model_keys=()):
+    """What fvcore's Checkpointer logs after a load (missing / unexpected / shape-mismatched keys) -- plus a hard
+    error when NOTHING (or no backbone tensor) matched: a checkpoint whose names do not fit would otherwise leave
+    the model at its random initialisation without a word, and in source-free training the pseudo-labels then come
+    from a random teacher."""
+    missing, unexpected, incorrect = inc
+    matched = n_model_keys - len(missing) - len([k for k, _, _ in incorrect])
+    for k, cs, ms in incorrect:
+        logger.warning("[%s] skip loading '%s' from %s: checkpoint shape %s, model shape %s", who, k, path, cs, ms)
+    if missing:
+        logger.warning("[%s] keys of the model missing in %s (left at their initialisation): %s", who, path,
+                       ", ".join(sorted(missing)))
+    if unexpected:
+        logger.warning("[%s] keys of %s not used by the model: %s", who, path, ", ".join(sorted(unexpected)))
+    logger.info("[%s] %s: %d of %d model tensors loaded", who, path, matched, n_model_keys)
+    if matched <= 0:
+        raise RuntimeError("{}: none of the checkpoint's {} keys matches a tensor of the {} "
+                           "(first keys: {})".format(path, len(unexpected), who, sorted(unexpected)[:5]))
+    if require_backbone:
+        bb = [k for k in model_keys if k.startswith("backbone.")]
+        if bb and all(k in set(missing) | {k2 for k2, _, _ in incorrect} for k in bb):
+            raise RuntimeError("{}: no backbone tensor of the {} was matched by the checkpoint".format(path, who))
+
+
+def load_model_weights(model, path, who="model"):
+    """``DetectionCheckpointer(model).resume_or_load(path, resume=False)``; ``""`` is a no-op.  Incompatible keys are
+    logged like fvcore does; a checkpoint that matches nothing raises."""
     if not path:
         return None
     if not os.path.isfile(path):
@@ -110,7 +139,10 @@ def load_model_weights(model, path):
     # would fail on; the reference's eval scripts strip the prefix the same way)
     if any(k.startswith("modelStudent.") for k in sd):
         sd = {k[len("modelStudent."):]: v for k, v in sd.items() if k.startswith("modelStudent.")}
-    return load_state_into(model, sd, heuristics=bool(ckpt.get("matching_heuristics", False)))
+    inc = load_state_into(model, sd, heuristics=bool(ckpt.get("matching_heuristics", False)))
+    keys = [k for k in model.state_dict().keys() if k not in ("pixel_mean", "pixel_std")]
+    report_incompatible(inc, len(keys), path, who=who, model_keys=keys)
+    return inc
 
 
 class DetectionTSCheckpointer:

@@ -149,7 +149,8 @@ class BaseTrainer:
         self.optimizer = self.build_optimizer(cfg, self.model)
         if cfg.MODEL.WEIGHTS:     # DetectionCheckpointer(model).resume_or_load(MODEL.WEIGHTS, resume=False), train_net_mt.py:75
             from ..checkpoint import load_model_weights
-            load_model_weights(self.model, cfg.MODEL.WEIGHTS)
+            load_model_weights(self.model, cfg.MODEL.WEIGHTS, who="model")
+        self._broadcast_initial_state()
         self._attach_reducer()
         self.scheduler = WarmupMultiStepLR(self.optimizer, cfg)
         self.data_loader = data_loader or self.build_train_loader(cfg)
@@ -158,6 +159,17 @@ class BaseTrainer:
         self.iter = 0
         self.storage = EventStorage(0)
         self.model.train()
+
+    def _broadcast_initial_state(self):
+        """DDP's constructor broadcast: every rank starts from rank 0's parameters and buffers -- also after loading
+        MODEL.WEIGHTS, because keys the checkpoint lacks (DC_img / DC_ins when a source-only GeneralizedRCNN
+        checkpoint goes into the adaptive-teacher architecture, shape-mismatched heads) keep their per-rank random
+        initialisation (seed = SEED + rank) and only gradients are exchanged afterwards."""
+        if get_world_size() > 1:
+            f = self.optimizer.flat
+            for t in (f.param, f.fbuf, f.ibuf):
+                if t.numel():
+                    dist.broadcast(t, 0)
 
     def _attach_reducer(self):
         """N > 1: overlap the heads' gradient all-reduce with the backbone backward.  The backbone's autograd
@@ -266,21 +278,34 @@ class BaseTrainer:
                                     for k, v in metrics_dict.items()})
 
     def after_step(self):
+        """d2 hook order (source_free_adaptive_teacher.py:622-679 ``build_hooks``): LRScheduler, PeriodicCheckpointer,
+        EvalHooks, ValLossHooks, and the PeriodicWriter LAST, so that what the evaluation of this iteration put into
+        the storage is written with this iteration's number."""
         self.scheduler.step()
-        self.storage.iter = self.iter + 1
-        if (self.iter + 1) % WRITER_PERIOD == 0 or self.iter + 1 == self.max_iter:
-            self._flush_metrics()
+        nxt = self.iter + 1
+        self.storage.iter = nxt
+        # PeriodicCheckpointer: every CHECKPOINT_PERIOD iterations, and ``model_final`` after the last one (what
+        # the reference's eval / AdaBN configs point MODEL.WEIGHTS at)
         p = self.cfg.SOLVER.CHECKPOINT_PERIOD
-        if p > 0 and (self.iter + 1) % p == 0 and get_rank() == 0 and self.cfg.OUTPUT_DIR:
-            self.save_checkpoint("model_{:07d}".format(self.iter))
+        if get_rank() == 0 and self.cfg.OUTPUT_DIR and p > 0:
+            if nxt % p == 0 and nxt != self.max_iter:
+                self.save_checkpoint("model_{:07d}".format(self.iter))
+            if nxt >= self.max_iter:
+                self.save_checkpoint("model_final")
         # d2 hooks.EvalHook(cfg.TEST.EVAL_PERIOD, ...): every EVAL_PERIOD iterations, and once after the last one
         ep = self.cfg.TEST.EVAL_PERIOD
-        nxt = self.iter + 1
+        evaluated = False
         if self.cfg.SFOD.EVAL_HOOK and ((ep > 0 and nxt % ep == 0 and nxt != self.max_iter) or nxt >= self.max_iter):
             self._do_eval()
+            evaluated = True
         # ValLossHook(cfg.TEST.EVAL_PERIOD, ...) when TEST.VAL_LOSS (val_loss.py:89-93: final iteration or period)
         if self.cfg.SFOD.EVAL_HOOK and self.cfg.TEST.VAL_LOSS and (nxt == self.max_iter or (ep > 0 and nxt % ep == 0)):
             self._do_val_loss()
+            evaluated = True
+        # PeriodicWriter(period 20) -- also whenever an evaluation ran (its scalars would otherwise be overwritten by
+        # the next evaluation before a flush, or be stamped with a later iteration) and after the last iteration
+        if nxt % WRITER_PERIOD == 0 or nxt >= self.max_iter or evaluated:
+            self._flush_metrics()
 
     def _eval_targets(self):
         """[(attribute suffix, result-key suffix, model)]: what the trainer's EvalHooks evaluate (base.py:254-258)."""
@@ -349,6 +374,8 @@ class BaseTrainer:
         for self.iter in range(self.start_iter, self.max_iter):
             self.run_step()
             self.after_step()
+        if self.storage._pending:        # nothing a hook logged after the last flush is lost
+            self._flush_metrics()
 
     def state_dict_for_checkpoint(self):
         return {"model": self.model.state_dict(), "iteration": self.iter, "optimizer": self.optimizer.state_dict(),
@@ -398,9 +425,15 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         # teacher (:51-64); loading is in place, so the flat buffers see it.  Without weights: teacher <- student.
         if cfg.MODEL.WEIGHTS:
             from ..checkpoint import load_model_weights
-            load_model_weights(self.model, cfg.MODEL.WEIGHTS)
-            load_model_weights(self.model_teacher, cfg.MODEL.WEIGHTS)
+            load_model_weights(self.model, cfg.MODEL.WEIGHTS, who="student")
+            load_model_weights(self.model_teacher, cfg.MODEL.WEIGHTS, who="teacher")
+            self._broadcast_initial_state()
+            if get_world_size() > 1:         # the teacher's unmatched keys: rank 0's draw as well
+                for t in (self.teacher_flat.param, self.teacher_flat.fbuf, self.teacher_flat.ibuf):
+                    if t.numel():
+                        dist.broadcast(t, 0)
         else:
+            self._broadcast_initial_state()
             self._copy_main_model()
         self.ema_enabled = bool(cfg.SFOD.EMA.ENABLED)
         if self.ema_enabled:

@@ -771,7 +771,7 @@ def segmented_sort_desc(keys):
     B, n = keys.shape
     dev = keys.device
     nbytes = query("sfod_sort_ws_bytes", B, n)
-    k = (dev, nbytes)
+    k = (dev, _stream(), nbytes)      # per stream: the teacher's side stream and the main stream may both sort
     if k not in _sort_ws:
         _sort_ws[k] = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     ws = _sort_ws[k]

@@ -221,3 +221,34 @@ def test_two_rank_gloo_evaluation_gathers_predictions_on_rank0(sfod):
     assert 0 < ref["AP"] < 100
     for k, v in ref.items():
         assert (v != v and table[k] != table[k]) or abs(table[k] - v) < 1e-9, k
+
+
+def test_self_launching_entry_point_starts_two_gloo_ranks(tmp_path):
+    """``python <script> --gpus 2`` without a launcher: the script starts its ranks itself through
+    simple-sfod_amd/launch.py (what bench.py --gpus N and train_net_mt.py --num-gpus N do, reference
+    train_net_mt.py:90-101) -- the parent never imports torch; the ranks find RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1,
+    form the group, and the trainer's constructor broadcast makes rank 0's initial state everybody's."""
+    import json
+    import subprocess
+    out = tmp_path / "r.json"
+    worker = os.path.join(ROOT, "tests", "helpers", "launch_worker.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    rc = subprocess.call([sys.executable, worker, "--gpus", "2", "--out", str(out)], env=env, timeout=300)
+    assert rc == 0
+    r = json.loads(out.read_text())
+    assert r["world"] == 2 and r["sum"] == 3.0
+    assert r["states_equal"] and r["running_mean0"] == 0.0 and r["nbt"][0] == 7      # rank 0's buffers everywhere
+    # a failing rank fails the launch (exit code propagates to the caller)
+    rc = subprocess.call([sys.executable, worker, "--gpus", "2", "--out", str(out), "--fail-rank", "1"], env=env, timeout=300)
+    assert rc != 0
+
+
+def test_launch_command_line():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sfod_launch", os.path.join(ROOT, "simple-sfod_amd", "launch.py"))
+    lm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(lm)
+    cmd = lm.launch_command("bench.py", ["--gpus", "8", "--steps", "5"], 8, port=29511)
+    assert cmd[1:] == ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+                       "--master-port", "29511", "bench.py", "--gpus", "8", "--steps", "5"]
+    assert not lm.under_launcher() or "WORLD_SIZE" in os.environ

@@ -1,16 +1,26 @@
 #!/usr/bin/env python
 """CLI drop-in for the reference's ``train_net_mt.py`` (``:34-101``): same config contract
 (``--config-file X.yaml [--num-gpus N] [--eval-only] [KEY VALUE ...]``) and trainer dispatch on
-``cfg.TRAINER``.  One process per GPU: launch N>1 with
-``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 train_net_mt.py ...``
-(the reference's ``launch()`` spawns the same topology itself)."""
+``cfg.TRAINER``.  One process per GPU: ``--num-gpus N`` starts the N ranks itself (``train_net_mt.py:90-101`` calls
+``detectron2.engine.launch``; here the script re-runs itself under ``python -m torch.distributed.run`` in a child
+process, before anything touches the GPU: ``simple-sfod_amd/launch.py``).  Started under an external launcher
+(``RANK`` / ``WORLD_SIZE`` in the environment) it is one rank of that job."""
 import argparse
 import importlib
+import importlib.util
 import os
 import sys
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _launcher():
+    """simple-sfod_amd/launch.py by file path: standard library only, no torch / package import in the parent"""
+    spec = importlib.util.spec_from_file_location("sfod_launch", os.path.join(ROOT, "simple-sfod_amd", "launch.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def main():
@@ -22,13 +32,15 @@ def main():
     ap.add_argument("--resume", action="store_true")
     ap.add_argument("opts", nargs=argparse.REMAINDER, default=[])
     args = ap.parse_args()
+    lm = _launcher()
+    if args.num_gpus > 1 and not lm.under_launcher():
+        sys.exit(lm.launch(os.path.abspath(__file__), sys.argv[1:], args.num_gpus))
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.num_gpus > 1 and world == 1:
-        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d --master-addr 127.0.0.1 "
-                         "train_net_mt.py ..." % args.num_gpus)
+    if world != args.num_gpus and world > 1:
+        raise SystemExit(f"--num-gpus {args.num_gpus} but the launcher started {world} ranks")
     torch.cuda.set_device(local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -48,12 +60,7 @@ def main():
         if rank == 0:
             print(results)
         return results
-    trainer = Trainer(cfg)
-    if world > 1 and not cfg.MODEL.WEIGHTS:      # same random initial weights on every rank (DDP constructor broadcast)
-        dist.broadcast(trainer.optimizer.flat.param, 0)
-        dist.broadcast(trainer.optimizer.flat.fbuf, 0)
-        if hasattr(trainer, "_copy_main_model"):
-            trainer._copy_main_model()
+    trainer = Trainer(cfg)       # N > 1: the constructor broadcasts rank 0's parameters / buffers (DDP semantics)
     if args.resume:                              # the reference keeps this call commented out (train_net_mt.py:86)
         trainer.resume_or_load(resume=True)
     trainer.train()
