@@ -31,7 +31,7 @@ struct W3Plan {
   int tiles_per_split, nsplit, nslab;
   int64_t ws_bytes;      // fp32 partial slabs [nslab][Cout][9][Cin]
 };
-W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy);
+W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split = 0);
 // out_mode 0: dw packed [Cout][9][Cin], accumulated into; 1 / 2: dw OIHW, overwritten / accumulated into
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split = 0);

@@ -817,7 +817,7 @@ k_wgrad_combine_split(const float* __restrict__ dwp, float* __restrict__ dw, int
 extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
   if (dt == SFOD_F32) return 0;
   if (ksize == 3) {
-    const W3Plan p = sfod_w3_plan(B, H, W, phys_ch(dt, Cin), phys_ch(dt, Cout), phys_ch(dt, lddy));
+    const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, dt == SFOD_BF16X3);
     if (use_patch_wgrad(p, ksize, dt)) return p.ws_bytes;
   }
   return dt == SFOD_BF16X3 ? (int64_t)16 * Cout * ksize * ksize * Cin : 0;
@@ -825,7 +825,7 @@ extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Co
 
 extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
   if (ksize != 3 || !is_bf16_storage(dt) || (int64_t)B * H * W == 0) return 0;
-  const W3Plan p = sfod_w3_plan(B, H, W, phys_ch(dt, Cin), phys_ch(dt, Cout), phys_ch(dt, lddy));
+  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, dt == SFOD_BF16X3);
   return use_patch_wgrad(p, ksize, dt) ? 1 : 0;
 }
 
@@ -834,10 +834,9 @@ extern "C" int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oih
                                     int64_t ws_bytes, void* stream) {
   SFOD_REQUIRE(sfod_conv_wgrad_oihw_supported(B, H, W, Cin, Cout, ksize, lddy, dt),
                "wgrad_oihw: shape not served by the halo-patch kernel (query sfod_conv_wgrad_oihw_supported)");
-  const int CinP = phys_ch(dt, Cin), CoutP = phys_ch(dt, Cout), lddyP = phys_ch(dt, lddy);
-  const W3Plan p = sfod_w3_plan(B, H, W, CinP, CoutP, lddyP);
+  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, dt == SFOD_BF16X3);
   SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
-  return sfod_w3_launch(p, x, dy, dw_oihw, ws, B, H, W, CinP, CoutP, lddyP, accumulate ? 2 : 1, (hipStream_t)stream,
+  return sfod_w3_launch(p, x, dy, dw_oihw, ws, B, H, W, Cin, Cout, lddy, accumulate ? 2 : 1, (hipStream_t)stream,
                         dt == SFOD_BF16X3);
 }
 
@@ -852,14 +851,14 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   const int split = (dt == SFOD_BF16X3);
   SFOD_REQUIRE(!split || Cout % 8 == 0, "wgrad: bf16x3 needs Cout % 8 == 0");
   const int CinL = Cin, CoutL = Cout;
-  Cin = phys_ch(dt, Cin); Cout = phys_ch(dt, Cout); lddy = phys_ch(dt, lddy);     // bf16 channels as stored
   if (ksize == 3 && is_bf16_storage(dt)) {
-    const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy);
+    const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, split);
     if (use_patch_wgrad(p, ksize, dt)) {
       SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
       return sfod_w3_launch(p, x, dy, dw, ws, B, H, W, Cin, Cout, lddy, 0, (hipStream_t)stream, split);
     }
   }
+  Cin = phys_ch(dt, Cin); Cout = phys_ch(dt, Cout); lddy = phys_ch(dt, lddy);     // generic kernel: bf16 channels as stored
   hipStream_t s = (hipStream_t)stream;
   float* dw_out = dw;
   if (split) {

@@ -83,18 +83,27 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 a, s16x4 b) {
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <int CO>
+// SPLIT (SFOD_BF16X3 operands, CO = 4): x / dy hold (8 hi | 8 lo) bf16 groups, 4 bytes per logical channel.  The DMA
+// de-interleaves them: a lane fetches every OTHER 16-byte chunk of its pixel, so that an LDS plane is again 32 channels
+// x 64-byte rows of ONE kind -- x planes = (hi, lo) of 32 logical input channels, dy planes = (hi, lo) x 2 fragments of
+// 32 logical output channels -- and the conflict-free transposed reads of the bf16 kernel apply unchanged.  A wave owns
+// one 32 (co) x 32 (ci) logical block for all nine taps and one of the four k-steps of every 64-pixel chunk (the four
+// k-step groups write separate slabs); per tap it issues hi*lo + lo*hi + hi*hi.  W3Args sizes are LOGICAL channels.
+template <int CO, bool SPLIT = false>
 __global__ void __launch_bounds__(512)
 k_wgrad3x3_patch(W3Args a) {
+  static_assert(!SPLIT || CO == 4, "bf16x3 operands use the four-plane dy ring");
   constexpr int ND = CO / 2;                 // dy DMA instructions per wave and chunk
-  constexpr int KG = (CO == 4) ? 1 : 2;      // k-step groups (CO=2: two wave groups split the k-steps)
+  constexpr int KG = SPLIT ? 4 : ((CO == 4) ? 1 : 2);      // k-step groups (wave groups that split a chunk's k-steps)
   constexpr int KS = 4 / KG;                 // k-steps (16 pixels) per wave and chunk
+  constexpr int EB = SPLIT ? 4 : 2;          // bytes per (logical) channel in global memory
+  constexpr int CO_TILE = SPLIT ? 64 : CO * 32, CI_TILE = SPLIT ? 32 : 64;   // logical channels per workgroup
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wco = (CO == 4) ? (wave >> 1) : ((wave >> 1) & 1);
-  const int wci = wave & 1;
-  const int kg = (CO == 4) ? 0 : (wave >> 2);
+  const int wco = SPLIT ? (wave & 1) : ((CO == 4) ? (wave >> 1) : ((wave >> 1) & 1));
+  const int wci = SPLIT ? 0 : (wave & 1);
+  const int kg = SPLIT ? (wave >> 1) : ((CO == 4) ? 0 : (wave >> 2));
   const int h = lane >> 5, g1 = (lane >> 4) & 1, t16 = lane & 15;
   const int tq = t16 >> 2, tp = t16 & 3;
 
@@ -108,7 +117,7 @@ k_wgrad3x3_patch(W3Args a) {
   const int pairs = a.co_tiles * a.ci_tiles;
   const int split = bid / pairs;
   const int pr = bid - split * pairs;
-  const int co0 = (pr / a.ci_tiles) * (CO * 32), ci0 = (pr % a.ci_tiles) * 64;
+  const int co0 = (pr / a.ci_tiles) * CO_TILE, ci0 = (pr % a.ci_tiles) * CI_TILE;
   const int t_begin = split * a.tiles_per_split;
   const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
   const int PW = a.PW;
@@ -137,29 +146,40 @@ k_wgrad3x3_patch(W3Args a) {
   __syncthreads();
 
   const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.x, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.Cin * 2), 0x00020000);
+      (void*)a.x, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.Cin * EB), 0x00020000);
   const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)a.dy, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.lddy * 2), 0x00020000);
+      (void*)a.dy, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.lddy * EB), 0x00020000);
 
   // per-lane constant parts of the DMA descriptors
   // patch piece k (0..5): instruction q = wave*6+k -> plane q/24, rows 16*(q%24) + lane/4, chunk lane%4
   int pr_pack[6];   // py<<8|px of this lane's patch row, or 0xffff
-  int pr_col[6];    // channel offset (elements) of this lane's chunk, -1 if beyond Cin
+  int pr_col[6];    // BYTE offset inside a pixel of this lane's 16-byte chunk, -1 if beyond Cin
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
     const int q = wave * 6 + k;
     const int plane = q / 24, row = (q % 24) * 16 + (lane >> 2);
     pr_pack[k] = tabR[row];
-    const int c = ci0 + plane * 32 + (lane & 3) * 8;
-    pr_col[k] = (c < a.Cin) ? c : -1;
+    if constexpr (SPLIT) {     // plane 0 / 1 = hi / lo of the 32 logical channels ci0 ..: group (lane & 3), every other chunk
+      const int c = ci0 + (lane & 3) * 8;
+      pr_col[k] = (c < a.Cin) ? (c * 4 + plane * 16) : -1;
+    } else {
+      const int c = ci0 + plane * 32 + (lane & 3) * 8;
+      pr_col[k] = (c < a.Cin) ? c * 2 : -1;
+    }
   }
   // dy piece i (0..ND-1): instruction q = wave*ND+i -> plane q/4, rows 16*(q%4) + lane/4
-  int dy_col[ND];
+  int dy_col[ND];   // BYTE offset inside a pixel, -1: no load
 #pragma unroll
   for (int i = 0; i < ND; ++i) {
     const int q = wave * ND + i;
-    const int c = co0 + (q >> 2) * 32 + (lane & 3) * 8;
-    dy_col[i] = (c + 8 <= a.lddy && c < a.Cout) ? c : -1;
+    if constexpr (SPLIT) {     // plane p: fragment p >> 1 (32 logical output channels), p & 1 = hi / lo
+      const int pl = q >> 2;
+      const int c = co0 + (pl >> 1) * 32 + (lane & 3) * 8;
+      dy_col[i] = (c + 8 <= a.lddy && c < a.Cout) ? (c * 4 + (pl & 1) * 16) : -1;
+    } else {
+      const int c = co0 + (q >> 2) * 32 + (lane & 3) * 8;
+      dy_col[i] = (c + 8 <= a.lddy && c < a.Cout) ? c * 2 : -1;
+    }
   }
 
   // Interior tiles (no image border inside the halo / the tile): every DMA offset is a per-tile scalar base plus a
@@ -170,7 +190,7 @@ k_wgrad3x3_patch(W3Args a) {
   for (int k = 0; k < 6; ++k) {
     const int py = pr_pack[k] >> 8, px = pr_pack[k] & 255;
     pr_rel[k] = (pr_pack[k] != 0xffff && pr_col[k] >= 0)
-                    ? (unsigned)((((py - 1) * a.W + (px - 1)) * a.Cin + pr_col[k]) * 2) : OOB_OFF;
+                    ? (unsigned)(((py - 1) * a.W + (px - 1)) * a.Cin * EB + pr_col[k]) : OOB_OFF;
   }
   unsigned dy_rel[4][ND];
 #pragma unroll
@@ -181,7 +201,7 @@ k_wgrad3x3_patch(W3Args a) {
       const int row = (q & 3) * 16 + (lane >> 2);
       const int tt = tabT[c * 64 + row];
       dy_rel[c][i] = (tt != 0xffff && dy_col[i] >= 0)
-                         ? (unsigned)((((tt >> 8) * a.W + (tt & 255)) * a.lddy + dy_col[i]) * 2) : OOB_OFF;
+                         ? (unsigned)(((tt >> 8) * a.W + (tt & 255)) * a.lddy * EB + dy_col[i]) : OOB_OFF;
     }
 
   // Tile origins (image, y0, x0) of the current and the next tile are carried in scalar registers and advanced
@@ -190,8 +210,8 @@ k_wgrad3x3_patch(W3Args a) {
   struct Org { int b, y0, x0; unsigned base_x, base_dy; bool in_x, in_dy; };
   auto finish = [&](Org o) {
     const int pix = (o.b * a.H + o.y0) * a.W + o.x0;
-    o.base_dy = (unsigned)(pix * a.lddy * 2);
-    o.base_x = (unsigned)(pix * a.Cin * 2);       // offset of the tile's first pixel; the halo starts one row / column before
+    o.base_dy = (unsigned)(pix * a.lddy * EB);
+    o.base_x = (unsigned)(pix * a.Cin * EB);       // offset of the tile's first pixel; the halo starts one row / column before
     o.in_dy = (o.y0 + a.TH <= a.H) && (o.x0 + a.TW <= a.W);
     o.in_x = o.in_dy && o.y0 >= 1 && o.x0 >= 1 && (o.y0 + a.TH + 1 <= a.H) && (o.x0 + a.TW + 1 <= a.W);
     return o;
@@ -224,7 +244,7 @@ k_wgrad3x3_patch(W3Args a) {
       const int py = pr_pack[k] >> 8, px = pr_pack[k] & 255;
       const int iy = y0 - 1 + py, ix = x0 - 1 + px;
       const bool ok = pr_pack[k] != 0xffff && pr_col[k] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      off = ok ? (unsigned)((((b * a.H + iy) * a.W + ix) * a.Cin + pr_col[k]) * 2) : OOB_OFF;
+      off = ok ? (unsigned)(((b * a.H + iy) * a.W + ix) * a.Cin * EB + pr_col[k]) : OOB_OFF;
     }
     bufload16(xres, off, 0u, smem + buf * XBUF + (wave * 6 + k) * 1024);
   };
@@ -243,7 +263,7 @@ k_wgrad3x3_patch(W3Args a) {
         const int tt = tabT[c * 64 + row];
         const int ty = tt >> 8, tx = tt & 255;
         const bool ok = tt != 0xffff && dy_col[i] >= 0 && y0 + ty < a.H && x0 + tx < a.W;
-        off = ok ? (unsigned)((((b * a.H + y0 + ty) * a.W + x0 + tx) * a.lddy + dy_col[i]) * 2) : OOB_OFF;
+        off = ok ? (unsigned)(((b * a.H + y0 + ty) * a.W + x0 + tx) * a.lddy * EB + dy_col[i]) : OOB_OFF;
       }
       bufload16(dres, off, 0u, smem + DY_OFF + slot * DYSLOT + q * 1024);
     }
@@ -257,8 +277,8 @@ k_wgrad3x3_patch(W3Args a) {
 
   // lane parts of the fragment addresses
   const int cbb = (g1 * 16 + 4 * tp) * 2;                       // byte column inside a 64-byte plane row
-  const int a_lane = wco * 4096 + (8 * h + tq) * 64 + cbb;       // dy: + slot base + (16 s + 4 e) * 64
-  const int b_lane = wci * XPLANE + cbb;                         // x : + buffer base + row * 64
+  const int a_lane = (SPLIT ? 2 * wco : wco) * 4096 + (8 * h + tq) * 64 + cbb;   // dy: + slot base + (16 s + 4 e) * 64 (SPLIT: hi plane; lo = + 4096)
+  const int b_lane = wci * XPLANE + cbb;                         // x : + buffer base + row * 64          (SPLIT: hi plane; lo = + XPLANE)
 
   // LDS byte addresses are 32-bit offsets from the start of the dynamic LDS segment (the kernel has
   // no static LDS, so the segment starts at LDS address 0).
@@ -271,6 +291,40 @@ k_wgrad3x3_patch(W3Args a) {
       const unsigned rx0 = (unsigned)(xb_off + tabP[p0] * 64 + b_lane);
       const unsigned rx1 = (unsigned)(xb_off + tabP[p0 + 4] * 64 + b_lane);
       const unsigned ra = (unsigned)(dyb_off + a_lane + s * 1024);
+      if constexpr (SPLIT) {
+        const s16x4 a0h = tr_read<0>(ra), a1h = tr_read<256>(ra), a0l = tr_read<4096>(ra), a1l = tr_read<4096 + 256>(ra);
+        s16x4 q[2][12];   // per filter row: (rx0, rx1) x kx 0..2 of the hi plane, then of the lo plane
+        auto issue_row = [&](s16x4* d, unsigned r0, unsigned r1) {
+          d[0] = tr_read<0>(r0);   d[1] = tr_read<0>(r1);
+          d[2] = tr_read<64>(r0);  d[3] = tr_read<64>(r1);
+          d[4] = tr_read<128>(r0); d[5] = tr_read<128>(r1);
+          d[6] = tr_read<XPLANE>(r0);       d[7] = tr_read<XPLANE>(r1);
+          d[8] = tr_read<XPLANE + 64>(r0);  d[9] = tr_read<XPLANE + 64>(r1);
+          d[10] = tr_read<XPLANE + 128>(r0); d[11] = tr_read<XPLANE + 128>(r1);
+        };
+        issue_row(q[0], rx0, rx1);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+          if (ky < 2) {
+            issue_row(q[(ky + 1) & 1], rx0 + (ky + 1) * PW * 64, rx1 + (ky + 1) * PW * 64);
+            wait_lgkm<12>();
+          } else {
+            wait_lgkm<0>();
+          }
+          const bf16x8 ah = cat8(a0h, a1h), al = cat8(a0l, a1l);
+          const s16x4* r = q[ky & 1];
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            const bf16x8 bh = cat8(r[2 * kx], r[2 * kx + 1]), bl = cat8(r[6 + 2 * kx], r[6 + 2 * kx + 1]);
+            f32x16 c = acc[ky * 3 + kx];
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+            acc[ky * 3 + kx] = c;
+          }
+        }
+        continue;
+      }
       const s16x4 a0 = tr_read<0>(ra), a1 = tr_read<256>(ra);
       s16x4 q[2][6];
       // group ky = 0
@@ -341,7 +395,7 @@ k_wgrad3x3_patch(W3Args a) {
   // ---- write the partial block into this split's slab ----------------------------------------------------
   const int slab_idx = split * KG + kg;
   float* out = a.slab + (int64_t)slab_idx * a.Cout * 9 * a.Cin;
-  const int ci = ci0 + wci * 32 + (lane & 31);
+  const int ci = ci0 + wci * 32 + (lane & 31);      // logical channels in both modes
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -401,71 +455,20 @@ k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int64_t n
   }
 }
 
-// SFOD_BF16X3 operands: the main kernel ran on PHYSICAL channels (per 8 logical channels: 8 hi | 8 lo), so a slab is
-// [2 Cout][9][2 Cin] and holds, for every logical (co, ci), the four partial products hi*hi, hi*lo, lo*hi, lo*lo of the
-// split operands.  This reduction sums the slabs (fixed order) and the four quadrants into the logical gradient
-// (lo*lo comes for free here, so it is kept).  Same output modes and slab-group scheme as k_wgrad_reduce;
-// Cin / n4 are LOGICAL sizes.
-template <int MODE, int SG>
-__global__ void __launch_bounds__(256)
-k_wgrad_reduce_split(const float* __restrict__ slab, float* __restrict__ dw, int64_t n4, int nslab, int64_t stride4,
-                     int Cin) {
-  constexpr int EPB = 256 / SG;
-  __shared__ float4 part[SG > 1 ? 256 : 1];
-  const int el = threadIdx.x % EPB, grp = threadIdx.x / EPB;
-  const int CinP = 2 * Cin;
-  for (int64_t base = (int64_t)blockIdx.x * EPB; base < n4; base += (int64_t)gridDim.x * EPB) {
-    const int64_t i = base + el;
-    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t e = i * 4;                       // logical packed element (co, tap, ci .. ci+3)
-    const int ci = (int)(e % Cin);
-    const int64_t ct = e / Cin;
-    const int tap = (int)(ct % 9);
-    const int64_t co = ct / 9;
-    if (i < n4) {
-      const int64_t rh = (co >> 3) * 16 + (co & 7);
-      const int ch = (ci >> 3) * 16 + (ci & 7);
-      const int64_t a_hh = ((rh * 9 + tap) * CinP + ch) >> 2;            // float4 index; ci % 4 == 0
-      const int64_t a_lh = (((rh + 8) * 9 + tap) * CinP + ch) >> 2;
-      for (int k = grp; k < nslab; k += SG) {
-        const float4* sl = reinterpret_cast<const float4*>(slab) + k * stride4;
-        const float4 v0 = sl[a_hh], v1 = sl[a_hh + 2], v2 = sl[a_lh], v3 = sl[a_lh + 2];   // +8 columns = +2 float4
-        s.x += (v1.x + v2.x + v3.x) + v0.x; s.y += (v1.y + v2.y + v3.y) + v0.y;
-        s.z += (v1.z + v2.z + v3.z) + v0.z; s.w += (v1.w + v2.w + v3.w) + v0.w;
-      }
-    }
-    if constexpr (SG > 1) {
-      __syncthreads();
-      part[threadIdx.x] = s;
-      __syncthreads();
-      if (grp != 0) continue;
-#pragma unroll
-      for (int g2 = 1; g2 < SG; ++g2) {
-        const float4 v = part[g2 * EPB + el];
-        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-      }
-    }
-    if (i >= n4) continue;
-    if constexpr (MODE == 0) {
-      float4 o = reinterpret_cast<const float4*>(dw)[i];
-      o.x += s.x; o.y += s.y; o.z += s.z; o.w += s.w;
-      reinterpret_cast<float4*>(dw)[i] = o;
-    } else {
-      const int64_t o = (co * Cin + ci) * 9 + tap;
-      if constexpr (MODE == 2) { s.x += dw[o]; s.y += dw[o + 9]; s.z += dw[o + 18]; s.w += dw[o + 27]; }
-      dw[o] = s.x; dw[o + 9] = s.y; dw[o + 18] = s.z; dw[o + 27] = s.w;
-    }
-  }
-}
-
 }  // namespace
 
-W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy) {
+// split != 0: SFOD_BF16X3 operands; Cin / Cout / lddy are LOGICAL channel counts in either case
+W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split) {
   W3Plan p;
   p.ok = 0;
   if (B < 1 || H < 1 || W < 1) return p;
-  if (Cin % 32 != 0 || Cout % 32 != 0 || lddy % 8 != 0) return p;
-  if ((int64_t)B * H * W * Cin >= ((int64_t)1 << 30) || (int64_t)B * H * W * lddy >= ((int64_t)1 << 30)) return p;
+  if (split) {
+    if (Cin % 8 != 0 || Cout % 8 != 0 || lddy % 8 != 0) return p;
+    if ((int64_t)B * H * W * Cin >= ((int64_t)1 << 29) || (int64_t)B * H * W * lddy >= ((int64_t)1 << 29)) return p;   // 32-bit byte offsets
+  } else {
+    if (Cin % 32 != 0 || Cout % 32 != 0 || lddy % 8 != 0) return p;
+    if ((int64_t)B * H * W * Cin >= ((int64_t)1 << 30) || (int64_t)B * H * W * lddy >= ((int64_t)1 << 30)) return p;
+  }
   double best = -1.0;
   for (int tw = 4; tw <= 128 && tw <= W + 3; ++tw) {
     int th = 256 / tw;
@@ -479,28 +482,28 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy) {
     if (score > best) { best = score; p.TH = th; p.TW = tw; p.tiles_y = ty; p.tiles_x = tx; }
   }
   if (best < 0.0) return p;
-  p.CO = (Cout <= 64) ? 2 : 4;
-  p.co_tiles = (Cout + p.CO * 32 - 1) / (p.CO * 32);
-  p.ci_tiles = (Cin + 63) / 64;
+  const int kg = split ? 4 : (Cout <= 64 ? 2 : 1);      // k-step groups = slabs per pixel split
+  p.CO = split ? 4 : ((Cout <= 64) ? 2 : 4);
+  p.co_tiles = split ? (Cout + 63) / 64 : (Cout + p.CO * 32 - 1) / (p.CO * 32);
+  p.ci_tiles = split ? (Cin + 31) / 32 : (Cin + 63) / 64;
   const int pairs = p.co_tiles * p.ci_tiles;
   const int ntiles = B * p.tiles_y * p.tiles_x;
   // one workgroup per CU (LDS-bound occupancy): aim at 256 workgroups; the slabs the splits write
   // (and the reduction reads back) are kept below 128 MiB
   int ns = 256 / pairs;
   if (ns < 1) ns = 1;
-  const int64_t slab_bytes = (int64_t)Cout * 9 * Cin * 4 * (Cout <= 64 ? 2 : 1);
+  const int64_t slab_bytes = (int64_t)Cout * 9 * Cin * 4 * kg;
   while (ns > 1 && ns * slab_bytes > ((int64_t)128 << 20)) --ns;
   if (ns > ntiles) ns = ntiles;
   p.tiles_per_split = (ntiles + ns - 1) / ns;
   p.nsplit = (ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
-  p.nslab = p.nsplit * (p.CO == 2 ? 2 : 1);
+  p.nslab = p.nsplit * kg;
   p.ws_bytes = (int64_t)p.nslab * Cout * 9 * Cin * 4;
   p.ok = 1;
   return p;
 }
 
-// split != 0 (SFOD_BF16X3): Cin / Cout / lddy are PHYSICAL bf16 channel counts (2 x logical) and the plan was made on
-// them; dw is the LOGICAL gradient
+// split != 0 (SFOD_BF16X3): x / dy hold (hi, lo) pairs; Cin / Cout / lddy are LOGICAL channel counts in either case
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split) {
   W3Args a;
@@ -513,33 +516,21 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
   a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.nsplit = p.nsplit;
   static bool attr_set = false;
   if (!attr_set) {
-    const void* ks[2] = {(const void*)k_wgrad3x3_patch<4>, (const void*)k_wgrad3x3_patch<2>};
-    for (int i = 0; i < 2; ++i) {
+    const void* ks[3] = {(const void*)k_wgrad3x3_patch<4>, (const void*)k_wgrad3x3_patch<2>,
+                         (const void*)k_wgrad3x3_patch<4, true>};
+    for (int i = 0; i < 3; ++i) {
       hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute(w3): %s", hipGetErrorString(e)); return -(int)e; }
     }
     attr_set = true;
   }
   dim3 grid(p.co_tiles * p.ci_tiles * p.nsplit), blk(512);
-  if (p.CO == 4) hipLaunchKernelGGL(k_wgrad3x3_patch<4>, grid, blk, LDS_TOTAL, s, a);
+  if (split) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true>), grid, blk, LDS_TOTAL, s, a);
+  else if (p.CO == 4) hipLaunchKernelGGL(k_wgrad3x3_patch<4>, grid, blk, LDS_TOTAL, s, a);
   else hipLaunchKernelGGL(k_wgrad3x3_patch<2>, grid, blk, LDS_TOTAL, s, a);
   int rc = sfod_check_launch("wgrad3x3_patch");
   if (rc) return rc;
-  if (split) {
-    const int CinL = Cin / 2, CoutL = Cout / 2;
-    const int64_t n4 = (int64_t)CoutL * 9 * CinL / 4;          // logical float4 groups (CinL % 16 == 0)
-    const int64_t stride4 = (int64_t)Cout * 9 * Cin / 4;       // physical slab
-    int g = (int)((n4 + 31) / 32);
-    if (g > 8192) g = 8192;
-    if (out_mode == 0)
-      hipLaunchKernelGGL((k_wgrad_reduce_split<0, 8>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, p.nslab, stride4, CinL);
-    else if (out_mode == 1)
-      hipLaunchKernelGGL((k_wgrad_reduce_split<1, 8>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, p.nslab, stride4, CinL);
-    else
-      hipLaunchKernelGGL((k_wgrad_reduce_split<2, 8>), dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, p.nslab, stride4, CinL);
-    return sfod_check_launch("wgrad_reduce_split");
-  }
-  const int64_t n = (int64_t)Cout * 9 * Cin;  // multiple of 4 (Cin % 32 == 0)
+  const int64_t n = (int64_t)Cout * 9 * Cin;  // multiple of 4 (Cin % 32 == 0; bf16x3: Cin % 8 == 0)
   const int64_t n4 = n / 4;
   const bool wide = true;                           // slabs spread over 8 groups per workgroup (more loads in flight)
   const int epb = wide ? 32 : 256;

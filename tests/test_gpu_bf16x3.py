@@ -178,14 +178,15 @@ def test_conv_dgrad_and_wgrad(native, shape, algo):
 
 @pytest.mark.parametrize("shape", [
     (2, 37, 75, 64, 128),
-    (1, 20, 50, 32, 32),      # CO=2 variant (64 physical output channels)
+    (1, 20, 50, 32, 32),      # half-empty output-channel tile (64 per workgroup)
     (1, 33, 40, 128, 64),
     (2, 9, 13, 16, 96),
     (1, 70, 150, 48, 80),
     (3, 5, 6, 256, 256),
 ])
 def test_conv3x3_patch_wgrad(native, shape):
-    """k_wgrad3x3_patch on the physical channels + the quadrant-summing slab reduction against fp64 autograd."""
+    """k_wgrad3x3_patch<4, SPLIT> (planes de-interleaved by the DMA, hi*lo + lo*hi + hi*hi per tap, four k-step slabs per
+    pixel split) + the slab reduction against fp64 autograd."""
     B, H, W, Cin, Cout = shape
     g = torch.Generator().manual_seed(sum(shape) + 1)
     x = torch.randn(B, Cin, H, W, generator=g)
@@ -195,7 +196,7 @@ def test_conv3x3_patch_wgrad(native, shape):
     xd, dyd = to_split(native, nhwc(x).to(DEV)), to_split(native, nhwc(dy).to(DEV))
     try:
         native.set_conv_algo(2)
-        assert native.query("sfod_conv_wgrad_ws_bytes", B, H, W, Cin, Cout, 3, Cout, native.BF16X3) > 16 * Cout * 9 * Cin
+        assert native.query("sfod_conv_wgrad_ws_bytes", B, H, W, Cin, Cout, 3, Cout, native.BF16X3) >= 16 * Cout * 9 * Cin
         dwp = native.conv_wgrad(xd, dyd, Cout, 3)
         dwp2 = native.conv_wgrad(xd, dyd, Cout, 3)
         assert native.conv_wgrad_oihw_supported(xd, dyd, Cout, 3)

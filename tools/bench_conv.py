@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--wgrad", action="store_true")
     ap.add_argument("--layers", default="")
+    ap.add_argument("--dtype", choices=["bf16", "bf16x3"], default="bf16x3")
     ap.add_argument("--variants", action="store_true",
                     help="time the halo-patch kernel's workgroup shapes 1..4 (and auto = 0) instead of algo 1 vs 2")
     args = ap.parse_args()
@@ -41,8 +42,9 @@ def main():
     dev = "cuda"
     for name, H, W, Cin, Cout in layers:
         g = torch.Generator(device=dev).manual_seed(1)
-        x = torch.randn(B, H, W, Cin, device=dev, generator=g).bfloat16()
-        w = (torch.randn(Cout, 9, Cin, device=dev, generator=g) / (3 * Cin ** 0.5)).bfloat16()
+        odt = torch.bfloat16 if args.dtype == "bf16" else native.SPLIT_DTYPE
+        x = native.cast(torch.randn(B, H, W, Cin, device=dev, generator=g), odt)
+        w = native.cast(torch.randn(Cout, 9, Cin, device=dev, generator=g) / (3 * Cin ** 0.5), odt)
         bias = torch.randn(Cout, device=dev, generator=g)
         flops = 2.0 * B * H * W * Cout * 9 * Cin
         if args.variants:
@@ -91,7 +93,7 @@ def main():
         line += f" | rel diff {err:.2e}"
         print(line, flush=True)
         if args.wgrad:
-            dy = torch.randn(B, H, W, Cout, device=dev, generator=g).bfloat16()
+            dy = native.cast(torch.randn(B, H, W, Cout, device=dev, generator=g), odt)
             ts = {1: [], 2: []}
             dws = {}
             for r in range(args.rounds + 1):
