@@ -198,3 +198,100 @@ def test_hot_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
     print(f"\n[fullsize parity {dtype}] relative errors vs the CPU oracle: " +
           ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+
+
+def _check_discrete_steps_on_captured_tensors(model, inputs, B, H, W, with_gt, native):
+    """One training-mode pass with the RPN's tensors captured; the oracle redoes every discrete step on them:
+    proposals (decode -> top-k -> NMS keep, scores ==) and, with ground truth, the sampled anchor labels (==)."""
+    ocfg = om.Cfg()
+    Hf, Wf, A = H // 32, W // 32, 15
+    rpn = model.proposal_generator
+    cap = {}
+    orig_props, orig_lf = rpn._proposals, rpn._loss_forward
+
+    def cap_props(st, *a, **k):
+        cap["rpn_out"] = st["rpn_out"].clone()
+        cap["props"] = orig_props(st, *a, **k)
+        return cap["props"]
+
+    def cap_lf(*a, **k):
+        loss, lab_state = orig_lf(*a, **k)
+        cap["labels"] = lab_state[0].clone()
+        return loss, lab_state
+    rpn._proposals, rpn._loss_forward = cap_props, cap_lf
+    g = torch.Generator().manual_seed(9)
+    rpn_keys = torch.randint(0, 2 ** 31 - 1, (B, Hf * Wf * A), generator=g, dtype=torch.int64)
+    rpn._forced_keys = rpn_keys.to(torch.int32).to(DEV)
+    try:
+        if with_gt:
+            out = model(inputs, branch="supervised_target", batched=True) if hasattr(model, "elide") else model(inputs)
+            losses = out[0] if isinstance(out, tuple) else out
+            sum(v for k, v in losses.items() if k != "loss_bpc").backward()
+        else:
+            with torch.no_grad():
+                model(inputs, branch="unsup_data_weak", batched=True)
+            losses = {}
+    finally:
+        rpn._proposals, rpn._loss_forward = orig_props, orig_lf
+        del rpn._forced_keys
+    torch.cuda.synchronize()
+    for k, v in losses.items():
+        assert np.isfinite(v.item()), k
+    anchors = om.anchors_for((Hf, Wf), ocfg)
+    out = cap["rpn_out"].cpu().view(B, Hf * Wf, -1)
+    logits = out[:, :, :A].reshape(B, Hf * Wf * A)
+    deltas = out[:, :, A:5 * A].reshape(B, Hf * Wf * A, 4)
+    sizes = [(H, W)] * B
+    ref = om.rpn_proposals(anchors, logits, deltas, sizes, ocfg, training=True)
+    props = cap["props"]
+    for b in range(B):
+        n = props.count[b].item()
+        assert n == len(ref[b][0]) and 0 < n <= ocfg.rpn_post_topk_train
+        assert torch.equal(props.logits[b, :n].cpu(), ref[b][1]), "NMS keep set / order differs"
+        torch.testing.assert_close(props.boxes[b, :n].cpu(), ref[b][0], rtol=1e-5, atol=1e-3)
+    if with_gt:
+        labels, _ = om.rpn_label_anchors(anchors, [d["instances"].gt_boxes.tensor.cpu() for d in inputs], list(rpn_keys), ocfg)
+        assert torch.equal(cap["labels"].cpu(), labels), "anchor labels after sampling must be bit-exact"
+        for name, p in model.named_parameters():
+            if not name.startswith("DC_") and p.requires_grad:
+                assert p.grad is not None and torch.isfinite(p.grad).all(), name
+    return losses
+
+
+def _with_gt(inputs, S, n, seed):
+    g = torch.Generator().manual_seed(seed)
+    for d in inputs:
+        H, W = d["height"], d["width"]
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([W * 0.7, H * 0.7])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([W * 0.25, H * 0.25]) + 24
+        inst = S.Instances((H, W))
+        inst.gt_boxes = S.Boxes(torch.cat([xy, xy + wh], 1))
+        inst.gt_classes = torch.randint(0, 8, (n,), generator=g)
+        d["instances"] = inst
+    return inputs
+
+
+SRC_YAML = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "faster_rcnn_VGG_cityscapes_source_new.yaml")
+
+
+@pytest.mark.parametrize("which", ["source_b8_600x1200", "hot_b8_600x1200", "source_b2_1024x2048", "hot_teacher_b2_1024x2048"])
+def test_configs_at_their_real_sizes(sfod, native, which):
+    """BASELINE configs #2 / #3 at the sizes bench.py runs them (B = 8 frames of 600x1200; 1024x2048 tensors with
+    30 720 anchors per image = the > 16 384-key path of the segmented sort), default bf16x3 mode: finite losses and
+    gradients, proposal counts, and the discrete steps bit-exact against the oracle on the captured tensors."""
+    S = sfod.structures
+    yaml = SRC_YAML if which.startswith("source") else HOT_YAML
+    B = 8 if "b8" in which else 2
+    H, W = (600, 1200) if "600x1200" in which else (1024, 2048)
+    cfg = sfod.config.setup_cfg(yaml, ["OUTPUT_DIR", ""])
+    assert cfg.SFOD.COMPUTE_DTYPE == "bf16x3"
+    torch.manual_seed(3)
+    model = sfod.modeling.build_model(cfg).train()
+    inputs = _frames(B, H, W, seed=33)
+    teacher_only = "teacher" in which
+    if not teacher_only:
+        inputs = _with_gt(inputs, S, 12, seed=4)
+    losses = _check_discrete_steps_on_captured_tensors(model, inputs, B, H, W, not teacher_only, native)
+    if not teacher_only:
+        assert {"loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"} <= set(losses)
+        assert 0.1 < losses["loss_rpn_cls"].item() < 2.0 and 1.0 < losses["loss_cls"].item() < 4.0     # ln 2, ln 9 at init
