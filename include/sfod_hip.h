@@ -154,8 +154,10 @@ int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                      float* mean, float* invstd, float* running_mean, float* running_var,
                      float momentum, float eps, int update_running, int64_t* num_batches_tracked,
                      float* ws, void* stream);
-/* num_batches_tracked: the BatchNorm buffer of that name (device int64 scalar), incremented by one when
- * update_running != 0; may be NULL. */
+/* update_running: 0 = leave the running statistics alone; k >= 1 = apply k momentum updates with this batch's
+ * statistics (k forward passes over the same batch between two optimiser steps -- the reference's student runs its
+ * backbone three times per step when its zero-weighted domain branch is on, source_free_adaptive_teacher.py:527-537).
+ * num_batches_tracked: the BatchNorm buffer of that name (device int64 scalar), incremented by k; may be NULL. */
 /* size (in floats, 8-byte aligned) of the `ws` scratch of sfod_bn_finalize */
 int sfod_bn_finalize_ws_floats(int C);
 /* z = relu(gamma*(y-mean)*invstd+beta); `pool` is a flag word: bit 0 additionally 2x2/2 max-pools z

@@ -276,7 +276,7 @@ k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __r
            float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
            float eps, int update_running, long long* __restrict__ nbt) {
   __shared__ double red[4][3][64];
-  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;   // BatchNorm's num_batches_tracked
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += update_running;   // BatchNorm's num_batches_tracked
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + lane;
   double a = 0.0, q = 0.0, m2 = 0.0;
@@ -299,9 +299,16 @@ k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __r
   mean[c] = (float)mu;
   invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
   if (update_running) {
+    // update_running = k >= 1 momentum updates with the SAME batch statistics folded into this call (k forward passes
+    // over one batch between two optimiser steps), each rounded to fp32 like k separate BatchNorm calls
     const double unbiased = (M > 1) ? tot / (double)(M - 1) : var;
-    rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
-    rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+    float rm = rmean[c], rv = rvar[c];
+    for (int k = 0; k < update_running; ++k) {
+      rm = (float)((1.0 - (double)momentum) * (double)rm + (double)momentum * mu);
+      rv = (float)((1.0 - (double)momentum) * (double)rv + (double)momentum * unbiased);
+    }
+    rmean[c] = rm;
+    rvar[c] = rv;
   }
 }
 

@@ -814,30 +814,67 @@ k_wgrad_combine_split(const float* __restrict__ dwp, float* __restrict__ dw, int
   }
 }
 
+// The halo-patch weight-gradient kernel addresses x / dy with 32-bit byte offsets, so a batch whose tensors exceed
+// 2 GiB (B = 8 frames of 1024x2048 at 64 / 128 channels) is processed in sub-batches of `nb` images: each sub-launch
+// writes its slabs and the slab reduction of every sub-batch but the first accumulates.  -> plan of the first (largest)
+// sub-batch; nb = images per sub-batch (0: the shape is not served by the kernel at all).
+static W3Plan w3_plan_chunked(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt, int& nb) {
+  nb = 0;
+  W3Plan p;
+  p.ok = 0;
+  if (ksize != 3 || !is_bf16_storage(dt) || (int64_t)B * H * W == 0) return p;
+  const int split = (dt == SFOD_BF16X3);
+  for (int n = B; n >= 1; n = (n == 1) ? 0 : (n + 1) / 2) {
+    p = sfod_w3_plan(n, H, W, Cin, Cout, lddy, split);
+    if (p.ok) { nb = n; break; }
+  }
+  if (!p.ok || !use_patch_wgrad(p, ksize, dt)) { nb = 0; p.ok = 0; }
+  return p;
+}
+
+static int w3_launch_chunked(const void* x, const void* dy, float* dw, void* ws, int64_t ws_bytes, int B, int H, int W,
+                             int Cin, int Cout, int lddy, int dt, int out_mode, int nb, hipStream_t s) {
+  const int split = (dt == SFOD_BF16X3);
+  const int64_t eb = split ? 4 : 2;
+  for (int b0 = 0; b0 < B; b0 += nb) {
+    const int n = (B - b0 < nb) ? (B - b0) : nb;
+    const W3Plan p = sfod_w3_plan(n, H, W, Cin, Cout, lddy, split);
+    if (!p.ok || ws == nullptr || ws_bytes < p.ws_bytes) {
+      sfod_set_error("wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
+      return SFOD_EBADARG;
+    }
+    const char* xb = (const char*)x + (int64_t)b0 * H * W * Cin * eb;
+    const char* dyb = (const char*)dy + (int64_t)b0 * H * W * lddy * eb;
+    // out_mode 0 (packed, += ) always accumulates; 1 (OIHW overwrite) becomes 2 (OIHW +=) after the first sub-batch
+    const int mode = (b0 == 0) ? out_mode : (out_mode == 1 ? 2 : out_mode);
+    const int rc = sfod_w3_launch(p, xb, dyb, dw, ws, n, H, W, Cin, Cout, lddy, mode, s, split);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
 extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
   if (dt == SFOD_F32) return 0;
-  if (ksize == 3) {
-    const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, dt == SFOD_BF16X3);
-    if (use_patch_wgrad(p, ksize, dt)) return p.ws_bytes;
-  }
+  int nb;
+  const W3Plan p = w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
+  if (nb > 0) return p.ws_bytes;      // the first sub-batch is the largest
   return dt == SFOD_BF16X3 ? (int64_t)16 * Cout * ksize * ksize * Cin : 0;
 }
 
 extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
-  if (ksize != 3 || !is_bf16_storage(dt) || (int64_t)B * H * W == 0) return 0;
-  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, dt == SFOD_BF16X3);
-  return use_patch_wgrad(p, ksize, dt) ? 1 : 0;
+  int nb;
+  w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
+  return nb > 0 ? 1 : 0;
 }
 
 extern "C" int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin,
                                     int Cout, int ksize, int lddy, int dt, int accumulate, void* ws,
                                     int64_t ws_bytes, void* stream) {
-  SFOD_REQUIRE(sfod_conv_wgrad_oihw_supported(B, H, W, Cin, Cout, ksize, lddy, dt),
-               "wgrad_oihw: shape not served by the halo-patch kernel (query sfod_conv_wgrad_oihw_supported)");
-  const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, dt == SFOD_BF16X3);
-  SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
-  return sfod_w3_launch(p, x, dy, dw_oihw, ws, B, H, W, Cin, Cout, lddy, accumulate ? 2 : 1, (hipStream_t)stream,
-                        dt == SFOD_BF16X3);
+  int nb;
+  w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
+  SFOD_REQUIRE(nb > 0, "wgrad_oihw: shape not served by the halo-patch kernel (query sfod_conv_wgrad_oihw_supported)");
+  return w3_launch_chunked(x, dy, dw_oihw, ws, ws_bytes, B, H, W, Cin, Cout, lddy, dt, accumulate ? 2 : 1, nb,
+                           (hipStream_t)stream);
 }
 
 extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
@@ -851,12 +888,10 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   const int split = (dt == SFOD_BF16X3);
   SFOD_REQUIRE(!split || Cout % 8 == 0, "wgrad: bf16x3 needs Cout % 8 == 0");
   const int CinL = Cin, CoutL = Cout;
-  if (ksize == 3 && is_bf16_storage(dt)) {
-    const W3Plan p = sfod_w3_plan(B, H, W, Cin, Cout, lddy, split);
-    if (use_patch_wgrad(p, ksize, dt)) {
-      SFOD_REQUIRE(ws != nullptr && ws_bytes >= p.ws_bytes, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
-      return sfod_w3_launch(p, x, dy, dw, ws, B, H, W, Cin, Cout, lddy, 0, (hipStream_t)stream, split);
-    }
+  {
+    int nb;
+    w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
+    if (nb > 0) return w3_launch_chunked(x, dy, dw, ws, ws_bytes, B, H, W, Cin, Cout, lddy, dt, 0, nb, (hipStream_t)stream);
   }
   Cin = phys_ch(dt, Cin); Cout = phys_ch(dt, Cout); lddy = phys_ch(dt, lddy);     // generic kernel: bf16 channels as stored
   hipStream_t s = (hipStream_t)stream;

@@ -447,6 +447,16 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         self.model.train()
         self.model_teacher.train()  # quirk q2: the teacher is never put in eval mode (:385-390)
         self.elide = bool(cfg.SFOD.ELIDE_DEAD_BRANCHES)
+        # Eliding the zero-weighted domain branch (:527-537) removes two of the student's three backbone passes per
+        # step.  They see the same images as the first (WEAK_STRONG_AUGMENT False: q is a copy of k) with the same
+        # weights, i.e. the same batch statistics, so their only effect -- two more momentum updates of every
+        # BatchNorm's running statistics and num_batches_tracked += 2 -- is applied in closed form by the one pass that
+        # runs.  With WEAK_STRONG_AUGMENT the two extra passes would see differently augmented frames: not
+        # reproducible without running them (documented deviation; ELIDE_DEAD_BRANCHES False runs everything).
+        dc_live = cfg.DOMAIN_CLASSIFIER.ENABLED and (cfg.DOMAIN_CLASSIFIER.IMAGE or cfg.DOMAIN_CLASSIFIER.INSTANCE)
+        if self.elide and cfg.DOMAIN_CLASSIFIER.ENABLED and not dc_live and not cfg.WEAK_STRONG_AUGMENT \
+                and hasattr(self.model.backbone, "bn_updates_per_forward"):
+            self.model.backbone.bn_updates_per_forward = 3
 
     @staticmethod
     def _frozen(cfg):

@@ -173,6 +173,7 @@ class ResNet(nn.Module):
         self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self.act_dtype = native.out_dtype_of(self.compute_dtype)
         self.bn_momentum = 0.1
+        self.bn_updates_per_forward = 1      # see backbone_vgg: momentum updates folded into one forward
         self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
 
     # ---- Detectron2 Backbone surface -----------------------------------------------------------------
@@ -277,7 +278,7 @@ class ResNet(nn.Module):
         if self.training:
             y, stats = native.conv_fwd(x, wp, None, conv.out_channels, k, want_stats=True)
             mean, invstd = native.bn_finalize(stats, B * H * W, conv.out_channels, bn.running_mean, bn.running_var,
-                                              self.bn_momentum, bn.eps, True,
+                                              self.bn_momentum, bn.eps, self.bn_updates_per_forward,
                                               num_batches_tracked=bn.num_batches_tracked)
         else:
             y = native.conv_fwd(x, wp, None, conv.out_channels, k)

@@ -104,6 +104,11 @@ class vgg_backbone(nn.Module):
         del self.vgg
         self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self.bn_momentum, self.bn_eps = 0.1, 1e-5
+        # momentum updates of the running statistics per training-mode forward.  The reference's student passes the same
+        # batch through its backbone three times per step when the (zero-weighted) domain branch is on; with
+        # SFOD.ELIDE_DEAD_BRANCHES only one pass runs and the trainer sets this to 3, which reproduces the side effect
+        # exactly: r <- r (1-m)^3 + s (1 - (1-m)^3), num_batches_tracked += 3.
+        self.bn_updates_per_forward = 1
         self.fuse_first = bool(cfg.SFOD.FUSE_FIRST_LAYER) if "SFOD" in cfg and "FUSE_FIRST_LAYER" in cfg.SFOD else True
         # execution plan: (conv, bn, pool_after, stage_end)
         self._plan = []
@@ -216,7 +221,7 @@ class vgg_backbone(nn.Module):
                 # pass that writes z directly; y (only a backward would need it) is never materialised
                 stats = native.conv_first_stats(x, wp, conv.bias.detach())
                 mean, invstd = native.bn_finalize(stats, B * H * W, cout, bn.running_mean, bn.running_var,
-                                                  self.bn_momentum, self.bn_eps, True,
+                                                  self.bn_momentum, self.bn_eps, self.bn_updates_per_forward,
                                                   num_batches_tracked=bn.num_batches_tracked)
                 scale = bn.weight.detach() * invstd
                 shift = bn.bias.detach() - mean * scale
@@ -225,7 +230,7 @@ class vgg_backbone(nn.Module):
             if training:
                 y, stats = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3, want_stats=True)
                 mean, invstd = native.bn_finalize(stats, B * H * W, cout, bn.running_mean, bn.running_var,
-                                                  self.bn_momentum, self.bn_eps, True,
+                                                  self.bn_momentum, self.bn_eps, self.bn_updates_per_forward,
                                                   num_batches_tracked=bn.num_batches_tracked)
             else:
                 y = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3)

@@ -650,7 +650,8 @@ def bias_grad(dy, n, db=None, accumulate=False):
 
 def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, update_running=True,
                 num_batches_tracked=None):
-    """``num_batches_tracked`` (int64 scalar buffer) is incremented in the same launch when given."""
+    """``update_running``: False / 0 = no update, True / k = k momentum updates with this batch's statistics;
+    ``num_batches_tracked`` (int64 scalar buffer) is incremented by k in the same launch when given."""
     mean = torch.empty(C, dtype=torch.float32, device=stats.device)
     invstd = torch.empty_like(mean)
     ws = torch.empty(query("sfod_bn_finalize_ws_floats", C), dtype=torch.float32, device=stats.device)
