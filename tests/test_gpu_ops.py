@@ -545,9 +545,9 @@ def test_nms_progressive_phases_mixed_images(native):
     assert counts[0] == max_keep and counts[1] < max_keep      # the two regimes the phases distinguish
 
 
-@pytest.mark.parametrize("n", [2, 100, 9990, 16000, 16384, 20000])
+@pytest.mark.parametrize("n", [2, 100, 9990, 16000, 16384, 16385, 20000, 30720, 34200, 98304, 131072])
 def test_segmented_sort_stable_descending_with_ties(native, n):
-    """LDS bitonic sort (n <= 16384) and the radix fallback: order identical to
+    """LDS bitonic sort (n <= 16384) and the chunk-sort + merge-path passes above it: order identical to
     torch.sort(descending=True, stable=True), incl. heavy ties, +-0.0, -inf / +inf."""
     g = torch.Generator().manual_seed(n)
     B = 3
