@@ -226,6 +226,18 @@ def gen_bpc():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "--upstream":
+        # on a machine with detectron2 + torchvision: record THEIR outputs on oracle/upstream_cases.py
+        # (tests/golden/upstream_ref.npz; checked by tests/test_oracle_upstream.py) -- pins the unpinned half
+        try:
+            from oracle import gen_upstream
+        except ImportError:
+            import gen_upstream
+        try:
+            sys.exit(gen_upstream.main())
+        except ImportError as e:
+            sys.exit("--upstream needs detectron2 and torchvision: %r (neither is in the build image; run this on a "
+                     "machine that has them and commit tests/golden/upstream_ref.npz)" % (e,))
     if len(sys.argv) > 1 and sys.argv[1] == "adaptive":
         gen_adaptive()
         sys.exit(0)

@@ -23,6 +23,7 @@
 #include "conv_internal.h"
 #include <type_traits>
 #include <stdlib.h>
+#include <atomic>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -507,10 +508,12 @@ k_conv3x3_patch(P3Args a) {
 // fragment read per MFMA instead of 1.5 (the 32 x 64 tile keeps the LDS array ~100 % busy at full MFMA rate)
 // and wins by 7-18 % wherever its 128-channel tiles still fill the chip (>= 512 workgroups).
 // SFOD_P3_VARIANT=1..4 / sfod_set_conv3x3_variant force a shape where the channel counts allow it (A/B, tests).
-static int g_p3_variant = -1;   // -1: not initialised (SFOD_P3_VARIANT or 0 = auto)
+// process-wide tuning knob for A/B runs and tests (relaxed atomic: a plain word, no ordering needed); -1: not
+// initialised (SFOD_P3_VARIANT or 0 = auto).  It selects among kernels that compute the same values.
+static std::atomic<int> g_p3_variant{-1};
 
 extern "C" int sfod_set_conv3x3_variant(int variant) {
-  g_p3_variant = (variant >= 1 && variant <= 4) ? variant : 0;
+  g_p3_variant.store((variant >= 1 && variant <= 4) ? variant : 0, std::memory_order_relaxed);
   return 0;
 }
 
@@ -538,11 +541,14 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   P3Plan p;
   p.ok = 0;
   if (H < 1 || W < 1 || B < 1) return p;
-  if (g_p3_variant < 0) {
+  int variant = g_p3_variant.load(std::memory_order_relaxed);
+  if (variant < 0) {
     const char* ev = getenv("SFOD_P3_VARIANT");
-    g_p3_variant = ev ? atoi(ev) : 0;
+    variant = ev ? atoi(ev) : 0;
+    int expect = -1;
+    g_p3_variant.compare_exchange_strong(expect, variant, std::memory_order_relaxed);   // a concurrent setter wins
+    variant = g_p3_variant.load(std::memory_order_relaxed);
   }
-  int variant = g_p3_variant;
   if (variant < 1 || variant > 4) {
     const int64_t mt = ((int64_t)B * H * W + 255) / 256;          // 256-pixel tiles (lower bound)
     const int64_t wg128 = mt * ((Cout + 127) / 128);
@@ -578,12 +584,10 @@ template <int G, int FM, typename OutT, bool SPLIT = false>
 static int p3_launch_one(const P3Args& a, hipStream_t s) {
   auto kern = k_conv3x3_patch<G, FM, OutT, SPLIT>;
   constexpr int LDS = Lay<G, FM>::TOTAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute(p3): %s", hipGetErrorString(e)); return -(int)e; }
-    attr_set = true;
-  }
+  // once per kernel instantiation and process (function-local static: initialised exactly once, thread-safe)
+  static const hipError_t attr_rc =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute(p3): %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
   hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(512), LDS, s, a);
   return sfod_check_launch("conv3x3_patch");
 }

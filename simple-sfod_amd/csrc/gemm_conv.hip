@@ -14,6 +14,7 @@
 // SOURCE address and again on the read.  Two LDS stages: stage t+1 is in flight while stage t
 // feeds the MFMAs.
 #include "conv_internal.h"
+#include <atomic>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -448,8 +449,11 @@ static int ilog2_exact(int v) {
   return ((1 << s) == v) ? s : -1;
 }
 
-static int g_conv_algo = 0;  // 0 auto, 1 generic implicit GEMM only, 2 halo-patch kernel whenever the shape allows
-extern "C" int sfod_set_conv_algo(int algo) { g_conv_algo = algo; return 0; }
+// process-wide kernel-selection knob for A/B runs and tests (0 auto, 1 generic implicit GEMM only, 2 halo-patch kernel
+// whenever the shape allows); a relaxed atomic word -- every choice computes the same values
+static std::atomic<int> g_conv_algo_v{0};
+#define g_conv_algo (g_conv_algo_v.load(std::memory_order_relaxed))
+extern "C" int sfod_set_conv_algo(int algo) { g_conv_algo_v.store(algo, std::memory_order_relaxed); return 0; }
 
 // SFOD_BF16X3 tensors are bf16 tensors with twice the channels (8 hi | 8 lo groups) as far as DMA, LDS layout and
 // tile plans are concerned: the kernels below are planned / launched on the PHYSICAL channel count.
@@ -491,13 +495,11 @@ static int launch_one(const void* x, const void* w, const float* bias, void* y, 
   constexpr int EPI = BM * (BN * 2 + 16) + WR * BN * 4;  // staged C tile + BN partial scratch
   constexpr int LDS = OPER > EPI ? OPER : EPI;
   auto kern = k_conv_fwd<T, OutT, 2, WN, UT, WR, NST, SPLIT>;
-  static bool attr_set = false;
-  if (!attr_set && LDS > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return -(int)e; }
-    attr_set = true;
-  }
+  // once per kernel instantiation and process (function-local static: initialised exactly once, thread-safe)
+  static const hipError_t attr_rc = (LDS > 64 * 1024)
+      ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
+      : hipSuccess;
+  if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Cout + BN - 1) / BN;
   const int nt = tiles_m * tiles_n;
   hipLaunchKernelGGL(kern, dim3(nt), dim3(WR * 128), LDS, s, (const T*)x, (const T*)w, bias, (OutT*)y, stats, a,

@@ -514,16 +514,16 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
   a.ntiles = B * p.tiles_y * p.tiles_x;
   a.tiles_per_split = p.tiles_per_split;
   a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.nsplit = p.nsplit;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static const hipError_t attr_rc = []() {     // once per process (function-local static: thread-safe)
     const void* ks[3] = {(const void*)k_wgrad3x3_patch<4>, (const void*)k_wgrad3x3_patch<2>,
                          (const void*)k_wgrad3x3_patch<4, true>};
     for (int i = 0; i < 3; ++i) {
       hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
-      if (e != hipSuccess) { sfod_set_error("hipFuncSetAttribute(w3): %s", hipGetErrorString(e)); return -(int)e; }
+      if (e != hipSuccess) return e;
     }
-    attr_set = true;
-  }
+    return hipSuccess;
+  }();
+  if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute(w3): %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
   dim3 grid(p.co_tiles * p.ci_tiles * p.nsplit), blk(512);
   if (split) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true>), grid, blk, LDS_TOTAL, s, a);
   else if (p.CO == 4) hipLaunchKernelGGL(k_wgrad3x3_patch<4>, grid, blk, LDS_TOTAL, s, a);
