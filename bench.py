@@ -406,7 +406,10 @@ def main():
         out["roofline"] = {
             "kernel": kname,
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
-            "frac": round(ach / PEAK[args.dtype], 4), "traffic": pmc_traffic("k_conv3x3_patchILi1E" if key.endswith("patch3x3") else "k_conv_fwd"),
+            "frac": round(ach / PEAK[args.dtype], 4),
+            # HBM bytes per launch from the committed PMC passes of THIS mode's kernel (tools/pmc_hbm_run.sh); null otherwise
+            "traffic": pmc_traffic({"bf16x3": "k_conv3x3_patch<1, 2, float, true>", "bf16": "k_conv3x3_patch<1, 2, __bf16, false>"}.get(args.dtype, "-")
+                                   if key.endswith("patch3x3") else "k_conv_fwd<"),
             "launches_per_step": k["launches"] // max(rl_steps, 1),
             "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
             "algorithmic_gflop_per_launch": round(k["flops"] / max(k["launches"], 1) / 1e9, 3),

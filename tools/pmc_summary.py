@@ -4,11 +4,12 @@ import csv, glob, sys, collections, json
 
 def load(pattern, counter):
     agg = collections.defaultdict(lambda: [0, 0.0, 0.0])
-    for f in glob.glob(pattern) + glob.glob(pattern.replace("/*/*", "/*")):
+    files = set(glob.glob(pattern) + glob.glob(pattern.replace("/*/*", "/*")) + glob.glob(pattern.split("/*")[0] + "/**/*counter_collection.csv", recursive=True))
+    for f in files:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = r["Kernel_Name"][:96]
+            name = r["Kernel_Name"][:120]
             a = agg[name]
             a[0] += 1
             a[1] += float(r["Counter_Value"])
