@@ -268,7 +268,10 @@ class ResNet(nn.Module):
         self._wp = {id(c): views[i] for i, c in enumerate(convs)}
         self._wr = {id(c): views[n + i] for i, c in enumerate(convs)} if with_dgrad else {}
 
-    def _live_conv_bn(self, x, conv, relu, dt, residual=None):
+    def _live_conv_bn(self, x, conv, relu, dt, residual=None, z_operand=False):
+        """conv + train-mode BatchNorm (+ ReLU / residual join).  ``x``: an MFMA operand tensor (bf16x3: pairs) or an
+        activation-dtype tensor (converted by conv_fwd).  ``z_operand``: write the output directly as the next
+        convolution's operand (bf16x3: the BatchNorm kernel emits the pairs; no separate conversion pass)."""
         bn = conv.norm
         k = conv.kernel_size[0]
         wp = self.__dict__.get("_wp", {}).get(id(conv)) if x.shape[-1] == conv.in_channels else None
@@ -286,7 +289,8 @@ class ResNet(nn.Module):
         if residual is not None:      # bottleneck tail: relu(bn(y) + shortcut) without materialising bn(y)
             z = native.bn_add_relu_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual)
         else:
-            z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False, relu=relu)
+            z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False, relu=relu,
+                                        out_dtype=self.compute_dtype if z_operand else None)
         return y, mean, invstd, z
 
     def _block_forward(self, blk, x, live, dt):
@@ -298,13 +302,17 @@ class ResNet(nn.Module):
             o = self._frozen_conv(o, blk.conv2, 1, dt)
             o = self._frozen_conv(o, blk.conv3, 0, dt)
             return native.add_act(o, sc, 1), None
-        y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt)
-        y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt)
+        # bf16x3: the block input (fp32 residual stream) becomes an operand ONCE, shared by conv1, the shortcut conv
+        # and both weight gradients; a1 / a2 only feed convolutions, so their BatchNorm kernels write pairs directly
+        xs_act, xs = xs, native.as_operand(xs, self.compute_dtype)
+        y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt, z_operand=True)
+        y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt, z_operand=True)
         if blk.shortcut is not None:
             ys, ms, is_, ts = self._live_conv_bn(xs, blk.shortcut, False, dt)
         else:
             ys = ms = is_ = None
             ts = x
+        del xs_act
         if self.fuse_residual:
             y3, m3, i3, out = self._live_conv_bn(a2, blk.conv3, False, dt, residual=ts)
         else:
@@ -337,7 +345,8 @@ class ResNet(nn.Module):
         direct_bn = gsink is not None and bsink is not None
         dy, dgamma, dbeta = native.bn_relu_pool_bwd(g, y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False,
                                                     relu=relu, dgamma_acc=gsink if direct_bn else None,
-                                                    dbeta_acc=bsink if direct_bn else None)
+                                                    dbeta_acc=bsink if direct_bn else None,
+                                                    out_dtype=self.compute_dtype)   # dy only feeds wgrad / dgrad MFMAs
         if direct_bn:
             dgamma = dbeta = None
         dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.compute_dtype)

@@ -145,7 +145,10 @@ def test_conv3x3_patch_kernel(native, shape, variant, wg):
 
 
 @pytest.mark.parametrize("shape", [(2, 9, 13, 64, 64, 3), (1, 11, 7, 128, 256, 3), (1, 6, 5, 512, 75, 1),
-                                   (3, 8, 8, 3, 64, 3), (1, 40, 1, 1024, 41, 1)])
+                                   (3, 8, 8, 3, 64, 3), (1, 40, 1, 1024, 41, 1),
+                                   # bottleneck shapes on odd-sized maps (ResNet-C4 path)
+                                   (2, 17, 23, 128, 128, 3), (2, 17, 23, 64, 64, 3), (2, 17, 23, 512, 128, 1),
+                                   (2, 17, 23, 128, 512, 1), (2, 17, 23, 64, 256, 1)])
 @pytest.mark.parametrize("algo", [1, 0])
 def test_conv_dgrad_and_wgrad(native, shape, algo):
     B, H, W, Cin, Cout, ks = shape
