@@ -396,21 +396,45 @@ k_conv3x3_patch(P3Args a) {
       }
     }
   } else {
+    // fp32 output (bf16x3 mode: every layer).  One 32-row fragment at a time is staged through the wave's LDS region
+    // (32 rows x 64 columns fp32, 272-byte pitch) and read back as 16-byte chunks: a store instruction then writes
+    // 4 pixels x 256 contiguous bytes instead of 2 x 128 bytes of one dword per lane -- 8 x dwordx4 per lane and
+    // fragment instead of 32 x dword (the epilogue of the short-K layers is store-issue bound).
     float* yo = reinterpret_cast<float*>(a.y);
+    constexpr int FP = 272;                                   // staged row pitch (bytes)
+    static_assert(8 * 32 * FP <= Lay<G, FM>::STG || 8 * 32 * FP <= Lay<G, FM>::OPER, "fp32 staging must fit the operand area");
+    unsigned char* stg = smem + wave * (32 * FP);
+    const bool vec_ok = (a.ldy % 4) == 0;
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+    for (int i = 0; i < FM; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int pix = pixtab[wm * WROWS + ml];
+      for (int j = 0; j < FN; ++j) {
+        const int nl = j * 32 + (lane & 31);
 #pragma unroll
-        for (int j = 0; j < FN; ++j) {
-          const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+        for (int r = 0; r < 16; ++r) {
+          const int ml = (r & 3) + 8 * (r >> 2) + 4 * h;
           const float v = acc[i][j][r] + bcol[j];
           acc[i][j][r] = v;
-          if (pix >= 0 && n < a.Cout) yo[(ybase + pix) * a.ldy + n] = act_f(v, actp);
+          *reinterpret_cast<float*>(stg + ml * FP + nl * 4) = act_f(v, actp);
         }
       }
+      // same-wave readback (LDS is in order per wave)
+#pragma unroll
+      for (int it = 0; it < 8; ++it) {
+        const int row = it * 4 + (lane >> 4), ch = lane & 15;
+        const int pix = pixtab[wm * WROWS + i * 32 + row];
+        const int n = n0 + wn * 64 + ch * 4;
+        if (pix < 0 || n >= a.Cout) continue;
+        const float4 v = *reinterpret_cast<const float4*>(stg + row * FP + ch * 16);
+        float* dst = yo + (ybase + pix) * a.ldy + n;
+        if (vec_ok && n + 4 <= a.Cout) {
+          *reinterpret_cast<float4*>(dst) = v;
+        } else {
+          const float e[4] = {v.x, v.y, v.z, v.w};
+          for (int q = 0; q < 4 && n + q < a.Cout; ++q) dst[q] = e[q];
+        }
+      }
+    }
   }
 
   if (a.stats != nullptr) {
