@@ -603,13 +603,19 @@ struct WgradArgs {
   int tiles_n, tiles_m;
 };
 
-template <typename T, int WM, int WN>
+// SPLIT (SFOD_BF16X3 operands; T = bf16, WgradArgs in LOGICAL channels): the workgroup tile is 64 output channels x 64
+// flattened (tap, ci) columns.  The DMA de-interleaves the (8 hi | 8 lo) groups -- a 256-byte LDS row is the 64 hi values
+// of the tile's channels followed by their 64 lo values -- so that a transposed fragment read again covers 32 channels of
+// ONE kind.  Every wave computes the whole 64 x 64 tile (hi*lo + lo*hi + hi*hi: 12 MFMAs and 16 transposed reads per
+// k-step) for one of the four 16-pixel k-steps of a stage; the four partial tiles are summed through LDS before the
+// float atomics (which go straight into the logical gradient: no quadrant temporary, no combine pass).
+template <typename T, int WM, int WN, bool SPLIT = false>
 __global__ void __launch_bounds__(256)
 k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ dw, WgradArgs a) {
-  constexpr int BM = 64 * WM, BN = 64 * WN;
+  constexpr int BM = SPLIT ? 64 : 64 * WM, BN = SPLIT ? 64 : 64 * WN;      // logical channels / columns per workgroup
   constexpr int E = Chunk<T>::E;
   constexpr int BKP = (sizeof(T) == 2) ? 64 : 32;  // pixels per stage
-  constexpr int RA = BM * sizeof(T), RB = BN * sizeof(T);  // LDS row bytes
+  constexpr int RA = SPLIT ? 256 : BM * sizeof(T), RB = SPLIT ? 256 : BN * sizeof(T);  // LDS row bytes
   constexpr int TA = BKP * RA, TB = BKP * RB;
   constexpr int STAGE = TA + TB;
   constexpr int AI = TA / 1024 / 4, BI = TB / 1024 / 4;  // DMA instructions per wave
@@ -637,7 +643,7 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
     const int o = (wave * AI + i) * 1024 + lane * 16;
     const int prow = o / RA, pcol = (o % RA) >> 4;
     a_prow[i] = prow;
-    a_lc[i] = (sizeof(T) == 2) ? (pcol ^ ((prow & 3) << 2)) : pcol;
+    a_lc[i] = (sizeof(T) == 2) ? (pcol ^ ((prow & 3) << 2)) : pcol;     // SPLIT: position p -> kind p >> 3, 8-channel group p & 7
   }
   int b_prow[BI], b_tap[BI], b_cc[BI], b_oy[BI], b_ox[BI];
   bool b_ok[BI];
@@ -646,11 +652,11 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
     const int prow = o / RB, pcol = (o % RB) >> 4;
     b_prow[i] = prow;
     const int lc = (sizeof(T) == 2) ? (pcol ^ ((prow & 3) << 2)) : pcol;
-    const int nq = n0 / E + lc;
+    const int nq = n0 / E + (SPLIT ? (lc & 7) : lc);      // 8-channel group along the flattened (tap, ci) axis
     int tap, cc;
     chunk_to_tap(nq, a.ks, a.cpt_shift, tap, cc);
     b_tap[i] = tap;
-    b_cc[i] = cc;
+    b_cc[i] = SPLIT ? (cc * 2 + (lc >> 3)) : cc;          // SPLIT: 16-byte chunk inside the pixel = 2 * group + kind
     b_ok[i] = (nq < a.nchunks) && (tap < taps);
     const int pix = p_begin + prow;
     const int rem = pix % (a.H * a.W);
@@ -665,9 +671,12 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int pix = pbase + a_prow[i];
-      const int col = co0 + a_lc[i] * E;
+      const int col = co0 + (SPLIT ? (a_lc[i] & 7) : a_lc[i]) * E;
       const void* src = g_zero_page;
-      if (pix < p_end && col + E <= a.lddy && col < a.Cout) src = dy + (int64_t)pix * a.lddy + col;
+      if (pix < p_end && col + E <= a.lddy && col < a.Cout) {
+        if constexpr (SPLIT) src = dy + ((int64_t)pix * a.lddy + col) * 2 + (a_lc[i] >> 3) * 8;   // bf16 units: 4 B per channel
+        else src = dy + (int64_t)pix * a.lddy + col;
+      }
       glds16(src, sA + (wave * AI + i) * 1024);
     }
 #pragma unroll
@@ -675,13 +684,14 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
       const int pix = pbase + b_prow[i];
       const void* src = g_zero_page;
       if (pix < p_end && b_ok[i]) {
+        constexpr int PS = SPLIT ? 2 : 1;       // bf16 elements per (logical) channel in global memory
         if (a.ks == 1) {
-          src = x + (int64_t)pix * a.Cin + (int64_t)b_cc[i] * E;
+          src = x + (int64_t)pix * a.Cin * PS + (int64_t)b_cc[i] * E;
         } else {
           const int ky = b_tap[i] / 3, kx = b_tap[i] - ky * 3;
           const int iy = b_oy[i] + ky - 1, ix = b_ox[i] + kx - 1;
           if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-            src = x + ((int64_t)pix + (int64_t)(ky - 1) * a.W + (kx - 1)) * a.Cin + (int64_t)b_cc[i] * E;
+            src = x + ((int64_t)pix + (int64_t)(ky - 1) * a.W + (kx - 1)) * a.Cin * PS + (int64_t)b_cc[i] * E;
         }
       }
       glds16(src, sB + (wave * BI + i) * 1024);
@@ -709,7 +719,38 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
   auto stage_compute = [&](int buf) {
     const unsigned char* sA = smem + buf * STAGE;
     const unsigned char* sB = sA + TA;
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (SPLIT) {
+      const int s = wave;                       // this wave's k-step (16 pixels) of the stage
+      s16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int prow = 16 * s + 8 * h + 4 * e + tq;
+        const int sw = (prow & 3) << 6;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int cb = (f * 32 + (g16 & 1) * 16 + 4 * tp) * 2;      // byte column of the hi value; lo = + 128
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sA + prow * 256 + (cb ^ sw)));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sA + prow * 256 + ((cb + 128) ^ sw)));
+          const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sB + prow * 256 + (cb ^ sw)));
+          const s16x4 v3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sB + prow * 256 + ((cb + 128) ^ sw)));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            ah[f][4 * e + k] = v0[k]; al[f][4 * e + k] = v1[k];
+            bh[f][4 * e + k] = v2[k]; bl[f][4 * e + k] = v3[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          f32x16 c = acc[i][j];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), c, 0, 0, 0);
+          acc[i][j] = c;
+        }
+    } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
       for (int s = 0; s < BKP / 16; ++s) {
         s16x8 af[WM], bfr[WN];
@@ -773,6 +814,27 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
   }
   stage_compute(cur);
 
+  if constexpr (SPLIT) {
+    // the four waves hold partial 64 x 64 tiles over different k-steps: sum them through LDS (the operand stages are
+    // dead), then one float atomic per element and pixel split
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);            // [wave][tile (i, j)][r][lane]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * 4 + i * 2 + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4096; e += 256) {
+      const float v = (red[e] + red[4096 + e]) + (red[8192 + e] + red[12288 + e]);
+      const int ln = e & 63, r = (e >> 6) & 15, t = e >> 10;
+      const int co = co0 + (t >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
+      const int n = n0 + (t & 1) * 32 + (ln & 31);
+      if (co < a.Cout && n < a.Ntot) atomicAdd(dw + (int64_t)co * a.Ntot + n, v);
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -791,29 +853,6 @@ static bool use_patch_wgrad(const W3Plan& p, int ksize, int dt) {
   if (g_conv_algo == 2) return true;
   // tiny problems: not enough pixel tiles to give every (co, ci) block a few tiles per split
   return p.nsplit * p.tiles_per_split >= 3;
-}
-
-// SFOD_BF16X3 on the generic kernel: it runs on the physical channels into a [2 Cout][taps][2 Cin] fp32 temporary
-// (in `ws`), whose four (hi | lo) x (hi | lo) quadrants per logical (co, ci) are then summed into dw.
-__global__ void __launch_bounds__(256)
-k_wgrad_combine_split(const float* __restrict__ dwp, float* __restrict__ dw, int64_t n4, int taps, int Cin) {
-  const int CinP = 2 * Cin;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t e = i * 4;
-    const int ci = (int)(e % Cin);
-    const int64_t ct = e / Cin;
-    const int tap = (int)(ct % taps);
-    const int64_t co = ct / taps;
-    const int64_t rh = (co >> 3) * 16 + (co & 7);
-    const int ch = (ci >> 3) * 16 + (ci & 7);
-    const float4* src = reinterpret_cast<const float4*>(dwp);
-    const int64_t a_hh = ((rh * taps + tap) * CinP + ch) >> 2, a_lh = (((rh + 8) * taps + tap) * CinP + ch) >> 2;
-    const float4 v0 = src[a_hh], v1 = src[a_hh + 2], v2 = src[a_lh], v3 = src[a_lh + 2];
-    float4 o = reinterpret_cast<float4*>(dw)[i];
-    o.x += (v1.x + v2.x + v3.x) + v0.x; o.y += (v1.y + v2.y + v3.y) + v0.y;
-    o.z += (v1.z + v2.z + v3.z) + v0.z; o.w += (v1.w + v2.w + v3.w) + v0.w;
-    reinterpret_cast<float4*>(dw)[i] = o;
-  }
 }
 
 // The halo-patch weight-gradient kernel addresses x / dy with 32-bit byte offsets, so a batch whose tensors exceed
@@ -860,7 +899,7 @@ extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Co
   int nb;
   const W3Plan p = w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
   if (nb > 0) return p.ws_bytes;      // the first sub-batch is the largest
-  return dt == SFOD_BF16X3 ? (int64_t)16 * Cout * ksize * ksize * Cin : 0;
+  return 0;      // the generic kernel accumulates with float atomics straight into dw
 }
 
 extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
@@ -889,22 +928,13 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   if ((int64_t)B * H * W == 0) return 0;
   const int split = (dt == SFOD_BF16X3);
   SFOD_REQUIRE(!split || Cout % 8 == 0, "wgrad: bf16x3 needs Cout % 8 == 0");
-  const int CinL = Cin, CoutL = Cout;
   {
     int nb;
     w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
     if (nb > 0) return w3_launch_chunked(x, dy, dw, ws, ws_bytes, B, H, W, Cin, Cout, lddy, dt, 0, nb, (hipStream_t)stream);
   }
-  Cin = phys_ch(dt, Cin); Cout = phys_ch(dt, Cout); lddy = phys_ch(dt, lddy);     // generic kernel: bf16 channels as stored
   hipStream_t s = (hipStream_t)stream;
   float* dw_out = dw;
-  if (split) {
-    const int64_t need = (int64_t)4 * Cout * ksize * ksize * Cin;
-    SFOD_REQUIRE(ws != nullptr && ws_bytes >= need, "wgrad: workspace too small (sfod_conv_wgrad_ws_bytes)");
-    hipError_t e = hipMemsetAsync(ws, 0, (size_t)need, s);
-    if (e != hipSuccess) { sfod_set_error("wgrad: memset: %s", hipGetErrorString(e)); return -(int)e; }
-    dw_out = (float*)ws;
-  }
   WgradArgs a;
   a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.lddy = lddy;
   const int cpt = Cin / E;
@@ -917,7 +947,8 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   a.Ntot = ksize * ksize * Cin;
   if (a.M == 0) return 0;
   const int BKP = (dt == SFOD_F32) ? 32 : 64;
-  const int tiles_n = (a.Ntot + 127) / 128, tiles_m = (Cout + 127) / 128;
+  const int TILE = split ? 64 : 128;        // bf16x3: 64 logical channels x 64 logical columns per workgroup
+  const int tiles_n = (a.Ntot + TILE - 1) / TILE, tiles_m = (Cout + TILE - 1) / TILE;
   // split the pixel axis so that the grid has ~4 workgroups per CU
   int splits = (1024 + tiles_n * tiles_m - 1) / (tiles_n * tiles_m);
   const int max_splits = (a.M + BKP - 1) / BKP;
@@ -933,14 +964,11 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   if (dt == SFOD_F32)
     hipLaunchKernelGGL((k_conv_wgrad<float, 2, 2>), grid, dim3(256), 2 * 2 * 32 * 512, s, (const float*)x,
                        (const float*)dy, dw_out, a);
+  else if (split)
+    hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2, true>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
+                       (const bf16_t*)dy, dw_out, a);
   else
     hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
                        (const bf16_t*)dy, dw_out, a);
-  int rc = sfod_check_launch("conv_wgrad");
-  if (rc || !split) return rc;
-  const int64_t n4 = (int64_t)CoutL * ksize * ksize * CinL / 4;
-  int g = (int)((n4 + 255) / 256);
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(k_wgrad_combine_split, dim3(g), dim3(256), 0, s, (const float*)ws, dw, n4, ksize * ksize, CinL);
-  return sfod_check_launch("wgrad_combine_split");
+  return sfod_check_launch("conv_wgrad");
 }
