@@ -88,7 +88,8 @@ int sfod_set_conv3x3_variant(int variant);
  * kernel (Cin = one padded 8-channel chunk, Cout = 64, bf16) */
 int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
 
-/* First VGG layer (3 real channels in one 8-wide chunk -> 64, bf16) with the train-mode BatchNorm + ReLU folded in
+/* dt: SFOD_BF16 (x, w, y bf16) or SFOD_BF16X3 (x, w operand pairs; y: the activated operand pairs of the next layer).
+ * First VGG layer (3 real channels in one 8-wide chunk -> 64, bf16) with the train-mode BatchNorm + ReLU folded in
  * by recomputation -- the layer's K is 27, its cost is writing 64 channels per pixel: pass 1 (y = NULL) produces
  * only the BatchNorm partial statistics (nothing stored), pass 2 (scale = gamma * invstd, shift = beta - mean *
  * scale, act = 1) recomputes the convolution and stores z = relu(scale * (conv + bias) + shift) directly, so
@@ -97,7 +98,7 @@ int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt
 int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, int ldy);
 int sfod_conv_first_fused(const void* x, const void* w, const float* bias, const float* scale,
                           const float* shift, void* y, float* stats, int B, int H, int W, int ldy,
-                          int act, void* stream);
+                          int act, int dt, void* stream);
 
 /* weight gradient: dw[n][tap][c] += sum_m dy[m][n] * x[pix(m)+tap][c]  (fp32, packed layout, added
  * into the caller's (zero-initialised) buffer).  3x3 bf16 layers run the halo-patch kernel: pixel

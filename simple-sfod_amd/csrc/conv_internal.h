@@ -36,8 +36,8 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split 
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split = 0);
 
-// ---- first layer (Cin = one padded chunk of 8, Cout = 64), bf16 ------------------------------------------
+// ---- first layer (Cin = one padded chunk of 8, Cout = 64), bf16 / bf16x3 ------------------------------------------
 int sfod_f1_nblk(int B, int H, int W);
 // y == nullptr: statistics only (no stores); scale / shift: optional per-channel affine before the activation
 int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int B, int H, int W,
-                   int ldy, int act, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr);
+                   int ldy, int act, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, int split = 0);

@@ -468,20 +468,21 @@ static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, in
   return (int64_t)B * p.tiles_y * p.tiles_x * p.tiles_n >= 8;
 }
 
-// first VGG layer: 3 real channels in one 8-wide chunk, 64 outputs, bf16 in / bf16 out
+// first VGG layer: 3 real channels in one 8-wide chunk, 64 outputs; bf16 in / bf16 out, or bf16x3 pairs in / fp32 out
 static bool use_first_kernel(int B, int H, int W, int Cin, int Cout, int ksize, int dt, int ldy, int out_dt) {
-  return ksize == 3 && dt == SFOD_BF16 && out_dt == SFOD_BF16 && Cin == 8 && Cout == 64 && ldy % 8 == 0 &&
+  const bool types = (dt == SFOD_BF16 && out_dt == SFOD_BF16) || (dt == SFOD_BF16X3 && out_dt == SFOD_F32);
+  return ksize == 3 && types && Cin == 8 && Cout == 64 && ldy % 8 == 0 &&
          g_conv_algo != 1 && (int64_t)B * H * W >= 4096;
 }
 
 extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
-  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, SFOD_BF16)) return 3;
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, dt == SFOD_BF16X3 ? SFOD_F32 : SFOD_BF16)) return 3;
   const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
   return use_patch_kernel(p, B, H, W, ksize, dt) ? 2 : 1;
 }
 
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
-  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, SFOD_BF16)) return sfod_f1_nblk(B, H, W);
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, dt == SFOD_BF16X3 ? SFOD_F32 : SFOD_BF16)) return sfod_f1_nblk(B, H, W);
   const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;
   return (B * H * W + 127) / 128;
@@ -534,17 +535,17 @@ static int launch_conv_fwd(const void* x, const void* w, const float* bias, void
 }
 
 extern "C" int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, int ldy) {
-  return use_first_kernel(B, H, W, Cin, Cout, 3, dt, ldy, SFOD_BF16) ? 1 : 0;
+  return use_first_kernel(B, H, W, Cin, Cout, 3, dt, ldy, dt == SFOD_BF16X3 ? SFOD_F32 : SFOD_BF16) ? 1 : 0;
 }
 
 extern "C" int sfod_conv_first_fused(const void* x, const void* w, const float* bias, const float* scale,
                                      const float* shift, void* y, float* stats, int B, int H, int W, int ldy,
-                                     int act, void* stream) {
-  SFOD_REQUIRE(use_first_kernel(B, H, W, 8, 64, 3, SFOD_BF16, ldy, SFOD_BF16),
+                                     int act, int dt, void* stream) {
+  SFOD_REQUIRE(sfod_conv_first_supported(B, H, W, 8, 64, dt, ldy),
                "conv_first_fused: shape not served by the first-layer kernel (sfod_conv_first_supported)");
   SFOD_REQUIRE(y != nullptr || stats != nullptr, "conv_first_fused: nothing to produce");
   SFOD_REQUIRE((scale == nullptr) == (shift == nullptr), "conv_first_fused: scale and shift come together");
-  return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, (hipStream_t)stream, scale, shift);
+  return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, (hipStream_t)stream, scale, shift, dt == SFOD_BF16X3);
 }
 
 extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
@@ -559,7 +560,7 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
   if ((int64_t)B * H * W == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, ldy, out_dt))
-    return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, s);
+    return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, s, nullptr, nullptr, dt == SFOD_BF16X3);
   const int split = (dt == SFOD_BF16X3);
   Cin = phys_ch(dt, Cin);           // from here on: bf16 channels as stored
   if (ksize == 3 && is_bf16_storage(dt)) {

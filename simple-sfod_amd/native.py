@@ -532,28 +532,29 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
 
 
 def conv_first_supported(x, cout):
-    if x.dim() != 4 or x.dtype != torch.bfloat16:
+    if x.dim() != 4 or x.dtype not in (torch.bfloat16, SPLIT_DTYPE):
         return False
     B, H, W, cin = x.shape
-    return bool(query("sfod_conv_first_supported", B, H, W, cin, cout, BF16, cout))
+    return bool(query("sfod_conv_first_supported", B, H, W, cin, cout, dt_of(x), cout))
 
 
 def conv_first_stats(x, w_packed, bias):
     """First VGG layer, pass 1 of the recompute-fused form: BatchNorm partial statistics only, nothing stored."""
     B, H, W, cin = x.shape
-    nb = query("sfod_conv_stats_blocks", B, H, W, cin, 64, 3, BF16)
+    nb = query("sfod_conv_stats_blocks", B, H, W, cin, 64, 3, dt_of(x))
     stats = torch.empty(nb * (2 * 64 + 1), dtype=torch.float32, device=x.device)
     stats.nblk = nb
-    call("sfod_conv_first_fused", x, w_packed, bias, None, None, None, stats, B, H, W, 64, 0)
+    call("sfod_conv_first_fused", x, w_packed, bias, None, None, None, stats, B, H, W, 64, 0, dt_of(x))
     return stats
 
 
 def conv_first_apply(x, w_packed, bias, scale, shift, relu=True):
-    """Pass 2: z = act(scale * (conv + bias) + shift), bf16 [B,H,W,64]; the pre-BatchNorm output is never stored."""
+    """Pass 2: z = act(scale * (conv + bias) + shift) [B,H,W,64] in x's operand dtype (bf16 / bf16x3 pairs); the
+    pre-BatchNorm output is never stored."""
     B, H, W, cin = x.shape
-    z = torch.empty(B, H, W, 64, dtype=torch.bfloat16, device=x.device)
+    z = torch.empty(B, H, W, 64, dtype=x.dtype, device=x.device)
     global _pending_flops
-    call("sfod_conv_first_fused", x, w_packed, bias, scale, shift, z, None, B, H, W, 64, 1 if relu else 0)
+    call("sfod_conv_first_fused", x, w_packed, bias, scale, shift, z, None, B, H, W, 64, 1 if relu else 0, dt_of(x))
     return z
 
 

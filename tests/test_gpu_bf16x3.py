@@ -293,3 +293,51 @@ def test_weight_packers_split(native):
     a = native.pack_fc_weight(small, native.F32, transpose=True, ld=48)
     b = native.pack_fc_weight(small, native.BF16X3, transpose=True, ld=48)
     assert torch.equal(b.view(torch.bfloat16), to_split(native, a).view(torch.bfloat16))
+
+
+@pytest.mark.parametrize("hw", [(50, 70), (64, 96), (9, 500)])
+def test_conv_first_layer_kernel_split(native, hw):
+    """The first-layer kernel in bf16x3 (pairs in, fp32 out + BatchNorm statistics): image edges, tiles hanging over
+    the right / bottom border; against fp64 on the unrounded operands, and equal statistics from the store-free pass."""
+    H, W = hw
+    B, Cout = 2, 64
+    g = torch.Generator().manual_seed(H * W)
+    x = torch.zeros(B, H, W, 8)
+    x[..., :3] = torch.randn(B, H, W, 3, generator=g) * 50
+    w = torch.randn(Cout, 3, 3, 3, generator=g) / 5
+    bias = torch.randn(Cout, generator=g)
+    ref = conv_ref64(nchw(x)[:, :3], w, bias, padding=1)
+    xd = to_split(native, x.to(DEV))
+    wp = native.pack_conv_weight(w.to(DEV), 8, native.BF16X3)
+    assert native.conv_first_supported(xd, 64)
+    assert native.query("sfod_conv_fwd_algo", B, H, W, 8, Cout, 3, native.BF16X3) == 3
+    y, st = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3, want_stats=True)
+    assert y.dtype == torch.float32
+    assert rel_err(nchw(y.cpu()), ref) < TOL
+    y2 = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
+    assert torch.equal(y, y2)
+    st2 = native.conv_first_stats(xd, wp, bias.to(DEV))
+    assert st.nblk == st2.nblk and torch.equal(st, st2)
+    rm, rv = torch.zeros(Cout, device=DEV), torch.ones(Cout, device=DEV)
+    mean, invstd = native.bn_finalize(st, B * H * W, Cout, rm, rv, 0.1, 1e-5)
+    torch.testing.assert_close(mean.cpu().double(), ref.mean(dim=(0, 2, 3)), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(invstd.cpu().double(), torch.rsqrt(ref.var(dim=(0, 2, 3), unbiased=False) + 1e-5),
+                               rtol=2e-5, atol=1e-9)
+    try:
+        native.set_conv_algo(1)
+        y_gen = native.conv_fwd(xd, wp, bias.to(DEV), Cout, 3)
+    finally:
+        native.set_conv_algo(0)
+    assert rel_err(y.cpu(), y_gen.cpu()) < TOL
+    # second pass of the forward-only (teacher) form: the next layer's operand pairs, written directly
+    gamma, beta = torch.rand(Cout, generator=g) + 0.5, torch.randn(Cout, generator=g) * 0.2
+    scale = gamma.to(DEV) * invstd
+    shift = beta.to(DEV) - mean * scale
+    z = native.conv_first_apply(xd, wp, bias.to(DEV), scale, shift, relu=True)
+    assert z.dtype == native.SPLIT_DTYPE
+    zref = F.relu(F.batch_norm(ref, None, None, gamma.double(), beta.double(), True, 0.1, 1e-5))
+    zf = native.cast(z, torch.float32).cpu()
+    assert rel_err(nchw(zf), zref) < TOL
+    # the pairs are the exact split of an fp32 value: the unfused path (fp32 y -> BN kernel -> pairs) agrees to fp32 rounding
+    z2 = native.bn_relu_pool_fwd(y, mean, invstd, gamma.to(DEV), beta.to(DEV), False, out_dtype=native.SPLIT_DTYPE)
+    assert rel_err(zf, native.cast(z2, torch.float32).cpu()) < 1e-6
