@@ -79,7 +79,9 @@ int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int 
 int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
 /* kernel selection for 3x3 bf16 convolutions: 0 auto, 1 generic implicit GEMM (im2col chunks
  * DMA'd per tap), 2 halo-patch kernel (input patch staged once per 32-channel slice and reused by
- * all nine taps) whenever the shape allows.  For A/B tests and benchmarks. */
+ * all nine taps) whenever the shape allows, 3 / 4 auto without / with the wide-tile bf16x3
+ * weight gradient wherever it applies.  For A/B tests
+ * and benchmarks. */
 int sfod_set_conv_algo(int algo);
 /* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
  * 4 = 512 x 64 (applied where the channel counts allow it).  For A/B runs and parity tests. */

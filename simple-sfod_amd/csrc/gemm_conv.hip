@@ -14,6 +14,7 @@
 // SOURCE address and again on the read.  Two LDS stages: stage t+1 is in flight while stage t
 // feeds the MFMAs.
 #include "conv_internal.h"
+#include <algorithm>
 #include <atomic>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -632,7 +633,9 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
   }
   const int tiles = a.tiles_n * a.tiles_m;
   const int split = bid / tiles, trem = bid % tiles;
-  const int n0 = (trem % a.tiles_n) * BN, co0 = (trem / a.tiles_n) * BM;
+  // output-channel tiles fastest: the workgroups that share a column block of x (the big operand; dy is small) run
+  // back to back on one XCD and hit its L2
+  const int n0 = (trem / a.tiles_m) * BN, co0 = (trem % a.tiles_m) * BM;
   const int p_begin = split * a.pix_per_split;
   const int p_end = min(a.M, p_begin + a.pix_per_split);
   if (p_begin >= p_end) return;
@@ -849,6 +852,180 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
     }
 }
 
+
+// SFOD_BF16X3 weight gradient of the wide layers (Cout >= 128 and >= 256 flattened (tap, ci) columns: fc1 / fc2, the
+// 1x1 convolutions of the bottlenecks).  The 64 x 64 kernel above re-reads both operands once per 64 outputs and drains
+// its DMA queue every 12 MFMAs; here a workgroup owns 128 output channels x 256 columns (8 waves = 2 x 4 of 64 x 64,
+// every wave over ALL pixels: no LDS reduction), a stage is 32 pixels = two k-steps (24 MFMAs per wave between
+// barriers) and three stages are in flight with a counted vmcnt, as in k_conv_fwd.  Same de-interleaving DMA: an LDS row
+// (one pixel) holds the tile's hi values followed by its lo values.
+__global__ void __launch_bounds__(512)
+k_conv_wgrad_x3w(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ dw, WgradArgs a) {
+  constexpr int BM = 128, BN = 256, BKP = 32;
+  constexpr int RA = BM * 4, RB = BN * 4;                  // LDS row bytes (hi half | lo half)
+  constexpr int TA = BKP * RA, TB = BKP * RB, STAGE = TA + TB;
+  constexpr int AI = TA / 1024 / 8, BI = TB / 1024 / 8;    // DMA instructions per wave and stage (2 + 4)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wr = wave >> 2, wc = wave & 3;
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt / 8, r = nt % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int tiles = a.tiles_n * a.tiles_m;
+  const int split = bid / tiles, trem = bid % tiles;
+  // output-channel tiles fastest: the workgroups that share a column block of x (the big operand; dy is small) run
+  // back to back on one XCD and hit its L2
+  const int n0 = (trem / a.tiles_m) * BN, co0 = (trem % a.tiles_m) * BM;
+  const int p_begin = split * a.pix_per_split;
+  const int p_end = min(a.M, p_begin + a.pix_per_split);
+  if (p_begin >= p_end) return;
+  const int taps = a.ks * a.ks;
+
+  int a_prow[AI], a_goff[AI];
+  bool a_ok[AI];
+  for (int i = 0; i < AI; ++i) {
+    const int o = (wave * AI + i) * 1024 + lane * 16;
+    const int prow = o / RA, pcol = (o % RA) >> 4;
+    const int lc = pcol ^ ((prow & 3) << 2);               // position -> kind lc >> 4, 8-channel group lc & 15
+    const int col = co0 + (lc & 15) * 8;
+    a_prow[i] = prow;
+    a_goff[i] = col * 2 + (lc >> 4) * 8;                   // bf16 units inside the pixel: 4 B per channel
+    a_ok[i] = (col + 8 <= a.lddy) && (col < a.Cout);
+  }
+  int b_prow[BI], b_tap[BI], b_cc[BI], b_oy[BI], b_ox[BI];
+  bool b_ok[BI];
+  for (int i = 0; i < BI; ++i) {
+    const int o = (wave * BI + i) * 1024 + lane * 16;
+    const int prow = o / RB, pcol = (o % RB) >> 4;
+    const int lc = pcol ^ ((prow & 3) << 2);               // kind lc >> 5, group lc & 31
+    const int nq = n0 / 8 + (lc & 31);
+    int tap, cc;
+    chunk_to_tap(nq, a.ks, a.cpt_shift, tap, cc);
+    b_prow[i] = prow;
+    b_tap[i] = tap;
+    b_cc[i] = cc * 2 + (lc >> 5);
+    b_ok[i] = (nq < a.nchunks) && (tap < taps);
+    const int rem = (p_begin + prow) % (a.H * a.W);
+    b_oy[i] = rem / a.W;
+    b_ox[i] = rem % a.W;
+  }
+
+  auto stage_load = [&](int kt, int buf) {
+    unsigned char* sA = smem + buf * STAGE;
+    unsigned char* sB = sA + TA;
+    const int pbase = p_begin + kt * BKP;
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int pix = pbase + a_prow[i];
+      const void* src = (pix < p_end && a_ok[i]) ? (const void*)(dy + (int64_t)pix * a.lddy * 2 + a_goff[i])
+                                                 : (const void*)g_zero_page;
+      glds16(src, sA + (wave * AI + i) * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int pix = pbase + b_prow[i];
+      const void* src = g_zero_page;
+      if (pix < p_end && b_ok[i]) {
+        if (a.ks == 1) {
+          src = x + (int64_t)pix * a.Cin * 2 + (int64_t)b_cc[i] * 8;
+        } else {
+          const int ky = b_tap[i] / 3, kx = b_tap[i] - ky * 3;
+          const int iy = b_oy[i] + ky - 1, ix = b_ox[i] + kx - 1;
+          if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            src = x + ((int64_t)pix + (int64_t)(ky - 1) * a.W + (kx - 1)) * a.Cin * 2 + (int64_t)b_cc[i] * 8;
+        }
+      }
+      glds16(src, sB + (wave * BI + i) * 1024);
+      if (a.ks != 1) {
+        b_ox[i] += BKP;
+        while (b_ox[i] >= a.W) {
+          b_ox[i] -= a.W;
+          if (++b_oy[i] == a.H) b_oy[i] = 0;
+        }
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+  for (int i = 0; i < 2; ++i)
+    for (int j = 0; j < 2; ++j)
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int h = lane >> 5;
+  const int g16 = lane >> 4, t16 = lane & 15;
+  const int tq = t16 >> 2, tp = t16 & 3;
+
+  auto stage_compute = [&](int buf) {
+    const unsigned char* sA = smem + buf * STAGE;
+    const unsigned char* sB = sA + TA;
+#pragma unroll
+    for (int s = 0; s < BKP / 16; ++s) {
+      s16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int prow = 16 * s + 8 * h + 4 * e + tq;
+        const int sw = (prow & 3) << 6;
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int ca = (wr * 64 + f * 32 + (g16 & 1) * 16 + 4 * tp) * 2;      // byte column of the hi value
+          const int cb = (wc * 64 + f * 32 + (g16 & 1) * 16 + 4 * tp) * 2;
+          const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sA + prow * RA + (ca ^ sw)));
+          const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sA + prow * RA + ((ca + RA / 2) ^ sw)));
+          const s16x4 v2 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sB + prow * RB + (cb ^ sw)));
+          const s16x4 v3 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(sB + prow * RB + ((cb + RB / 2) ^ sw)));
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            ah[f][4 * e + k] = v0[k]; al[f][4 * e + k] = v1[k];
+            bh[f][4 * e + k] = v2[k]; bl[f][4 * e + k] = v3[k];
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bl[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah[i]), __builtin_bit_cast(bf16x8, bh[j]), acc[i][j], 0, 0, 0);
+    }
+  };
+
+  const int KT = (p_end - p_begin + BKP - 1) / BKP;
+  stage_load(0, 0);
+  if (KT > 1) stage_load(1, 1);
+  int cur = 0, nxt = 2;
+  for (int kt = 0; kt < KT; ++kt) {
+    if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AI + BI) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // stage kt landed for every wave; everyone is done with stage kt-1
+    asm volatile("" ::: "memory");
+    if (kt + 2 < KT) stage_load(kt + 2, nxt);
+    stage_compute(cur);
+    cur = (cur == 2) ? 0 : cur + 1;
+    nxt = (nxt == 2) ? 0 : nxt + 1;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + wc * 64 + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < a.Cout && n < a.Ntot) atomicAdd(dw + (int64_t)co * a.Ntot + n, acc[i][j][r]);
+      }
+    }
+}
+
 static bool use_patch_wgrad(const W3Plan& p, int ksize, int dt) {
   if (ksize != 3 || !is_bf16_storage(dt) || !p.ok || g_conv_algo == 1) return false;
   if (g_conv_algo == 2) return true;
@@ -947,6 +1124,39 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   a.nchunks = ksize * ksize * cpt;
   a.Ntot = ksize * ksize * Cin;
   if (a.M == 0) return 0;
+  // wide tiles pay off when the OUTPUT is big (fc1: 1024 x 25088 -> 784 tiles; 1.29 -> 1.02 ms); a small output with a
+  // long pixel axis (1x1 bottleneck convolutions, fc2) needs many pixel splits either way and the 64 x 64 kernel's
+  // shorter prologue wins there (profiles/r2d_bench_wgrad.txt).  algo 3: A/B hook, always the 64 x 64 kernel
+  const bool wide = split && Cout >= 128 && a.Ntot >= 256 && g_conv_algo != 3 &&
+                    (g_conv_algo == 4 || (int64_t)((a.Ntot + 255) / 256) * ((Cout + 127) / 128) >= 256);
+  if (wide) {
+    // wide layers: 128 x 256 tiles, one 8-wave workgroup per CU.  Pixel splits: the fewest that fill >= 85 % of the
+    // last round of 256 workgroups (more splits = more float-atomic traffic), each at least 8 stages long
+    constexpr int BKP = 32, LDS = 3 * 32 * (128 + 256) * 4;
+    const int tiles_n = (a.Ntot + 255) / 256, tiles_m = (Cout + 127) / 128, tiles = tiles_n * tiles_m;
+    const int max_splits = std::max(1, a.M / (8 * BKP));
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sp = 1; sp <= std::min(max_splits, 512); ++sp) {
+      const int64_t wgs = (int64_t)tiles * sp;
+      const double eff = (double)wgs / (double)((wgs + 255) / 256 * 256);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+      if (eff >= 0.85 && wgs >= 512) { best = sp; break; }
+      if (wgs >= 4096) break;
+    }
+    int pps = (a.M + best - 1) / best;
+    pps = (pps + BKP - 1) / BKP * BKP;
+    const int splits = (a.M + pps - 1) / pps;
+    a.pix_per_split = pps;
+    a.tiles_n = tiles_n;
+    a.tiles_m = tiles_m;
+    static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_x3w),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+    SFOD_REQUIRE(attr_rc == hipSuccess, "wgrad: cannot raise the dynamic LDS limit");
+    hipLaunchKernelGGL(k_conv_wgrad_x3w, dim3(tiles * splits), dim3(512), LDS, s, (const bf16_t*)x, (const bf16_t*)dy,
+                       dw_out, a);
+    return sfod_check_launch("conv_wgrad_x3w");
+  }
   const int BKP = (dt == SFOD_F32) ? 32 : 64;
   const int TILE = split ? 64 : 128;        // bf16x3: 64 logical channels x 64 logical columns per workgroup
   const int tiles_n = (a.Ntot + TILE - 1) / TILE, tiles_m = (Cout + TILE - 1) / TILE;

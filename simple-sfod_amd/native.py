@@ -632,6 +632,9 @@ def conv_weight_grad(x, dy, weight, operand=None):
     if sink is not None and k == 3 and x.shape[-1] == cin and conv_wgrad_oihw_supported(x, dy, cout, 3):
         conv_wgrad_oihw(x, dy, sink, accumulate=True)     # the slab reduction writes OIHW directly
         return None
+    if sink is not None and k == 1 and x.shape[-1] == cin and (dt_of(x) != BF16X3 or cout % 8 == 0):
+        conv_wgrad(x, dy, cout, 1, dw_packed=sink.view(cout, 1, cin))    # packed [Cout,1,Cin] IS the OIHW layout: the
+        return None                                                     # kernel's atomics accumulate in place
     dwp = conv_wgrad(x, dy, cout, k)
     if sink is not None:
         unpack_conv_wgrad(dwp, sink, accumulate=True)

@@ -148,8 +148,10 @@ def test_conv3x3_patch_kernel(native, shape, variant, wg):
                                    (3, 8, 8, 3, 64, 3), (1, 40, 1, 1024, 41, 1),
                                    # bottleneck shapes on odd-sized maps (ResNet-C4 path)
                                    (2, 17, 23, 128, 128, 3), (2, 17, 23, 64, 64, 3), (2, 17, 23, 512, 128, 1),
-                                   (2, 17, 23, 128, 512, 1), (2, 17, 23, 64, 256, 1)])
-@pytest.mark.parametrize("algo", [1, 0])
+                                   (2, 17, 23, 128, 512, 1), (2, 17, 23, 64, 256, 1),
+                                   # wide-tile weight gradient (128 x 256 per workgroup): ragged tiles, many pixel splits
+                                   (1, 300, 1, 1000, 200, 1), (4, 10, 10, 256, 136, 1), (2, 40, 64, 264, 128, 1)])
+@pytest.mark.parametrize("algo", [1, 0, 4])      # 1: generic kernels only, 4: wide-tile weight gradient wherever it applies
 def test_conv_dgrad_and_wgrad(native, shape, algo):
     B, H, W, Cin, Cout, ks = shape
     g = torch.Generator().manual_seed(11)
