@@ -16,7 +16,7 @@ sfod = importlib.import_module("simple-sfod_amd")
 yaml = {"vgg": "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml",
         "r101": "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml"}[args.model]
 cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs", yaml),
-                            ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", "bf16", "SOLVER.IMS_PER_BATCH_TARGET", str(args.batch),
+                            ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", "bf16x3", "SOLVER.IMS_PER_BATCH_TARGET", str(args.batch),
                              "SOLVER.CHECKPOINT_PERIOD", "0", "SFOD.SYNTHETIC.NUM_IMAGES", "16", "MODEL.DEVICE", "cuda:0"])
 tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
 for i in range(3):
