@@ -70,7 +70,11 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // inside the loop).
 // SPLIT (SFOD_BF16X3): T = bf16 over 2 * Cin physical channels holding (8 hi | 8 lo) groups; a 128-byte LDS row is
 // then 32 logical channels = two k-steps, each fed as hi*lo + lo*hi + hi*hi (fp32-equivalent product, see sfod_hip.h).
-template <typename T, typename OutT, int WM, int WN, bool UT, int WR, int NST, bool SPLIT = false>
+// BKB = bytes per LDS row (K extent of a stage): 128 (8 chunks), or 64 (4 chunks; bf16x3: ONE k-step per stage) for the
+// 256 x 256 tile (WN = 4: wave tile 64 x 128) whose three stages of 128-byte rows would not fit LDS.  The wide tile moves
+// 1/3 fewer operand bytes L2 -> LDS per MFMA than 256 x 128 -- the bound of the long-K linear layers in bf16x3, whose
+// operands are 4 bytes per element.
+template <typename T, typename OutT, int WM, int WN, bool UT, int WR, int NST, bool SPLIT = false, int BKB = 128>
 __global__ void __launch_bounds__(WR * 128)
 k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
            OutT* __restrict__ y, float* __restrict__ stats, ConvArgs a, int tiles_n, int ntiles) {
@@ -78,8 +82,13 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   constexpr int NT = WR * 128;
   constexpr int BM = WR * 32 * WM, BN = 64 * WN;
   constexpr int E = Chunk<T>::E;
-  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int CPR = BKB / 16;            // 16-byte chunks per LDS row
+  constexpr int RPI = 1024 / BKB;          // rows per 1-KiB DMA instruction
+  constexpr int STAGE = (BM + BN) * BKB;
+  static_assert(BKB == 128 || BKB == 64, "LDS rows of 128 or 64 bytes");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  // chunk c of row r is stored at chunk c ^ swz(r): conflict-free ds_read_b128 lane groups for either row length
+  auto swz = [](int r) { return BKB == 128 ? ((r >> 1) & 7) : ((r >> 2) & 3); };
 
   // XCD-aware tile order: workgroups that share an XCD (same blockIdx % 8) walk consecutive tiles
   int bid = blockIdx.x;
@@ -95,14 +104,14 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   const int HW = a.H * a.W;
 
   // ---- per-thread DMA descriptors ---------------------------------------------------------------
-  constexpr int AI = BM / (16 * WR), BI = BN / (16 * WR);  // 1-KiB DMA instructions per wave and stage
+  constexpr int AI = BM / (RPI * 2 * WR), BI = BN / (RPI * 2 * WR);  // 1-KiB DMA instructions per wave and stage
   static_assert(BI >= 1, "tile too narrow for this wave count");
   int a_row[AI];      // row inside the tile
   int a_oy[AI], a_ox[AI];
   int64_t a_pix[AI];  // flat pixel index (== m) or -1
   for (int i = 0; i < AI; ++i) {
     const int q = wave * AI + i;
-    const int row = q * 8 + (lane >> 3);
+    const int row = q * RPI + lane / CPR;
     a_row[i] = row;
     const int m = m0 + row;
     if (m < a.M) {
@@ -113,9 +122,9 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
     } else { a_pix[i] = -1; a_oy[i] = 0; a_ox[i] = 0; }
   }
   int b_row[BI];
-  for (int i = 0; i < BI; ++i) b_row[i] = (wave * BI + i) * 8 + (lane >> 3);
-  const int pc = lane & 7;
-  const int KT = (a.kchunks + 7) / 8;
+  for (int i = 0; i < BI; ++i) b_row[i] = (wave * BI + i) * RPI + lane / CPR;
+  const int pc = lane % CPR;
+  const int KT = (a.kchunks + CPR - 1) / CPR;
   const int64_t wrow_elems = (int64_t)a.kchunks * E;
 
   // hoisted per-row state of the uniform-tap path
@@ -127,7 +136,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   bool b_ok[BI];
   if (UT) {
     for (int i = 0; i < AI; ++i) {
-      const int lc = pc ^ ((a_row[i] >> 1) & 7);
+      const int lc = pc ^ swz(a_row[i]);
       a_lcs[i] = lc;
       a_base[i] = (a_pix[i] >= 0 ? a_pix[i] : 0) * a.Cin + (int64_t)lc * E;
       unsigned m = 0;
@@ -142,7 +151,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
       a_mask[i] = m;
     }
     for (int i = 0; i < BI; ++i) {
-      const int lc = pc ^ ((b_row[i] >> 1) & 7);
+      const int lc = pc ^ swz(b_row[i]);
       b_lcs[i] = lc;
       const int n = n0 + b_row[i];
       b_ok[i] = n < a.Cout;
@@ -152,10 +161,10 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
 
   auto stage_load = [&](int kt, int buf) {
     unsigned char* sA = smem + buf * STAGE;
-    unsigned char* sB = sA + BM * 128;
+    unsigned char* sB = sA + BM * BKB;
     if (UT) {
       // scalar (wave-uniform) tap decode for the whole K tile
-      const int gq0 = kt * 8;
+      const int gq0 = kt * CPR;
       int tap = 0, cc0 = gq0;
       if (a.ks != 1) { tap = gq0 >> a.cpt_shift; cc0 = gq0 & ((1 << a.cpt_shift) - 1); }
       const int ky = tap / 3, kx = tap - ky * 3;
@@ -178,8 +187,8 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int row = a_row[i];
-      const int lc = pc ^ ((row >> 1) & 7);
-      const int gq = kt * 8 + lc;
+      const int lc = pc ^ swz(row);
+      const int gq = kt * CPR + lc;
       const void* src = g_zero_page;
       if (a_pix[i] >= 0 && gq < a.kchunks) {
         int tap, cc;
@@ -198,8 +207,8 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int row = b_row[i];
-      const int lc = pc ^ ((row >> 1) & 7);
-      const int gq = kt * 8 + lc;
+      const int lc = pc ^ swz(row);
+      const int gq = kt * CPR + lc;
       const int n = n0 + row;
       const void* src = g_zero_page;
       if (n < a.Cout && gq < a.kchunks) src = w + (int64_t)n * wrow_elems + (int64_t)gq * E;
@@ -211,13 +220,13 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   int offA[WM], swzA[WM], offB[WN], swzB[WN];
   for (int i = 0; i < WM; ++i) {
     const int r = wr * 32 * WM + i * 32 + (lane & 31);
-    offA[i] = r * 128;
-    swzA[i] = (r >> 1) & 7;
+    offA[i] = r * BKB;
+    swzA[i] = swz(r);
   }
   for (int j = 0; j < WN; ++j) {
     const int r = wc * 32 * WN + j * 32 + (lane & 31);
-    offB[j] = r * 128;
-    swzB[j] = (r >> 1) & 7;
+    offB[j] = r * BKB;
+    swzB[j] = swz(r);
   }
   const int h = lane >> 5;
 
@@ -228,10 +237,10 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
 
   auto stage_compute = [&](int buf) {
     const unsigned char* sA = smem + buf * STAGE;
-    const unsigned char* sB = sA + BM * 128;
+    const unsigned char* sB = sA + BM * BKB;
     if constexpr (SPLIT) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < BKB / 64; ++t) {
         bf16x8 ah[WM], al[WM], bh[WN], bl[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i) {
@@ -261,7 +270,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
       }
     } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
+      for (int s = 0; s < BKB / 32; ++s) {
         bf16x8 af[WM], bfr[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -277,7 +286,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
       }
     } else {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) {
+      for (int c = 0; c < CPR; ++c) {
         f32x4 af[WM], bfr[WN];
 #pragma unroll
         for (int i = 0; i < WM; ++i)
@@ -342,7 +351,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   }
   constexpr bool STAGED = (sizeof(OutT) == 2);   // 2-byte outputs go through LDS for 16-byte stores
   constexpr int CPITCH = BN * 2 + 16;            // bytes per staged row (+16: spread the banks)
-  constexpr int SRED_OFF = BM * CPITCH;          // scratch for the BN partials, behind the staged tile
+  constexpr int SRED_OFF = STAGED ? BM * CPITCH : 0;   // scratch for the BN partials, behind the staged tile (if any)
   if (STAGED) __syncthreads();                   // every wave is done with the operand stages
 #pragma unroll
   for (int i = 0; i < WM; ++i)
@@ -489,14 +498,16 @@ extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, in
   return (B * H * W + 127) / 128;
 }
 
-template <typename T, typename OutT, int WN, bool UT, int WR, int NST, bool SPLIT = false>
+template <typename T, typename OutT, int WN, bool UT, int WR, int NST, bool SPLIT = false, int BKB = 128>
 static int launch_one(const void* x, const void* w, const float* bias, void* y, float* stats,
                       const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WR * 64, BN = 64 * WN;
-  constexpr int OPER = NST * (BM + BN) * 128;
-  constexpr int EPI = BM * (BN * 2 + 16) + WR * BN * 4;  // staged C tile + BN partial scratch
+  constexpr int OPER = NST * (BM + BN) * BKB;
+  // staged C tile (2-byte outputs only) + BN partial scratch
+  constexpr int EPI = (sizeof(OutT) == 2 ? BM * (BN * 2 + 16) : 0) + WR * BN * 4;
   constexpr int LDS = OPER > EPI ? OPER : EPI;
-  auto kern = k_conv_fwd<T, OutT, 2, WN, UT, WR, NST, SPLIT>;
+  static_assert(LDS <= 160 * 1024, "LDS budget");
+  auto kern = k_conv_fwd<T, OutT, 2, WN, UT, WR, NST, SPLIT, BKB>;
   // once per kernel instantiation and process (function-local static: initialised exactly once, thread-safe)
   static const hipError_t attr_rc = (LDS > 64 * 1024)
       ? hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS)
@@ -519,6 +530,18 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
   if constexpr (UT) {
     if (tall > 0 && a.ks == 1 && a.Cin >= 4096 && (int64_t)((a.M + 255) / 256) * ((a.Cout + 63) / 64) <= tall)
       return launch_one<T, OutT, 1, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);
+  }
+  // bf16x3 linear layers / 1x1 convolutions with wide outputs: 256 x 256 tiles (64-byte K stages) when their rounds of
+  // 256 workgroups (one per CU) are filled well enough to beat 256 x 128 (profiles/r2d_bench_gemm.txt)
+  if constexpr (UT && SPLIT && sizeof(OutT) == 4) {
+    static const int wide = []() { const char* e = getenv("SFOD_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+    if (wide > 0 && a.ks == 1 && a.Cout >= 256) {
+      const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
+      const int64_t t128 = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
+      const double r256 = (double)((t256 + 255) / 256), r128 = (double)((t128 + 255) / 256) * 0.5;   // rounds, in 256-wide tile times
+      if (wide == 2 || (t256 >= 200 && r256 * 0.80 <= r128))
+        return launch_one<T, OutT, 4, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
+    }
   }
   // 256 x 128 tiles with a 3-stage DMA pipeline once the grid still fills the chip (>= 2 tiles / CU)
   const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
