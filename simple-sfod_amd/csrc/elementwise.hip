@@ -431,6 +431,49 @@ k_bn_add_relu_fwd(const T* __restrict__ y, const float* __restrict__ mean, const
   }
 }
 
+// fp32 in / out plus the same values as SFOD_BF16X3 operand pairs (the next convolution's input): the bottleneck output
+// feeds both the residual stream (fp32) and conv1 of the next block, whose operand would otherwise be made by a separate
+// conversion pass re-reading the tensor
+__global__ void __launch_bounds__(256)
+k_bn_add_relu_fwd_dual(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                       const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
+                       float* __restrict__ z, split_t* __restrict__ zp, int64_t rows, int C) {
+  constexpr int V = 8;
+  const int cv = C / V;
+  const int64_t total = rows * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(t % cv) * V;
+    float v[V], r[V];
+    load_n<float, V>(y + t * V, v);
+    load_n<float, V>(res + t * V, r);
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+      v[i] = fmaxf((v[i] - mean[c0 + i]) * (invstd[c0 + i] * gamma[c0 + i]) + beta[c0 + i] + r[i], 0.f);
+    store_n<float, V>(z + t * V, v);
+    store_n<split_t, V>(zp + t * V, v);
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_add_act_dual(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
+               split_t* __restrict__ op, int64_t nvec, int act) {
+  constexpr int V = 8;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float x[V], y[V];
+    load_n<float, V>(a + t * V, x);
+    load_n<float, V>(b + t * V, y);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float v = x[i] + y[i];
+      x[i] = act ? fmaxf(v, 0.f) : v;
+    }
+    store_n<float, V>(o + t * V, x);
+    store_n<split_t, V>(op + t * V, x);
+  }
+}
+
 static inline int ew_grid(int64_t total) {
   int64_t g = (total + 255) / 256;
   if (g > 256 * 16) g = 256 * 16;
@@ -439,14 +482,18 @@ static inline int ew_grid(int64_t total) {
 }
 
 extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
-                                    const float* beta, const void* residual, void* z, int64_t rows, int C, int dt,
-                                    void* stream) {
-  const int V = (dt == SFOD_F32) ? 4 : 8;
+                                    const float* beta, const void* residual, void* z, void* z_pairs, int64_t rows,
+                                    int C, int dt, void* stream) {
+  const int V = (dt == SFOD_F32 && z_pairs == nullptr) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "bn_add_relu: C not a multiple of the vector width");
+  SFOD_REQUIRE(z_pairs == nullptr || dt == SFOD_F32, "bn_add_relu: the operand-pair copy is made from fp32 data");
   if (rows == 0) return 0;
   const int grid = ew_grid(rows * (C / V));
   hipStream_t s = (hipStream_t)stream;
-  if (dt == SFOD_F32)
+  if (z_pairs != nullptr)
+    hipLaunchKernelGGL(k_bn_add_relu_fwd_dual, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma, beta,
+                       (const float*)residual, (float*)z, (split_t*)z_pairs, rows, C);
+  else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_bn_add_relu_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
                        beta, (const float*)residual, (float*)z, rows, C);
   else
@@ -906,12 +953,17 @@ __global__ void k_add_act(const T* __restrict__ a, const T* __restrict__ b, T* _
   }
 }
 
-extern "C" int sfod_add_act(const void* a, const void* b, void* out, int64_t n, int act, int dt, void* stream) {
-  const int V = (dt == SFOD_F32) ? 4 : 8;
+extern "C" int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, int64_t n, int act, int dt,
+                            void* stream) {
+  const int V = (dt == SFOD_F32 && out_pairs == nullptr) ? 4 : 8;
   SFOD_REQUIRE(n % V == 0, "add_act: n not a multiple of the vector width");
+  SFOD_REQUIRE(out_pairs == nullptr || dt == SFOD_F32, "add_act: the operand-pair copy is made from fp32 data");
   const int64_t nvec = n / V;
   if (nvec == 0) return 0;
-  if (dt == SFOD_F32)
+  if (out_pairs != nullptr)
+    hipLaunchKernelGGL(k_add_act_dual, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                       (const float*)b, (float*)out, (split_t*)out_pairs, nvec, act);
+  else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_add_act<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
                        (const float*)b, (float*)out, nvec, act);
   else

@@ -175,6 +175,7 @@ class ResNet(nn.Module):
         self.bn_momentum = 0.1
         self.bn_updates_per_forward = 1      # see backbone_vgg: momentum updates folded into one forward
         self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
+        self.dual_join = os.environ.get("SFOD_NO_DUAL_JOIN", "0") != "1"           # A/B hook: join kernels also emit the operand pairs
 
     # ---- Detectron2 Backbone surface -----------------------------------------------------------------
     @property
@@ -268,7 +269,7 @@ class ResNet(nn.Module):
         self._wp = {id(c): views[i] for i, c in enumerate(convs)}
         self._wr = {id(c): views[n + i] for i, c in enumerate(convs)} if with_dgrad else {}
 
-    def _live_conv_bn(self, x, conv, relu, dt, residual=None, z_operand=False):
+    def _live_conv_bn(self, x, conv, relu, dt, residual=None, z_operand=False, dual=False):
         """conv + train-mode BatchNorm (+ ReLU / residual join).  ``x``: an MFMA operand tensor (bf16x3: pairs) or an
         activation-dtype tensor (converted by conv_fwd).  ``z_operand``: write the output directly as the next
         convolution's operand (bf16x3: the BatchNorm kernel emits the pairs; no separate conversion pass)."""
@@ -287,24 +288,37 @@ class ResNet(nn.Module):
             y = native.conv_fwd(x, wp, None, conv.out_channels, k)
             mean, invstd = bn.running_mean, torch.rsqrt(bn.running_var + bn.eps)
         if residual is not None:      # bottleneck tail: relu(bn(y) + shortcut) without materialising bn(y)
-            z = native.bn_add_relu_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual)
+            # dual: z = (fp32 block output, the same as operand pairs for the next block's conv1 / shortcut)
+            z = native.bn_add_relu_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual,
+                                       with_operand=dual)
         else:
             z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False, relu=relu,
                                         out_dtype=self.compute_dtype if z_operand else None)
         return y, mean, invstd, z
 
-    def _block_forward(self, blk, x, live, dt):
-        """-> (block output, saved activations or None)."""
-        xs = native.subsample2(x) if blk.stride == 2 else x
+    def _block_forward(self, blk, x, live, dt, x_op=None, want_op=False):
+        """-> (block output, its operand-pair copy or None, saved activations or None).  ``x_op``: the block input as
+        MFMA operand when the producer already wrote it (bf16x3: the previous block's join kernel emits the fp32
+        residual stream AND the pairs in one pass); ``want_op``: do the same for the next block."""
+        dual = want_op and self.dual_join and self.compute_dtype == native.SPLIT_DTYPE and x.shape[-1] % 8 == 0
+        if blk.stride == 2:
+            xs, x_op = native.subsample2(x), None
+        else:
+            xs = x
+        # the block input becomes an operand ONCE, shared by conv1, the shortcut conv and (live blocks) both weight
+        # gradients
+        xs_op = x_op if x_op is not None else native.as_operand(xs, self.compute_dtype)
         if not live:
-            sc = x if blk.shortcut is None else self._frozen_conv(xs, blk.shortcut, 0, dt)
-            o = self._frozen_conv(xs, blk.conv1, 1, dt)
+            sc = x if blk.shortcut is None else self._frozen_conv(xs_op, blk.shortcut, 0, dt)
+            o = self._frozen_conv(xs_op, blk.conv1, 1, dt)
             o = self._frozen_conv(o, blk.conv2, 1, dt)
             o = self._frozen_conv(o, blk.conv3, 0, dt)
-            return native.add_act(o, sc, 1), None
-        # bf16x3: the block input (fp32 residual stream) becomes an operand ONCE, shared by conv1, the shortcut conv
-        # and both weight gradients; a1 / a2 only feed convolutions, so their BatchNorm kernels write pairs directly
-        xs_act, xs = xs, native.as_operand(xs, self.compute_dtype)
+            if dual:
+                out, out_op = native.add_act(o, sc, 1, with_operand=True)
+                return out, out_op, None
+            return native.add_act(o, sc, 1), None, None
+        # a1 / a2 only feed convolutions, so their BatchNorm kernels write pairs directly
+        xs_act, xs = xs, xs_op
         y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt, z_operand=True)
         y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt, z_operand=True)
         if blk.shortcut is not None:
@@ -313,12 +327,17 @@ class ResNet(nn.Module):
             ys = ms = is_ = None
             ts = x
         del xs_act
+        out_op = None
         if self.fuse_residual:
-            y3, m3, i3, out = self._live_conv_bn(a2, blk.conv3, False, dt, residual=ts)
+            y3, m3, i3, out = self._live_conv_bn(a2, blk.conv3, False, dt, residual=ts, dual=dual)
+            if dual:
+                out, out_op = out
         else:
             y3, m3, i3, t3 = self._live_conv_bn(a2, blk.conv3, False, dt)
-            out = native.add_act(t3, ts, 1)
-        return out, (x.shape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out)
+            out = native.add_act(t3, ts, 1, with_operand=dual)
+            if dual:
+                out, out_op = out
+        return out, out_op, (x.shape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out)
 
     def _forward_impl(self, x, save=True):
         dt = native.dt_of_dtype(self.compute_dtype)
@@ -327,13 +346,16 @@ class ResNet(nn.Module):
         saved, outs = [], {}
         self._pack_live_weights(dt, with_dgrad=save)
         x = self._stem_forward(x, dt)
-        for name in self.stage_names:
+        x_op = None
+        blocks = [(name, blk) for name in self.stage_names for blk in getattr(self, name)]
+        for bi, (name, blk) in enumerate(blocks):
             live = name not in self.frozen
-            for blk in getattr(self, name):
-                x, sv = self._block_forward(blk, x, live, dt)
-                if live and save:
-                    saved.append(sv)
-            if name in self._out_features:
+            # the next block reads this output as a convolution operand unless it subsamples first (stride 2)
+            want_op = bi + 1 < len(blocks) and blocks[bi + 1][1].stride != 2
+            x, x_op, sv = self._block_forward(blk, x, live, dt, x_op=x_op, want_op=want_op)
+            if live and save:
+                saved.append(sv)
+            if name in self._out_features and (bi + 1 == len(blocks) or blocks[bi + 1][0] != name):
                 outs[name] = x
         return saved, [outs[n] for n in self._out_features]
 

@@ -674,13 +674,15 @@ def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True, out_dtype=No
     return z
 
 
-def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual):
-    """relu(bn(y) + residual) in one pass (bottleneck tail)."""
+def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual, with_operand=False):
+    """relu(bn(y) + residual) in one pass (bottleneck tail).  ``with_operand`` (fp32 data of a bf16x3 model): also return
+    the same values as (hi, lo) operand pairs -> (z, z_pairs)."""
     assert residual.shape == y.shape and residual.dtype == y.dtype
     z = torch.empty_like(y)
     C = y.shape[-1]
-    call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, y.numel() // C, C, dt_of(y))
-    return z
+    zp = torch.empty(y.shape, dtype=SPLIT_DTYPE, device=y.device) if with_operand else None
+    call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, zp, y.numel() // C, C, dt_of(y))
+    return (z, zp) if with_operand else z
 
 
 def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None, relu=True,
@@ -716,10 +718,12 @@ def mul_mask_(a, mask_u8, scale):
     return a
 
 
-def add_act(a, b, act=1):
+def add_act(a, b, act=1, with_operand=False):
+    """act(a + b); ``with_operand`` (fp32 data of a bf16x3 model): also the (hi, lo) operand pairs -> (out, out_pairs)."""
     out = torch.empty_like(a)
-    call("sfod_add_act", a, b, out, a.numel(), int(act), dt_of(a))
-    return out
+    op = torch.empty(a.shape, dtype=SPLIT_DTYPE, device=a.device) if with_operand else None
+    call("sfod_add_act", a, b, out, op, a.numel(), int(act), dt_of(a))
+    return (out, op) if with_operand else out
 
 
 def subsample2(x):

@@ -24,7 +24,7 @@ ref = F.relu(cbn(o2, "conv3") + xr)
 w = torch.randn(ref.shape, generator=g)
 (ref * w).sum().backward()
 xd = x.permute(0, 2, 3, 1).contiguous().cuda()
-out, sv = net._block_forward(blk, xd, True, native.dt_of_dtype(net.compute_dtype))
+out, _, sv = net._block_forward(blk, xd, True, native.dt_of_dtype(net.compute_dtype))
 print("out", rel(out.cpu().permute(0, 3, 1, 2), ref.detach()))
 (xshape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, outs) = sv
 f32 = lambda t: native.cast(t, torch.float32) if t.dtype != torch.float32 else t

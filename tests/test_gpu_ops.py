@@ -980,6 +980,14 @@ def test_bn_add_relu_fwd_equals_the_two_pass_form(native, dtype):
         two = native.add_act(native.bn_relu_pool_fwd(yd, *args, False, relu=False), rd, 1)
         assert torch.equal(got, two)
         torch.testing.assert_close(got.cpu(), ref, rtol=1e-6, atol=1e-6)
+        # dual form: the fp32 result plus the same values as bf16x3 operand pairs, one pass (vector width 8 instead of
+        # 4: the fp32 half may differ by FMA contraction, the pairs are the exact split of that half)
+        z, zp = native.bn_add_relu_fwd(yd, *args, rd, with_operand=True)
+        torch.testing.assert_close(z, got, rtol=2e-7, atol=1e-7)
+        assert zp.dtype == native.SPLIT_DTYPE and torch.equal(zp.view(torch.bfloat16), native.cast(z, native.SPLIT_DTYPE).view(torch.bfloat16))
+        o, op = native.add_act(yd, rd, 1, with_operand=True)
+        assert torch.equal(o, native.add_act(yd, rd, 1))
+        assert torch.equal(op.view(torch.bfloat16), native.cast(o, native.SPLIT_DTYPE).view(torch.bfloat16))
     else:
         ref16 = torch.relu((yd.float().cpu() - mean) * (invstd * gamma) + beta + rd.float().cpu())
         torch.testing.assert_close(got.float().cpu(), ref16, rtol=1e-2, atol=1e-2)

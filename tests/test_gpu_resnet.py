@@ -135,7 +135,7 @@ def test_bottleneck_block_forward_backward_tight(native, dtype, cin, cout, bott,
         w = w.bfloat16().float()
     (ref * w).sum().backward()
     xd = x.permute(0, 2, 3, 1).contiguous().cuda().to(cd)
-    out, sv = net._block_forward(blk, xd, True, native.dt_of_dtype(net.compute_dtype))
+    out, _, sv = net._block_forward(blk, xd, True, native.dt_of_dtype(net.compute_dtype))
     tol = {"fp32": 2e-5, "bf16x3": 3e-5}.get(dtype, 2e-2)
     assert rel(out.float().cpu().permute(0, 3, 1, 2), ref.detach()) < tol
     dout = w.permute(0, 2, 3, 1).contiguous().cuda().to(cd)
