@@ -83,6 +83,17 @@ int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, in
  * weight gradient wherever it applies.  For A/B tests
  * and benchmarks. */
 int sfod_set_conv_algo(int algo);
+/* Data gradient of a 3x3 convolution with the BatchNorm-backward REDUCTION of the layer below folded into its epilogue
+ * (the hand-written backward of vgg.py's conv-BN-ReLU chain; torch autograd runs these as separate kernels).
+ * x: the upper layer's dy [B,H,W,Cin] (operand dtype dt), w: its rotated weights, dz [B,H,W,Cout] fp32 (dense): the
+ * gradient w.r.t. the lower layer's activated output.  y / mean / invstd / gamma / beta: the lower layer's saved
+ * pre-BatchNorm output (fp32 [B,H,W,Cout]) and BatchNorm inputs; red_ws receives sfod_conv_dgrad_bnred_blocks(...) rows
+ * of 2 * Cout partial sums for sfod_bn_relu_pool_bwd(reduced_blocks = that count).  _blocks returns 0 when the shape /
+ * dtype is not served by the halo-patch kernel: use sfod_conv_fwd and the unfused BatchNorm backward then. */
+int sfod_conv_dgrad_bnred_blocks(int B, int H, int W, int Cin, int Cout, int dt);
+int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, int W, int Cin, int Cout, int dt,
+                          const float* y, const float* mean, const float* invstd, const float* gamma,
+                          const float* beta, float* red_ws, void* stream);
 /* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
  * 4 = 512 x 64 (applied where the channel counts allow it).  For A/B runs and parity tests. */
 int sfod_set_conv3x3_variant(int variant);
@@ -182,7 +193,9 @@ int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, 
 int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* dy, float* dgamma,
                           float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
-                          int W, int C, int pool, int dt, int out_dt, void* stream);
+                          int W, int C, int pool, int dt, int out_dt, int reduced_blocks, void* stream);
+/* reduced_blocks > 0: `ws` already holds that many rows of partial (dbeta | dgamma) sums, written by the epilogue of the
+ * data-gradient convolution that produced dz (sfod_conv_dgrad_bnred): the reduction pass over dz and y is skipped. */
 int sfod_bn_bwd_ws_floats(int M, int C);
 /* ---- ResNet-101-C4 backbone helpers (d2 build_resnet_backbone selected by the r101 yaml's missing
  * BACKBONE.NAME, configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28) ----

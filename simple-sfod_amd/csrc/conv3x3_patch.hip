@@ -71,6 +71,16 @@ struct P3Args {
   int nbody;    // Cin / (32 * G)
   int ntiles;
   int nblk;
+  // data-gradient launches only (fp32 output): the BatchNorm-backward reduction of the layer whose output gradient this
+  // kernel produces, folded into the epilogue.  The output tile dz and the saved pre-BatchNorm tensor red_y share one
+  // shape; per workgroup (sum g, sum g * xhat) with g = dz * [bn(y) > 0] go to red_ws[mtile][2][Cout] -- what
+  // k_bn_bwd_reduce would write, so k_bn_bwd_finalize / k_bn_bwd_apply follow unchanged.  nullptr: off.
+  const float* red_y;
+  const float* red_mean;
+  const float* red_invstd;
+  const float* red_gamma;
+  const float* red_beta;
+  float* red_ws;
 };
 
 // 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16), through a raw buffer
@@ -405,6 +415,19 @@ k_conv3x3_patch(P3Args a) {
     static_assert(8 * 32 * FP <= Lay<G, FM>::STG || 8 * 32 * FP <= Lay<G, FM>::OPER, "fp32 staging must fit the operand area");
     unsigned char* stg = smem + wave * (32 * FP);
     const bool vec_ok = (a.ldy % 4) == 0;
+    // fused BatchNorm-backward reduction (see P3Args): this lane's 4 channels are fixed over the whole tile
+    const bool red = (a.red_y != nullptr);
+    float rmu[4], rsc[4], rsh[4], ris[4], rdb[4] = {0.f, 0.f, 0.f, 0.f}, rdg[4] = {0.f, 0.f, 0.f, 0.f};
+    if (red) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = min(n0 + wn * 64 + (lane & 15) * 4 + q, a.Cout - 1);
+        rmu[q] = a.red_mean[n];
+        ris[q] = a.red_invstd[n];
+        rsc[q] = ris[q] * a.red_gamma[n];
+        rsh[q] = a.red_beta[n];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -429,11 +452,60 @@ k_conv3x3_patch(P3Args a) {
         float* dst = yo + (ybase + pix) * a.ldy + n;
         if (vec_ok && n + 4 <= a.Cout) {
           *reinterpret_cast<float4*>(dst) = v;
+          if (red) {      // (the host only enables it for Cout % 4 == 0, ldy == Cout)
+            const float4 yv = *reinterpret_cast<const float4*>(a.red_y + (ybase + pix) * a.ldy + n);
+            const float ye[4] = {yv.x, yv.y, yv.z, yv.w}, ge[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float d = ye[q] - rmu[q];
+              const float g = (d * rsc[q] + rsh[q] > 0.f) ? ge[q] : 0.f;      // the mask k_bn_bwd_apply recomputes
+              rdb[q] += g;
+              rdg[q] = fmaf(g, d * ris[q], rdg[q]);
+            }
+          }
         } else {
           const float e[4] = {v.x, v.y, v.z, v.w};
           for (int q = 0; q < 4 && n + q < a.Cout; ++q) dst[q] = e[q];
         }
       }
+    }
+    if (red) {
+      // lanes l, l ^ 16, l ^ 32 hold the same 4 channels (different rows); then the waves that share the columns
+      float* sred = reinterpret_cast<float*>(smem + SRED_OFF);     // [wave][64 cols][2]
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        rdb[q] += __shfl_xor(rdb[q], 16);
+        rdb[q] += __shfl_xor(rdb[q], 32);
+        rdg[q] += __shfl_xor(rdg[q], 16);
+        rdg[q] += __shfl_xor(rdg[q], 32);
+      }
+      if (lane < 16) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sred[(wave * 64 + lane * 4 + q) * 2 + 0] = rdb[q];
+          sred[(wave * 64 + lane * 4 + q) * 2 + 1] = rdg[q];
+        }
+      }
+      __syncthreads();
+      if (threadIdx.x < BN) {
+        const int col = threadIdx.x;
+        const int cwn = (G == 1) ? (col >> 6) : 0;
+        const int cl = col & 63;
+        constexpr int NWM = (G == 1) ? 4 : 8;
+        float sb = 0.f, sg = 0.f;
+#pragma unroll
+        for (int k = 0; k < NWM; ++k) {
+          const int wv = (G == 1) ? (k * 2 + cwn) : k;
+          sb += sred[(wv * 64 + cl) * 2 + 0];
+          sg += sred[(wv * 64 + cl) * 2 + 1];
+        }
+        const int n = n0 + col;
+        if (n < a.Cout) {
+          a.red_ws[(int64_t)mtile * 2 * a.Cout + n] = sb;               // k_bn_bwd_finalize: [blk][0..C) = dbeta part,
+          a.red_ws[(int64_t)mtile * 2 * a.Cout + a.Cout + n] = sg;      //                     [blk][C..2C) = dgamma part
+        }
+      }
+      if (a.stats != nullptr) __syncthreads();      // sred is reused by the statistics below
     }
   }
 
@@ -621,8 +693,15 @@ static int p3_launch_one(const P3Args& a, hipStream_t s) {
 
 // split != 0: SFOD_BF16X3 operands; Cin is then the PHYSICAL bf16 channel count (2 x logical), the output is fp32
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
-                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split) {
+                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split,
+                   const P3BnRed* red) {
   P3Args a;
+  a.red_y = nullptr; a.red_mean = a.red_invstd = a.red_gamma = a.red_beta = nullptr; a.red_ws = nullptr;
+  if (red != nullptr) {
+    if (!out_f32 || ldy != Cout || Cout % 4 != 0) { sfod_set_error("conv3x3_patch: BatchNorm-backward epilogue needs a dense fp32 output"); return SFOD_EBADARG; }
+    a.red_y = red->y; a.red_mean = red->mean; a.red_invstd = red->invstd; a.red_gamma = red->gamma; a.red_beta = red->beta;
+    a.red_ws = red->ws;
+  }
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = y; a.stats = stats;
   a.B = B; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.act = act;
   a.TH = p.TH; a.TW = p.TW; a.PW = p.TW + 2;

@@ -15,8 +15,18 @@ struct P3Plan {
   int nblk;              // BatchNorm statistics blocks = B * tiles_y * tiles_x
 };
 P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout);
+// BatchNorm-backward reduction folded into a data-gradient launch (fp32 output [B,H,W,Cout] dense): see P3Args
+struct P3BnRed {
+  const float* y;        // saved pre-BatchNorm output of the layer whose output gradient is being produced
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+  float* ws;             // [plan.nblk][2][Cout] partial (dbeta, dgamma) sums
+};
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
-                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split = 0);
+                   int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split = 0,
+                   const P3BnRed* red = nullptr);
 
 // BatchNorm statistics buffer layout shared by every conv kernel:
 //   stats[blk][0][c] = sum over the block's valid rows, stats[blk][1][c] = sum of squared deviations

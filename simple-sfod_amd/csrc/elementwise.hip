@@ -793,9 +793,12 @@ extern "C" int sfod_bn_bwd_ws_floats(int M, int C) {
 extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, void* dy, float* dgamma,
                                      float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
-                                     int W, int C, int pool_flags, int dt, int dy_dt, void* stream) {
+                                     int W, int C, int pool_flags, int dt, int dy_dt, int reduced_blocks,
+                                     void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
+  SFOD_REQUIRE(reduced_blocks >= 0 && (reduced_blocks == 0 || (!pool && !norelu)),
+               "bn_bwd: a pre-reduced workspace (sfod_conv_dgrad_bnred) is for ReLU layers without pooling");
   SFOD_REQUIRE(dt != SFOD_BF16X3 && (dy_dt == dt || (dt == SFOD_F32 && dy_dt == SFOD_BF16X3)),
                "bn_bwd: dz / y are fp32 or bf16; dy has the same type, or bf16x3 from fp32");
   const int V = (dt == SFOD_F32) ? 4 : 8;            // reduce pass (reads only)
@@ -811,10 +814,11 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
   const int grid3 = ew_grid(units * (C / VO));
 #define LAUNCH(T, P, R, TO)                                                                            \
   do {                                                                                                 \
-    hipLaunchKernelGGL((k_bn_bwd_reduce<T, P, R>), dim3(grid1), dim3(256), lds, s, (const T*)dz,       \
-                       (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                        \
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws, grid1, C,      \
-                       dgamma, dbeta, dgamma_acc, dbeta_acc);                                          \
+    if (reduced_blocks == 0)                                                                           \
+      hipLaunchKernelGGL((k_bn_bwd_reduce<T, P, R>), dim3(grid1), dim3(256), lds, s, (const T*)dz,     \
+                         (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                      \
+    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws,                 \
+                       reduced_blocks ? reduced_blocks : grid1, C, dgamma, dbeta, dgamma_acc, dbeta_acc); \
     hipLaunchKernelGGL((k_bn_bwd_apply<T, P, R, TO>), dim3(grid3), dim3(256), 0, s, (const T*)dz,      \
                        (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (TO*)dy, B, H, W, C);    \
   } while (0)

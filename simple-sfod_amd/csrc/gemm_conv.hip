@@ -610,6 +610,31 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
   return launch_conv_fwd<bf16_t, bf16_t>(x, w, bias, y, stats, a, s);
 }
 
+// Data gradient of a 3x3 convolution (x = dy of the layer above as operand, w = its rotated weights) whose epilogue also
+// makes the BatchNorm-backward partial sums of the layer BELOW, i.e. of the tensor this launch writes (dz): halo-patch
+// kernel with fp32 output only.  sfod_conv_dgrad_bnred_blocks: number of partial rows it writes (0: shape / dtype not
+// served -- run sfod_conv_fwd and the separate reduction instead).
+extern "C" int sfod_conv_dgrad_bnred_blocks(int B, int H, int W, int Cin, int Cout, int dt) {
+  if (dt != SFOD_BF16X3 && dt != SFOD_BF16) return 0;
+  if (dt == SFOD_BF16) return 0;        // bf16 mode writes bf16 gradients: no fp32 tile to reduce
+  if (Cout % 4 != 0) return 0;
+  const P3Plan p = sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout);
+  return use_patch_kernel(p, B, H, W, 3, dt) ? p.nblk : 0;
+}
+
+extern "C" int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, int W, int Cin, int Cout,
+                                     int dt, const float* y, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, float* red_ws, void* stream) {
+  SFOD_REQUIRE(sfod_conv_dgrad_bnred_blocks(B, H, W, Cin, Cout, dt) > 0,
+               "conv_dgrad_bnred: shape not served (sfod_conv_dgrad_bnred_blocks)");
+  SFOD_REQUIRE(y && mean && invstd && gamma && beta && red_ws, "conv_dgrad_bnred: null argument");
+  const int pc = phys_ch(dt, Cin);
+  const P3Plan p = sfod_p3_plan(B, H, W, pc, Cout);
+  const P3BnRed red{y, mean, invstd, gamma, beta, red_ws};
+  return sfod_p3_launch(p, x, w, nullptr, dz, nullptr, B, H, W, pc, Cout, Cout, 0, 1, (hipStream_t)stream,
+                        dt == SFOD_BF16X3, &red);
+}
+
 // =============================================================================================
 // weight gradient.  GEMM over the pixel axis: dw[co][nf] += sum_pix dy[pix][co] * xs[pix][nf],
 // nf = flattened (tap, ci).  Both operands arrive pixel-major ([pix][channels]), i.e. transposed

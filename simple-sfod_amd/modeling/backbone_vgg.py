@@ -110,6 +110,7 @@ class vgg_backbone(nn.Module):
         # exactly: r <- r (1-m)^3 + s (1 - (1-m)^3), num_batches_tracked += 3.
         self.bn_updates_per_forward = 1
         self.fuse_first = bool(cfg.SFOD.FUSE_FIRST_LAYER) if "SFOD" in cfg and "FUSE_FIRST_LAYER" in cfg.SFOD else True
+        self.fuse_bn_reduce = os.environ.get("SFOD_NO_FUSE_BN_REDUCE", "0") != "1"   # A/B hook
         # execution plan: (conv, bn, pool_after, stage_end)
         self._plan = []
         for s, stage in enumerate(self.stages):
@@ -258,7 +259,7 @@ class vgg_backbone(nn.Module):
             stage_of.append(s if stage_end else None)
             if stage_end:
                 s += 1
-        dz = None
+        dz = dz_red = None
         mid_hook = getattr(self, "_mid_backward", None)
         mid_layer = self._first_layer_of_stage(2) if mid_hook is not None else -1
         for li in range(len(self._plan) - 1, -1, -1):
@@ -277,7 +278,9 @@ class vgg_backbone(nn.Module):
                                                         bn.bias.detach(), pool,
                                                         dgamma_acc=gsink if direct_bn else None,
                                                         dbeta_acc=bsink if direct_bn else None,
-                                                        out_dtype=dtype)    # bf16x3: dz / y fp32 -> dy pairs
+                                                        out_dtype=dtype,    # bf16x3: dz / y fp32 -> dy pairs
+                                                        reduced=dz_red)
+            dz_red = None
             if direct_bn:
                 dgamma = dbeta = None
             cout, cin = conv.out_channels, conv.in_channels
@@ -287,8 +290,19 @@ class vgg_backbone(nn.Module):
             db = None if native.grad_sink(conv.bias) is not None else torch.zeros_like(conv.bias)
             pgrads[4 * li:4 * li + 4] = [dw, db, dgamma, dbeta]
             if li > 0:
-                # rotated weights were packed together with the forward ones (same step, same values)
-                dz = native.conv_fwd(dy, self._rot_w[li], None, cin, 3)
+                # rotated weights were packed together with the forward ones (same step, same values).  When the layer
+                # below has no pooling and takes no extra stage gradient, its BatchNorm-backward reduction rides in
+                # this data-gradient kernel's epilogue (one pass over dz and y less)
+                fused = None
+                _, bn_b, pool_b, stage_end_b = self._plan[li - 1]
+                if self.fuse_bn_reduce and not pool_b and not (stage_end_b and out_grads[stage_of[li - 1]] is not None):
+                    yb, mb, ib = saved[li - 1][1], saved[li - 1][2], saved[li - 1][3]
+                    fused = native.conv_dgrad_bnred(dy, self._rot_w[li], cin, yb, mb, ib, bn_b.weight.detach(),
+                                                    bn_b.bias.detach())
+                if fused is not None:
+                    dz, dz_red = fused
+                else:
+                    dz = native.conv_fwd(dy, self._rot_w[li], None, cin, 3)
             del saved[li]
             if li == mid_layer and mid_hook is not None:
                 mid_hook()   # gradients of vgg2..vgg4 are in the flat buffer: GradientReducer.launch_mid

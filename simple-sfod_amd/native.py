@@ -686,9 +686,10 @@ def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual, with_operand=False):
 
 
 def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=None, dy=None, relu=True,
-                     dgamma_acc=None, dbeta_acc=None, out_dtype=None):
+                     dgamma_acc=None, dbeta_acc=None, out_dtype=None, reduced=None):
     """``dgamma_acc`` / ``dbeta_acc``: gradient accumulators (see ``grad_sink``) updated in the same launch.
-    ``out_dtype``: dtype of dy (y.dtype, or SPLIT_DTYPE from fp32 inputs: dy only feeds the wgrad / dgrad MFMAs)."""
+    ``out_dtype``: dtype of dy (y.dtype, or SPLIT_DTYPE from fp32 inputs: dy only feeds the wgrad / dgrad MFMAs).
+    ``reduced``: the partial-sum workspace ``conv_dgrad_bnred`` returned with dz -- the reduction pass is skipped."""
     B, H, W, C = y.shape
     if dy is None:
         dy = torch.empty(y.shape, dtype=out_dtype or y.dtype, device=y.device)
@@ -696,11 +697,34 @@ def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=
         dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
     if dbeta is None:
         dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
-    ws = torch.empty(query("sfod_bn_bwd_ws_floats", B * H * W, C), dtype=torch.float32, device=y.device)
+    if reduced is not None:
+        ws, nred = reduced, reduced.shape[0]
+        assert reduced.shape[1] == 2 * C and not pool and relu
+    else:
+        ws, nred = torch.empty(query("sfod_bn_bwd_ws_floats", B * H * W, C), dtype=torch.float32, device=y.device), 0
     call("sfod_bn_relu_pool_bwd", dz, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, dgamma_acc, dbeta_acc, ws,
          B, H, W, C,
-         int(pool) | (0 if relu else 2), dt_of(y), dt_of(dy))
+         int(pool) | (0 if relu else 2), dt_of(y), dt_of(dy), nred)
     return dy, dgamma, dbeta
+
+
+def conv_dgrad_bnred(dy, w_rot, cout, y_below, mean, invstd, gamma, beta):
+    """3x3 data gradient dz = conv(dy, rotated weights) [B,H,W,cout] fp32, with the BatchNorm-backward reduction of the
+    layer below (whose saved pre-BatchNorm output is ``y_below``, same shape as dz) folded into the epilogue.
+    -> (dz, partial-sum workspace for ``bn_relu_pool_bwd(reduced=...)``), or None when the shape / dtype is not served
+    (caller: plain ``conv_fwd`` + unfused BatchNorm backward)."""
+    B, H, W, cin = dy.shape
+    if y_below.dtype != torch.float32 or tuple(y_below.shape) != (B, H, W, cout) or not y_below.is_contiguous():
+        return None
+    nb = query("sfod_conv_dgrad_bnred_blocks", B, H, W, cin, cout, dt_of(dy))
+    if nb <= 0:
+        return None
+    dz = torch.empty(B, H, W, cout, dtype=torch.float32, device=dy.device)
+    ws = torch.empty(nb, 2 * cout, dtype=torch.float32, device=dy.device)
+    global _pending_flops
+    _pending_flops = 2.0 * B * H * W * cout * 9 * cin
+    call("sfod_conv_dgrad_bnred", dy, w_rot, dz, B, H, W, cin, cout, dt_of(dy), y_below, mean, invstd, gamma, beta, ws)
+    return dz, ws
 
 
 def act_bwd_(dy, y, act):

@@ -343,3 +343,53 @@ def test_conv_first_layer_kernel_split(native, hw):
     # the pairs are the exact split of an fp32 value: the unfused path (fp32 y -> BN kernel -> pairs) agrees to fp32 rounding
     z2 = native.bn_relu_pool_fwd(y, mean, invstd, gamma.to(DEV), beta.to(DEV), False, out_dtype=native.SPLIT_DTYPE)
     assert rel_err(zf, native.cast(z2, torch.float32).cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 37, 75, 64, 128), (1, 40, 64, 128, 64), (2, 18, 25, 256, 256), (1, 33, 31, 64, 64)])
+@pytest.mark.parametrize("variant", [0, 1, 4])
+def test_dgrad_with_fused_batchnorm_backward_reduction(native, shape, variant):
+    """sfod_conv_dgrad_bnred: the data-gradient kernel's epilogue also makes the (dbeta, dgamma) partial sums of the layer
+    below.  dz must be bit-identical to the plain kernel's, and BatchNorm backward fed with the pre-reduced workspace must
+    give the dy / dgamma / dbeta of the unfused three-kernel form (different summation order: 1e-5)."""
+    B, H, W, Cup, C = shape          # upper layer: C -> Cup channels; its data gradient has C channels
+    g = torch.Generator().manual_seed(B * H + W + C)
+    dy_up = torch.randn(B, H, W, Cup, generator=g) * 1e-3
+    w = torch.randn(Cup, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    y = torch.randn(B, H, W, C, generator=g) * 2 + 0.3
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    yd = y.to(DEV)
+    mean = yd.mean(dim=(0, 1, 2))
+    invstd = torch.rsqrt(yd.var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+    gd, bd = gamma.to(DEV), beta.to(DEV)
+    dys = to_split(native, dy_up.to(DEV))
+    wr = native.pack_conv_weight(w.to(DEV), Cup, native.BF16X3, rot180=True)
+    try:
+        native.set_conv3x3_variant(variant)
+        # small maps / narrow layers may go to the generic kernel, which has no such epilogue: then the op must refuse
+        served = native.query("sfod_conv_dgrad_bnred_blocks", B, H, W, Cup, C, native.BF16X3) > 0
+        assert served or variant != 0 or shape == (1, 33, 31, 64, 64)
+        dz_ref = native.conv_fwd(dys, wr, None, C, 3)
+        fused = native.conv_dgrad_bnred(dys, wr, C, yd, mean, invstd, gd, bd)
+    finally:
+        native.set_conv3x3_variant(0)
+    if not served:
+        assert fused is None
+        return
+    assert fused is not None
+    dz, ws = fused
+    assert torch.equal(dz, dz_ref)
+    ref = native.bn_relu_pool_bwd(dz_ref, yd, mean, invstd, gd, bd, False, out_dtype=native.SPLIT_DTYPE)
+    got = native.bn_relu_pool_bwd(dz, yd, mean, invstd, gd, bd, False, out_dtype=native.SPLIT_DTYPE, reduced=ws)
+    for a, b, name in zip(got[1:], ref[1:], ("dgamma", "dbeta")):
+        assert rel_err(a.cpu(), b.cpu()) < 1e-5, name
+    assert rel_err(native.cast(got[0], torch.float32).cpu(), native.cast(ref[0], torch.float32).cpu()) < 1e-5
+    # and against fp64 autograd of relu(bn(y)) with the same upstream gradient
+    y64 = y.double().requires_grad_(True)
+    g64, b64 = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    z = F.relu(F.batch_norm(y64.permute(0, 3, 1, 2), None, None, g64, b64, True, 0.1, 1e-5))
+    z.backward(dz_ref.cpu().double().permute(0, 3, 1, 2))
+    assert rel_err(got[1].cpu(), g64.grad) < 2e-5 and rel_err(got[2].cpu(), b64.grad) < 2e-5
+    assert rel_err(native.cast(got[0], torch.float32).cpu(), y64.grad) < 2e-5
+    # shapes the halo-patch kernel does not serve are refused by the query, not silently mis-served
+    assert native.query("sfod_conv_dgrad_bnred_blocks", B, H, W, Cup, C, native.BF16) == 0
+    assert native.conv_dgrad_bnred(dys, wr, C, yd.bfloat16(), mean, invstd, gd, bd) is None
