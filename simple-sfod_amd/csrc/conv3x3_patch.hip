@@ -134,7 +134,7 @@ template <> struct WaitTab<2, 1> {   // 3 patch pieces per slice (stages 0-2 / 5
 // values, so the kernel sees 2 * Cin "physical" bf16 channels and its DMA / LDS side is unchanged; a 64-byte patch
 // row is then 16 logical channels as chunks (hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15), ONE MFMA k-step, fed as
 // hi*lo + lo*hi + hi*hi: the same four fragment reads as two bf16 k-steps, three MFMAs instead of two.
-template <int G, int FM, typename OutT, bool SPLIT = false>
+template <int G, int FM, typename OutT, bool SPLIT = false, bool RED = false>
 __global__ void __launch_bounds__(512, (Lay<G, FM>::SMALL ? 4 : 2))   // 2nd arg: waves per SIMD (small tiles: 2 workgroups / CU)
 k_conv3x3_patch(P3Args a) {
   using L = Lay<G, FM>;
@@ -415,19 +415,6 @@ k_conv3x3_patch(P3Args a) {
     static_assert(8 * 32 * FP <= Lay<G, FM>::STG || 8 * 32 * FP <= Lay<G, FM>::OPER, "fp32 staging must fit the operand area");
     unsigned char* stg = smem + wave * (32 * FP);
     const bool vec_ok = (a.ldy % 4) == 0;
-    // fused BatchNorm-backward reduction (see P3Args): this lane's 4 channels are fixed over the whole tile
-    const bool red = (a.red_y != nullptr);
-    float rmu[4], rsc[4], rsh[4], ris[4], rdb[4] = {0.f, 0.f, 0.f, 0.f}, rdg[4] = {0.f, 0.f, 0.f, 0.f};
-    if (red) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = min(n0 + wn * 64 + (lane & 15) * 4 + q, a.Cout - 1);
-        rmu[q] = a.red_mean[n];
-        ris[q] = a.red_invstd[n];
-        rsc[q] = ris[q] * a.red_gamma[n];
-        rsh[q] = a.red_beta[n];
-      }
-    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
 #pragma unroll
@@ -452,61 +439,68 @@ k_conv3x3_patch(P3Args a) {
         float* dst = yo + (ybase + pix) * a.ldy + n;
         if (vec_ok && n + 4 <= a.Cout) {
           *reinterpret_cast<float4*>(dst) = v;
-          if (red) {      // (the host only enables it for Cout % 4 == 0, ldy == Cout)
-            const float4 yv = *reinterpret_cast<const float4*>(a.red_y + (ybase + pix) * a.ldy + n);
-            const float ye[4] = {yv.x, yv.y, yv.z, yv.w}, ge[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float d = ye[q] - rmu[q];
-              const float g = (d * rsc[q] + rsh[q] > 0.f) ? ge[q] : 0.f;      // the mask k_bn_bwd_apply recomputes
-              rdb[q] += g;
-              rdg[q] = fmaf(g, d * ris[q], rdg[q]);
-            }
-          }
         } else {
           const float e[4] = {v.x, v.y, v.z, v.w};
           for (int q = 0; q < 4 && n + q < a.Cout; ++q) dst[q] = e[q];
         }
       }
     }
-    if (red) {
-      // lanes l, l ^ 16, l ^ 32 hold the same 4 channels (different rows); then the waves that share the columns
-      float* sred = reinterpret_cast<float*>(smem + SRED_OFF);     // [wave][64 cols][2]
+  }
+
+  if constexpr (RED) {
+    // Fused BatchNorm-backward reduction (see P3Args), on the accumulators in their MFMA layout (acc now holds dz): a lane
+    // owns one column per N fragment, so the per-channel constants are 4 registers and y is fetched value by value --
+    // 32 lanes x 4 B = one 128-byte run per pixel row, like the statistics below.  Kept out of the store loop on
+    // purpose: there the constants and sums of 4 channels per lane cost 24 registers that the 128-VGPR variants spill.
+    static_assert(sizeof(OutT) == 4, "the reduction epilogue belongs to fp32 data-gradient launches");
+    float* sred = reinterpret_cast<float*>(smem + SRED_OFF);     // [wave][64 cols][2]
+    const float* __restrict__ yb = a.red_y + ybase * a.ldy;      // this image (wave-uniform base)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        rdb[q] += __shfl_xor(rdb[q], 16);
-        rdb[q] += __shfl_xor(rdb[q], 32);
-        rdg[q] += __shfl_xor(rdg[q], 16);
-        rdg[q] += __shfl_xor(rdg[q], 32);
-      }
-      if (lane < 16) {
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * 64 + j * 32 + (lane & 31);
+      const int nc = min(n, a.Cout - 1);
+      const float mu = a.red_mean[nc], is = a.red_invstd[nc];
+      const float sc = is * a.red_gamma[nc], sh = a.red_beta[nc];
+      float sb = 0.f, sg = 0.f;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          sred[(wave * 64 + lane * 4 + q) * 2 + 0] = rdb[q];
-          sred[(wave * 64 + lane * 4 + q) * 2 + 1] = rdg[q];
-        }
-      }
-      __syncthreads();
-      if (threadIdx.x < BN) {
-        const int col = threadIdx.x;
-        const int cwn = (G == 1) ? (col >> 6) : 0;
-        const int cl = col & 63;
-        constexpr int NWM = (G == 1) ? 4 : 8;
-        float sb = 0.f, sg = 0.f;
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int k = 0; k < NWM; ++k) {
-          const int wv = (G == 1) ? (k * 2 + cwn) : k;
-          sb += sred[(wv * 64 + cl) * 2 + 0];
-          sg += sred[(wv * 64 + cl) * 2 + 1];
+        for (int r = 0; r < 16; ++r) {
+          const int ml = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int pix = pixtab[wm * WROWS + ml];
+          const float yv = yb[(unsigned)(max(pix, 0) * a.ldy + nc)];      // 32-bit offset: H * W * C < 2^30 (plan)
+          const float d = yv - mu;
+          const float g = (pix >= 0 && d * sc + sh > 0.f) ? acc[i][j][r] : 0.f;     // the mask k_bn_bwd_apply recomputes
+          sb += g;
+          sg = fmaf(g, d * is, sg);
         }
-        const int n = n0 + col;
-        if (n < a.Cout) {
-          a.red_ws[(int64_t)mtile * 2 * a.Cout + n] = sb;               // k_bn_bwd_finalize: [blk][0..C) = dbeta part,
-          a.red_ws[(int64_t)mtile * 2 * a.Cout + a.Cout + n] = sg;      //                     [blk][C..2C) = dgamma part
-        }
+      sb += __shfl_xor(sb, 32);
+      sg += __shfl_xor(sg, 32);
+      if (h == 0) {
+        sred[(wave * 64 + j * 32 + (lane & 31)) * 2 + 0] = sb;
+        sred[(wave * 64 + j * 32 + (lane & 31)) * 2 + 1] = sg;
       }
-      if (a.stats != nullptr) __syncthreads();      // sred is reused by the statistics below
     }
+    __syncthreads();
+    if (threadIdx.x < BN) {
+      const int col = threadIdx.x;
+      const int cwn = (G == 1) ? (col >> 6) : 0;
+      const int cl = col & 63;
+      constexpr int NWM = (G == 1) ? 4 : 8;
+      float sb = 0.f, sg = 0.f;
+#pragma unroll
+      for (int k = 0; k < NWM; ++k) {
+        const int wv = (G == 1) ? (k * 2 + cwn) : k;
+        sb += sred[(wv * 64 + cl) * 2 + 0];
+        sg += sred[(wv * 64 + cl) * 2 + 1];
+      }
+      const int n = n0 + col;
+      if (n < a.Cout) {
+        a.red_ws[(int64_t)mtile * 2 * a.Cout + n] = sb;               // k_bn_bwd_finalize: [blk][0..C) = dbeta part,
+        a.red_ws[(int64_t)mtile * 2 * a.Cout + a.Cout + n] = sg;      //                     [blk][C..2C) = dgamma part
+      }
+    }
+    if (a.stats != nullptr) __syncthreads();      // sred is reused by the statistics below
   }
 
   if (a.stats != nullptr) {
@@ -679,9 +673,9 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   return p;
 }
 
-template <int G, int FM, typename OutT, bool SPLIT = false>
+template <int G, int FM, typename OutT, bool SPLIT = false, bool RED = false>
 static int p3_launch_one(const P3Args& a, hipStream_t s) {
-  auto kern = k_conv3x3_patch<G, FM, OutT, SPLIT>;
+  auto kern = k_conv3x3_patch<G, FM, OutT, SPLIT, RED>;
   constexpr int LDS = Lay<G, FM>::TOTAL;
   // once per kernel instantiation and process (function-local static: initialised exactly once, thread-safe)
   static const hipError_t attr_rc =
@@ -714,6 +708,12 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
   a.nblk = p.nblk;
   if (split) {
     if (!out_f32) { sfod_set_error("conv3x3_patch: bf16x3 operands write fp32"); return SFOD_EBADARG; }
+    if (red != nullptr) {
+      if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, true, true>(a, s);
+      if (p.G == 1) return p3_launch_one<1, 4, float, true, true>(a, s);
+      if (p.FM == 2) return p3_launch_one<2, 2, float, true, true>(a, s);
+      return p3_launch_one<2, 1, float, true, true>(a, s);
+    }
     if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, true>(a, s);
     if (p.G == 1) return p3_launch_one<1, 4, float, true>(a, s);
     if (p.FM == 2) return p3_launch_one<2, 2, float, true>(a, s);
