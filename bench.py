@@ -128,21 +128,24 @@ def cpu_baseline(res, planted):
             "seconds_per_stage": {k: round(v, 3) for k, v in stages.items()}}
 
 
-def pmc_traffic(kernel_substr):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes (rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py).
-    bench.py cannot collect counters itself; the figure is per launch like `achieved`."""
+def pmc_traffic(*kernel_substrs):
+    """HBM bytes per launch of the dominant kernel family from the committed PMC passes (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py): the
+    launch-weighted mean over the family's template instantiations (tile shapes, with / without the BatchNorm-backward
+    epilogue), i.e. per launch over the same set of launches as `achieved`.  bench.py cannot collect counters itself."""
     path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
     if not os.path.exists(path):
         return None
     try:
-        for row in json.load(open(path)):
-            if kernel_substr in row["kernel"]:
-                return {"hbm_read_MB_per_launch": row["hbm_read_MB_per_launch"],
-                        "hbm_write_MB_per_launch": row["hbm_write_MB_per_launch"], "source": "profiles/pmc_hbm_traffic_latest.json"}
+        rows = [r for r in json.load(open(path)) if all(k in r["kernel"] for k in kernel_substrs)]
+        n = sum(r["launches"] for r in rows)
+        if n == 0:
+            return None
+        return {"hbm_read_MB_per_launch": round(sum(r["hbm_read_MB_per_launch"] * r["launches"] for r in rows) / n, 3),
+                "hbm_write_MB_per_launch": round(sum(r["hbm_write_MB_per_launch"] * r["launches"] for r in rows) / n, 3),
+                "kernels": len(rows), "launches_counted": n, "source": "profiles/pmc_hbm_traffic_latest.json"}
     except Exception:
         return None
-    return None
 
 
 def _launcher():
@@ -408,8 +411,8 @@ def main():
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
             "frac": round(ach / PEAK[args.dtype], 4),
             # HBM bytes per launch from the committed PMC passes of THIS mode's kernel (tools/pmc_hbm_run.sh); null otherwise
-            "traffic": pmc_traffic({"bf16x3": "k_conv3x3_patch<1, 2, float, true>", "bf16": "k_conv3x3_patch<1, 2, __bf16, false>"}.get(args.dtype, "-")
-                                   if key.endswith("patch3x3") else "k_conv_fwd<"),
+            "traffic": (pmc_traffic("k_conv3x3_patch<", {"bf16x3": "float, true", "bf16": "__bf16, false"}.get(args.dtype, "-"))
+                        if key.endswith("patch3x3") else pmc_traffic("k_conv_fwd<")),
             "launches_per_step": k["launches"] // max(rl_steps, 1),
             "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
             "algorithmic_gflop_per_launch": round(k["flops"] / max(k["launches"], 1) / 1e9, 3),

@@ -207,17 +207,18 @@ def set_timer(timer):
     _timer = timer
 
 
-def call(name, *args):
-    """Raw call: tensors are converted to device pointers, the current stream is appended."""
+def call(name, *args, timer_name=None):
+    """Raw call: tensors are converted to device pointers, the current stream is appended.  ``timer_name``: the entry
+    point a KernelTimer files this launch under (sfod_conv_dgrad_bnred runs the sfod_conv_fwd kernel family)."""
     global _pending_flops
     lib = load()
     conv = [(_p(a) if isinstance(a, torch.Tensor) else a) for a in args]
-    if _timer is not None and name in _timer.watch:
+    if _timer is not None and (timer_name or name) in _timer.watch:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = getattr(lib, name)(*conv, _stream())
         b.record()
-        _timer.records.append((name + _pending_tag, _pending_flops, a, b))
+        _timer.records.append(((timer_name or name) + _pending_tag, _pending_flops, a, b))
         _pending_flops = 0.0
     else:
         rc = getattr(lib, name)(*conv, _stream())
@@ -721,9 +722,14 @@ def conv_dgrad_bnred(dy, w_rot, cout, y_below, mean, invstd, gamma, beta):
         return None
     dz = torch.empty(B, H, W, cout, dtype=torch.float32, device=dy.device)
     ws = torch.empty(nb, 2 * cout, dtype=torch.float32, device=dy.device)
-    global _pending_flops
+    global _pending_flops, _pending_tag
     _pending_flops = 2.0 * B * H * W * cout * 9 * cin
-    call("sfod_conv_dgrad_bnred", dy, w_rot, dz, B, H, W, cin, cout, dt_of(dy), y_below, mean, invstd, gamma, beta, ws)
+    _pending_tag = ":patch3x3"       # the halo-patch kernel with one more epilogue: same roofline line as sfod_conv_fwd's
+    try:
+        call("sfod_conv_dgrad_bnred", dy, w_rot, dz, B, H, W, cin, cout, dt_of(dy), y_below, mean, invstd, gamma, beta,
+             ws, timer_name="sfod_conv_fwd")
+    finally:
+        _pending_tag = ""
     return dz, ws
 
 

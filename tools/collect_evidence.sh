@@ -1,0 +1,29 @@
+# Collect the per-round evidence set on the GPU box (one gpurun call; ~12 GPU-minutes):
+#   bash tools/collect_evidence.sh <tag> [pmc|bench|all]
+# pmc:   rocprofv3 kernel trace + SQ counters + HBM traffic counters of the default bench workload (writes the traffic file
+#        bench.py reads, gpurun_out/<tag>_pmc_hbm_traffic.json -> copy to profiles/pmc_hbm_traffic_latest.json BEFORE the
+#        bench part so that the bench line carries it)
+# bench: the default bench line (with cpu_baseline and the secondary block) and the side configurations
+export TMPDIR=/tmp
+TAG=${1:-rX}; WHAT=${2:-all}
+O=gpurun_out
+if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
+  rm -rf $O/prof_kt
+  rocprofv3 --kernel-trace --stats -d $O/prof_kt -o kt -- python3 bench.py --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --steps 20 --warmup 5 > /dev/null 2> $O/${TAG}_kt.err
+  DB=$(find $O/prof_kt -name "*.db" | head -1)
+  python3 tools/rocpd_stats.py $DB 25 > $O/${TAG}_bf16x3_B8_r600_single_stream_kernel_stats.csv
+  rm -rf $O/prof_kt
+  bash tools/pmc_sq_run.sh $O/${TAG}_sq_counters.json > $O/${TAG}_sq.log 2>&1
+  bash tools/pmc_hbm_run.sh $O/${TAG}_pmc_hbm_traffic_bf16x3.json > $O/${TAG}_hbm.log 2>&1
+  python3 tools/bench_conv.py --dtype bf16x3 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bf16x3_conv_layers.txt
+  python3 tools/bench_conv.py --dtype bf16x3 --wgrad 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bf16x3_conv_layers_wgrad.txt
+fi
+if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
+  python3 bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
+  python3 bench.py --kernel-table --steps 30 --no-cpu-baseline --no-secondary > /dev/null 2> $O/${TAG}_kernel_table.txt
+  for cfg in "--trainer base" "--trainer base --res full --steps 40" "--res full --steps 40" "--batch 1 --steps 200" "--model r101 --steps 40" "--opts SFOD.ELIDE_DEAD_BRANCHES False"; do
+    name=$(echo $cfg | tr -d ' -' | tr '.' '_')
+    python3 bench.py $cfg --no-cpu-baseline --no-secondary > $O/${TAG}_bench_${name}.json 2> $O/${TAG}_bench_${name}.err
+  done
+fi
+ls -la $O | grep ${TAG}_ | awk '{print $5, $9}'
