@@ -105,8 +105,9 @@ def test_three_steps_match_the_oracle_trajectory(sfod, native, dtype, elide):
             return 6e-2 if x3 else 4e-2
         if name.startswith("roi_heads"):
             return 4e-3 if x3 else 2e-3
-        if ".rpn_head.conv." in name:   # few hidden units under sparse gradients: ONE flipped ReLU shows as 1e-3 .. 1e-2
-            return 3e-2 if x3 else 1e-2
+        if ".rpn_head.conv." in name:   # few hidden units under sparse gradients: ONE flipped ReLU shows as 1e-3 .. 2e-2
+            return 3e-2                 # (fp32 mode too: its weight gradients use float atomics, so WHICH unit flips varies
+                                        # from run to run -- 1 run in 8 reached 1.6e-2 at step 2)
         return 2e-3 if x3 else 2e-4
 
     names = [n for n, _ in tr.model.named_parameters()]
