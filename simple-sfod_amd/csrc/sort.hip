@@ -3,11 +3,13 @@
 // Every key is the 64-bit pair (~orderable(score), original index): ascending u64 order == descending score with
 // ascending original index on ties -- the rule the oracle defines (torch.sort(stable=True, descending=True)) -- and
 // all keys are distinct, so any comparison sort gives the one stable result.
-// Segments of up to 16384 keys (the hot path at 600x1200: 9990 / 12000 anchors, 16000 ROI candidates) are sorted
-// by one workgroup each with a bitonic network over the keys held in LDS.  Larger segments (1024x2048 frames: 30 720
-// anchors; ResNet-C4: 34 200 / 98 304) are cut into 16384-key chunks, each chunk is sorted by one workgroup with the
-// same network, and the sorted chunks are merged pairwise by merge-path passes (every thread finds its diagonal's
-// split by binary search and merges 8 outputs): 1 + ceil(log2(chunks)) + 1 launches.
+// Segments of up to 4096 keys are sorted by one workgroup each with a bitonic network over the keys held in LDS.
+// Larger segments are cut into chunks, each chunk is sorted by one workgroup with the same network, and the sorted
+// chunks are merged pairwise by merge-path passes (every thread finds its diagonal's split by binary search and merges
+// 8 outputs): 1 + ceil(log2(chunks)) + 1 launches.  Chunk size: 4096 keys for segments up to 131072 (the hot path at
+// 600x1200: 9990 / 12000 anchors, 16000 ROI candidates -- B = 8 segments as 32 workgroups of 78 network passes + 2
+// merge passes instead of 8 workgroups of 105 passes over 4x the keys per thread: 156 -> 63 us; 1024x2048 frames:
+// 30 720 anchors 173 -> 74 us; ResNet-C4: 34 200 / 98 304 keys 185 -> 85 / 212 -> 125 us), 16384-key chunks beyond.
 #include "common.h"
 
 static inline int64_t align256(int64_t v) { return (v + 255) & ~(int64_t)255; }
@@ -19,8 +21,11 @@ __device__ __forceinline__ uint32_t f32_orderable(float f) {
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
-#define BITONIC_MAX 16384
-#define SORT_CHUNK 16384
+#define BITONIC_MAX 16384          // LDS capacity of one workgroup's network (keys)
+#define SINGLE_MAX 4096            // segments up to this size: one workgroup, one launch
+#define SORT_CHUNK_BIG 16384
+#define SORT_CHUNK_SMALL 4096
+static inline int sort_chunk_of(int n) { return n <= 131072 ? SORT_CHUNK_SMALL : SORT_CHUNK_BIG; }
 #define MERGE_ITEMS 8
 #define MERGE_THREADS 256
 
@@ -61,26 +66,26 @@ k_bitonic_sort_desc(const float* __restrict__ keys, int n, int npow2, float* __r
 }
 
 // ---- larger segments: sorted chunks + merge-path passes ----------------------------------------------------------
-// chunk c of segment b: its <= SORT_CHUNK keys sorted ascending into dst[b][c * SORT_CHUNK ..]; positions beyond n
+// chunk c of segment b: its <= CH keys sorted ascending into dst[b][c * CH ..]; positions beyond n
 // hold ~0 (they sort last and are never emitted)
 __global__ void __launch_bounds__(1024)
-k_bitonic_chunk(const float* __restrict__ keys, int n, int nchunks, unsigned long long* __restrict__ dst) {
+k_bitonic_chunk(const float* __restrict__ keys, int n, int nchunks, int CH, unsigned long long* __restrict__ dst) {
   extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
   const int b = blockIdx.x / nchunks, c = blockIdx.x % nchunks, tid = threadIdx.x;
   const float* src = keys + (int64_t)b * n;
-  const int base = c * SORT_CHUNK;
-  for (int i = tid; i < SORT_CHUNK; i += 1024) {
+  const int base = c * CH;
+  for (int i = tid; i < CH; i += 1024) {
     const int g = base + i;
     sk[i] = (g < n) ? (((unsigned long long)(~f32_orderable(src[g])) << 32) | (unsigned)g) : ~0ull;
   }
   __syncthreads();
-  bitonic_network(sk, SORT_CHUNK, tid);
-  unsigned long long* out = dst + ((int64_t)b * nchunks + c) * SORT_CHUNK;
-  for (int i = tid; i < SORT_CHUNK; i += 1024) out[i] = sk[i];
+  bitonic_network(sk, CH, tid);
+  unsigned long long* out = dst + ((int64_t)b * nchunks + c) * CH;
+  for (int i = tid; i < CH; i += 1024) out[i] = sk[i];
 }
 
-// one merge pass over the sorted runs of length L (a multiple of SORT_CHUNK) inside every segment of
-// NP = nchunks * SORT_CHUNK keys: runs (2r, 2r+1) -> one run of length 2L; a last run without partner is copied
+// one merge pass over the sorted runs of length L (a multiple of the chunk size) inside every segment of
+// NP = nchunks * chunk keys: runs (2r, 2r+1) -> one run of length 2L; a last run without partner is copied
 __global__ void __launch_bounds__(MERGE_THREADS)
 k_merge_pass(const unsigned long long* __restrict__ src, unsigned long long* __restrict__ dst, int NP, int L) {
   const int b = blockIdx.y;
@@ -126,8 +131,9 @@ k_sort_emit(const unsigned long long* __restrict__ sorted, const float* __restri
 }
 
 extern "C" int64_t sfod_sort_ws_bytes(int B, int n) {
-  if (n <= BITONIC_MAX) return 256;
-  const int64_t NP = (int64_t)((n + SORT_CHUNK - 1) / SORT_CHUNK) * SORT_CHUNK;
+  if (n <= SINGLE_MAX) return 256;
+  const int ch = sort_chunk_of(n);
+  const int64_t NP = (int64_t)((n + ch - 1) / ch) * ch;
   return align256(2 * (int64_t)B * NP * 8) + 256;       // two key buffers (ping-pong of the merge passes)
 }
 
@@ -148,22 +154,23 @@ extern "C" int sfod_segmented_sort_desc(const float* keys, int B, int n, float* 
     return rc ? rc : sort_set_lds_attr(reinterpret_cast<const void*>(k_bitonic_chunk));
   }();
   if (attr_rc) return attr_rc;
-  if (n <= BITONIC_MAX) {
+  if (n <= SINGLE_MAX) {
     int npow2 = 2;
     while (npow2 < n) npow2 <<= 1;
     hipLaunchKernelGGL(k_bitonic_sort_desc, dim3(B), dim3(1024), npow2 * 8, s, keys, n, npow2, out_keys, out_idx);
     return sfod_check_launch("bitonic_sort");
   }
-  SFOD_REQUIRE(ws != nullptr, "sort: workspace required above 16384 keys per segment");
-  const int nchunks = (n + SORT_CHUNK - 1) / SORT_CHUNK;
-  const int NP = nchunks * SORT_CHUNK;
+  SFOD_REQUIRE(ws != nullptr, "sort: workspace required above 4096 keys per segment");
+  const int CH = sort_chunk_of(n);
+  const int nchunks = (n + CH - 1) / CH;
+  const int NP = nchunks * CH;
   unsigned long long* src = reinterpret_cast<unsigned long long*>(ws);
   unsigned long long* dst = src + (int64_t)B * NP;
-  hipLaunchKernelGGL(k_bitonic_chunk, dim3(B * nchunks), dim3(1024), SORT_CHUNK * 8, s, keys, n, nchunks, src);
+  hipLaunchKernelGGL(k_bitonic_chunk, dim3(B * nchunks), dim3(1024), CH * 8, s, keys, n, nchunks, CH, src);
   int rc = sfod_check_launch("bitonic_chunk");
   if (rc) return rc;
   const dim3 mgrid(cdiv(NP, MERGE_THREADS * MERGE_ITEMS), B);
-  for (int L = SORT_CHUNK; L < NP; L *= 2) {
+  for (int L = CH; L < NP; L *= 2) {
     hipLaunchKernelGGL(k_merge_pass, mgrid, dim3(MERGE_THREADS), 0, s, (const unsigned long long*)src, dst, NP, L);
     rc = sfod_check_launch("merge_pass");
     if (rc) return rc;
