@@ -195,7 +195,9 @@ int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float* mean, cons
                           float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
                           int W, int C, int pool, int dt, int out_dt, int reduced_blocks, void* stream);
 /* reduced_blocks > 0: `ws` already holds that many rows of partial (dbeta | dgamma) sums, written by the epilogue of the
- * data-gradient convolution that produced dz (sfod_conv_dgrad_bnred): the reduction pass over dz and y is skipped. */
+ * data-gradient convolution that produced dz (sfod_conv_dgrad_bnred): the reduction pass over dz and y is skipped.
+ * `ws` must then have SFOD_BN_BWD_SCRATCH_ROWS more rows of 2 * C floats behind them (scratch of the two-stage sum). */
+#define SFOD_BN_BWD_SCRATCH_ROWS 32
 int sfod_bn_bwd_ws_floats(int M, int C);
 /* ---- ResNet-101-C4 backbone helpers (d2 build_resnet_backbone selected by the r101 yaml's missing
  * BACKBONE.NAME, configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28) ----

@@ -719,6 +719,37 @@ k_bn_bwd_finalize(const float* __restrict__ ws, int nblk, int C, float* __restri
   }
 }
 
+// First stage for long partial matrices (the fused data-gradient epilogue writes one row per pixel tile: 22 800 rows for
+// conv1_1 at B = 8, 600x1200): slice s of the rows -> out[s][2C], so that the finalize kernel above (2C / 64 workgroups)
+// only sees BNB_SLICES rows.  Same fixed summation order inside a slice.
+#define BNB_SLICES 32
+static_assert(BNB_SLICES == SFOD_BN_BWD_SCRATCH_ROWS, "scratch rows of the pre-reduced workspace");
+__global__ void __launch_bounds__(1024)
+k_bn_bwd_slices(const float* __restrict__ ws, int nblk, int C, float* __restrict__ out) {
+  __shared__ double red[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t = blockIdx.x * 64 + lane;  // over 2*C
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int b0 = blockIdx.y * per, b1 = min(nblk, b0 + per);
+  double a0 = 0.0, a1 = 0.0;
+  if (t < 2 * C) {
+    int b = b0 + wave;
+    for (; b + 16 < b1; b += 32) {
+      a0 += (double)ws[(int64_t)b * 2 * C + t];
+      a1 += (double)ws[(int64_t)(b + 16) * 2 * C + t];
+    }
+    for (; b < b1; b += 16) a0 += (double)ws[(int64_t)b * 2 * C + t];
+  }
+  red[wave][lane] = a0 + a1;
+  __syncthreads();
+  if (wave == 0 && t < 2 * C) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][lane];
+    out[(int64_t)blockIdx.y * 2 * C + t] = (float)v;
+  }
+}
+
 template <typename T, int POOL, int RELU, typename TO = T>
 __global__ void __launch_bounds__(256)
 k_bn_bwd_apply(const T* __restrict__ dz, const T* __restrict__ y, const float* __restrict__ mean,
@@ -859,8 +890,15 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
     if (reduced_blocks == 0)                                                                           \
       hipLaunchKernelGGL((k_bn_bwd_reduce<T, P, R>), dim3(grid1), dim3(256), lds, s, (const T*)dz,     \
                          (const T*)y, mean, invstd, gamma, beta, ws, B, H, W, C);                      \
-    hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws,                 \
-                       reduced_blocks ? reduced_blocks : grid1, C, dgamma, dbeta, dgamma_acc, dbeta_acc); \
+    if (reduced_blocks > 2048) {  /* long pre-reduced matrix: slice it first (scratch rows behind it) */   \
+      float* sl = ws + (int64_t)reduced_blocks * 2 * C;                                                \
+      hipLaunchKernelGGL(k_bn_bwd_slices, dim3(cdiv(2 * C, 64), BNB_SLICES), dim3(1024), 0, s, ws,     \
+                         reduced_blocks, C, sl);                                                       \
+      hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, sl, BNB_SLICES, C, \
+                         dgamma, dbeta, dgamma_acc, dbeta_acc);                                        \
+    } else                                                                                             \
+      hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(2 * C, 64)), dim3(1024), 0, s, ws,               \
+                         reduced_blocks ? reduced_blocks : grid1, C, dgamma, dbeta, dgamma_acc, dbeta_acc); \
     hipLaunchKernelGGL((k_bn_bwd_apply<T, P, R, TO>), dim3(grid3), dim3(256), 0, s, (const T*)dz,      \
                        (const T*)y, mean, invstd, gamma, beta, dgamma, dbeta, (TO*)dy, B, H, W, C);    \
   } while (0)

@@ -699,14 +699,17 @@ def bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, pool, dgamma=None, dbeta=
     if dbeta is None:
         dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
     if reduced is not None:
-        ws, nred = reduced, reduced.shape[0]
-        assert reduced.shape[1] == 2 * C and not pool and relu
+        ws, nred = reduced, reduced.shape[0] - BN_BWD_SCRATCH_ROWS
+        assert reduced.shape[1] == 2 * C and nred > 0 and not pool and relu
     else:
         ws, nred = torch.empty(query("sfod_bn_bwd_ws_floats", B * H * W, C), dtype=torch.float32, device=y.device), 0
     call("sfod_bn_relu_pool_bwd", dz, y, mean, invstd, gamma, beta, dy, dgamma, dbeta, dgamma_acc, dbeta_acc, ws,
          B, H, W, C,
          int(pool) | (0 if relu else 2), dt_of(y), dt_of(dy), nred)
     return dy, dgamma, dbeta
+
+
+BN_BWD_SCRATCH_ROWS = 32     # SFOD_BN_BWD_SCRATCH_ROWS of include/sfod_hip.h
 
 
 def conv_dgrad_bnred(dy, w_rot, cout, y_below, mean, invstd, gamma, beta):
@@ -721,7 +724,7 @@ def conv_dgrad_bnred(dy, w_rot, cout, y_below, mean, invstd, gamma, beta):
     if nb <= 0:
         return None
     dz = torch.empty(B, H, W, cout, dtype=torch.float32, device=dy.device)
-    ws = torch.empty(nb, 2 * cout, dtype=torch.float32, device=dy.device)
+    ws = torch.empty(nb + BN_BWD_SCRATCH_ROWS, 2 * cout, dtype=torch.float32, device=dy.device)   # partial rows + scratch
     global _pending_flops, _pending_tag
     _pending_flops = 2.0 * B * H * W * cout * 9 * cin
     _pending_tag = ":patch3x3"       # the halo-patch kernel with one more epilogue: same roofline line as sfod_conv_fwd's
