@@ -98,7 +98,8 @@ int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, 
  * 4 = 512 x 64 (applied where the channel counts allow it).  For A/B runs and parity tests. */
 int sfod_set_conv3x3_variant(int variant);
 /* which kernel sfod_conv_fwd runs for this shape: 1 generic implicit GEMM, 2 halo-patch, 3 first-layer
- * kernel (Cin = one padded 8-channel chunk, Cout = 64, bf16) */
+ * kernel (Cin = one padded 8-channel chunk, Cout = 64), 4 generic implicit GEMM on its 256 x 256 tile (bf16x3 linear
+ * layers / 1x1 convolutions with wide outputs) */
 int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
 
 /* dt: SFOD_BF16 (x, w, y bf16) or SFOD_BF16X3 (x, w operand pairs; y: the activated operand pairs of the next layer).

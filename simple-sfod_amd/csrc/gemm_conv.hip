@@ -485,10 +485,13 @@ static bool use_first_kernel(int B, int H, int W, int Cin, int Cout, int ksize, 
          g_conv_algo != 1 && (int64_t)B * H * W >= 4096;
 }
 
+static bool use_wide_gemm(int M, int Cout, int ks);
+
 extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, dt == SFOD_BF16X3 ? SFOD_F32 : SFOD_BF16)) return 3;
   const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
-  return use_patch_kernel(p, B, H, W, ksize, dt) ? 2 : 1;
+  if (use_patch_kernel(p, B, H, W, ksize, dt)) return 2;
+  return (dt == SFOD_BF16X3 && use_wide_gemm(B * H * W, Cout, ksize)) ? 4 : 1;     // (fp32 output assumed: bf16x3 has no other)
 }
 
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
@@ -520,6 +523,16 @@ static int launch_one(const void* x, const void* w, const float* bias, void* y, 
   return sfod_check_launch("conv_fwd");
 }
 
+// bf16x3, ksize 1, fp32 out: does the 256 x 256 tile serve this shape?  (SFOD_GEMM_WIDE = 0 never / 2 always: A/B runs)
+static bool use_wide_gemm(int M, int Cout, int ks) {
+  static const int wide = []() { const char* e = getenv("SFOD_GEMM_WIDE"); return e ? atoi(e) : 1; }();
+  if (wide <= 0 || ks != 1 || Cout < 256) return false;
+  const int64_t t256 = (int64_t)((M + 255) / 256) * ((Cout + 255) / 256);
+  const int64_t t128 = (int64_t)((M + 255) / 256) * ((Cout + 127) / 128);
+  const double r256 = (double)((t256 + 255) / 256), r128 = (double)((t128 + 255) / 256) * 0.5;   // rounds, in 256-wide tile times
+  return wide == 2 || (t256 >= 200 && r256 * 0.80 <= r128);
+}
+
 template <typename T, typename OutT, bool UT, bool SPLIT = false>
 static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
                               const ConvArgs& a, hipStream_t s) {
@@ -534,14 +547,7 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
   // bf16x3 linear layers / 1x1 convolutions with wide outputs: 256 x 256 tiles (64-byte K stages) when their rounds of
   // 256 workgroups (one per CU) are filled well enough to beat 256 x 128 (profiles/r2d_bench_gemm.txt)
   if constexpr (UT && SPLIT && sizeof(OutT) == 4) {
-    static const int wide = []() { const char* e = getenv("SFOD_GEMM_WIDE"); return e ? atoi(e) : 1; }();
-    if (wide > 0 && a.ks == 1 && a.Cout >= 256) {
-      const int64_t t256 = (int64_t)((a.M + 255) / 256) * ((a.Cout + 255) / 256);
-      const int64_t t128 = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
-      const double r256 = (double)((t256 + 255) / 256), r128 = (double)((t128 + 255) / 256) * 0.5;   // rounds, in 256-wide tile times
-      if (wide == 2 || (t256 >= 200 && r256 * 0.80 <= r128))
-        return launch_one<T, OutT, 4, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
-    }
+    if (use_wide_gemm(a.M, a.Cout, a.ks)) return launch_one<T, OutT, 4, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
   }
   // 256 x 128 tiles with a 3-stage DMA pipeline once the grid still fills the chip (>= 2 tiles / CU)
   const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);

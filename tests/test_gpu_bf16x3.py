@@ -393,3 +393,37 @@ def test_dgrad_with_fused_batchnorm_backward_reduction(native, shape, variant):
     # shapes the halo-patch kernel does not serve are refused by the query, not silently mis-served
     assert native.query("sfod_conv_dgrad_bnred_blocks", B, H, W, Cup, C, native.BF16) == 0
     assert native.conv_dgrad_bnred(dys, wr, C, yd.bfloat16(), mean, invstd, gd, bd) is None
+
+
+@pytest.mark.parametrize("shape", [(12900, 264, 1000), (17000, 1032, 520), (51300, 72, 256)])
+def test_linear_wide_tile_kernel(native, shape):
+    """k_conv_fwd<.., WN = 4, BKB = 64>: the 256 x 256 tile with 64-byte K stages that the long-K linear layers of the
+    benchmark shapes select (teacher fc1: 16000 rows).  Ragged M, N and K tails; bias + ReLU epilogue, the BatchNorm
+    statistics epilogue, and agreement with the 256 x 128 kernel (SFOD_GEMM_WIDE is read once per process, so the
+    selection is checked through the tile count the rule uses: >= 200 wide tiles that fill their rounds)."""
+    M, K, N = shape
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    t256 = ((M + 255) // 256) * ((N + 255) // 256)
+    t128 = ((M + 255) // 256) * ((N + 127) // 128)
+    assert t256 >= 200 and ((t256 + 255) // 256) * 0.8 <= ((t128 + 255) // 256) * 0.5, "shape must select the wide tile"
+    assert native.query("sfod_conv_fwd_algo", M, 1, 1, K, N, 1, native.BF16X3) == 4
+    assert native.query("sfod_conv_fwd_algo", M // 2, 1, 1, K, N, 1, native.BF16X3) == 1
+    xd = to_split(native, x.to(DEV))
+    wp = native.pack_fc_weight(w.to(DEV), native.BF16X3)
+    y, st = native.conv_fwd(xd.view(M, 1, 1, K), wp, bias.to(DEV), N, 1, act=0, want_stats=True)
+    ref = x.double() @ w.double().t() + bias.double()
+    assert rel_err(y.view(M, N).cpu(), ref) < TOL
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    mean, invstd = native.bn_finalize(st, M, N, rm, rv, 0.1, 1e-5)
+    torch.testing.assert_close(mean.cpu().double(), ref.mean(0), rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(invstd.cpu().double(), torch.rsqrt(ref.var(0, unbiased=False) + 1e-5), rtol=2e-5, atol=1e-9)
+    yr = native.conv_fwd(xd.view(M, 1, 1, K), wp, bias.to(DEV), N, 1, act=1)
+    assert rel_err(yr.view(M, N).cpu(), F.relu(ref)) < TOL
+    # the same rows in two halves take the 256 x 128 kernel (fewer than 200 wide tiles): same values to fp32 rounding
+    h = M // 2
+    y2 = torch.cat([native.conv_fwd(xd[:h].contiguous().view(h, 1, 1, K), wp, bias.to(DEV), N, 1).view(h, N),
+                    native.conv_fwd(xd[h:].contiguous().view(M - h, 1, 1, K), wp, bias.to(DEV), N, 1).view(M - h, N)])
+    assert rel_err(y.view(M, N).cpu(), y2.cpu()) < 1e-6
