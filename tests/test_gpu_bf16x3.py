@@ -427,3 +427,22 @@ def test_linear_wide_tile_kernel(native, shape):
     y2 = torch.cat([native.conv_fwd(xd[:h].contiguous().view(h, 1, 1, K), wp, bias.to(DEV), N, 1).view(h, N),
                     native.conv_fwd(xd[h:].contiguous().view(M - h, 1, 1, K), wp, bias.to(DEV), N, 1).view(M - h, N)])
     assert rel_err(y.view(M, N).cpu(), y2.cpu()) < 1e-6
+
+
+@pytest.mark.parametrize("rows", [1, 700, 2049, 22800])
+def test_bn_backward_with_a_prereduced_workspace_of_any_length(native, rows):
+    """sfod_bn_relu_pool_bwd(reduced_blocks): the (dbeta | dgamma) partial rows of the fused data-gradient epilogue are summed
+    by one kernel up to 2048 rows and in two stages (32 slices) beyond -- conv1_1 at B = 8, 600x1200 has 22 800 rows."""
+    C, B, H, W = 64, 1, 8, 8
+    g = torch.Generator().manual_seed(rows)
+    part = torch.randn(rows + native.BN_BWD_SCRATCH_ROWS, 2 * C, generator=g)
+    part[rows:] = float("nan")                       # scratch rows: must be overwritten before they are read
+    y = torch.randn(B, H, W, C, generator=g).to(DEV)
+    dz = torch.randn(B, H, W, C, generator=g).to(DEV)
+    mean, invstd = y.mean(dim=(0, 1, 2)), torch.rsqrt(y.var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+    gamma, beta = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    dy, dgamma, dbeta = native.bn_relu_pool_bwd(dz, y, mean, invstd, gamma, beta, False, reduced=part.to(DEV))
+    ref = part[:rows].double().sum(0)
+    torch.testing.assert_close(dbeta.cpu().double(), ref[:C], rtol=1e-6, atol=1e-5)
+    torch.testing.assert_close(dgamma.cpu().double(), ref[C:], rtol=1e-6, atol=1e-5)
+    assert torch.isfinite(dy).all()
