@@ -209,8 +209,10 @@ int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, int64
  * stride-2 conv, STRIDE_IN_1X1); backward=1: the adjoint (dst [B,H,W,C] zero except even pixels) */
 int sfod_subsample2(const void* src, void* dst, int B, int H, int W, int C, int backward, int dt,
                     void* stream);
-/* im2col of BasicStem's 7x7 stride-2 pad-3 conv: out [B,Ho,Wo,Kpad], column (ky*7+kx)*3+c */
-int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, void* stream);
+/* im2col of BasicStem's 7x7 stride-2 pad-3 conv: out [B,Ho,Wo,Kpad], column (ky*7+kx)*3+c; out_dt = dt, or
+ * SFOD_BF16X3 from fp32 input (the stem GEMM's operand pairs, written directly) */
+int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, int out_dt,
+                     void* stream);
 /* BasicStem max_pool2d(kernel 3, stride 2, padding 1), forward (the stem is frozen) */
 int sfod_maxpool3s2(const void* x, void* y, int B, int H, int W, int C, int dt, void* stream);
 /* elementwise: dx = dy * (y > 0) (ReLU) or dy * (y > 0 ? 1 : 0.2) (LeakyReLU) in place on dy */

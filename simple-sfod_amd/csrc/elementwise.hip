@@ -1110,8 +1110,8 @@ extern "C" int sfod_subsample2(const void* src, void* dst, int B, int H, int W, 
 // im2col of the 7x7 stride-2 pad-3 stem convolution: out [B,Ho,Wo,Kpad], k = (ky*7+kx)*3 + c for the
 // first 147 columns, zeros up to Kpad.  The stem is frozen (FREEZE_AT=2), so only the forward exists;
 // the GEMM itself (K = Kpad, N = 64, FrozenBN folded into the weights, ReLU) runs on sfod_conv_fwd.
-template <typename T>
-__global__ void k_im2col_stem(const T* __restrict__ x, T* __restrict__ out, int B, int H, int W, int Cp, int Kpad) {
+template <typename T, typename TO = T>
+__global__ void k_im2col_stem(const T* __restrict__ x, TO* __restrict__ out, int B, int H, int W, int Cp, int Kpad) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int kv = Kpad / 8;   // 8-element groups per row
   const int64_t total = (int64_t)B * Ho * Wo * kv;
@@ -1123,7 +1123,7 @@ __global__ void k_im2col_stem(const T* __restrict__ x, T* __restrict__ out, int 
     pix /= Wo;
     const int oy = (int)(pix % Ho);
     const int b = (int)(pix / Ho);
-    T v[8];
+    float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = g * 8 + e;
@@ -1134,21 +1134,24 @@ __global__ void k_im2col_stem(const T* __restrict__ x, T* __restrict__ out, int 
         const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
         if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = to_f32(x[(((int64_t)b * H + iy) * W + ix) * Cp + c]);
       }
-      v[e] = from_f32<T>(val);
+      v[e] = val;
     }
-    T* o = out + t * 8;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = v[e];
+    store_n<TO, 8>(out + t * 8, v);       // 16 / 32-byte stores; TO = split_t: the GEMM's operand pairs directly
   }
 }
 
-extern "C" int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, void* stream) {
+extern "C" int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, int out_dt,
+                                void* stream) {
   SFOD_REQUIRE(Kpad >= 152 && Kpad % 8 == 0 && Cp >= 3, "im2col_stem: Kpad must be a multiple of 8 >= 152");
+  SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && out_dt == SFOD_BF16X3), "im2col_stem: output is the input type, or bf16x3 from fp32");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int64_t total = (int64_t)B * Ho * Wo * (Kpad / 8);
   if (total == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (dt == SFOD_F32)
+  if (out_dt == SFOD_BF16X3)
+    hipLaunchKernelGGL((k_im2col_stem<float, split_t>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x,
+                       (split_t*)out, B, H, W, Cp, Kpad);
+  else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_im2col_stem<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, (float*)out, B, H,
                        W, Cp, Kpad);
   else

@@ -238,7 +238,7 @@ class ResNet(nn.Module):
         kpad = 192
         wk = torch.zeros(conv.out_channels, kpad, dtype=torch.float32, device=x.device)
         wk[:, :147] = w
-        cols = native.im2col_stem(x, kpad)
+        cols = native.im2col_stem(x, kpad, out_dtype=self.compute_dtype if self.compute_dtype == native.SPLIT_DTYPE else None)
         B, Ho, Wo, _ = cols.shape
         wp = native.pack_fc_weight(wk, dt)
         y = native.conv_fwd(cols.view(B * Ho * Wo, kpad), wp, shift.contiguous(), conv.out_channels, 1, act=1)

@@ -773,10 +773,11 @@ def subsample2_bwd(dy, full_shape):
     return dx
 
 
-def im2col_stem(x, kpad=192):
+def im2col_stem(x, kpad=192, out_dtype=None):
+    """``out_dtype``: x.dtype, or SPLIT_DTYPE from fp32 (the stem GEMM's operand, no separate conversion pass)."""
     B, H, W, Cp = x.shape
-    out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, kpad, dtype=x.dtype, device=x.device)
-    call("sfod_im2col_stem", x, out, B, H, W, Cp, kpad, dt_of(x))
+    out = torch.empty(B, (H - 1) // 2 + 1, (W - 1) // 2 + 1, kpad, dtype=out_dtype or x.dtype, device=x.device)
+    call("sfod_im2col_stem", x, out, B, H, W, Cp, kpad, dt_of(x), dt_of(out))
     return out
 
 
