@@ -219,6 +219,9 @@ int sfod_maxpool3s2(const void* x, void* y, int B, int H, int W, int C, int dt, 
 int sfod_act_bwd(void* dy, const void* y, int64_t n, int act, int dt, void* stream);
 /* a += b  (fp32 or bf16 elementwise) */
 int sfod_add_inplace(void* a, const void* b, int64_t n, int dt, void* stream);
+/* a = (a + b) * [y > 0]: sum of a residual join's two gradient branches taken through the ReLU of the block below
+ * (its output y) in one pass -- sfod_add_inplace followed by sfod_act_bwd(act 1) */
+int sfod_add_act_bwd(void* a, const void* b, const void* y, int64_t n, int dt, void* stream);
 /* a = mask ? a * scale : 0 (mask: one 0/1 byte per element): F.dropout forward and backward of the
  * instance-level domain discriminator (daod/modeling/dann/dann.py:146-151), scale = 1 / (1 - p) */
 int sfod_mul_mask(void* a, const uint8_t* mask, int64_t n, float scale, int dt, void* stream);

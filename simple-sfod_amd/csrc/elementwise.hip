@@ -988,6 +988,37 @@ extern "C" int sfod_add_inplace(void* a, const void* b, int64_t n, int dt, void*
   return sfod_check_launch("add_inplace");
 }
 
+// a = (a + b) * [y > 0]: the residual join's two gradient branches summed and taken through the ReLU of the block
+// below in one pass (was k_add_inplace followed by that block's k_act_bwd: one read and one write of the tensor less)
+template <typename T>
+__global__ void k_add_act_bwd(T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ y, int64_t nvec) {
+  constexpr int V = VecT<T>::N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    float x[V], bv[V], yv[V];
+    load_vec<T>(a + t * V, x);
+    load_vec<T>(b + t * V, bv);
+    load_vec<T>(y + t * V, yv);
+#pragma unroll
+    for (int i = 0; i < V; ++i) x[i] = yv[i] > 0.f ? x[i] + bv[i] : 0.f;
+    store_vec<T>(a + t * V, x);
+  }
+}
+
+extern "C" int sfod_add_act_bwd(void* a, const void* b, const void* y, int64_t n, int dt, void* stream) {
+  const int V = (dt == SFOD_F32) ? 4 : 8;
+  SFOD_REQUIRE(n % V == 0, "add_act_bwd: n not a multiple of the vector width");
+  const int64_t nvec = n / V;
+  if (nvec == 0) return 0;
+  if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_add_act_bwd<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (float*)a,
+                       (const float*)b, (const float*)y, nvec);
+  else
+    hipLaunchKernelGGL(k_add_act_bwd<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)a,
+                       (const bf16_t*)b, (const bf16_t*)y, nvec);
+  return sfod_check_launch("add_act_bwd");
+}
+
 // a *= mask * scale  (dropout forward / backward: mask is a 0/1 byte per element, scale = 1 / (1 - p))
 template <typename T>
 __global__ void k_mul_mask(T* __restrict__ a, const uint8_t* __restrict__ m, int64_t nvec, float scale) {

@@ -381,10 +381,13 @@ class ResNet(nn.Module):
             dx = native.conv_fwd(dy, wr, None, conv.in_channels, k)
         return dx, [dw, dgamma, dbeta]
 
-    def _block_backward(self, blk, sv, dout, need_dx=True):
-        """dout (grad of the block output, consumed) -> (dx or None, [dw, dgamma, dbeta] per conv)."""
+    def _block_backward(self, blk, sv, dout, need_dx=True, masked=False, below_out=None):
+        """dout (grad of the block output, consumed) -> (dx or None, [dw, dgamma, dbeta] per conv, dx already taken
+        through the ReLU of the block below).  ``masked``: dout already went through this block's joining ReLU (the
+        block above fused it into its own last pass); ``below_out``: output of the block below -- with an identity
+        shortcut the sum of the two input-gradient branches and that block's ReLU mask are one pass."""
         (xshape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out) = sv
-        g = native.act_bwd_(dout, out, 1)                      # through the joining ReLU
+        g = dout if masked else native.act_bwd_(dout, out, 1)  # through the joining ReLU
         da2, p3 = self._conv_bwd(g, a2, y3, m3, i3, blk.conv3, False, True)
         da1, p2 = self._conv_bwd(da2, a1, y2, m2, i2, blk.conv2, True, True)
         dxs, p1 = self._conv_bwd(da1, xs, y1, m1, i1, blk.conv1, True, need_dx)
@@ -394,11 +397,13 @@ class ResNet(nn.Module):
             if need_dx:
                 dxs = native.add_(dxs, dsc)
         elif need_dx:
+            if below_out is not None and blk.stride != 2:
+                return native.add_act_bwd_(dxs, g, below_out), p1 + p2 + p3 + ps, True
             dxs = native.add_(dxs, g)
         dx = None
         if need_dx:
             dx = native.subsample2_bwd(dxs, xshape) if blk.stride == 2 else dxs
-        return dx, p1 + p2 + p3 + ps
+        return dx, p1 + p2 + p3 + ps, False
 
     def _backward_impl(self, saved, out_grads):
         hook = getattr(self, "_pre_backward", None)
@@ -412,17 +417,24 @@ class ResNet(nn.Module):
         stage_last = {n: max(i for i, s in enumerate(block_stage) if s == n) for n in live_names}
         gmap = {n: g for n, g in zip(self._out_features, out_grads) if g is not None}
         pg = {}
-        dx = None
+        dx, masked = None, False
         for bi in range(len(blocks) - 1, -1, -1):
             blk = blocks[bi]
             name = block_stage[bi]
             if stage_last[name] == bi and name in gmap:
+                assert not masked, "a stage output gradient must be added before the ReLU mask"
                 g_in = gmap[name].permute(0, 2, 3, 1).to(self.act_dtype).contiguous()
                 dx = g_in if dx is None else native.add_(dx, g_in)
             if dx is None:
                 saved[bi] = None
                 continue
-            dx, pg[bi] = self._block_backward(blk, saved[bi], dx, need_dx=bi > 0)  # first live block: frozen input
+            # the block below's output (its joining ReLU's mask) -- unless a stage gradient still has to be added there
+            below = None
+            if bi > 0 and saved[bi - 1] is not None and not (stage_last[block_stage[bi - 1]] == bi - 1
+                                                              and block_stage[bi - 1] in gmap):
+                below = saved[bi - 1][-1]
+            dx, pg[bi], masked = self._block_backward(blk, saved[bi], dx, need_dx=bi > 0,   # first live block: frozen input
+                                                      masked=masked, below_out=below)
             saved[bi] = None
         out = []
         for bi, blk in enumerate(blocks):

@@ -746,6 +746,12 @@ def add_(a, b):
     return a
 
 
+def add_act_bwd_(a, b, y):
+    """a = (a + b) * (y > 0) in place (add_ followed by act_bwd_(.., y, 1))."""
+    call("sfod_add_act_bwd", a, b, y, a.numel(), dt_of(a))
+    return a
+
+
 def mul_mask_(a, mask_u8, scale):
     call("sfod_mul_mask", a, mask_u8, a.numel(), float(scale), dt_of(a))
     return a

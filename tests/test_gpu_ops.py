@@ -985,6 +985,10 @@ def test_bn_add_relu_fwd_equals_the_two_pass_form(native, dtype):
         z, zp = native.bn_add_relu_fwd(yd, *args, rd, with_operand=True)
         torch.testing.assert_close(z, got, rtol=2e-7, atol=1e-7)
         assert zp.dtype == native.SPLIT_DTYPE and torch.equal(zp.view(torch.bfloat16), native.cast(z, native.SPLIT_DTYPE).view(torch.bfloat16))
+        # backward-side fusion of the same join: (a + b) * [y > 0] == add_ followed by act_bwd_
+        a1, b1 = torch.randn_like(yd), torch.randn_like(yd)
+        ref_g = native.act_bwd_(native.add_(a1.clone(), b1), got, 1)
+        assert torch.equal(native.add_act_bwd_(a1.clone(), b1, got), ref_g)
         o, op = native.add_act(yd, rd, 1, with_operand=True)
         assert torch.equal(o, native.add_act(yd, rd, 1))
         assert torch.equal(op.view(torch.bfloat16), native.cast(o, native.SPLIT_DTYPE).view(torch.bfloat16))
