@@ -337,12 +337,16 @@ k_conv3x3_patch(P3Args a) {
       if (sg0 + j + D < nstages) issue_b(sg0 + j + D);
       // -- compute stage j
       const unsigned char* bsl = smem + BRING_OFF + ((sg0 + j) % NBS) * BSLOT;
+      // raised priority over the stage's fragment reads + MFMAs (cdna_hip_programming.md T5): +0.7-1 % per layer in a
+      // same-box A/B (profiles/r2d_rejected_experiments.txt has the static-priority form, which lost)
+      __builtin_amdgcn_s_setprio(1);
       if constexpr (G == 1) {
         compute_pair(j, smem + (body & 1) * PATCH_BYTES, bsl);
       } else {
         compute_pair((2 * j) % 9, smem + ((2 * j) / 9) * PATCH_BYTES, bsl);
         compute_pair((2 * j + 1) % 9, smem + ((2 * j + 1) / 9) * PATCH_BYTES, bsl + BN * 64);
       }
+      __builtin_amdgcn_s_setprio(0);
     };
     stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{}); stage(IC<4>{});
     stage(IC<5>{}); stage(IC<6>{}); stage(IC<7>{}); stage(IC<8>{});
