@@ -108,7 +108,8 @@ def report_incompatible(inc, n_model_keys, path, who="model", require_backbone=T
     the model at its random initialisation without a word, and in source-free training the pseudo-labels then come
     from a random teacher."""
     missing, unexpected, incorrect = inc
-    matched = n_model_keys - len(missing) - len([k for k, _, _ in incorrect])
+    # shape-mismatched keys were popped before load_state_dict, so they are in ``missing`` as well: count them once
+    matched = n_model_keys - len(set(missing) | {k for k, _, _ in incorrect})
     for k, cs, ms in incorrect:
         logger.warning("[%s] skip loading '%s' from %s: checkpoint shape %s, model shape %s", who, k, path, cs, ms)
     if missing:

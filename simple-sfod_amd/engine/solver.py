@@ -42,6 +42,7 @@ class FlatModelState:
         norm = [(n, p) for n, p in named if id(p) in norm_ids and not is_frozen(n, p)]
         frozen = [(n, p) for n, p in named if is_frozen(n, p)]
         self.order = decay + norm + frozen
+        self.named_order = [n for n, _ in named]       # model.named_parameters() order (torch / Detectron2 indexing)
         dev = named[0][1].device
 
         def pad4(n):
@@ -160,9 +161,69 @@ class FusedSGD:
         return {"momentum_buffer": self.mom, "steps": self._steps, "lr": self.param_groups[0]["lr"]}
 
     def load_state_dict(self, sd):
+        if "param_groups" in sd and "state" in sd:     # written by torch.optim.SGD (the reference stack's checkpoints)
+            return self._load_torch_sgd_state(sd)
         self.mom.copy_(sd["momentum_buffer"])
         self._steps = sd["steps"]
         self.set_lr(sd["lr"])
+
+    def torch_param_order(self):
+        """Names of the reference stack's optimiser parameters in ``torch.optim.SGD`` index order: Detectron2's
+        ``get_default_optimizer_params`` walks the modules' own parameters (= ``named_parameters()`` order), skips
+        ``requires_grad == False``, gives norm-layer parameters ``WEIGHT_DECAY_NORM`` and everything else
+        ``WEIGHT_DECAY`` (bias factor / bias decay equal the defaults in the named yamls), ``reduce_param_groups``
+        merges the per-parameter groups by hyper-parameters in first-seen order, and torch numbers the parameters
+        group by group.  -> [[names of group 0], [names of group 1], ...]."""
+        f = self.flat
+        norm = {n for n, (o, _, _) in f.offsets.items() if f.n_decay <= o < f.n_norm_end}
+        if self.weight_decay_norm == self.weight_decay:
+            norm = set()
+        groups, index = [], {}
+        for n in f.named_order:
+            if not f.params[n].requires_grad:
+                continue
+            key = n in norm
+            if key not in index:
+                index[key] = len(groups)
+                groups.append([])
+            groups[index[key]].append(n)
+        return groups
+
+    @torch.no_grad()
+    def _load_torch_sgd_state(self, sd):
+        """Momentum buffers + learning rate from a ``torch.optim.SGD.state_dict()`` (fvcore ``Checkpointer.save``
+        stores it under "optimizer", daod/engine/trainers/source_free_adaptive_teacher.py:84-89).  Accepts the merged
+        groups of current Detectron2 and the one-group-per-parameter layout of older versions.  Parameters this
+        optimiser does not update (zero-gradient domain-classifier heads with DOMAIN_CLASSIFIER off) are skipped."""
+        f = self.flat
+        ours = self.torch_param_order()
+        theirs = [list(g["params"]) for g in sd["param_groups"]]
+        if [len(g) for g in theirs] == [len(g) for g in ours]:
+            names = {i: n for g_t, g_o in zip(theirs, ours) for i, n in zip(g_t, g_o)}
+        elif all(len(g) == 1 for g in theirs) and len(theirs) == sum(len(g) for g in ours):
+            order = [n for n in f.named_order if f.params[n].requires_grad]   # one group per parameter, in walk order
+            names = {g[0]: n for g, n in zip(theirs, order)}
+        else:
+            raise ValueError("optimizer state does not fit this model: checkpoint groups {} vs {} here".format(
+                [len(g) for g in theirs], [len(g) for g in ours]))
+        self.mom.zero_()
+        loaded = 0
+        for i, st in sd["state"].items():
+            buf = st.get("momentum_buffer")
+            n = names.get(int(i))
+            if buf is None or n is None:
+                continue
+            o, k, shp = f.offsets[n]
+            if tuple(buf.shape) != tuple(shp):
+                raise ValueError("momentum buffer {} of the checkpoint is {} but '{}' is {}".format(
+                    i, tuple(buf.shape), n, tuple(shp)))
+            if o >= f.n_norm_end:         # not updated here (see build_optimizer: never-run domain-classifier heads)
+                continue
+            self.mom[o:o + k].view(shp).copy_(buf)
+            loaded += 1
+        self._steps = 1 if loaded else 0      # torch initialises a missing buffer with the gradient: same as mu * 0 + g
+        self.set_lr(sd["param_groups"][0]["lr"])
+        return loaded
 
 
 def build_optimizer(cfg, model):

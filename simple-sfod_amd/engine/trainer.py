@@ -21,6 +21,7 @@ MI355X-first differences (documented in DESIGN.md):
   * zero-weighted dead branches (2nd ROI pass, BPC, domain classifier) are elided
     (``SFOD.ELIDE_DEAD_BRANCHES``).
 """
+import contextlib
 import json
 import os
 import time
@@ -60,13 +61,25 @@ class EventStorage:
     def put_scalars(self, **kw):
         self._pending.update(kw)
 
-    def flush(self):
+    def flush(self, reduce_over_ranks=False):
+        """-> the record of this writer period.  ``reduce_over_ranks``: the reference gathers every rank's metrics dict
+        each step and logs the mean (``data_time``: the max) over ranks (daod/engine/trainers/base.py:198-209,
+        ``comm.gather`` + ``np.mean``); here the device scalars of the period are stacked and averaged with ONE small
+        all-reduce per writer period (+ one MAX all-reduce for ``data_time``).  Every rank must call it with the same
+        tensor-valued keys (they follow from the config, not from the data)."""
         if not self._pending:
             return {}
         names = list(self._pending)
         vals = [v.detach().float().reshape(()) if isinstance(v, torch.Tensor) else None for v in self._pending.values()]
         dev_vals = [v for v in vals if v is not None]
-        host = torch.stack(dev_vals).cpu().tolist() if dev_vals else []
+        world = get_world_size() if reduce_over_ranks else 1
+        host = []
+        if dev_vals:
+            stacked = torch.stack(dev_vals)
+            if world > 1:
+                dist.all_reduce(stacked)
+                stacked = stacked / world
+            host = stacked.cpu().tolist()
         out, j = {"iteration": self.iter}, 0
         for n, v in zip(names, vals):
             if v is None:
@@ -74,6 +87,10 @@ class EventStorage:
             else:
                 out[n] = host[j]
                 j += 1
+        if world > 1 and "data_time" in out and dev_vals:
+            t = torch.tensor([out["data_time"]], dtype=torch.float32, device=dev_vals[0].device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out["data_time"] = t.item()
         self._pending = {}
         self.history.append(out)
         return out
@@ -288,7 +305,7 @@ class BaseTrainer:
         # the reference's eval / AdaBN configs point MODEL.WEIGHTS at)
         p = self.cfg.SOLVER.CHECKPOINT_PERIOD
         if get_rank() == 0 and self.cfg.OUTPUT_DIR and p > 0:
-            if nxt % p == 0 and nxt != self.max_iter:
+            if nxt % p == 0:          # fvcore PeriodicCheckpointer: the numbered file on the last iteration too
                 self.save_checkpoint("model_{:07d}".format(self.iter))
             if nxt >= self.max_iter:
                 self.save_checkpoint("model_final")
@@ -337,7 +354,7 @@ class BaseTrainer:
                     acc[k] = acc[k] + v if k in acc else v
                 nb += 1
             losses = {k: v / max(nb, 1) for k, v in acc.items() if k[:4] == "loss"}
-            if get_rank() == 0 and losses:
+            if losses:     # every rank logs its share of the test set; the flush averages over ranks
                 self.storage.put_scalar("total_loss" + name + "_val", sum(losses.values()))
                 if len(losses) > 1:
                     self.storage.put_scalars(**{k + name + "_val": v for k, v in losses.items()})
@@ -362,7 +379,7 @@ class BaseTrainer:
         rpn = getattr(self.model, "proposal_generator", None)
         if rpn is not None:
             rpn.check_finite()
-        rec = self.storage.flush()
+        rec = self.storage.flush(reduce_over_ranks=True)
         rec["lr"] = self.optimizer.param_groups[0]["lr"]
         if get_rank() == 0 and self.cfg.OUTPUT_DIR:
             os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
@@ -454,9 +471,12 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         # runs.  With WEAK_STRONG_AUGMENT the two extra passes would see differently augmented frames: not
         # reproducible without running them (documented deviation; ELIDE_DEAD_BRANCHES False runs everything).
         dc_live = cfg.DOMAIN_CLASSIFIER.ENABLED and (cfg.DOMAIN_CLASSIFIER.IMAGE or cfg.DOMAIN_CLASSIFIER.INSTANCE)
+        # Scoped to the student pass inside run_step: every other training-mode forward of the student (ValLossHook,
+        # AdaBN passes, user code) is one backbone pass in the reference as well and must count as one.
+        self._elided_bn_updates = 1
         if self.elide and cfg.DOMAIN_CLASSIFIER.ENABLED and not dc_live and not cfg.WEAK_STRONG_AUGMENT \
                 and hasattr(self.model.backbone, "bn_updates_per_forward"):
-            self.model.backbone.bn_updates_per_forward = 3
+            self._elided_bn_updates = 3
 
     @staticmethod
     def _frozen(cfg):
@@ -532,6 +552,23 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             d["instances"] = label.view(i) if isinstance(label, BatchedGT) else label[i]
         return unlabeled_data
 
+    @contextlib.contextmanager
+    def _student_pass_bn_updates(self):
+        """The closed-form BatchNorm side effect of the elided passes (see __init__) applies to the student's
+        backbone pass of ``run_step`` only; restored afterwards so that ValLossHook / AdaBN / user forwards count
+        one momentum update per pass like the reference's."""
+        bb = self.model.backbone
+        k = self.__dict__.get("_elided_bn_updates", 1)
+        if k == 1 or not hasattr(bb, "bn_updates_per_forward"):
+            yield
+            return
+        prev = bb.bn_updates_per_forward
+        bb.bn_updates_per_forward = k
+        try:
+            yield
+        finally:
+            bb.bn_updates_per_forward = prev
+
     def _teacher_pass(self, unlabel_data_k):
         """Steps 1-2 of run_step: train-mode teacher under no_grad, score threshold -> pseudo ground truth."""
         cfg = self.cfg
@@ -592,7 +629,8 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             side.wait_stream(main)       # EMA'd teacher weights, input frames, last step's readers of side buffers
             with torch.cuda.stream(side):
                 pseudo = self._teacher_pass(unlabel_data_k)
-            self.model.prefetch_features(unlabel_data_q)
+            with self._student_pass_bn_updates():
+                self.model.prefetch_features(unlabel_data_q)
             main.wait_stream(side)
         else:
             pseudo = self._teacher_pass(unlabel_data_k)
@@ -600,7 +638,8 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         unlabel_data_q = self.add_label(unlabel_data_q, pseudo)
         unlabel_data_k = self.add_label(unlabel_data_k, pseudo)
         # 5. student on the pseudo-labelled target data
-        record_all_unlabel_data, _, _, _ = self.model(unlabel_data_q, branch="supervised_target", batched=True)
+        with self._student_pass_bn_updates():
+            record_all_unlabel_data, _, _, _ = self.model(unlabel_data_q, branch="supervised_target", batched=True)
         for key, v in record_all_unlabel_data.items():
             record_dict[key + "_pseudo"] = v
         # 6. domain-classifier branch (:527-537): zero-weighted unless DOMAIN_CLASSIFIER.IMAGE/INSTANCE

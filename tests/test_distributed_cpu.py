@@ -90,6 +90,14 @@ def _worker(rank, world, port, q):
                                                                       _reducer=redm))
     ok_sum = ok_sum and ok_model and torch.equal(bflat.grad, sum(parts))
     del big, bflat, parts
+    # logged metrics: mean over ranks of the period's device scalars with one small all-reduce, data_time = max over
+    # ranks (reference base.py:198-209: comm.gather + np.mean / np.max)
+    st = sfod.engine.trainer.EventStorage(0)
+    st.put_scalars(loss_cls=torch.tensor(float(rank + 1)), total_loss=torch.tensor(10.0 * (rank + 1)),
+                   data_time=0.25 * (rank + 1), **{"lr_note": 3.0})
+    rec = st.flush(reduce_over_ranks=True)
+    ok_sum = ok_sum and rec["loss_cls"] == 1.5 and rec["total_loss"] == 15.0 and rec["data_time"] == 0.5 \
+        and rec["lr_note"] == 3.0 and st.flush(reduce_over_ranks=True) == {}
     # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream
     s = iter(sfod.data.TrainingSampler(10, seed=7, rank=rank, world=world))
     mine = [next(s) for _ in range(10)]

@@ -512,6 +512,11 @@ def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     # 3 training steps + the ValLossHook's train-mode passes over the test set after the last one (the reference's
     # hook runs ``model(data)`` on the model as it is, so BatchNorm statistics move there too)
     assert all(int(v.item()) == 3 + cfg.SFOD.SYNTHETIC.NUM_TEST_IMAGES for v in nbt)
+    # student: 3 momentum updates per training step (the reference's three backbone passes, two of them elided and
+    # applied in closed form), but ONE per ValLossHook image -- the hook is a single pass in the reference as well
+    nbt_s = [v for k, v in tr.model.state_dict().items() if "num_batches_tracked" in k]
+    assert tr._elided_bn_updates == 3 and tr.model.backbone.bn_updates_per_forward == 1
+    assert all(int(v.item()) == 3 * 3 + cfg.SFOD.SYNTHETIC.NUM_TEST_IMAGES for v in nbt_s), nbt_s[0]
     sd = tr.state_dict_for_checkpoint()["model"]
     assert "modelTeacher.backbone.vgg0.0.weight" in sd and "modelStudent.roi_heads.box_head.fc1.weight" in sd
     # EvalHooks (source_free_adaptive_teacher.py:648-662): after the last iteration the student and the teacher were

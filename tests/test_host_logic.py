@@ -203,3 +203,98 @@ def test_ema_attach_raises_the_reference_error_for_a_key_the_student_lacks(sfod)
     ok = E.FlatModelState(torch.nn.Sequential(torch.nn.Linear(3, 2)), with_grad=False)
     opt.attach_teacher(ok, 0.9996)
     assert opt.teacher is ok and opt.ema_keep == 0.9996
+
+
+def test_reads_checkpoints_in_the_reference_stacks_formats(sfod, tmp_path):
+    """SURVEY 8f rank 2 pinned on files this package did NOT write (tests/golden/make_reference_format_checkpoints.py
+    builds them by hand from the reference's key lists, manifest committed as tests/golden/ref_ckpt_manifest.json):
+    (i) the ``.pkl`` layout of convert_pretrained_model/convert_vgg_bn.py:142-157 as MODEL.WEIGHTS; (ii) the ensemble
+    ``.pth`` of fvcore's Checkpointer.save for DetectionTSCheckpointer(EnsembleTSModel, optimizer, scheduler)
+    (source_free_adaptive_teacher.py:81-89) with a real torch.optim.SGD state dict, resumed from."""
+    import importlib.util
+    import json
+    import pickle
+    from types import SimpleNamespace
+    import numpy as np
+    spec = importlib.util.spec_from_file_location("mk_ref_ckpt", os.path.join(ROOT, "tests", "golden",
+                                                                              "make_reference_format_checkpoints.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    man = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_ckpt_manifest.json")))
+    assert man == json.loads(json.dumps(mk.manifest())), "regenerate with --manifest"
+    ck = importlib.import_module("simple-sfod_amd.checkpoint")
+    E = sfod.engine
+    yaml = os.path.join(ROOT, "configs", "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml")
+    cfg = sfod.config.setup_cfg(yaml, ["MODEL.ROI_BOX_HEAD.FC_DIM", "64"])          # small heads: small files
+
+    def build(seed):
+        torch.manual_seed(seed)
+        return sfod.registry.META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+
+    # ---- (i) convert_vgg_bn.py layout ---------------------------------------------------------------------------
+    pkl_path = str(tmp_path / "vgg16_bn.pkl")
+    tv, _ = mk.write_pkl(pkl_path, seed=3)
+    raw = pickle.load(open(pkl_path, "rb"))
+    assert list(raw.keys()) == man["pkl"]["top_level"] and raw["__author__"] == "torchvision"
+    assert {k: list(v.shape) for k, v in raw["model"].items()} == man["pkl"]["model"]
+    assert all(isinstance(v, np.ndarray) and v.dtype == np.float32 for v in raw["model"].values())
+    model = build(0)
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    inc = ck.load_model_weights(model, pkl_path, who="student")
+    sd = model.state_dict()
+    # every conv / BatchNorm tensor of the trunk comes from the torchvision layer of the same ordinal
+    tv_convs = [k[:-7] for k in tv if k.startswith("features") and k.endswith(".weight") and tv[k].dim() == 4]
+    ours = [k[:-7] for k in sd if k.startswith("backbone") and k.endswith(".weight") and sd[k].dim() == 4]
+    assert len(tv_convs) == len(ours) == 13
+    for a, b in zip(tv_convs, ours):
+        n = int(a.split(".")[1])
+        stage, idx = b.split(".")[1], int(b.split(".")[2])
+        assert torch.equal(sd[b + ".weight"], tv[a + ".weight"]) and torch.equal(sd[b + ".bias"], tv[a + ".bias"])
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            assert torch.equal(sd[f"backbone.{stage}.{idx + 1}.{s}"], tv[f"features.{n + 1}.{s}"]), (b, s)
+    assert inc.unexpected_keys == [] and inc.incorrect_shapes == []
+    missing = set(inc.missing_keys)
+    # (num_batches_tracked: torch's BatchNorm loader fills a version-less state dict's missing counter with 0)
+    assert not any(k.startswith("backbone") for k in missing)
+    assert "roi_heads.box_head.fc1.weight" in missing and "proposal_generator.rpn_head.conv.weight" in missing
+    assert torch.equal(sd["roi_heads.box_head.fc1.weight"], before["roi_heads.box_head.fc1.weight"])
+
+    # ---- (ii) ensemble .pth with a torch.optim.SGD state, resumed from ----------------------------------------------
+    student, teacher = build(1), build(2)
+    path, moms = mk.write_ensemble_pth(str(tmp_path / "run"), student, teacher, iteration=1999, base_lr=0.0025, seed=5)
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert list(raw.keys()) == man["pth"]["top_level"] and list(raw["optimizer"].keys()) == man["pth"]["optimizer"]["top_level"]
+    assert all(k.startswith(tuple(man["pth"]["model_prefixes"])) for k in raw["model"])
+    assert [len(g["params"]) for g in raw["optimizer"]["param_groups"]] == [len(moms) - 26, 26]   # decayed | 13 x (gamma, beta)
+    s2, t2 = build(7), build(8)
+    opt = E.build_optimizer(cfg, s2)
+    tr = SimpleNamespace(model=s2, model_teacher=t2, optimizer=opt, scheduler=E.WarmupMultiStepLR(opt, cfg),
+                         start_iter=0, iter=0)
+    ck.DetectionTSCheckpointer(tr, str(tmp_path / "run")).resume_or_load("", resume=True)
+    assert tr.start_iter == 2000 and tr.iter == 2000 and tr.scheduler.last_epoch == 2000
+    assert abs(opt.param_groups[0]["lr"] - 0.0025) < 1e-12           # past the 1000-iteration warm-up
+    for k, v in student.state_dict().items():
+        assert torch.equal(s2.state_dict()[k], v), k
+    for k, v in teacher.state_dict().items():
+        assert torch.equal(t2.state_dict()[k], v), k
+    assert len(moms) == len(opt.flat.offsets)
+    for n, m in moms.items():
+        o, k, shp = opt.flat.offsets[n]
+        assert torch.equal(opt.mom[o:o + k].view(shp), m), n
+    assert opt._steps == 1
+    # Detectron2 before reduce_param_groups: one group per parameter, same index order
+    sd_old = {"state": raw["optimizer"]["state"], "param_groups": []}
+    order = [i for g in raw["optimizer"]["param_groups"] for i in g["params"]]
+    names_by_idx = {i: n for g_t, g_o in zip(raw["optimizer"]["param_groups"], opt.torch_param_order())
+                    for i, n in zip(g_t["params"], g_o)}
+    walk = [n for n in opt.flat.named_order]
+    renum = {n: j for j, n in enumerate(walk)}
+    sd_old["state"] = {renum[names_by_idx[i]]: st for i, st in raw["optimizer"]["state"].items()}
+    sd_old["param_groups"] = [{"lr": 0.001, "weight_decay": 1e-4, "params": [j]} for j in range(len(walk))]
+    opt.mom.zero_()
+    assert opt.load_state_dict(sd_old) == len(moms)
+    for n, m in moms.items():
+        o, k, shp = opt.flat.offsets[n]
+        assert torch.equal(opt.mom[o:o + k].view(shp), m), n
+    with pytest.raises(ValueError, match="does not fit this model"):
+        opt.load_state_dict({"state": {}, "param_groups": [{"lr": 0.1, "params": [0, 1, 2]}]})
