@@ -7,10 +7,12 @@ fused SGD + EMA.  Inputs are resident in HBM before the timed region (the mapper
 uint8 CHW tensors, 1024x2048 frames resized to 600x1200 by INPUT.MIN_SIZE_TRAIN=600 of the
 named config; ``--res full`` overrides the config to feed 1024x2048 tensors).
 
-``value`` is measured in ``SFOD.COMPUTE_DTYPE bf16x3`` -- fp32-equivalent arithmetic, the mode whose 1e-4 parity
-against the CPU oracle is gated at this frame size by tests/test_gpu_fullsize.py.  The reduced-precision ``bf16``
-mode (one bf16 pass, bf16 activations; NOT a parity mode) is measured afterwards in the same process and reported
-as the labelled secondary block ``reduced_precision_mode``, never as ``value``.
+``value`` is measured in the arithmetic mode whose parity against the CPU oracle is gated AT THIS FRAME SIZE by
+tests/test_gpu_fullsize.py for the config being run: ``bf16x3`` for the VGG16 configs (split-precision products on the
+bf16 matrix pipe, about 16 significand bits per operand: losses and boxes within 1e-4, intermediates within 2e-4), ``fp32``
+(fp32 MFMA) for ``--model r101`` -- on that 101-layer network bf16x3 reaches only ~1e-3 (the test says so), so it is
+NOT reported as ``value`` there.  Faster, less exact modes are measured afterwards by a child process and reported as
+the labelled secondary block ``reduced_precision_mode``, never as ``value``.
 
 Contract: ``python bench.py --gpus N --steps K --warmup W``; rank 0 prints ONE JSON line.  N > 1: either started under
 ``python -m torch.distributed.run`` (RANK / WORLD_SIZE in the environment), or plainly -- then the script starts the N
@@ -43,6 +45,12 @@ YAML = {"vgg": "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.ya
 # dense MFMA TFLOP/s (MI355X_MICROARCH.md) per ALGORITHMIC flop: bf16x3 issues three bf16 MFMAs per product
 # (hi*hi + hi*lo + lo*hi), so its ceiling for the convolution's own 2*M*N*K count is the bf16 peak / 3
 PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0}
+# the mode test_gpu_fullsize.py gates at the north star's 1e-4 for each model = what `value` is measured in
+PARITY_DTYPE = {"vgg": "bf16x3", "r101": "fp32"}
+# "planted-label" scale on cls_score: 10-30 teacher detections per image clear the 0.8 threshold
+PLANT = {"vgg": 60.0, "r101": 3.0}
+# the committed PMC capture (profiles/pmc_hbm_traffic_latest.json) was taken on exactly this run configuration
+PMC_CAPTURE = {"model": "vgg", "trainer": "source_free", "res": "r600", "batch": 8}
 
 
 def step_flops(res, model="vgg", trainer="source_free"):
@@ -79,7 +87,7 @@ def physical_cores():
     return max(1, (os.cpu_count() or 2) // 2)
 
 
-def cpu_baseline(res, planted):
+def cpu_baseline(res, planted, model="vgg"):
     """The CPU oracle (kind "port": the PyTorch-CPU restatement of the reference's Detectron2 path -- the reference
     itself cannot run here, Detectron2 is absent) on a bounded sample: ONE image per step, 1 warm-up + 3 timed
     teacher+student steps, one thread per physical core, with the split over the stages."""
@@ -87,19 +95,19 @@ def cpu_baseline(res, planted):
     from oracle import model as om
     cores = physical_cores()
     torch.set_num_threads(cores)
-    cfg = om.Cfg()
+    cfg = om.Cfg.r101_c4() if model == "r101" else om.Cfg()
     sd_t = om.init_state(cfg, seed=0)
     if planted:
-        sd_t["roi_heads.box_predictor.cls_score.weight"] *= 60.0
+        sd_t["roi_heads.box_predictor.cls_score.weight"] *= PLANT[model]
     sd_s = om.clone_state(sd_t, requires_grad=True)
     h, w = (600, 1200) if res == "r600" else (1024, 2048)
     g = torch.Generator().manual_seed(42)
-    hf, wf = h // 32, w // 32
+    hf, wf = (-(-h // 16), -(-w // 16)) if model == "r101" else (h // 32, w // 32)
     stages = {"teacher_forward": 0.0, "student_forward": 0.0, "student_backward": 0.0, "sgd_ema": 0.0}
     bufs, total, timed = {}, 0.0, 3
     for it in range(1 + timed):
         img = [torch.randint(0, 256, (3, h, w), generator=g, dtype=torch.uint8)]
-        rk = [torch.randint(0, 2 ** 31 - 1, (hf * wf * 15,), generator=g)]
+        rk = [torch.randint(0, 2 ** 31 - 1, (hf * wf * cfg.num_anchors,), generator=g)]
         ok = [torch.randint(0, 2 ** 31 - 1, (2100,), generator=g)]
         t0 = time.perf_counter()
         props, dets = om.teacher_forward(sd_t, img, cfg)
@@ -148,6 +156,11 @@ def pmc_traffic(*kernel_substrs):
         return None
 
 
+def pmc_matches(args):
+    return (args.model == PMC_CAPTURE["model"] and args.trainer == PMC_CAPTURE["trainer"] and args.res == PMC_CAPTURE["res"]
+            and args.batch == PMC_CAPTURE["batch"] and not args.opts)
+
+
 def _launcher():
     spec = importlib.util.spec_from_file_location("sfod_launch", os.path.join(ROOT, "simple-sfod_amd", "launch.py"))
     mod = importlib.util.module_from_spec(spec)
@@ -177,7 +190,7 @@ def build_trainer(sfod, args, dtype, world, rank, local_rank):
         trainer = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
         if not args.no_planted:
             with torch.no_grad():  # "planted-label" mode: confident teacher scores
-                trainer.model.roi_heads.box_predictor.cls_score.weight.mul_(60.0)
+                trainer.model.roi_heads.box_predictor.cls_score.weight.mul_(PLANT[args.model])
                 trainer._copy_main_model()
     return cfg, trainer
 
@@ -195,9 +208,9 @@ def main():
     ap.add_argument("--steps", type=int, default=100, help="timed steps (default: >= 5 s of timed region at N=1)")
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU per step")
-    ap.add_argument("--dtype", choices=["bf16x3", "fp32", "bf16"], default="bf16x3",
-                    help="bf16x3: fp32-equivalent arithmetic (the headline mode, parity-gated at 1e-4); fp32: fp32 MFMA; "
-                         "bf16: reduced precision (not a parity mode)")
+    ap.add_argument("--dtype", choices=["bf16x3", "fp32", "bf16"], default=None,
+                    help="default: the model's parity-gated mode (vgg: bf16x3, r101: fp32).  bf16x3: split-precision "
+                         "products (3 bf16 MFMAs, ~16-bit operands); fp32: fp32 MFMA; bf16: reduced precision")
     ap.add_argument("--res", choices=["r600", "full"], default="r600")
     ap.add_argument("--model", choices=["vgg", "r101"], default="vgg",
                     help="vgg: the headline VGG16-BN config; r101: r101_c4_..._source_free.yaml (BASELINE config #5)")
@@ -213,6 +226,8 @@ def main():
                     help="teacher pass on the main stream (SFOD.OVERLAP_TEACHER False)")
     ap.add_argument("--kernel-table", action="store_true", help="stderr: per-shape table of the MFMA kernels")
     args = ap.parse_args()
+    if args.dtype is None:
+        args.dtype = PARITY_DTYPE[args.model]
     t_start = time.perf_counter()
 
     def note(msg):      # progress on stderr (the JSON line is the only thing on stdout)
@@ -310,9 +325,25 @@ def main():
         run_steps(trainer, args.warmup + args.steps + 12, nc)
         sync()
         nocomm_ms = (time.perf_counter() - tn) * 1000.0 / nc
-        t = torch.tensor([ar_ms, nocomm_ms], device="cuda")
+        # what each phase exposes: the same steps with only the early (heads) phase, then early + mid (trunk) -- the
+        # differences to the exchange-free step and to the full step are the phases' exposed times
+        per_phase = {}
+        if red is not None:
+            trainer._reducer = red
+            bb._pre_backward, bb._mid_backward = hooks
+            del trainer._reduce_gradients              # back to the class's method
+            for tag, ph in (("early", ("early",)), ("early_mid", ("early", "mid"))):
+                red.phases = ph
+                run_steps(trainer, args.warmup + args.steps + 40, 2)
+                sync()
+                tp = time.perf_counter()
+                run_steps(trainer, args.warmup + args.steps + 42, nc)
+                sync()
+                per_phase[tag] = (time.perf_counter() - tp) * 1000.0 / nc
+            red.phases = ("early", "mid", "final")
+        t = torch.tensor([ar_ms, nocomm_ms, per_phase.get("early", 0.0), per_phase.get("early_mid", 0.0)], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ar_ms, nocomm_ms = t.tolist()
+        ar_ms, nocomm_ms, early_ms, early_mid_ms = t.tolist()
         nbytes = flat.grad.numel() * 4
         step_ms = 1000.0 * elapsed / args.steps
         comm = {"collective": "sum all-reduce of the flat fp32 student gradient, 3 phases overlapping the backbone backward "
@@ -322,30 +353,46 @@ def main():
                 "allreduce_bus_GBps": round(2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1),
                 "step_without_exchange_ms": round(nocomm_ms, 3),
                 "exposed_exchange_ms_per_step": round(max(0.0, step_ms - nocomm_ms), 3),
+                "exposed_ms_per_phase": ({"heads_slice_async": round(max(0.0, early_ms - nocomm_ms), 3),
+                                          "trunk_slice_async": round(max(0.0, early_mid_ms - early_ms), 3),
+                                          "final_slice_blocking": round(max(0.0, step_ms - early_mid_ms), 3),
+                                          "slices_MB": [round(4e-6 * (red.hi - red.lo), 1), round(4e-6 * (red.mhi - red.mlo), 1),
+                                                        round(4e-6 * (flat.grad.numel() - (red.hi - red.lo) - (red.mhi - red.mlo)), 2)]}
+                                         if red is not None else None),
                 "overlap_fraction": round(min(1.0, max(0.0, 1.0 - max(0.0, step_ms - nocomm_ms) / max(ar_ms, 1e-9))), 3)}
 
     # ---- secondary block: the reduced-precision mode, same shapes, in a CHILD process started now (a second trainer in
     # this process measured 27 % low -- allocator / stream state left by the first one -- so it gets a clean process;
     # starting a child is fine, replacing this process would not be).  N = 1 only; never `value`. ------------------
     secondary = None
-    if not args.no_secondary and args.dtype != "bf16" and world == 1:
+    SECONDARY_NOTE = {
+        "bf16": "one bf16 MFMA pass per product, bf16 activations: NOT a parity mode (losses within a few % of the oracle, "
+                "tests/test_gpu_model.py::test_student_bf16_mode_tracks_the_fp32_oracle)",
+        "bf16x3": "split-precision products (3 bf16 MFMAs, ~16-bit operands): NOT a parity mode on this 101-layer network "
+                  "(RPN logits 1.7e-3, loss_box_reg 3.7e-4 vs the oracle where fp32 holds 1e-4; tracking gates in "
+                  "tests/test_gpu_fullsize.py::test_r101_yaml_teacher_and_student_at_600x1200[bf16x3])"}
+    faster = {"fp32": ["bf16x3", "bf16"] if args.model == "r101" else ["bf16"], "bf16x3": ["bf16"], "bf16": []}[args.dtype]
+    if not args.no_secondary and faster and world == 1:
         import subprocess
         n2 = max(5, min(40, args.steps))
-        cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "bf16", "--steps", str(n2), "--warmup", "5",
-               "--batch", str(args.batch), "--res", args.res, "--model", args.model, "--trainer", args.trainer,
-               "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"]
-        cmd += (["--no-planted"] if args.no_planted else []) + (["--no-overlap"] if args.no_overlap else [])
-        cmd += (["--opts"] + list(args.opts)) if args.opts else []
-        try:
-            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
-            d2 = json.loads(r.stdout.decode().strip().splitlines()[-1])
-            secondary = {"dtype": "bf16", "value": d2["value"], "unit": "images/s", "steps": d2["steps"],
-                         "ms_per_step": d2["ms_per_step"],
-                         "note": "one bf16 MFMA pass per product, bf16 activations: NOT a parity mode (losses within a few % "
-                                 "of the oracle, tests/test_gpu_model.py::test_student_bf16_mode_tracks_the_fp32_oracle); "
-                                 "measured by a child process of this run, reported for reference only"}
-        except Exception as e:      # the secondary block must never take the headline down with it
-            secondary = {"dtype": "bf16", "error": repr(e)[:200]}
+        secondary = []
+        for dt2 in faster:
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt2, "--steps", str(n2), "--warmup", "5",
+                   "--batch", str(args.batch), "--res", args.res, "--model", args.model, "--trainer", args.trainer,
+                   "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"]
+            cmd += (["--no-planted"] if args.no_planted else []) + (["--no-overlap"] if args.no_overlap else [])
+            cmd += (["--opts"] + list(args.opts)) if args.opts else []
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+                d2 = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                secondary.append({"dtype": dt2, "value": d2["value"], "unit": "images/s", "steps": d2["steps"],
+                                  "ms_per_step": d2["ms_per_step"],
+                                  "note": SECONDARY_NOTE[dt2] + "; measured by a child process of this run, reported for "
+                                                                "reference only"})
+            except Exception as e:      # the secondary block must never take the headline down with it
+                secondary.append({"dtype": dt2, "error": repr(e)[:200]})
+        if len(secondary) == 1:
+            secondary = secondary[0]
     note("secondary block done")
     if rank != 0:
         if world > 1:
@@ -364,11 +411,18 @@ def main():
         "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "dtype_note": {"bf16x3": "fp32-equivalent: operands as (hi, lo) bf16 pairs, hi*hi + hi*lo + lo*hi on "
-                                 "v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 activations / statistics / losses; "
-                                 "1e-4 parity vs the CPU oracle gated at 600x1200 by tests/test_gpu_fullsize.py",
-                       "fp32": "v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains)",
-                       "bf16": "reduced precision, not a parity mode"}[args.dtype],
+        "dtype_note": {
+            "bf16x3": ("split precision: operands as (hi, lo) bf16 pairs (~16 significand bits each), hi*hi + hi*lo + lo*hi on "
+                       "v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 activations / statistics / losses.  Gated at "
+                       "600x1200 by tests/test_gpu_fullsize.py: " +
+                       ("losses and decoded boxes within 1e-4 of the CPU oracle, intermediates (RPN logits / deltas, box "
+                        "scores / deltas) within 2e-4 (measured 6e-5 .. 1e-4), every discrete decision bit-exact"
+                        if args.model == "vgg" else
+                        "on this 101-layer network only ~1e-3 (tracking gates) -- fp32 is this config's parity mode")),
+            "fp32": "v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains); losses and decoded boxes within 1e-4 of the CPU oracle at "
+                    "600x1200 (tests/test_gpu_fullsize.py), intermediates within 3x the reference arithmetic's own fp32-vs-fp64 "
+                    "error on the network",
+            "bf16": "reduced precision, not a parity mode"}[args.dtype],
         "timed_region_s": round(elapsed, 3),
         "config": {
             "workload": f"{yaml}: {'VGG16-BN' if args.model == 'vgg' or args.trainer == 'base' else 'ResNet-101-C4'} {what}, "
@@ -410,9 +464,13 @@ def main():
             "kernel": kname,
             "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK[args.dtype], "unit": "TFLOP/s",
             "frac": round(ach / PEAK[args.dtype], 4),
+            # bf16x3: `frac` is matrix-pipe utilisation (3 MFMAs per algorithmic product, peak = 2500 / 3); per ALGORITHMIC
+            # FLOP the same measurement is this fraction of the dense bf16 peak -- useful work, not pipe occupancy
+            "frac_of_bf16_peak_algorithmic": round(ach / PEAK["bf16"], 4),
             # HBM bytes per launch from the committed PMC passes of THIS mode's kernel (tools/pmc_hbm_run.sh); null otherwise
+            # only when THIS run is the configuration the counters were captured on (else null)
             "traffic": (pmc_traffic("k_conv3x3_patch<", {"bf16x3": "float, true", "bf16": "__bf16, false"}.get(args.dtype, "-"))
-                        if key.endswith("patch3x3") else pmc_traffic("k_conv_fwd<")),
+                        if key.endswith("patch3x3") and pmc_matches(args) else None),
             "launches_per_step": k["launches"] // max(rl_steps, 1),
             "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
             "algorithmic_gflop_per_launch": round(k["flops"] / max(k["launches"], 1) / 1e9, 3),
@@ -434,7 +492,7 @@ def main():
                                      "share_of_step_time": round(wk["ms"] / (1000.0 * rl_elapsed), 4)}
     if world == 1 and not args.no_cpu_baseline and args.trainer != "base":
         note("cpu baseline ...")
-        out["cpu_baseline"] = cpu_baseline(args.res, not args.no_planted)
+        out["cpu_baseline"] = cpu_baseline(args.res, not args.no_planted, args.model)
     note("done")
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -4,7 +4,9 @@ Functional PyTorch-CPU model over a flat ``state`` dict that uses the REFERENCE'
 key names, so the same weights load into this oracle and into the HIP product model.
 
 Follows (reference file:line)
-  backbone            daod/modeling/meta_arch/vgg.py:10-24 (layers), :70-74 (stages), :102-113 (init)
+  backbone            daod/modeling/meta_arch/vgg.py:10-24 (layers), :70-74 (stages), :102-113 (init); or, for
+                      configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28 (``Cfg.r101_c4()``), Detectron2's
+                      ResNet-C4 trunk restated in oracle/resnet.py (res4, stride 16, 1024 channels)
   RPN forward         daod/modeling/proposal_generator/rpn.py:16-58   (+ d2 RPN, Appendix A.4/A.7/A.10)
   ROI heads           daod/modeling/roi_heads/source_free_adaptive_teacher_roi_heads.py:68-215
   meta-arch branches  daod/modeling/meta_arch/source_free_adaptive_teacher_rcnn.py:212-225,259-339
@@ -21,6 +23,7 @@ import torch
 import torch.nn.functional as F
 
 from . import box_ops as B
+from . import resnet
 from .roi_align import roi_align
 
 VGG16 = [64, 64, "M", 128, 128, "M", 256, 256, 256, "M", 512, 512, 512, "M", 512, 512, 512, "M"]
@@ -59,6 +62,9 @@ class Cfg:
     bn_momentum = 0.1
     bn_eps = 1e-5
     nms_numel_limit = 20000  # torchvision batched_nms strategy switch for GPU tensors
+    backbone = "vgg"         # "vgg" (build_vgg_backbone, feature vgg4) | "resnet" (d2 build_resnet_backbone, feature res4)
+    resnet_depth = 101
+    freeze_at = 2
 
     def __init__(self, **kw):
         for k, v in kw.items():
@@ -69,6 +75,18 @@ class Cfg:
     @property
     def num_anchors(self):
         return len(self.anchor_sizes) * len(self.anchor_ratios)
+
+    @classmethod
+    def r101_c4(cls, **kw):
+        """Effective values of configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml (last
+        column): no BACKBONE.NAME -> build_resnet_backbone, RESNETS.DEPTH 101 ``:5-7``, RPN / ROI heads on ``res4``
+        (stride 16, 1024 channels), ANCHOR_GENERATOR.SIZES [[64, 128, 256, 512]] ``:19`` x 3 ratios = 12 anchors per
+        location, RPN.BATCH_SIZE_PER_IMAGE 256 ``:23``, ROI_HEADS.BATCH_SIZE_PER_IMAGE 256 ``:11``, FastRCNNConvFCHead
+        with NUM_FC 2 / FC_DIM 2048 ``:14-17``, ROIAlignV2 7x7 at scale 1/16."""
+        vals = dict(backbone="resnet", resnet_depth=101, freeze_at=2, anchor_sizes=(64, 128, 256, 512), stride=16,
+                    feat_channels=1024, rpn_batch=256, roi_batch=256, fc_dim=2048)
+        vals.update(kw)
+        return cls(**vals)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -99,7 +117,9 @@ def init_state(cfg, seed=0, with_dc=False):
     def normal(shape, std):
         return torch.randn(shape, generator=g) * std
 
-    for s, i, kind, cin, cout in vgg_layer_names():
+    if cfg.backbone == "resnet":
+        sd.update(resnet.init_state(cfg.resnet_depth, seed + 1000, cfg.freeze_at))
+    for s, i, kind, cin, cout in (vgg_layer_names() if cfg.backbone == "vgg" else ()):
         p = f"backbone.vgg{s}.{i}"
         if kind == "conv":
             fan_out = cout * 9
@@ -139,13 +159,20 @@ def init_state(cfg, seed=0, with_dc=False):
     return sd
 
 
+FROZEN_PREFIXES = ("backbone.stem.", "backbone.res2.")   # FREEZE_AT 2 of the ResNet-C4 config: FrozenBatchNorm2d buffers
+                                                          # + requires_grad False conv weights (not optimised, no grad)
+
+
 def is_param(name):
+    """a trainable parameter (what d2's optimizer sees): not a buffer, not in a frozen ResNet stage"""
     return not (name.endswith("running_mean") or name.endswith("running_var")
-                or name.endswith("num_batches_tracked"))
+                or name.endswith("num_batches_tracked") or name.startswith(FROZEN_PREFIXES))
 
 
 def is_norm_param(name):
     """BN affine params (weight_decay_norm = 0 in d2's optimizer)."""
+    if name.startswith("backbone.res"):
+        return ".norm." in name and is_param(name)
     if not name.startswith("backbone.vgg"):
         return False
     idx = int(name.split(".")[2])
@@ -195,6 +222,14 @@ def vgg_forward(sd, x, cfg, training=True, return_all=False):
             x = F.max_pool2d(x, 2, 2)
         feats[f"vgg{s}"] = x
     return feats if return_all else feats["vgg4"]
+
+
+def backbone_forward(sd, x, cfg, training=True):
+    """normalised image batch -> the feature map the heads read (``vgg4`` / ``res4``); train mode refreshes the live
+    BatchNorm statistics and counters in ``sd`` (the AdaBN side effect, also under no_grad)."""
+    if cfg.backbone == "resnet":
+        return resnet.forward(sd, x, depth=cfg.resnet_depth, training=training, freeze_at=cfg.freeze_at)
+    return vgg_forward(sd, x, cfg, training=training)
 
 
 def rpn_head(sd, feat):
@@ -476,7 +511,7 @@ def teacher_forward(sd, images_u8, cfg):
     """branch='unsup_data_weak' on the train-mode teacher under no_grad (trainer :385-390)."""
     with torch.no_grad():
         x, sizes = preprocess(images_u8)
-        feat = vgg_forward(sd, x, cfg, training=True)
+        feat = backbone_forward(sd, x, cfg, training=True)
         logits, deltas = rpn_head(sd, feat)
         anchors = anchors_for(feat.shape[-2:], cfg)
         props = rpn_proposals(anchors, logits, deltas, sizes, cfg, training=True)
@@ -491,7 +526,7 @@ def eval_inference(sd, images_u8, cfg, out_sizes=None):
     ``source_free_adaptive_teacher_rcnn.py:129-130`` and ``DefaultTrainer.test``)."""
     with torch.no_grad():
         x, sizes = preprocess(images_u8)
-        feat = vgg_forward(sd, x, cfg, training=False)
+        feat = backbone_forward(sd, x, cfg, training=False)
         logits, deltas = rpn_head(sd, feat)
         anchors = anchors_for(feat.shape[-2:], cfg)
         props = rpn_proposals(anchors, logits, deltas, sizes, cfg, training=False)
@@ -516,7 +551,7 @@ def student_losses(sd, images_u8, gt_boxes_list, gt_classes_list, rpn_keys, roi_
     to give both implementations the same discrete proposal set, because a 1e-7 difference in a
     logit can legitimately flip an NMS decision (``given_proposals`` in the reference's signature)."""
     x, sizes = preprocess(images_u8)
-    feat = vgg_forward(sd, x, cfg, training=True)
+    feat = backbone_forward(sd, x, cfg, training=True)
     logits, deltas = rpn_head(sd, feat)
     anchors = anchors_for(feat.shape[-2:], cfg)
     labels, matched = rpn_label_anchors(anchors, gt_boxes_list, rpn_keys, cfg)

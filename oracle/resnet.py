@@ -31,7 +31,10 @@ def frozen_bn(x, sd, prefix, eps=1e-5):
 
 
 def live_bn(x, sd, prefix, training, momentum=0.1, eps=1e-5):
-    """nn.BatchNorm2d; in training mode the running statistics in `sd` are refreshed in place."""
+    """nn.BatchNorm2d; in training mode the running statistics in `sd` are refreshed in place and
+    ``num_batches_tracked`` (when the state carries it) advances by one, also under no_grad."""
+    if training and prefix + ".num_batches_tracked" in sd:
+        sd[prefix + ".num_batches_tracked"] += 1
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
                         sd[prefix + ".bias"], training, momentum, eps)
 
@@ -59,3 +62,34 @@ def forward(sd, x, depth=101, training=True, freeze_at=2, prefix="backbone."):
         o = norm(F.conv2d(o, sd[b + "conv3.weight"], None), b + "conv3.norm", fz)
         x = F.relu(o + sc)
     return x
+
+
+def init_state(depth=101, seed=0, freeze_at=2, prefix="backbone."):
+    """Detectron2's initialisation of the C4 trunk under its state-dict keys: ``c2_msra_fill`` =
+    ``kaiming_normal_(mode="fan_out", nonlinearity="relu")`` for every (bias-free) conv, norm weight 1 / bias 0,
+    running mean 0 / var 1; frozen stages (FREEZE_AT: stem, res2) carry FrozenBatchNorm2d's four buffers
+    (``running_var = 1 - eps`` as in its constructor, no counter), live stages nn.BatchNorm2d's five entries."""
+    import math
+    from collections import OrderedDict
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict()
+
+    def conv(name, cout, cin, k, frozen, eps=1e-5):
+        sd[name + ".weight"] = torch.randn(cout, cin, k, k, generator=g) * math.sqrt(2.0 / (cout * k * k))
+        sd[name + ".norm.weight"] = torch.ones(cout)
+        sd[name + ".norm.bias"] = torch.zeros(cout)
+        sd[name + ".norm.running_mean"] = torch.zeros(cout)
+        sd[name + ".norm.running_var"] = torch.ones(cout) - (eps if frozen else 0.0)
+        if not frozen:
+            sd[name + ".norm.num_batches_tracked"] = torch.zeros((), dtype=torch.int64)
+
+    conv(prefix + "stem.conv1", 64, 3, 7, freeze_at >= 1)
+    for stage, bi, cin, cout, bott, stride in block_specs(depth):
+        fz = freeze_at >= int(stage[3])
+        b = f"{prefix}{stage}.{bi}."
+        if cin != cout:
+            conv(b + "shortcut", cout, cin, 1, fz)
+        conv(b + "conv1", bott, cin, 1, fz)
+        conv(b + "conv2", bott, bott, 3, fz)
+        conv(b + "conv3", cout, bott, 1, fz)
+    return sd

@@ -130,16 +130,25 @@ class GradientReducer:
                 cur = None
         return best
 
+    # measurement only (bench.py's ``exchange`` block): run a subset of the phases to see what each one exposes
+    phases = ("early", "mid", "final")
+
     def launch_early(self):
-        if self.work is None and self.hi > self.lo and get_world_size() > 1:
+        if "early" in self.phases and self.work is None and self.hi > self.lo and get_world_size() > 1:
             self.work = dist.all_reduce(self.flat.grad[self.lo:self.hi], async_op=True)
 
     def launch_mid(self):
-        if self.work_mid is None and self.mhi > self.mlo and get_world_size() > 1:
+        if "mid" in self.phases and self.work_mid is None and self.mhi > self.mlo and get_world_size() > 1:
             self.work_mid = dist.all_reduce(self.flat.grad[self.mlo:self.mhi], async_op=True)
 
     def finish(self):
         g = self.flat.grad
+        if "final" not in self.phases:       # timing variant: only what was launched asynchronously
+            for w in (self.work, self.work_mid):
+                if w is not None:
+                    w.wait()
+            self.work = self.work_mid = None
+            return
         done = sorted([(lo, hi) for lo, hi, w in ((self.lo, self.hi, self.work), (self.mlo, self.mhi, self.work_mid))
                        if w is not None])
         if not done:
@@ -197,9 +206,17 @@ class BaseTrainer:
                    (cfg.DOMAIN_CLASSIFIER.IMAGE or cfg.DOMAIN_CLASSIFIER.INSTANCE or not cfg.SFOD.ELIDE_DEAD_BRANCHES))
         self._reducer = None
         if get_world_size() > 1 and not dc_live:
-            self._reducer = GradientReducer(self.optimizer.flat)
+            # where the mid phase starts: with enough pixels per rank the backward of vgg0 alone (its two most expensive
+            # layers) hides the 57 MB message, so vgg1's weights ride in it too and the final phase shrinks to
+            # vgg0 + the norm parameters; the yaml's one 600x1200 frame per rank keeps the earlier launch point
+            b_local = max(1, int(getattr(cfg.SOLVER, "IMS_PER_BATCH_TARGET", cfg.SOLVER.IMS_PER_BATCH)) // get_world_size())
+            short = min(cfg.INPUT.MIN_SIZE_TRAIN) if len(cfg.INPUT.MIN_SIZE_TRAIN) else 600
+            stage = 1 if b_local * short * short * 2 >= 2 * 600 * 1200 else 2
+            mids = tuple("backbone.vgg{}.".format(i) for i in range(stage, 5))
+            self._reducer = GradientReducer(self.optimizer.flat, mid_prefixes=mids)
             self.model.backbone._pre_backward = self._reducer.launch_early
-            self.model.backbone._mid_backward = self._reducer.launch_mid      # VGG: after stage vgg2's gradients
+            self.model.backbone._mid_backward = self._reducer.launch_mid      # VGG: after stage vgg<stage>'s gradients
+            self.model.backbone._mid_stage = stage
 
     @classmethod
     def build_model(cls, cfg):

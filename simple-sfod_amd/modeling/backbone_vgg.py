@@ -261,7 +261,7 @@ class vgg_backbone(nn.Module):
                 s += 1
         dz = dz_red = None
         mid_hook = getattr(self, "_mid_backward", None)
-        mid_layer = self._first_layer_of_stage(2) if mid_hook is not None else -1
+        mid_layer = self._first_layer_of_stage(getattr(self, "_mid_stage", 2)) if mid_hook is not None else -1
         for li in range(len(self._plan) - 1, -1, -1):
             conv, bn, pool, stage_end = self._plan[li]
             x, y, mean, invstd = saved[li]

@@ -51,21 +51,67 @@ def _frames(B, H, W, seed):
     return out
 
 
-@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
-def test_hot_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
+R101_YAML = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml")
+
+# What "within 1e-4" is asserted on (BASELINE.json north_star: "losses/boxes within 1e-4 fp32; bit-exact anchor/label
+# assignment and NMS indices"), per quantity, and what the intermediates are held to:
+#   losses                      |dev / ref - 1| < 1e-4
+#   decoded anchor boxes        relative L2 over all B x A x 4 coordinates < 1e-4, and max |d| of the boxes CLIPPED to the
+#                               frame (what find_top_rpn_proposals hands on) < 1e-4 * W pixels
+#   decoded detection boxes     the same over all R x K x 4 coordinates
+#   intermediates               RPN logits / deltas, box-head scores / deltas: relative L2 < GATE_INTERMEDIATE[dtype], or
+#                               3 x the reference arithmetic's OWN error on this network when that is larger (below)
+# bf16x3 carries 16 significand bits per operand (4.4e-6 rms per dot product, profiles/r2_mfma_split_precision.txt);
+# over 14 VGG convolutions the intermediates reach ~1e-4 relative L2, which is why they get 2e-4 and NOT the 1e-4 of the
+# north-star quantities (bench.py's dtype_note says the same).
+#
+# Noise floor.  A randomly initialised ResNet-101-C4 is ill-conditioned: the fp32 ORACLE itself is 7e-5 away from the
+# same network evaluated in fp64 at the RPN logits (VGG16: 3e-6), growing linearly over the 33 bottleneck blocks
+# (2.8e-6 per res4 block); two correct fp32 implementations cannot agree better than that.  For a ResNet config the
+# test therefore evaluates the oracle in fp64 as well and gates the intermediates at max(GATE_INTERMEDIATE, 3 x floor),
+# floor = err(fp32 oracle, fp64 oracle), printed with the result.  The north-star quantities keep their fixed 1e-4.
+GATE_NORTH_STAR = 1e-4
+GATE_INTERMEDIATE = {"fp32": 2e-5, "bf16x3": 2e-4}
+# bf16x3 on the 101-layer config is NOT a parity mode (16-bit operands x the network's 20x worse conditioning:
+# measured 1.7e-3 at the RPN logits, loss_box_reg 3.7e-4): bench.py --model r101 therefore reports fp32.  The mode is
+# still checked to TRACK the oracle at these looser, labelled gates, with every discrete step bit-exact as usual.
+GATE_TRACKING = {"north_star": 2e-3, "intermediate": 5e-3, "px": 2e-3}
+
+
+def _report(tag, errs, gates):
+    rows = []
+    for k, v in errs.items():
+        g = gates[k]
+        rows.append(f"{k} {v:.2e} (gate {g:.0e}, margin {g / max(v, 1e-30):.1f}x)")
+    print(f"\n[fullsize parity {tag}] vs the CPU oracle: " + "; ".join(rows))
+    bad = {k: (v, gates[k]) for k, v in errs.items() if not v < gates[k]}
+    assert not bad, f"{tag}: outside the gate: {bad}"
+
+
+def _teacher_student_parity(sfod, yaml, ocfg, dtype, B, plant, tag, seed=7, tracking_only=False):
+    """Teacher pass (captured intermediates) and student pass of ``yaml`` at 600x1200 against the oracle ``ocfg``.
+    ``tracking_only``: the looser GATE_TRACKING set (a mode that is not the config's parity mode)."""
+    NS = GATE_TRACKING["north_star"] if tracking_only else GATE_NORTH_STAR
+    PX = GATE_TRACKING["px"] if tracking_only else GATE_NORTH_STAR
     S = sfod.structures
-    B, H, W = 2, 600, 1200
-    cfg = sfod.config.setup_cfg(HOT_YAML, ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", dtype])
-    torch.manual_seed(7)
+    H, W = 600, 1200
+    cfg = sfod.config.setup_cfg(yaml, ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", dtype])
+    torch.manual_seed(seed)
     model = sfod.modeling.build_model(cfg).train()
     with torch.no_grad():       # planted labels: some detections clear the 0.8 pseudo-label threshold
-        model.roi_heads.box_predictor.cls_score.weight.mul_(60.0)
-        model.roi_heads.box_predictor.bbox_pred.weight.mul_(20.0)
-    ocfg = om.Cfg()
-    sd = om.clone_state({k: v.detach().float().cpu() for k, v in model.state_dict().items()})
+        model.roi_heads.box_predictor.cls_score.weight.mul_(plant[0])
+        model.roi_heads.box_predictor.bbox_pred.weight.mul_(plant[1])
+    sd = om.clone_state({k: v.detach().float().cpu() if v.dtype != torch.int64 else v.detach().cpu()
+                         for k, v in model.state_dict().items()})
+    sd0 = om.clone_state(sd)        # before the train-mode passes move the running statistics
     inputs = _frames(B, H, W, seed=21)
     images = [d["image"] for d in inputs]
-    Hf, Wf, A = H // 32, W // 32, 15
+    stride, A, K = ocfg.stride, ocfg.num_anchors, ocfg.num_classes
+    Hf, Wf = -(-H // stride) if ocfg.backbone == "resnet" else H // stride, -(-W // stride) if ocfg.backbone == "resnet" else W // stride
+    gates, errs = {}, {}
+
+    def put(name, value, gate):
+        errs[name], gates[name] = value, gate
 
     # ---------------- teacher pass on the device, intermediates captured ----------------------------------------
     cap = {}
@@ -90,25 +136,34 @@ def test_hot_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
     # ---------------- oracle: the same pass on the CPU ---------------------------------------------------------------
     with torch.no_grad():
         x, sizes = om.preprocess(images)
-        feat = om.vgg_forward(sd, x, ocfg, training=True)
+        feat = om.backbone_forward(sd, x, ocfg, training=True)
         logits_ref, deltas_ref = om.rpn_head(sd, feat)
+    assert tuple(feat.shape[-2:]) == (Hf, Wf)
     anchors = om.anchors_for((Hf, Wf), ocfg)
+    assert anchors.shape[0] == Hf * Wf * A
     out = cap["rpn_out"].cpu().view(B, Hf * Wf, -1)
     logits_dev = out[:, :, :A].reshape(B, Hf * Wf * A)
     deltas_dev = out[:, :, A:5 * A].reshape(B, Hf * Wf * A, 4)
-    # Intermediate tensors, 14 convolutions + 13 BatchNorms deep (relative L2).  Measured: fp32 8e-6, bf16x3 9.5e-5
-    # (4.4e-6 per dot product, tools/experiments/mfma_split_precision.hip, accumulating over the layers); the
-    # north-star quantities -- losses and boxes -- are gated at 1e-4 below.
-    TI = 2e-5 if dtype == "fp32" else 2e-4
-    errs = {"rpn_logits": rel_err(logits_dev, logits_ref), "rpn_deltas": rel_err(deltas_dev, deltas_ref)}
-    assert errs["rpn_logits"] < TI and errs["rpn_deltas"] < TI, errs
-    # boxes within 1e-4: every anchor's decoded box (all B x 9990, before any ranking) from the device's deltas against
-    # the oracle's, relative to the coordinate scale (the frame's 1200 px)
+    TI = GATE_TRACKING["intermediate"] if tracking_only else GATE_INTERMEDIATE[dtype]
+    if ocfg.backbone == "resnet":       # the reference arithmetic's own error on this network (see the header)
+        sd64 = {k: (v.double() if v.is_floating_point() else v.clone()) for k, v in sd0.items()}
+        with torch.no_grad():
+            l64, d64 = om.rpn_head(sd64, om.backbone_forward(sd64, x.double(), ocfg, training=True))
+        floor = max(rel_err(logits_ref, l64), rel_err(deltas_ref, d64))
+        del sd64, l64, d64
+        if not tracking_only:
+            TI = max(TI, 3.0 * floor)
+        put("reference_fp32_vs_fp64_floor", floor, 2e-4)
+    put("rpn_logits", rel_err(logits_dev, logits_ref), TI)
+    put("rpn_deltas", rel_err(deltas_dev, deltas_ref), TI)
+    # boxes within 1e-4: every anchor's decoded box (all B x A, before any ranking) from the device's deltas against
+    # the oracle's -- relative L2 of the coordinates, and the largest deviation relative to the frame's 1200 px
     from oracle import box_ops as OB
     bx_dev = torch.stack([OB.apply_deltas(deltas_dev[b], anchors, ocfg.rpn_bbox_weights) for b in range(B)])
     bx_ref = torch.stack([OB.apply_deltas(deltas_ref[b], anchors, ocfg.rpn_bbox_weights) for b in range(B)])
-    errs["anchor_boxes_px"] = (bx_dev - bx_ref).abs().max().item()
-    assert errs["anchor_boxes_px"] < 1e-4 * W, errs
+    put("anchor_boxes_relL2", rel_err(bx_dev, bx_ref), NS)
+    clip = lambda t: OB.clip_boxes(t.reshape(-1, 4).clone(), (H, W))
+    put("anchor_boxes_px", (clip(bx_dev) - clip(bx_ref)).abs().max().item(), PX * W)
 
     # proposals: the oracle's decode / top-k / NMS on the DEVICE's logits and deltas == the device's proposal set
     pr_ref = om.rpn_proposals(anchors, logits_dev, deltas_dev, sizes, ocfg, training=True)
@@ -124,16 +179,20 @@ def test_hot_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
         scores_ref, bdeltas_ref, _ = om.box_head(sd, feat, given, ocfg)
     P = props.boxes.shape[1]
     pred = cap["pred"].cpu().view(B, P, -1)
-    scores_dev = torch.cat([pred[b, : len(given[b]), :9] for b in range(B)])
-    bdeltas_dev = torch.cat([pred[b, : len(given[b]), 9:41] for b in range(B)])
-    errs["box_scores"], errs["box_deltas"] = rel_err(scores_dev, scores_ref), rel_err(bdeltas_dev, bdeltas_ref)
-    assert errs["box_scores"] < TI and errs["box_deltas"] < TI, errs
+    scores_dev = torch.cat([pred[b, : len(given[b]), :K + 1] for b in range(B)])
+    bdeltas_dev = torch.cat([pred[b, : len(given[b]), K + 1:5 * K + 1] for b in range(B)])
+    put("box_scores", rel_err(scores_dev, scores_ref), TI)
+    put("box_deltas", rel_err(bdeltas_dev, bdeltas_ref), TI)
     # detection boxes within 1e-4: per-class decode of every proposal from the device's deltas against the oracle's
     pb = torch.cat(given)
     db_dev = OB.apply_deltas(bdeltas_dev, pb, ocfg.roi_bbox_weights)
     db_ref = OB.apply_deltas(bdeltas_ref, pb, ocfg.roi_bbox_weights)
-    errs["det_boxes_px"] = (db_dev - db_ref).abs().max().item()
-    assert errs["det_boxes_px"] < 1e-4 * W, errs
+    put("det_boxes_relL2", rel_err(db_dev, db_ref), NS)
+    put("det_boxes_px", (clip(db_dev) - clip(db_ref)).abs().max().item(), PX * W)
+    # class probabilities (what the 0.05 / 0.8 thresholds read)
+    # (informational gate: the planted x60 / x3 scale on cls_score multiplies the logit error before the softmax)
+    put("det_probs_max_abs", (torch.softmax(scores_dev, -1) - torch.softmax(scores_ref, -1)).abs().max().item(),
+        1e-2 if tracking_only else 1e-3)
 
     # detections + pseudo-labels: the oracle's post-processing of the DEVICE's predictions == the device's
     det_ref = om.fast_rcnn_inference(scores_dev, bdeltas_dev, given, sizes, ocfg)
@@ -154,10 +213,14 @@ def test_hot_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
             torch.testing.assert_close(dets.d["gt_boxes"][b, :ng].cpu(), pl["gt_boxes"], rtol=1e-5, atol=2e-3)
         n_pseudo += ng
     assert n_pseudo >= 4, "planted labels should yield pseudo ground truth"
-    # BatchNorm running statistics refreshed by the train-mode teacher (AdaBN)
+    # BatchNorm running statistics refreshed by the train-mode teacher (AdaBN); frozen statistics untouched
+    worst_rs = 0.0
     for name, buf in model.state_dict().items():
         if "running" in name:
-            torch.testing.assert_close(buf.cpu(), sd[name], rtol=1e-4, atol=1e-6 if dtype == "fp32" else 2e-5)
+            worst_rs = max(worst_rs, rel_err(buf, sd[name]))     # per tensor (a mean close to 0 has no relative error of its own)
+        elif name.endswith("num_batches_tracked"):
+            assert int(buf) == int(sd[name]) == 1, name
+    put("running_stats_relL2", worst_rs, NS)
 
     # ---------------- student pass on the pseudo labels -------------------------------------------------------------
     for b, d in enumerate(inputs):
@@ -191,13 +254,29 @@ def test_hot_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
     assert torch.equal(cap["labels"].cpu(), aux["labels"]), "anchor labels after sampling must be bit-exact"
     for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"):
         assert np.isfinite(losses[k].item())
-        np.testing.assert_allclose(losses[k].item(), ref[k].item(), rtol=1e-4, atol=1e-7, err_msg=k)
-        errs[k] = abs(losses[k].item() / ref[k].item() - 1.0)
+        put(k, abs(losses[k].item() / ref[k].item() - 1.0), NS)
     for name, p in model.named_parameters():
-        if not name.startswith("DC_"):
+        if not name.startswith("DC_") and p.requires_grad:
             assert p.grad is not None and torch.isfinite(p.grad).all(), name
-    print(f"\n[fullsize parity {dtype}] relative errors vs the CPU oracle: " +
-          ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+    _report(f"{tag} {dtype} B={B}", errs, gates)
+    return errs
+
+
+@pytest.mark.parametrize("dtype,B", [("bf16x3", 2), ("fp32", 2), ("bf16x3", 8)])
+def test_hot_yaml_teacher_and_student_at_600x1200(sfod, native, dtype, B):
+    """BASELINE config #3; B = 8 is the batch bench.py times (the float comparison at that batch, once)."""
+    _teacher_student_parity(sfod, HOT_YAML, om.Cfg(), dtype, B, plant=(60.0, 20.0), tag="VGG16 hot yaml")
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3"])
+def test_r101_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
+    """BASELINE config #5 (r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28): ResNet-101-C4 trunk (frozen stem /
+    res2, live BatchNorm res3 / res4), RPN on res4 at stride 16 with 4 sizes x 3 ratios = 12 anchors per location
+    (38 x 75 x 12 = 34 200 anchors: the multi-chunk sort), ROIAlign at 1/16 on 1024 channels, FC_DIM 2048, 256 sampled
+    ROIs per image -- same structure as the VGG test.  ``fp32`` is this config's parity mode (what bench.py --model
+    r101 reports): losses / boxes at 1e-4.  ``bf16x3`` is held to the labelled tracking gates only (header)."""
+    _teacher_student_parity(sfod, R101_YAML, om.Cfg.r101_c4(), dtype, 2, plant=(3.0, 4.0), tag="R101-C4 yaml",
+                            tracking_only=(dtype != "fp32"))
 
 
 def _check_discrete_steps_on_captured_tensors(model, inputs, B, H, W, with_gt, native):

@@ -955,15 +955,39 @@ def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native):
         assert mid and all(n.startswith(("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4.")) for n in mid)
         assert "backbone.vgg2.0.weight" in mid and "backbone.vgg4.6.bias" in mid and red.mhi <= red.lo
         assert (red.mhi - red.mlo) > 0.9 * sum(p_.numel() for n, p_ in tr.model.backbone.named_parameters() if p_.dim() == 4)
-        launched, mids = [], []
-        orig_launch, orig_mid = red.launch_early, red.launch_mid
-        red.launch_early = lambda: (launched.append(1), orig_launch())[1]
-        red.launch_mid = lambda: (mids.append(1), orig_mid())[1]
+        # Ordering of the three phases: a phase may only be launched once every gradient of its slice is FINAL.  A copy
+        # of the slice enqueued right behind each launch (same stream order the collective is ordered against) must
+        # equal the slice of the finished backward -- a kernel that still wrote into it afterwards would show.  The
+        # buffer is poisoned before each backward instead of zeroed on the parts nobody accumulates into... it IS
+        # accumulated into (direct gradient sinks), so the check is on values, not on NaNs.
+        launched, mids, snaps = [], [], []
+        flat = tr.optimizer.flat
+        orig_launch, orig_mid, orig_finish = red.launch_early, red.launch_mid, red.finish
+
+        def launch_early():
+            orig_launch()
+            launched.append(flat.grad[red.lo:red.hi].clone())
+
+        def launch_mid():
+            orig_mid()
+            mids.append(flat.grad[red.mlo:red.mhi].clone())
+
+        def finish():
+            assert red.work is not None and red.work_mid is not None, "both asynchronous phases in flight at the end"
+            orig_finish()
+            snaps.append(flat.grad.clone())
+        red.launch_early, red.launch_mid, red.finish = launch_early, launch_mid, finish
         tr.model.backbone._pre_backward = red.launch_early
         tr.model.backbone._mid_backward = red.launch_mid
         p0 = tr.optimizer.flat.param.clone()
         tr.train()
-        assert len(launched) == 2 and len(mids) == 2 and red.work is None and red.work_mid is None
+        assert len(launched) == 2 and len(mids) == 2 and len(snaps) == 2 and red.work is None and red.work_mid is None
+        for early, mid_s, final in zip(launched, mids, snaps):
+            assert early.abs().sum() > 0 and mid_s.abs().sum() > 0
+            assert torch.equal(early, final[red.lo:red.hi]), "heads slice changed after its all-reduce was launched"
+            assert torch.equal(mid_s, final[red.mlo:red.mhi]), "trunk slice changed after its all-reduce was launched"
+            rest = torch.cat([final[:red.mlo], final[red.mhi:red.lo], final[red.hi:]])
+            assert rest.abs().sum() > 0 and torch.isfinite(final).all()
         assert tr.optimizer.grad_scale == 0.5
         assert torch.isfinite(tr.optimizer.flat.param).all() and not torch.equal(p0, tr.optimizer.flat.param)
     finally:
