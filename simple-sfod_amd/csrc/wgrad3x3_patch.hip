@@ -24,6 +24,8 @@
 //         ahead behind counted s_waitcnt vmcnt(N).
 #include "conv_internal.h"
 #include <type_traits>
+#include <atomic>
+#include <stdlib.h>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -45,7 +47,9 @@ constexpr int TAB_OFF = DY_OFF + 3 * DYSLOT;     // 147456
 constexpr int TABP_OFF = TAB_OFF;                // u16 [256]  tile pixel -> patch row (tap 0,0)
 constexpr int TABT_OFF = TAB_OFF + 512;          // u16 [256]  tile pixel -> ty<<8|tx, 0xffff outside the tile
 constexpr int TABR_OFF = TAB_OFF + 1024;         // u16 [384]  patch row -> py<<8|px, 0xffff unused
-constexpr int LDS_TOTAL = TAB_OFF + 1024 + 768;
+constexpr int TABX_OFF = TAB_OFF + 1024 + 768;   // PIPE: i32 [384]  patch row -> byte offset relative to the tile's first pixel (interior tiles), REL_NONE unused
+constexpr int TABD_OFF = TABX_OFF + 1536;        // PIPE: i32 [256]  tile pixel -> byte offset of its dy row relative to the tile's first pixel, REL_NONE outside
+constexpr int LDS_TOTAL = TABD_OFF + 1024;
 constexpr unsigned OOB_OFF = 0x80000000u;
 
 struct W3Args {
@@ -89,10 +93,21 @@ __device__ __forceinline__ bf16x8 cat8(s16x4 a, s16x4 b) {
 // 32 logical output channels -- and the conflict-free transposed reads of the bf16 kernel apply unchanged.  A wave owns
 // one 32 (co) x 32 (ci) logical block for all nine taps and one of the four k-steps of every 64-pixel chunk (the four
 // k-step groups write separate slabs); per tap it issues hi*lo + lo*hi + hi*hi.  W3Args sizes are LOGICAL channels.
-template <int CO, bool SPLIT = false>
+//
+// PIPE (SPLIT only, round 3): the same arithmetic with the per-chunk critical path shortened --
+//   * the tile-pixel -> patch-row lookups (tabP) of the wave's four chunks are read ONCE before the loop (they do not
+//     depend on the tile), instead of a dependent LDS read in front of every chunk's fragment reads;
+//   * the first filter row of the NEXT chunk's x fragments is requested during the last filter row's MFMAs of this
+//     chunk (the patch of the current tile is complete and nobody writes it before the next tile), so that only the
+//     four dy reads wait behind the stage barrier;
+//   * the stage's LDS-DMA instructions are issued between the three filter rows' MFMA groups instead of in front of
+//     the fragment reads (both waves of a SIMD leave the barrier together: DMA issue in front kept the matrix pipe idle);
+//   * raised wave priority over the MFMA groups.
+template <int CO, bool SPLIT = false, bool PIPE = false>
 __global__ void __launch_bounds__(512)
 k_wgrad3x3_patch(W3Args a) {
   static_assert(!SPLIT || CO == 4, "bf16x3 operands use the four-plane dy ring");
+  static_assert(!PIPE || SPLIT, "the pipelined chunk loop exists for the bf16x3 variant");
   constexpr int ND = CO / 2;                 // dy DMA instructions per wave and chunk
   constexpr int KG = SPLIT ? 4 : ((CO == 4) ? 1 : 2);      // k-step groups (wave groups that split a chunk's k-steps)
   constexpr int KS = 4 / KG;                 // k-steps (16 pixels) per wave and chunk
@@ -152,57 +167,84 @@ k_wgrad3x3_patch(W3Args a) {
 
   // per-lane constant parts of the DMA descriptors
   // patch piece k (0..5): instruction q = wave*6+k -> plane q/24, rows 16*(q%24) + lane/4, chunk lane%4
-  int pr_pack[6];   // py<<8|px of this lane's patch row, or 0xffff
-  int pr_col[6];    // BYTE offset inside a pixel of this lane's 16-byte chunk, -1 if beyond Cin
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int q = wave * 6 + k;
-    const int plane = q / 24, row = (q % 24) * 16 + (lane >> 2);
-    pr_pack[k] = tabR[row];
+  // (the patch row of piece k is re-read from tabR where it is needed: six registers less to carry through the loop)
+  // plane = q / 24 = wave / 4 and the chunk (lane & 3) do not depend on k: ONE byte offset inside a pixel per lane
+  int pr_col;       // BYTE offset inside a pixel of this lane's 16-byte chunk, -1 if beyond Cin
+  {
+    const int plane = wave >> 2;
     if constexpr (SPLIT) {     // plane 0 / 1 = hi / lo of the 32 logical channels ci0 ..: group (lane & 3), every other chunk
       const int c = ci0 + (lane & 3) * 8;
-      pr_col[k] = (c < a.Cin) ? (c * 4 + plane * 16) : -1;
+      pr_col = (c < a.Cin) ? (c * 4 + plane * 16) : -1;
     } else {
       const int c = ci0 + plane * 32 + (lane & 3) * 8;
-      pr_col[k] = (c < a.Cin) ? c * 2 : -1;
+      pr_col = (c < a.Cin) ? c * 2 : -1;
     }
   }
-  // dy piece i (0..ND-1): instruction q = wave*ND+i -> plane q/4, rows 16*(q%4) + lane/4
-  int dy_col[ND];   // BYTE offset inside a pixel, -1: no load
-#pragma unroll
-  for (int i = 0; i < ND; ++i) {
-    const int q = wave * ND + i;
+  auto patch_row = [&](int k) { return (int)tabR[((wave * 6 + k) % 24) * 16 + (lane >> 2)]; };
+  // dy piece i (0..ND-1): instruction q = wave*ND+i -> plane q/4, rows 16*(q%4) + lane/4.  ND = 2: both pieces of a
+  // wave lie in one plane ((2 wave + i) >> 2 does not depend on i), ND = 1 trivially: ONE byte offset per lane
+  int dy_col;       // BYTE offset inside a pixel, -1: no load
+  {
+    const int q = wave * ND;
     if constexpr (SPLIT) {     // plane p: fragment p >> 1 (32 logical output channels), p & 1 = hi / lo
       const int pl = q >> 2;
       const int c = co0 + (pl >> 1) * 32 + (lane & 3) * 8;
-      dy_col[i] = (c + 8 <= a.lddy && c < a.Cout) ? (c * 4 + (pl & 1) * 16) : -1;
+      dy_col = (c + 8 <= a.lddy && c < a.Cout) ? (c * 4 + (pl & 1) * 16) : -1;
     } else {
       const int c = co0 + (q >> 2) * 32 + (lane & 3) * 8;
-      dy_col[i] = (c + 8 <= a.lddy && c < a.Cout) ? c * 2 : -1;
+      dy_col = (c + 8 <= a.lddy && c < a.Cout) ? c * 2 : -1;
     }
   }
 
   // Interior tiles (no image border inside the halo / the tile): every DMA offset is a per-tile scalar base plus a
   // per-lane constant; lanes that never load (table padding, channel tails) carry 0x80000000, which lands
   // beyond num_records for any base (< 2^31) -> zeros.  Border tiles take the general path below.
-  unsigned pr_rel[6];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-    const int py = pr_pack[k] >> 8, px = pr_pack[k] & 255;
-    pr_rel[k] = (pr_pack[k] != 0xffff && pr_col[k] >= 0)
-                    ? (unsigned)(((py - 1) * a.W + (px - 1)) * a.Cin * EB + pr_col[k]) : OOB_OFF;
-  }
-  unsigned dy_rel[4][ND];
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-#pragma unroll
-    for (int i = 0; i < ND; ++i) {
-      const int q = wave * ND + i;
-      const int row = (q & 3) * 16 + (lane >> 2);
-      const int tt = tabT[c * 64 + row];
-      dy_rel[c][i] = (tt != 0xffff && dy_col[i] >= 0)
-                         ? (unsigned)(((tt >> 8) * a.W + (tt & 255)) * a.lddy * EB + dy_col[i]) : OOB_OFF;
+  // PIPE: these per-lane constants live in two small LDS tables instead (14 registers the pipelined loop does not have:
+  // with them it spilled, and a scratch reload in front of a DMA drains vmcnt); the look-up goes out behind an MFMA group.
+  unsigned pr_rel[PIPE ? 1 : 6];
+  unsigned dy_rel[PIPE ? 1 : 4][ND];
+  unsigned* tabX = reinterpret_cast<unsigned*>(smem + TABX_OFF);
+  unsigned* tabD = reinterpret_cast<unsigned*>(smem + TABD_OFF);
+  // table entries are SIGNED byte offsets relative to the tile's first pixel (the halo's first row / column lies before
+  // it); REL_NONE marks rows / lanes that never load (no real offset comes near it: |offset| < (TH + 2) * W * C * 4)
+  constexpr unsigned REL_NONE = 0x40000000u;
+  const unsigned colx = pr_col >= 0 ? (unsigned)pr_col : REL_NONE, cold = dy_col >= 0 ? (unsigned)dy_col : REL_NONE;
+  if constexpr (PIPE) {
+    if (threadIdx.x < XROWS) {
+      const int pk = tabR[threadIdx.x];
+      const int py = pk >> 8, px = pk & 255;
+      tabX[threadIdx.x] = (pk != 0xffff) ? (unsigned)(((py - 1) * a.W + (px - 1)) * a.Cin * EB) : REL_NONE;
     }
+    if (threadIdx.x < 256) {
+      const int tt = tabT[threadIdx.x];
+      tabD[threadIdx.x] = (tt != 0xffff) ? (unsigned)(((tt >> 8) * a.W + (tt & 255)) * a.lddy * EB) : REL_NONE;
+    }
+    __syncthreads();
+    pr_rel[0] = 0u;
+    dy_rel[0][0] = 0u;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int pk = patch_row(k);
+      const int py = pk >> 8, px = pk & 255;
+      pr_rel[PIPE ? 0 : k] = (pk != 0xffff && pr_col >= 0)
+                      ? (unsigned)(((py - 1) * a.W + (px - 1)) * a.Cin * EB + pr_col) : OOB_OFF;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+      for (int i = 0; i < ND; ++i) {
+        const int q = wave * ND + i;
+        const int row = (q & 3) * 16 + (lane >> 2);
+        const int tt = tabT[c * 64 + row];
+        dy_rel[PIPE ? 0 : c][i] = (tt != 0xffff && dy_col >= 0)
+                           ? (unsigned)(((tt >> 8) * a.W + (tt & 255)) * a.lddy * EB + dy_col) : OOB_OFF;
+      }
+  }
+  // interior-tile offset from a table entry and the lane's column part (either may be "never loads")
+  auto rel_off = [&](unsigned base, unsigned t, unsigned col) {
+    return (t == REL_NONE || col == REL_NONE) ? OOB_OFF : base + t + col;
+  };
 
   // Tile origins (image, y0, x0) of the current and the next tile are carried in scalar registers and advanced
   // once per tile: decoding them with two runtime integer divisions at every DMA issue (~10 per tile) cost
@@ -235,38 +277,49 @@ k_wgrad3x3_patch(W3Args a) {
     }
     return finish(o);
   };
-  auto issue_patch = [&](int k, Org o, int buf) {
-    unsigned off;
+  // byte offset of patch piece k / dy piece i of chunk c for tile o (OOB_OFF: the lane reads zeros)
+  auto patch_off = [&](int k, Org o) -> unsigned {
     if (o.in_x) {
-      off = o.base_x + pr_rel[k];
-    } else {
-      const int b = o.b, y0 = o.y0, x0 = o.x0;
-      const int py = pr_pack[k] >> 8, px = pr_pack[k] & 255;
-      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-      const bool ok = pr_pack[k] != 0xffff && pr_col[k] >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-      off = ok ? (unsigned)(((b * a.H + iy) * a.W + ix) * a.Cin * EB + pr_col[k]) : OOB_OFF;
+      if constexpr (PIPE) return rel_off(o.base_x, tabX[((wave * 6 + k) % 24) * 16 + (lane >> 2)], colx);
+      else return o.base_x + pr_rel[PIPE ? 0 : k];
     }
-    bufload16(xres, off, 0u, smem + buf * XBUF + (wave * 6 + k) * 1024);
+    const int b = o.b, y0 = o.y0, x0 = o.x0;
+    const int pk = patch_row(k);             // border tiles only: an LDS read instead of a carried register
+    const int py = pk >> 8, px = pk & 255;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = pk != 0xffff && pr_col >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    return ok ? (unsigned)(((b * a.H + iy) * a.W + ix) * a.Cin * EB + pr_col) : OOB_OFF;
+  };
+  auto issue_patch = [&](int k, Org o, int buf) {
+    bufload16(xres, patch_off(k, o), 0u, smem + buf * XBUF + (wave * 6 + k) * 1024);
+  };
+  // two pieces: both look-ups first (one LDS round trip in the table-driven PIPE path), then both DMAs
+  auto issue_patch2 = [&](int k0, int k1, Org o, int buf) {
+    const unsigned o0 = patch_off(k0, o), o1 = patch_off(k1, o);
+    bufload16(xres, o0, 0u, smem + buf * XBUF + (wave * 6 + k0) * 1024);
+    bufload16(xres, o1, 0u, smem + buf * XBUF + (wave * 6 + k1) * 1024);
   };
   // dy chunk c of tile t into ring slot
   auto issue_dy = [&](Org o, auto cc, int slot) {
     constexpr int c = decltype(cc)::value;
     const int b = o.b, y0 = o.y0, x0 = o.x0;
+    unsigned offs[ND];
 #pragma unroll
     for (int i = 0; i < ND; ++i) {
       const int q = wave * ND + i;
-      unsigned off;
       if (o.in_dy) {
-        off = o.base_dy + dy_rel[c][i];
+        if constexpr (PIPE) offs[i] = rel_off(o.base_dy, tabD[c * 64 + (q & 3) * 16 + (lane >> 2)], cold);
+        else offs[i] = o.base_dy + dy_rel[PIPE ? 0 : c][i];
       } else {
         const int row = (q & 3) * 16 + (lane >> 2);
         const int tt = tabT[c * 64 + row];
         const int ty = tt >> 8, tx = tt & 255;
-        const bool ok = tt != 0xffff && dy_col[i] >= 0 && y0 + ty < a.H && x0 + tx < a.W;
-        off = ok ? (unsigned)(((b * a.H + y0 + ty) * a.W + x0 + tx) * a.lddy * EB + dy_col[i]) : OOB_OFF;
+        const bool ok = tt != 0xffff && dy_col >= 0 && y0 + ty < a.H && x0 + tx < a.W;
+        offs[i] = ok ? (unsigned)(((b * a.H + y0 + ty) * a.W + x0 + tx) * a.lddy * EB + dy_col) : OOB_OFF;
       }
-      bufload16(dres, off, 0u, smem + DY_OFF + slot * DYSLOT + q * 1024);
     }
+#pragma unroll
+    for (int i = 0; i < ND; ++i) bufload16(dres, offs[i], 0u, smem + DY_OFF + slot * DYSLOT + (wave * ND + i) * 1024);
   };
 
   f32x16 acc[9];
@@ -351,6 +404,82 @@ k_wgrad3x3_patch(W3Args a) {
     }
   };
 
+  // ---- PIPE: per-wave constants and the pipelined chunk -------------------------------------------------
+  // rows of this lane's two transposed reads (tile pixels p0, p0 + 4) for the wave's k-step of chunks 0..3, as byte
+  // offsets inside a patch plane, two per register
+  unsigned prow[4] = {0u, 0u, 0u, 0u};
+  if constexpr (PIPE) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int p0 = c * 64 + kg * 16 + 8 * h + tq;
+      prow[c] = (unsigned)tabP[p0] | ((unsigned)tabP[p0 + 4] << 16);
+    }
+  }
+  s16x4 qq[2][12];   // PIPE: fragment rows, alternating; the NEXT chunk's first row is requested a stage early
+  auto issue_row_p = [&](s16x4* d, unsigned r0, unsigned r1) {
+    d[0] = tr_read<0>(r0);   d[1] = tr_read<0>(r1);
+    d[2] = tr_read<64>(r0);  d[3] = tr_read<64>(r1);
+    d[4] = tr_read<128>(r0); d[5] = tr_read<128>(r1);
+    d[6] = tr_read<XPLANE>(r0);       d[7] = tr_read<XPLANE>(r1);
+    d[8] = tr_read<XPLANE + 64>(r0);  d[9] = tr_read<XPLANE + 64>(r1);
+    d[10] = tr_read<XPLANE + 128>(r0); d[11] = tr_read<XPLANE + 128>(r1);
+  };
+  // chunk c of the current tile.  have0: its first filter row is already in flight in qq[c & 1] (requested by chunk
+  // c - 1); dma0 / dma1 / dma2: the stage's DMA issue, split over the three filter rows
+  auto compute_chunk_pipe = [&](auto cc, int xb_off, int dyb_off, auto&& dma0, auto&& dma1) {
+    constexpr int c = decltype(cc)::value;
+    constexpr int P = c & 1;
+    constexpr bool have0 = (c > 0), pref = (c < 3);
+    unsigned pw = prow[c];
+    asm volatile("" : "+v"(pw));     // keeps the per-chunk fragment addresses from being hoisted out of the tile loop (VGPRs)
+    const unsigned rx0 = (unsigned)(xb_off + (int)(pw & 0xffffu) * 64 + b_lane);
+    const unsigned rx1 = (unsigned)(xb_off + (int)(pw >> 16) * 64 + b_lane);
+    const unsigned ra = (unsigned)(dyb_off + a_lane + kg * 1024);
+    const s16x4 a0h = tr_read<0>(ra), a1h = tr_read<256>(ra), a0l = tr_read<4096>(ra), a1l = tr_read<4096 + 256>(ra);
+    if constexpr (!have0) issue_row_p(qq[P], rx0, rx1);
+    auto mfma_row = [&](const s16x4* r, int ky) {
+      const bf16x8 ah = cat8(a0h, a1h), al = cat8(a0l, a1l);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bf16x8 bh = cat8(r[2 * kx], r[2 * kx + 1]), bl = cat8(r[6 + 2 * kx], r[6 + 2 * kx + 1]);
+        f32x16 v = acc[ky * 3 + kx];
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, v, 0, 0, 0);
+        acc[ky * 3 + kx] = v;
+      }
+      __builtin_amdgcn_s_setprio(0);
+      // the row's MFMAs stay in front of the next row's reads: sunk below them (the scheduler likes to) they would keep
+      // a third fragment row alive (24 VGPRs -> spills at the 256-register budget of two waves per SIMD)
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    // filter row 0.  The stage's DMA instructions go BEHIND an MFMA group, where one fragment row (not two) is alive:
+    // their address arithmetic (border tiles: table lookups + bounds tests) otherwise pushes the wave over its 256
+    // registers; the matrix pipe works on the group just issued while they go out.
+    issue_row_p(qq[P ^ 1], rx0 + PW * 64, rx1 + PW * 64);
+    wait_lgkm<12>();
+    mfma_row(qq[P], 0);
+    dma0();
+    // filter row 1
+    issue_row_p(qq[P], rx0 + 2 * PW * 64, rx1 + 2 * PW * 64);
+    wait_lgkm<12>();
+    mfma_row(qq[P ^ 1], 1);
+    dma1();
+    // filter row 2 (+ the next chunk's first row)
+    if constexpr (pref) {
+      unsigned pn = prow[(c + 1) & 3];
+      asm volatile("" : "+v"(pn));
+      const unsigned nx0 = (unsigned)(xb_off + (int)(pn & 0xffffu) * 64 + b_lane);
+      const unsigned nx1 = (unsigned)(xb_off + (int)(pn >> 16) * 64 + b_lane);
+      issue_row_p(qq[P ^ 1], nx0, nx1);
+      wait_lgkm<12>();
+    } else {
+      wait_lgkm<0>();
+    }
+    mfma_row(qq[P], 2);
+  };
+
   if (t_begin < t_end) {
     // ---- prologue: patch of the first tile, dy chunks 0 and 1 ---------------------------------------
     Org cur = tile_origin(t_begin);
@@ -370,13 +499,15 @@ k_wgrad3x3_patch(W3Args a) {
         if (last) wait_vm<NL>(); else wait_vm<N>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (!last) {
-          if constexpr (c == 0) { issue_patch(0, nxt, xbuf ^ 1); issue_patch(1, nxt, xbuf ^ 1); }
-          else if constexpr (c == 1) { issue_patch(2, nxt, xbuf ^ 1); issue_patch(3, nxt, xbuf ^ 1); }
-          else if constexpr (c == 2) issue_patch(4, nxt, xbuf ^ 1);
-          else issue_patch(5, nxt, xbuf ^ 1);
-        }
-        {
+        auto dma_patch = [&]() {
+          if (!last) {
+            if constexpr (c == 0) issue_patch2(0, 1, nxt, xbuf ^ 1);
+            else if constexpr (c == 1) issue_patch2(2, 3, nxt, xbuf ^ 1);
+            else if constexpr (c == 2) issue_patch(4, nxt, xbuf ^ 1);
+            else issue_patch(5, nxt, xbuf ^ 1);
+          }
+        };
+        auto dma_dy = [&]() {
           // dy chunk two stages ahead
           constexpr int c2 = (c + 2) & 3;
           const int t2 = (c >= 2) ? t + 1 : t;
@@ -384,8 +515,15 @@ k_wgrad3x3_patch(W3Args a) {
           slot -= (slot >= 3) ? 3 : 0;
           slot -= (slot >= 3) ? 3 : 0;
           if (t2 < t_end) issue_dy((c >= 2) ? nxt : cur, IC<c2>{}, slot);
+        };
+        if constexpr (PIPE) {
+          // per-wave DMA order unchanged (patch pieces, then dy): the counted vmcnt waits above still hold
+          compute_chunk_pipe(cc, xbuf * XBUF, DY_OFF + gc * DYSLOT, dma_patch, dma_dy);
+        } else {
+          dma_patch();
+          dma_dy();
+          compute_chunk(c, xbuf * XBUF, DY_OFF + gc * DYSLOT);
         }
-        compute_chunk(c, xbuf * XBUF, DY_OFF + gc * DYSLOT);
         gc = (gc == 2) ? 0 : gc + 1;
       };
       stage(IC<0>{}); stage(IC<1>{}); stage(IC<2>{}); stage(IC<3>{});
@@ -503,6 +641,13 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split)
   return p;
 }
 
+// A/B knob: 1 (default) the pipelined bf16x3 chunk loop, 0 the round-2 loop.  Same values either way.
+static std::atomic<int> g_w3_pipe{-1};   // -1: not initialised (SFOD_W3_PIPE or 1)
+extern "C" int sfod_set_wgrad3x3_pipe(int on) {
+  g_w3_pipe.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+
 // split != 0 (SFOD_BF16X3): x / dy hold (hi, lo) pairs; Cin / Cout / lddy are LOGICAL channel counts in either case
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split) {
@@ -515,9 +660,9 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
   a.tiles_per_split = p.tiles_per_split;
   a.co_tiles = p.co_tiles; a.ci_tiles = p.ci_tiles; a.nsplit = p.nsplit;
   static const hipError_t attr_rc = []() {     // once per process (function-local static: thread-safe)
-    const void* ks[3] = {(const void*)k_wgrad3x3_patch<4>, (const void*)k_wgrad3x3_patch<2>,
-                         (const void*)k_wgrad3x3_patch<4, true>};
-    for (int i = 0; i < 3; ++i) {
+    const void* ks[4] = {(const void*)k_wgrad3x3_patch<4>, (const void*)k_wgrad3x3_patch<2>,
+                         (const void*)k_wgrad3x3_patch<4, true>, (const void*)k_wgrad3x3_patch<4, true, true>};
+    for (int i = 0; i < 4; ++i) {
       hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) return e;
     }
@@ -525,7 +670,16 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
   }();
   if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute(w3): %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
   dim3 grid(p.co_tiles * p.ci_tiles * p.nsplit), blk(512);
-  if (split) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true>), grid, blk, LDS_TOTAL, s, a);
+  int pipe = g_w3_pipe.load(std::memory_order_relaxed);
+  if (pipe < 0) {
+    const char* ev = getenv("SFOD_W3_PIPE");
+    pipe = (ev && atoi(ev) == 0) ? 0 : 1;
+    int expect = -1;
+    g_w3_pipe.compare_exchange_strong(expect, pipe, std::memory_order_relaxed);
+    pipe = g_w3_pipe.load(std::memory_order_relaxed);
+  }
+  if (split && pipe) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true, true>), grid, blk, LDS_TOTAL, s, a);
+  else if (split) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true>), grid, blk, LDS_TOTAL, s, a);
   else if (p.CO == 4) hipLaunchKernelGGL(k_wgrad3x3_patch<4>, grid, blk, LDS_TOTAL, s, a);
   else hipLaunchKernelGGL(k_wgrad3x3_patch<2>, grid, blk, LDS_TOTAL, s, a);
   int rc = sfod_check_launch("wgrad3x3_patch");

@@ -234,6 +234,11 @@ def set_conv_algo(algo):
     load().sfod_set_conv_algo(int(algo))
 
 
+def set_wgrad3x3_pipe(on):
+    """Pipelined chunk loop of the bf16x3 halo-patch weight gradient (A/B knob, include/sfod_hip.h)."""
+    load().sfod_set_wgrad3x3_pipe(int(bool(on)))
+
+
 def set_conv3x3_variant(variant):
     """Workgroup shape of the halo-patch kernel: 0 auto, 1..4 see include/sfod_hip.h (A/B runs, tests)."""
     load().sfod_set_conv3x3_variant(int(variant))

@@ -189,10 +189,13 @@ def test_conv_dgrad_and_wgrad(native, shape, algo):
     (1, 70, 150, 48, 80),
     (3, 5, 6, 256, 256),
 ])
-def test_conv3x3_patch_wgrad(native, shape):
+@pytest.mark.parametrize("pipe", [1, 0])
+def test_conv3x3_patch_wgrad(native, shape, pipe):
     """k_wgrad3x3_patch<4, SPLIT> (planes de-interleaved by the DMA, hi*lo + lo*hi + hi*hi per tap, four k-step slabs per
-    pixel split) + the slab reduction against fp64 autograd."""
+    pixel split) + the slab reduction against fp64 autograd; ``pipe``: the round-3 pipelined chunk loop (default) and
+    the round-2 loop behind sfod_set_wgrad3x3_pipe."""
     B, H, W, Cin, Cout = shape
+    native.set_wgrad3x3_pipe(pipe)
     g = torch.Generator().manual_seed(sum(shape) + 1)
     x = torch.randn(B, Cin, H, W, generator=g)
     dy = torch.randn(B, Cout, H, W, generator=g) * 1e-4
@@ -209,12 +212,16 @@ def test_conv3x3_patch_wgrad(native, shape):
         native.conv_wgrad_oihw(xd, dyd, direct, accumulate=False)
         acc = torch.ones(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
         native.conv_wgrad_oihw(xd, dyd, acc, accumulate=True)
+        native.set_wgrad3x3_pipe(1 - pipe)
+        other = native.conv_wgrad(xd, dyd, Cout, 3)
     finally:
         native.set_conv_algo(0)
+        native.set_wgrad3x3_pipe(1)
     dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
     native.unpack_conv_wgrad(dwp, dw)
     assert rel_err(dw.cpu(), w.grad) < TOL
     assert torch.equal(dwp, dwp2), "slab reduction must be deterministic"
+    assert torch.equal(dwp, other), "both chunk loops issue the same MFMA sequence per accumulator"
     assert torch.equal(direct, dw)
     torch.testing.assert_close(acc, dw + 1.0, rtol=0, atol=1e-6)
 
@@ -446,3 +453,24 @@ def test_bn_backward_with_a_prereduced_workspace_of_any_length(native, rows):
     torch.testing.assert_close(dbeta.cpu().double(), ref[:C], rtol=1e-6, atol=1e-5)
     torch.testing.assert_close(dgamma.cpu().double(), ref[C:], rtol=1e-6, atol=1e-5)
     assert torch.isfinite(dy).all()
+
+
+def test_conv3x3_patch_wgrad_pipelined_loop_under_load(native):
+    """The pipelined chunk loop on a layer-sized problem (many tiles per workgroup, border and interior tiles, every CU
+    busy): run-to-run identical and bit-equal to the round-2 loop -- an ordering hazard between the early fragment reads
+    and the LDS-DMA would show as scattered wrong tiles."""
+    B, H, W, Cin, Cout = 8, 75, 150, 256, 256
+    g = torch.Generator(device=DEV).manual_seed(3)
+    xd = native.cast(torch.randn(B, H, W, Cin, device=DEV, generator=g), native.SPLIT_DTYPE)
+    dyd = native.cast(torch.randn(B, H, W, Cout, device=DEV, generator=g) * 1e-3, native.SPLIT_DTYPE)
+    try:
+        native.set_conv_algo(2)
+        native.set_wgrad3x3_pipe(0)
+        ref = native.conv_wgrad(xd, dyd, Cout, 3).clone()
+        native.set_wgrad3x3_pipe(1)
+        for _ in range(6):
+            out = native.conv_wgrad(xd, dyd, Cout, 3)
+            assert torch.equal(out, ref)
+    finally:
+        native.set_conv_algo(0)
+        native.set_wgrad3x3_pipe(1)

@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "bf16x3"], default="bf16x3")
     ap.add_argument("--variants", action="store_true",
                     help="time the halo-patch kernel's workgroup shapes 1..4 (and auto = 0) instead of algo 1 vs 2")
+    ap.add_argument("--w3pipe", action="store_true",
+                    help="halo-patch weight gradient: round-2 chunk loop vs the pipelined one, interleaved (sfod_set_wgrad3x3_pipe)")
     args = ap.parse_args()
     sfod = importlib.import_module("simple-sfod_amd")
     native = sfod.native
@@ -47,6 +49,32 @@ def main():
         w = native.cast(torch.randn(Cout, 9, Cin, device=dev, generator=g) / (3 * Cin ** 0.5), odt)
         bias = torch.randn(Cout, device=dev, generator=g)
         flops = 2.0 * B * H * W * Cout * 9 * Cin
+        if args.w3pipe:
+            if name == "conv1_1":
+                continue
+            dy = native.cast(torch.randn(B, H, W, Cout, device=dev, generator=g), odt)
+            native.set_conv_algo(2)
+            ts, dws = {0: [], 1: []}, {}
+            for r in range(args.rounds + 1):
+                for v in ts:
+                    native.set_wgrad3x3_pipe(v)
+                    dw = torch.zeros(Cout, 9, Cin, dtype=torch.float32, device=dev)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    native.conv_wgrad(x, dy, Cout, 3, dw)
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r > 0:
+                        ts[v].append(e0.elapsed_time(e1))
+                    dws[v] = dw
+            native.set_wgrad3x3_pipe(1)
+            native.set_conv_algo(0)
+            line = f"{name:9s} {B}x{H}x{W} {Cin:4d}->{Cout:4d} {flops / 1e9:8.1f} GF wgrad"
+            for v in ts:
+                t = sorted(ts[v])[len(ts[v]) // 2]
+                line += f" | {'pipelined' if v else 'round 2 '} {t:6.3f} ms {flops / t / 1e9:6.0f} TF/s"
+            print(line + f" | equal {torch.equal(dws[0], dws[1])}", flush=True)
+            continue
         if args.variants:
             native.set_conv_algo(2)
             vt = {v: [] for v in (0, 1, 2, 3, 4)}
