@@ -405,6 +405,16 @@ int sfod_sgd_ema(float* param, const float* grad, float* mom, float* teacher, in
                  float ema_keep, int first_step, void* stream);
 /* t = s*(1-k) + t*k  on fp32 buffers (BN running stats) */
 int sfod_ema(float* teacher, const float* student, int64_t n, float keep, void* stream);
+/* the same update on the int64 buffers (num_batches_tracked): fp32 arithmetic, truncated on the way back like the
+ * reference's load_state_dict copy (source_free_adaptive_teacher.py:583-603, SURVEY A.17 iv).  Both factors are passed
+ * as the caller rounded them (torch rounds the Python doubles k and 1 - k to fp32 separately). */
+int sfod_ema_i64(int64_t* teacher, const int64_t* student, int n, float keep, float one_minus_keep, void* stream);
+/* the scalars the trainer logs after the teacher pass (source_free_adaptive_teacher.py:411-423,445-452): out[0] mean over
+ * images of the mean detection score, out[1] RPN proposals with logit > thr per image, out[2] mean pseudo-label count.
+ * det_scores [B,D] / det_count [B], rpn_logits [B,P] / rpn_count [B], gt_count [B]; out: 3 floats. */
+int sfod_teacher_metrics(const float* det_scores, const int* det_count, int D, const float* rpn_logits,
+                         const int* rpn_count, int P, const int* gt_count, int B, float thr, float* out,
+                         void* stream);
 
 /* utilities */
 int sfod_fill_f32(float* p, int64_t n, float v, void* stream);

@@ -1642,6 +1642,63 @@ extern "C" int sfod_ema(float* teacher, const float* student, int64_t n, float k
   return sfod_check_launch("ema");
 }
 
+// int64 buffers (num_batches_tracked) in the reference's EMA: s * (1 - k) + t * k in fp32, truncated by the copy back
+// into the int64 buffer (source_free_adaptive_teacher.py:583-603 + load_state_dict; SURVEY A.17 iv) -- one launch
+// instead of torch's cast / mul / mul / add / cast / copy chain
+__global__ void k_ema_i64(long long* __restrict__ t, const long long* __restrict__ s, int n, float keep, float omk) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    // torch's operation order: two rounded fp32 products, then a rounded sum (no fused multiply-add: with equal
+    // counters the result sits exactly on an integer and one contracted rounding decides the truncation)
+    const float a = __fmul_rn((float)s[i], omk);
+    const float b = __fmul_rn((float)t[i], keep);
+    t[i] = (long long)__fadd_rn(a, b);
+  }
+}
+extern "C" int sfod_ema_i64(int64_t* teacher, const int64_t* student, int n, float keep, float one_minus_keep,
+                            void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_ema_i64, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long*)teacher,
+                     (const long long*)student, n, keep, one_minus_keep);
+  return sfod_check_launch("ema_i64");
+}
+
+// The three scalars the trainer logs after the teacher pass (source_free_adaptive_teacher.py:411-423,445-452), one
+// workgroup: out[0] = mean over images of the mean detection score (0 for an image without detections),
+// out[1] = #(RPN proposals with objectness logit > thr) / B, out[2] = mean pseudo-label count.
+__global__ void __launch_bounds__(256)
+k_teacher_metrics(const float* __restrict__ det_scores, const int* __restrict__ det_count, int D,
+                  const float* __restrict__ rpn_logits, const int* __restrict__ rpn_count, int P,
+                  const int* __restrict__ gt_count, int B, float thr, float* __restrict__ out) {
+  __shared__ float red[3][256];
+  float conf = 0.f, npp = 0.f, ngt = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const int nd = min(det_count[b], D), np = min(rpn_count[b], P);
+    float s = 0.f, c = 0.f;
+    for (int i = threadIdx.x; i < nd; i += 256) s += det_scores[(int64_t)b * D + i];
+    for (int i = threadIdx.x; i < np; i += 256) c += rpn_logits[(int64_t)b * P + i] > thr ? 1.f : 0.f;
+    conf += s / (float)max(nd, 1);
+    npp += c;
+    if (threadIdx.x == 0) ngt += (float)gt_count[b];
+  }
+  red[0][threadIdx.x] = conf; red[1][threadIdx.x] = npp; red[2][threadIdx.x] = ngt;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (threadIdx.x < st)
+      for (int k = 0; k < 3; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x < 3) out[threadIdx.x] = red[threadIdx.x][0] / (float)B;
+}
+extern "C" int sfod_teacher_metrics(const float* det_scores, const int* det_count, int D, const float* rpn_logits,
+                                    const int* rpn_count, int P, const int* gt_count, int B, float thr, float* out,
+                                    void* stream) {
+  if (B <= 0) return SFOD_EBADARG;
+  hipLaunchKernelGGL(k_teacher_metrics, dim3(1), dim3(256), 0, (hipStream_t)stream, det_scores, det_count, D, rpn_logits,
+                     rpn_count, P, gt_count, B, thr, out);
+  return sfod_check_launch("teacher_metrics");
+}
+
 __global__ void k_fill(float* p, int64_t n, float v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     p[i] = v;

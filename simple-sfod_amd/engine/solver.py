@@ -151,10 +151,8 @@ class FusedSGD:
             if f.n_total > f.n_norm_end:  # frozen (never updated) parameters still take part in the EMA
                 native.ema_(t[f.n_norm_end:f.n_total], f.param[f.n_norm_end:f.n_total], self.ema_keep)
             native.ema_(self.teacher.fbuf, f.fbuf, self.ema_keep)
-            k = self.ema_keep
             # int64 buffers: float32 arithmetic, truncated on the copy back (SURVEY A.17 iv)
-            ti = self.teacher.ibuf
-            ti.copy_((f.ibuf.to(torch.float32) * (1 - k) + ti.to(torch.float32) * k).to(torch.int64))
+            native.ema_i64_(self.teacher.ibuf, f.ibuf, self.ema_keep)
         self._steps += 1
 
     def state_dict(self):

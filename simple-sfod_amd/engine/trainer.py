@@ -304,10 +304,11 @@ class BaseTrainer:
                 dist.all_reduce(self.optimizer.flat.grad)
             self.optimizer.grad_scale = 1.0 / w
 
-    def _write_metrics(self, metrics_dict):
+    def _write_metrics(self, metrics_dict, total=None):
         loss_keys = [k for k in metrics_dict if k[:4] == "loss"]
         if loss_keys:
-            self.storage.put_scalar("total_loss", sum(metrics_dict[k].detach() for k in loss_keys))
+            self.storage.put_scalar("total_loss", total if total is not None
+                                    else sum(metrics_dict[k].detach() for k in loss_keys))
         self.storage.put_scalars(**{k: (v.detach() if isinstance(v, torch.Tensor) else v)
                                     for k, v in metrics_dict.items()})
 
@@ -425,6 +426,29 @@ class BaseTrainer:
         scheduler, iteration) when ``resume`` and it exists, else (re)load ``MODEL.WEIGHTS``."""
         from ..checkpoint import DetectionTSCheckpointer
         return DetectionTSCheckpointer(self, self.cfg.OUTPUT_DIR).resume_or_load(self.cfg.MODEL.WEIGHTS, resume=resume)
+
+
+class _WeightedLossSum(torch.autograd.Function):
+    """(w, l_0 .. l_{n-1}) -> (w * l as one [n] tensor, sum(w * l)); backward: d l_i = w_i * (g_sum + g_i)."""
+
+    @staticmethod
+    def forward(ctx, w, *losses):
+        stacked = torch.stack([l.detach().reshape(()).float() for l in losses])
+        weighted = stacked * w
+        ctx.save_for_backward(w)
+        ctx.n = len(losses)
+        return weighted, weighted.sum()
+
+    @staticmethod
+    def backward(ctx, g_weighted, g_total):
+        (w,) = ctx.saved_tensors
+        g = w * g_total if g_weighted is None else w * (g_total + g_weighted)
+        return (None,) + tuple(g[i] for i in range(ctx.n))
+
+
+def weighted_loss_sum(w, losses):
+    """``w``: device float32 [n]; ``losses``: n scalar tensors (autograd leaves of the step).  -> (weighted [n], total)."""
+    return _WeightedLossSum.apply(w, *losses)
 
 
 def threshold_bbox(proposal_bbox_inst, thres=0.7, proposal_type="roih"):
@@ -593,15 +617,8 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             _, proposals_rpn_k, proposals_roih_k = self.model_teacher(unlabel_data_k, branch="unsup_data_weak",
                                                                       batched=True)
         d = proposals_roih_k.d
-        B = d["det_count"].shape[0]
-        live = torch.arange(d["det_scores"].shape[1], device=self.device)[None, :] < d["det_count"][:, None]
-        per_image = (d["det_scores"] * live).sum(1) / d["det_count"].clamp(min=1)
-        self.storage.put_scalar("roi_head/mean_confidence", per_image.mean())
         # 2. thresholding (fused into the teacher post-processing kernel: score > BBOX_THRESHOLD)
         cur_threshold = cfg.SEMISUPNET.BBOX_THRESHOLD
-        rpn_live = torch.arange(proposals_rpn_k.logits.shape[1], device=self.device)[None, :] < proposals_rpn_k.count[:, None]
-        self.storage.put_scalar("rpn/num_pseudo_proposals",
-                                ((proposals_rpn_k.logits > cur_threshold) & rpn_live).sum().float() / B)
         if "ADAPTIVE_THRESHOLD" in cfg and cfg.ADAPTIVE_THRESHOLD.ENABLED:
             # :393-404 ring of per-class counts -> class-wise accuracy; :461-466 after WARM_UP the pseudo labels
             # are score >= thr * acc/(2-acc) per class instead of the fixed threshold (one launch, no sync)
@@ -616,7 +633,13 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             for i in range(min(8, K)):
                 self.storage.put_scalar("acc_thres/class_" + str(i), acc[i])
         pseudo = proposals_roih_k.pseudo_gt()
-        self.storage.put_scalar("roi_head/num_pseudo_proposals", pseudo.count.float().mean())
+        # logged scalars of the pass (:411-423, :445-452) in one launch: mean detection confidence (detection arrays are
+        # not touched by the adaptive selection), RPN proposals above the threshold per image, mean pseudo-label count
+        m = native.teacher_metrics(d["det_scores"], d["det_count"], proposals_rpn_k.logits, proposals_rpn_k.count,
+                                   pseudo.count, cur_threshold)
+        self.storage.put_scalar("roi_head/mean_confidence", m[0])
+        self.storage.put_scalar("rpn/num_pseudo_proposals", m[1])
+        self.storage.put_scalar("roi_head/num_pseudo_proposals", m[2])
         return pseudo
 
     # ---- step (:335-581) ----------------------------------------------------------------------------
@@ -667,27 +690,33 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
                     unlabel_data_k[i][k + "_unlabeled"] = v
             record_all_domain_data, _, _ = self.model(unlabel_data_k, branch="domain_classifier")
             record_dict.update(record_all_domain_data)
-        # loss weighting (:540-564)
-        loss_dict = {}
+        # loss weighting (:540-564): the same weights key by key; the products and their sum are ONE autograd node over
+        # the stacked scalars (3 small kernels forward, 1 backward) instead of a multiply and an add per key and
+        # direction -- ~30 single-element launches per step otherwise
+        keys, weights = [], []
         for key in record_dict.keys():
             if key.startswith("loss") and key[-3:] != "val":
                 if key == "loss_rpn_loc_pseudo" or key == "loss_box_reg_pseudo":
-                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
+                    w = cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
                 elif key == "loss_bpc_pseudo":
-                    loss_dict[key] = record_dict[key] * 0
+                    w = 0
                 elif key[-6:] == "pseudo":
-                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
+                    w = cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
                 elif (key == "loss_DC_img_s" or key == "loss_DC_img_t") and cfg.DOMAIN_CLASSIFIER.IMAGE:
-                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.DIS_LOSS_WEIGHT
+                    w = cfg.SEMISUPNET.DIS_LOSS_WEIGHT
                 elif (key == "loss_DC_ins_s" or key == "loss_DC_ins_t") and cfg.DOMAIN_CLASSIFIER.INSTANCE:
-                    loss_dict[key] = record_dict[key] * cfg.SEMISUPNET.DIS_LOSS_WEIGHT
+                    w = cfg.SEMISUPNET.DIS_LOSS_WEIGHT
                 else:
-                    loss_dict[key] = record_dict[key] * 0
+                    w = 0
+                keys.append(key)
+                weights.append(float(w))
+        wdev = native.dev_const(tuple(weights), torch.float32, self.device)
+        weighted, losses = weighted_loss_sum(wdev, [record_dict[k] for k in keys])
+        loss_dict = {k: weighted[i] for i, k in enumerate(keys)}
         self.storage.put_scalar("calibration/bpc_loss", loss_dict["loss_bpc_pseudo"])
-        losses = sum(loss_dict.values())
         metrics_dict = dict(loss_dict)
         metrics_dict["data_time"] = data_time
-        self._write_metrics(metrics_dict)
+        self._write_metrics(metrics_dict, total=losses.detach())
         self.optimizer.zero_grad()
         losses.backward()
         self._reduce_gradients()

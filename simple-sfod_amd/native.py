@@ -1047,3 +1047,18 @@ def sgd_ema_(param, grad, mom, teacher, lr, momentum, weight_decay, grad_scale, 
 
 def ema_(teacher, student, keep):
     call("sfod_ema", teacher, student, teacher.numel(), float(keep))
+
+
+def ema_i64_(teacher, student, keep):
+    """int64 buffers: float32 arithmetic, truncated on the way back (the reference's EMA + load_state_dict copy)."""
+    assert teacher.dtype == torch.int64 and student.dtype == torch.int64 and teacher.numel() == student.numel()
+    call("sfod_ema_i64", teacher, student, teacher.numel(), float(keep), float(1.0 - keep))
+
+
+def teacher_metrics(det_scores, det_count, rpn_logits, rpn_count, gt_count, thr):
+    """-> float32 [3]: mean detection confidence, RPN proposals above ``thr`` per image, mean pseudo-label count."""
+    B, D = det_scores.shape
+    out = torch.empty(3, dtype=torch.float32, device=det_scores.device)
+    call("sfod_teacher_metrics", det_scores, det_count, D, rpn_logits, rpn_count, rpn_logits.shape[1], gt_count, B,
+         float(thr), out)
+    return out
