@@ -549,6 +549,24 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
   if constexpr (UT && SPLIT && sizeof(OutT) == 4) {
     if (use_wide_gemm(a.M, a.Cout, a.ks)) return launch_one<T, OutT, 4, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
   }
+  // fp32 (MFMA-bound at 1/16 of the bf16 rate: a tile's time is its FLOPs, the operand stream is never the limit): pick
+  // the tile shape by whole-chip rounds.  The ResNet-C4 layers at 600x1200 have few tiles per CU (res4: 22 800 rows x
+  // 256 channels = 358 tiles of 128 x 128 on 256 CUs: two rounds for 1.4 rounds of work); 128 x 64 tiles pack the same
+  // layer into 716 / 768 slots (three per CU) -- cost = ceil(workgroups / 256) x tile area, smaller is better, ties to
+  // the larger tile.  SFOD_GEMM_FP32_TILES=0 restores the fixed rule (A/B).
+  if constexpr (sizeof(T) == 4 && UT) {
+    static const int cost_rule = []() { const char* e = getenv("SFOD_GEMM_FP32_TILES"); return e ? atoi(e) : 1; }();
+    if (cost_rule) {
+      auto rounds = [&](int bm, int bn) {
+        const int64_t wgs = (int64_t)((a.M + bm - 1) / bm) * ((a.Cout + bn - 1) / bn);
+        return (double)((wgs + 255) / 256) * bm * bn;
+      };
+      const double c256 = rounds(256, 128) * 0.98, c128 = rounds(128, 128), c64 = rounds(128, 64) * 1.03;
+      if (c64 < c128 && c64 < c256) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
+      if (c256 <= c128) return launch_one<T, OutT, 2, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);
+      return launch_one<T, OutT, 2, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
+    }
+  }
   // 256 x 128 tiles with a 3-stage DMA pipeline once the grid still fills the chip (>= 2 tiles / CU)
   const int64_t big_tiles = (int64_t)((a.M + 255) / 256) * ((a.Cout + 127) / 128);
   if (UT && big_tiles >= 384) return launch_one<T, OutT, 2, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);

@@ -4,7 +4,7 @@ import argparse, importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
-ap.add_argument("--dtype", choices=["bf16", "bf16x3"], default="bf16x3")
+ap.add_argument("--dtype", choices=["bf16", "bf16x3", "fp32"], default="bf16x3")
 args = ap.parse_args()
 sfod = importlib.import_module("simple-sfod_amd"); native = sfod.native; native.load()
 dev = "cuda"
@@ -13,7 +13,8 @@ SHAPES = [("vgg fc1 teacher", 16000, 25088, 1024), ("vgg fc1 student", 4096, 250
           ("r101 fc1 teacher", 16000, 50176, 2048), ("r101 fc1 student", 2048, 50176, 2048),
           ("r101 res4 256->1024", 22800, 256, 1024), ("r101 res4 1024->256", 22800, 1024, 256),
           ("r101 res3 128->512", 90000, 128, 512), ("r101 res3 512->128", 90000, 512, 128),
-          ("r101 res2 64->256", 360000, 64, 256), ("r101 res2 256->64", 360000, 256, 64)]
+          ("r101 res2 64->256", 360000, 64, 256), ("r101 res2 256->64", 360000, 256, 64),
+          ("r101 res4 1024->1024 (shortcut-like)", 22800, 1024, 1024), ("r101 rpn 1x1 1024->60", 22800, 1024, 60)]
 split = args.dtype == "bf16x3"
 for (name, M, K, N) in SHAPES:
     g = torch.Generator(device=dev).manual_seed(1)
@@ -21,7 +22,7 @@ for (name, M, K, N) in SHAPES:
     w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
     if split:
         a, w = native.cast(a, native.SPLIT_DTYPE), native.cast(w, native.SPLIT_DTYPE)
-    else:
+    elif args.dtype == "bf16":
         a, w = a.bfloat16(), w.bfloat16()
     ts = []
     for r in range(8):

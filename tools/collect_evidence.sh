@@ -1,5 +1,5 @@
 # Collect the per-round evidence set on the GPU box (one gpurun call; ~12 GPU-minutes):
-#   bash tools/collect_evidence.sh <tag> [pmc|bench|all]
+#   bash tools/collect_evidence.sh <tag> [pmc|bench|r101|all]
 # pmc:   rocprofv3 kernel trace + SQ counters + HBM traffic counters of the default bench workload (writes the traffic file
 #        bench.py reads, gpurun_out/<tag>_pmc_hbm_traffic.json -> copy to profiles/pmc_hbm_traffic_latest.json BEFORE the
 #        bench part so that the bench line carries it)
@@ -25,5 +25,16 @@ if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
     name=$(echo $cfg | tr -d ' -' | tr '.' '_')
     python3 bench.py $cfg --no-cpu-baseline --no-secondary > $O/${TAG}_bench_${name}.json 2> $O/${TAG}_bench_${name}.err
   done
+fi
+if [ "$WHAT" = r101 ] || [ "$WHAT" = all ]; then
+  # config #5 in its parity mode (fp32): kernel trace of single-stream steps, GPU busy fraction (union of kernel intervals
+  # over the span of the timed steps, and the un-profiled step time of the bench line beside the profiled kernel-time sum)
+  rm -rf $O/prof_r101
+  rocprofv3 --kernel-trace --stats -d $O/prof_r101 -o r101 -- python3 bench.py --model r101 --no-overlap --steps 12 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timer > $O/${TAG}_r101_fp32_profiled_bench.json 2> $O/${TAG}_r101_prof.err
+  DB=$(find $O/prof_r101 -name "*.db" | head -1)
+  python3 tools/rocpd_stats.py $DB 15 > $O/${TAG}_r101_fp32_kernel_stats.csv
+  python3 tools/busy_fraction.py $DB 0.3 > $O/${TAG}_r101_fp32_busy_fraction.txt
+  rm -rf $O/prof_r101
+  python3 bench.py --model r101 --no-overlap --steps 20 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_r101_fp32_single_stream.json 2> /dev/null
 fi
 ls -la $O | grep ${TAG}_ | awk '{print $5, $9}'
