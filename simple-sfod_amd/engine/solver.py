@@ -28,6 +28,7 @@ class FlatModelState:
 
     def __init__(self, model, frozen_prefixes=(), with_grad=True):
         norm_ids = set()
+        self._gen_holders = [m for m in model.modules() if hasattr(m, "_frozen_gen")]
         for m in model.modules():
             if _is_norm_module(m):
                 for p in m.parameters(recurse=False):
@@ -41,6 +42,7 @@ class FlatModelState:
         decay = [(n, p) for n, p in named if id(p) not in norm_ids and not is_frozen(n, p)]
         norm = [(n, p) for n, p in named if id(p) in norm_ids and not is_frozen(n, p)]
         frozen = [(n, p) for n, p in named if is_frozen(n, p)]
+        self.model = model
         self.order = decay + norm + frozen
         self.named_order = [n for n, _ in named]       # model.named_parameters() order (torch / Detectron2 indexing)
         dev = named[0][1].device
@@ -89,6 +91,13 @@ class FlatModelState:
                 view = self.ibuf[i:i + 1].view(b.shape)
                 view.copy_(b)
                 m._buffers[bname] = view
+
+    def values_rewritten(self):
+        """Call after writing parameters / buffers through the flat buffers (EMA kernels, teacher <- student copies):
+        modules that cache derived tensors of never-trained parameters (ResNet: FrozenBN folded into packed weights)
+        drop them -- in-place writes through the flat buffer do not bump the views' version counters."""
+        for m in self._gen_holders:
+            m._frozen_gen += 1
 
     def attach_grads(self):
         for n, p in self.order:
@@ -153,6 +162,7 @@ class FusedSGD:
             native.ema_(self.teacher.fbuf, f.fbuf, self.ema_keep)
             # int64 buffers: float32 arithmetic, truncated on the copy back (SURVEY A.17 iv)
             native.ema_i64_(self.teacher.ibuf, f.ibuf, self.ema_keep)
+            self.teacher.values_rewritten()
         self._steps += 1
 
     def state_dict(self):

@@ -196,6 +196,7 @@ class BaseTrainer:
             for t in (f.param, f.fbuf, f.ibuf):
                 if t.numel():
                     dist.broadcast(t, 0)
+            f.values_rewritten()
 
     def _attach_reducer(self):
         """N > 1: overlap the heads' gradient all-reduce with the backbone backward.  The backbone's autograd
@@ -209,7 +210,8 @@ class BaseTrainer:
             # where the mid phase starts: with enough pixels per rank the backward of vgg0 alone (its two most expensive
             # layers) hides the 57 MB message, so vgg1's weights ride in it too and the final phase shrinks to
             # vgg0 + the norm parameters; the yaml's one 600x1200 frame per rank keeps the earlier launch point
-            b_local = max(1, int(getattr(cfg.SOLVER, "IMS_PER_BATCH_TARGET", cfg.SOLVER.IMS_PER_BATCH)) // get_world_size())
+            total = cfg.SOLVER.IMS_PER_BATCH if type(self) is BaseTrainer else cfg.SOLVER.IMS_PER_BATCH_TARGET
+            b_local = max(1, int(total) // get_world_size())
             short = min(cfg.INPUT.MIN_SIZE_TRAIN) if len(cfg.INPUT.MIN_SIZE_TRAIN) else 600
             stage = 1 if b_local * short * short * 2 >= 2 * 600 * 1200 else 2
             mids = tuple("backbone.vgg{}.".format(i) for i in range(stage, 5))
@@ -490,6 +492,7 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
                 for t in (self.teacher_flat.param, self.teacher_flat.fbuf, self.teacher_flat.ibuf):
                     if t.numel():
                         dist.broadcast(t, 0)
+                self.teacher_flat.values_rewritten()
         else:
             self._broadcast_initial_state()
             self._copy_main_model()
@@ -533,6 +536,7 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         self.teacher_flat.param.copy_(s.param)
         self.teacher_flat.fbuf.copy_(s.fbuf)
         self.teacher_flat.ibuf.copy_(s.ibuf)
+        self.teacher_flat.values_rewritten()
 
     def _val_loss_targets(self):
         """source_free_adaptive_teacher.py:663-675: the student (``_student``), then the teacher."""

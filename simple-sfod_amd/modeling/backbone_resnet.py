@@ -173,6 +173,7 @@ class ResNet(nn.Module):
         self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
         self.act_dtype = native.out_dtype_of(self.compute_dtype)
         self.bn_momentum = 0.1
+        self._frozen_gen = 0                 # generation of the frozen stages' values (see _frozen_packed)
         self.bn_updates_per_forward = 1      # see backbone_vgg: momentum updates folded into one forward
         self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
         self.dual_join = os.environ.get("SFOD_NO_DUAL_JOIN", "0") != "1"           # A/B hook: join kernels also emit the operand pairs
@@ -213,8 +214,12 @@ class ResNet(nn.Module):
     def _frozen_packed(self, conv, cin_pad, dt):
         """(packed weights with the FrozenBN scale folded in, shift) of a frozen conv, cached: frozen tensors
         only change through load_state_dict / EMA copies, which bump their version counters."""
+        # _frozen_gen: bumped by whoever rewrites parameters through the flat buffers (the fused EMA step updates every
+        # key of the teacher, frozen ones included -- source_free_adaptive_teacher.py:583-603 -- without touching the
+        # views' version counters)
         key = (conv.weight._version, conv.norm.weight._version, conv.norm.bias._version,
-               conv.norm.running_mean._version, conv.norm.running_var._version, conv.weight.data_ptr(), cin_pad, dt)
+               conv.norm.running_mean._version, conv.norm.running_var._version, conv.weight.data_ptr(), cin_pad, dt,
+               self._frozen_gen)
         hit = getattr(conv, "_packed_cache", None)
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
