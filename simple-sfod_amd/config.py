@@ -365,11 +365,15 @@ def add_native_config(cfg):
     SFOD.EMA.ENABLED      quirk q1: the dispatched reference trainer has the EMA call commented
                           out (source_free_adaptive_teacher.py:581); its twins have it on.
     SFOD.EMA.KEEP_RATE    hard-coded 0.9996 in the reference (:584).
-    SFOD.COMPUTE_DTYPE    arithmetic of the convolutions / GEMMs.  "bf16x3" (default): fp32-equivalent products on the
-                          bf16 matrix pipe (operands as (hi, lo) bf16 pairs, hi*hi + hi*lo + lo*hi in fp32: ~4e-6
-                          relative per dot product, fp32 activations / statistics / losses elsewhere; gated by the
-                          same 1e-4 oracle tests as "fp32");  "fp32": v_mfma_f32_32x32x2_f32 (bit-exact fp32 FMA
-                          chains, 1/16 of the bf16 rate);  "bf16": one bf16 pass, bf16 activations (reduced precision,
+    SFOD.COMPUTE_DTYPE    arithmetic of the convolutions / GEMMs.  "bf16x3" (default): split-precision products on the
+                          bf16 matrix pipe -- operands as (hi, lo) bf16 pairs = about 16 significand bits each,
+                          hi*hi + hi*lo + lo*hi accumulated in fp32 (~4e-6 relative per dot product, ~100x fp32's
+                          2^-24 per product), fp32 activations / statistics / losses elsewhere.  NOT fp32 arithmetic:
+                          it is gated at 1e-4 (losses, decoded boxes) on the VGG16 yamls at 600x1200
+                          (tests/test_gpu_fullsize.py); on the 101-layer ResNet-C4 yaml it only reaches ~1e-3 and
+                          long trajectories can drift -- use "fp32" there.
+                          "fp32": v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains (1/16 of the bf16 rate): the exact
+                          parity mode of every config.  "bf16": one bf16 pass, bf16 activations (reduced precision,
                           NOT a parity mode: losses within a few % of the oracle).
     SFOD.ELIDE_DEAD_BRANCHES  skip the zero-weighted 2nd ROI pass / BPC / domain branch.
     SFOD.OVERLAP_TEACHER  run the teacher's pseudo-labelling pass on a second HIP stream beside the
