@@ -118,11 +118,13 @@ def test_three_steps_match_the_oracle_trajectory(sfod, native, model, dtype, eli
                 return 8e-2
             return 6e-2 if x3 else 4e-2
         if name.startswith("roi_heads"):
+            if resnet:      # the heads read res4 features that already carry the network's 1e-4 forward noise (section 1a
+                return 8e-3  # of DESIGN.md): more ReLU flips in fc1 / fc2 than behind VGG16 (seen: 2.2e-3)
             return 4e-3 if x3 else 2e-3
         if ".rpn_head.conv." in name:   # few hidden units under sparse gradients: ONE flipped ReLU shows as 1e-3 .. 2e-2
             return 3e-2                 # (fp32 mode too: its weight gradients use float atomics, so WHICH unit flips varies
                                         # from run to run -- 1 run in 8 reached 1.6e-2 at step 2)
-        return 2e-3 if x3 else 2e-4
+        return 2e-3 if (x3 or resnet) else 2e-4
 
     names = [n for n, p_ in tr.model.named_parameters() if p_.requires_grad]     # frozen stem / res2: no gradient, no momentum
     frozen = [n for n, p_ in tr.model.named_parameters() if not p_.requires_grad]
