@@ -289,11 +289,12 @@ def test_r101_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
                             tracking_only=(dtype != "fp32"))
 
 
-def _check_discrete_steps_on_captured_tensors(model, inputs, B, H, W, with_gt, native):
+def _check_discrete_steps_on_captured_tensors(model, inputs, B, H, W, with_gt, native, ocfg=None):
     """One training-mode pass with the RPN's tensors captured; the oracle redoes every discrete step on them:
     proposals (decode -> top-k -> NMS keep, scores ==) and, with ground truth, the sampled anchor labels (==)."""
-    ocfg = om.Cfg()
-    Hf, Wf, A = H // 32, W // 32, 15
+    ocfg = ocfg or om.Cfg()
+    A = ocfg.num_anchors
+    Hf, Wf = (-(-H // ocfg.stride), -(-W // ocfg.stride)) if ocfg.backbone == "resnet" else (H // ocfg.stride, W // ocfg.stride)
     rpn = model.proposal_generator
     cap = {}
     orig_props, orig_lf = rpn._proposals, rpn._loss_forward
@@ -384,3 +385,28 @@ def test_configs_at_their_real_sizes(sfod, native, which):
     if not teacher_only:
         assert {"loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"} <= set(losses)
         assert 0.1 < losses["loss_rpn_cls"].item() < 2.0 and 1.0 < losses["loss_cls"].item() < 4.0     # ln 2, ln 9 at init
+
+
+@pytest.mark.parametrize("which", ["r101_b8_600x1200", "r101_teacher_b2_1024x2048"])
+def test_r101_config_at_its_real_sizes(sfod, native, which):
+    """BASELINE config #5 at the batch bench.py --model r101 runs (B = 8 frames of 600x1200: 34 200 anchors per image)
+    and on 1024x2048 tensors (64 x 128 x 12 = 98 304 anchors per image: six 16 384-key chunks + merge passes of the
+    segmented sort), in its parity mode fp32: finite losses and gradients, frozen stages without gradients, and the
+    discrete steps bit-exact against the oracle on the captured tensors."""
+    S = sfod.structures
+    B = 8 if "b8" in which else 2
+    H, W = (600, 1200) if "600x1200" in which else (1024, 2048)
+    cfg = sfod.config.setup_cfg(R101_YAML, ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", "fp32"])
+    torch.manual_seed(3)
+    model = sfod.modeling.build_model(cfg).train()
+    inputs = _frames(B, H, W, seed=33)
+    teacher_only = "teacher" in which
+    if not teacher_only:
+        inputs = _with_gt(inputs, S, 12, seed=4)
+    losses = _check_discrete_steps_on_captured_tensors(model, inputs, B, H, W, not teacher_only, native,
+                                                       ocfg=om.Cfg.r101_c4())
+    if not teacher_only:
+        assert {"loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"} <= set(losses)
+        for n, p in model.named_parameters():
+            if n.startswith(("backbone.stem", "backbone.res2")):
+                assert p.grad is None and not p.requires_grad, n
