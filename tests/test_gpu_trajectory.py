@@ -231,3 +231,55 @@ def test_three_steps_match_the_oracle_trajectory(sfod, native, model, dtype, eli
     print(f"\n[trajectory {model} {dtype} elide={elide}] pseudo labels per step {n_pseudo}; worst update error per group after {STEPS} steps: " + ", ".join(
         f"{grp} {max(v for (i, n), v in worst.items() if n.startswith(grp)):.2e}"
         for grp in ("backbone", "proposal_generator", "roi_heads")))
+
+
+def test_bf16x3_stays_with_fp32_over_a_longer_horizon(sfod, native):
+    """Free-running comparison (no re-synchronisation): 16 teacher+student steps of the hot yaml from the same seed in
+    ``fp32``, in ``fp32`` from weights perturbed by 1e-7 relative (= "another correct fp32 implementation": the step is
+    chaotic at the bit level -- a detection crossing the 0.8 threshold, an NMS or ReLU flip -- so even that run leaves
+    the first one), and in ``bf16x3``.  What is pinned is the SCALE of the split-precision mode's drift: after 16 steps
+    its student is not further from the fp32 student than a few times the distance between the two fp32 runs, and both
+    stay a small fraction of the distance the weights travelled."""
+    B, H, W, STEPS = 2, 256, 384, 16
+    runs = {}
+    for tag, dtype, eps in (("fp32", "fp32", 0.0), ("fp32_perturbed", "fp32", 1e-7), ("bf16x3", "bf16x3", 0.0)):
+        cfg = sfod.config.setup_cfg(HOT_YAML, [
+            "OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", dtype, "SOLVER.IMS_PER_BATCH_TARGET", str(B),
+            "SFOD.SYNTHETIC.HEIGHT", str(H), "SFOD.SYNTHETIC.WIDTH", str(W), "SFOD.SYNTHETIC.NUM_IMAGES", "8",
+            "INPUT.MIN_SIZE_TRAIN", f"({H},)", "SOLVER.WARMUP_ITERS", "0", "SOLVER.BASE_LR", "2.5e-4",
+            "SOLVER.CHECKPOINT_PERIOD", "0", "TEST.EVAL_PERIOD", "0", "TEST.VAL_LOSS", "False", "SFOD.EVAL_HOOK", "False"])
+        torch.manual_seed(11)
+        tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+        with torch.no_grad():
+            tr.model.roi_heads.box_predictor.cls_score.weight.mul_(30.0)
+            if eps:
+                gen = torch.Generator(device=DEV).manual_seed(3)
+                f = tr.optimizer.flat.param
+                f.mul_(1.0 + eps * torch.randn(f.shape, device=DEV, generator=gen))
+            tr._copy_main_model()
+        g = torch.Generator().manual_seed(1)      # identical sampling keys in all runs
+        tr.model.proposal_generator._forced_keys = torch.randint(0, 2 ** 31 - 1, (B, (H // 32) * (W // 32) * 15),
+                                                                 generator=g).to(torch.int32).to(DEV)
+        tr.model.roi_heads._forced_keys = torch.randint(0, 2 ** 31 - 1, (B, 2100), generator=g).to(torch.int32).to(DEV)
+        p0 = tr.optimizer.flat.param.clone()
+        hist = []
+        for it in range(STEPS):
+            tr.iter = it
+            tr.run_step()
+            tr.scheduler.step()
+            rec = tr.storage.flush()
+            hist.append([rec[k] for k in ("loss_rpn_cls_pseudo", "loss_rpn_loc_pseudo", "loss_cls_pseudo", "loss_box_reg_pseudo")])
+        runs[tag] = (np.array(hist), tr.optimizer.flat.param.clone(), p0)
+        del tr
+        torch.cuda.empty_cache()
+    h32, p32, p0 = runs["fp32"]
+    assert all(np.isfinite(runs[k][0]).all() for k in runs)
+    moved = (p32 - p0).norm().item()
+    d_fp32 = (runs["fp32_perturbed"][1] - p32).norm().item()
+    d_x3 = (runs["bf16x3"][1] - p32).norm().item()
+    med = {k: np.median(np.abs(runs[k][0] - h32) / np.maximum(np.abs(h32), 1e-3), axis=0) for k in ("fp32_perturbed", "bf16x3")}
+    print(f"\n[{STEPS} free-running steps] student distance from the fp32 run / distance travelled: another fp32 run "
+          f"{d_fp32 / moved:.3f}, bf16x3 {d_x3 / moved:.3f}; median relative loss difference per key: fp32' {med['fp32_perturbed']}, "
+          f"bf16x3 {med['bf16x3']}")
+    assert d_x3 < 0.5 * moved
+    assert d_x3 < 4.0 * d_fp32 + 0.02 * moved
