@@ -121,7 +121,9 @@ def test_three_steps_match_the_oracle_trajectory(sfod, native, model, dtype, eli
             if resnet:      # the heads read res4 features that already carry the network's 1e-4 forward noise (section 1a
                 return 8e-3  # of DESIGN.md): more ReLU flips in fc1 / fc2 than behind VGG16 (seen: 2.2e-3)
             return 4e-3 if x3 else 2e-3
-        if ".rpn_head.conv." in name:   # few hidden units under sparse gradients: ONE flipped ReLU shows as 1e-3 .. 2e-2
+        if ".rpn_head." in name:        # few hidden units under sparse gradients: ONE flipped ReLU shows as 1e-3 .. 2e-2
+                                        # in the 3x3 conv's gradient and, through the hidden map, in the 1x1 heads' (seen:
+                                        # anchor_deltas.weight 1.4e-2 at step 2 in 1 of 3 runs, the others 1e-4);
             return 3e-2                 # (fp32 mode too: its weight gradients use float atomics, so WHICH unit flips varies
                                         # from run to run -- 1 run in 8 reached 1.6e-2 at step 2)
         return 2e-3 if (x3 or resnet) else 2e-4
