@@ -34,6 +34,11 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// Knock-out switches for tools/experiments/wgrad_knockout.sh (time floors of the pipelined bf16x3 loop; results are
+// WRONG by construction, the product build defines none of them):
+//   W3_KO_MFMA   no MFMAs (the fragment registers are still consumed)      W3_KO_XREADS  x fragment rows read once per
+//   W3_KO_DMA    no LDS-DMA inside the tile loop (prologue data is reused)                tile instead of per chunk / row
+//   W3_KO_BARRIER no s_barrier inside the tile loop
 namespace {
 
 template <int J> using IC = std::integral_constant<int, J>;
@@ -417,6 +422,12 @@ k_wgrad3x3_patch(W3Args a) {
   }
   s16x4 qq[2][12];   // PIPE: fragment rows, alternating; the NEXT chunk's first row is requested a stage early
   auto issue_row_p = [&](s16x4* d, unsigned r0, unsigned r1) {
+#ifdef W3_KO_XREADS
+    asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]));
+    asm volatile("" : "+v"(d[6]), "+v"(d[7]), "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]));
+    (void)r0; (void)r1;
+    return;
+#endif
     d[0] = tr_read<0>(r0);   d[1] = tr_read<0>(r1);
     d[2] = tr_read<64>(r0);  d[3] = tr_read<64>(r1);
     d[4] = tr_read<128>(r0); d[5] = tr_read<128>(r1);
@@ -444,9 +455,14 @@ k_wgrad3x3_patch(W3Args a) {
       for (int kx = 0; kx < 3; ++kx) {
         const bf16x8 bh = cat8(r[2 * kx], r[2 * kx + 1]), bl = cat8(r[6 + 2 * kx], r[6 + 2 * kx + 1]);
         f32x16 v = acc[ky * 3 + kx];
+#ifdef W3_KO_MFMA
+        asm volatile("" ::"v"(ah), "v"(al), "v"(bh), "v"(bl));      // operands stay live, no matrix work
+        v[kx] += 1.0f;
+#else
         v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, v, 0, 0, 0);
         v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, v, 0, 0, 0);
         v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, v, 0, 0, 0);
+#endif
         acc[ky * 3 + kx] = v;
       }
       __builtin_amdgcn_s_setprio(0);
@@ -457,13 +473,18 @@ k_wgrad3x3_patch(W3Args a) {
     // filter row 0.  The stage's DMA instructions go BEHIND an MFMA group, where one fragment row (not two) is alive:
     // their address arithmetic (border tiles: table lookups + bounds tests) otherwise pushes the wave over its 256
     // registers; the matrix pipe works on the group just issued while they go out.
+#ifdef W3_KO_XREADS
+#define W3_WAIT12() wait_lgkm<0>()
+#else
+#define W3_WAIT12() wait_lgkm<12>()
+#endif
     issue_row_p(qq[P ^ 1], rx0 + PW * 64, rx1 + PW * 64);
-    wait_lgkm<12>();
+    W3_WAIT12();
     mfma_row(qq[P], 0);
     dma0();
     // filter row 1
     issue_row_p(qq[P], rx0 + 2 * PW * 64, rx1 + 2 * PW * 64);
-    wait_lgkm<12>();
+    W3_WAIT12();
     mfma_row(qq[P ^ 1], 1);
     dma1();
     // filter row 2 (+ the next chunk's first row)
@@ -473,7 +494,7 @@ k_wgrad3x3_patch(W3Args a) {
       const unsigned nx0 = (unsigned)(xb_off + (int)(pn & 0xffffu) * 64 + b_lane);
       const unsigned nx1 = (unsigned)(xb_off + (int)(pn >> 16) * 64 + b_lane);
       issue_row_p(qq[P ^ 1], nx0, nx1);
-      wait_lgkm<12>();
+      W3_WAIT12();
     } else {
       wait_lgkm<0>();
     }
@@ -496,10 +517,19 @@ k_wgrad3x3_patch(W3Args a) {
         constexpr int c = decltype(cc)::value;
         constexpr int N = (c == 0) ? ND : (c == 3 ? 1 + ND : 2 + ND);
         constexpr int NL = (c == 3) ? 0 : ND;
+#ifdef W3_KO_DMA
+        wait_vm<0>();
+#else
         if (last) wait_vm<NL>(); else wait_vm<N>();
+#endif
+#ifndef W3_KO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
         asm volatile("" ::: "memory");
         auto dma_patch = [&]() {
+#ifdef W3_KO_DMA
+          return;
+#endif
           if (!last) {
             if constexpr (c == 0) issue_patch2(0, 1, nxt, xbuf ^ 1);
             else if constexpr (c == 1) issue_patch2(2, 3, nxt, xbuf ^ 1);
@@ -508,6 +538,9 @@ k_wgrad3x3_patch(W3Args a) {
           }
         };
         auto dma_dy = [&]() {
+#ifdef W3_KO_DMA
+          return;
+#endif
           // dy chunk two stages ahead
           constexpr int c2 = (c + 2) & 3;
           const int t2 = (c >= 2) ? t + 1 : t;
