@@ -97,8 +97,10 @@ int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, 
 /* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
  * 4 = 512 x 64 (applied where the channel counts allow it).  For A/B runs and parity tests. */
 int sfod_set_conv3x3_variant(int variant);
-/* A/B knob: 1 (default; environment SFOD_W3_PIPE=0 turns it off) the pipelined chunk loop of the bf16x3 halo-patch
- * weight gradient (k_wgrad3x3_patch<4, true, true>), 0 the round-2 loop.  Same values either way. */
+/* A/B knob of the bf16x3 halo-patch weight gradient (environment SFOD_W3_PIPE): 2 (default) the 64 co x 64 ci block on
+ * 128-pixel tiles (k_wgrad3x3_w64; layers with Cin >= 64, else as 1), 1 the pipelined 64 x 32-block loop
+ * (k_wgrad3x3_patch<4, true, true>), 0 the round-2 loop.  0 and 1 give bit-identical results, 2 sums the same products over
+ * other pixel tiles (equal to fp32 summation order). */
 int sfod_set_wgrad3x3_pipe(int on);
 /* which kernel sfod_conv_fwd runs for this shape: 1 generic implicit GEMM, 2 halo-patch, 3 first-layer
  * kernel (Cin = one padded 8-channel chunk, Cout = 64), 4 generic implicit GEMM on its 256 x 256 tile (bf16x3 linear

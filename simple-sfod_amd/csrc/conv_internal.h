@@ -40,6 +40,7 @@ struct W3Plan {
   int co_tiles, ci_tiles;
   int tiles_per_split, nsplit, nslab;
   int64_t ws_bytes;      // fp32 partial slabs [nslab][Cout][9][Cin]
+  int w64;               // bf16x3 only: the 64 co x 64 ci block / 128-pixel tile kernel (k_wgrad3x3_w64)
 };
 W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split = 0);
 // out_mode 0: dw packed [Cout][9][Cin], accumulated into; 1 / 2: dw OIHW, overwritten / accumulated into

@@ -576,6 +576,298 @@ k_wgrad3x3_patch(W3Args a) {
     }
 }
 
+// =================================================================================================================
+// W64 (bf16x3 operands, round 3): a 64 co x 64 ci block per workgroup on 128-pixel tiles.
+//
+// The knock-out runs of the 64 x 32 kernel above (profiles/r3_wgrad_knockout.txt) say what bounds it: not the matrix
+// pipe, not the barriers -- the operand stream L2 -> LDS (5.7 GB per conv4_2 launch), because the split format's LDS
+// footprint leaves a workgroup only a 64 x 32 block of dw: 84 FLOP per DMA'd byte.  Same LDS budget, different cut:
+//   x patch[2] : 4 planes (ci fragment 0 / 1 x hi / lo) x 192 rows x 64 B = 48 KiB each   (128-pixel tile + halo)
+//   dy ring[3] : 4 planes (co fragment 0 / 1 x hi / lo) x  64 rows x 64 B = 16 KiB each
+//   waves 8 = (co fragment) x (ci fragment) x (k-step pair): wave (wco, wci, kg) owns one 32 x 32 block x 9 taps and the
+//   k-steps 2 kg, 2 kg + 1 of every 64-pixel chunk; two k-step groups -> two slabs per pixel split (was four).
+// Per 128 pixels a workgroup now DMAs 48 + 32 KiB for 9.4 MFLOP: 118 FLOP/B.  The chunk loop is the pipelined one
+// (look-ups hoisted, next k-step's first fragment row requested early, DMA behind the MFMA groups, LDS offset tables);
+// a stage = one chunk = two k-steps = 54 MFMAs per wave between barriers (was 27).  Same MFMA sequence per accumulator
+// element?  No: the pixel tiles differ (128 instead of 256 pixels, other tile shapes), so partial sums are grouped
+// differently -- results agree with the other loops to fp32 summation order, not bit for bit.
+// =================================================================================================================
+constexpr int X2_ROWS = 192;
+constexpr int X2_PLANE = X2_ROWS * 64;          // 12288
+constexpr int X2_BUF = 4 * X2_PLANE;            // 49152
+constexpr int D2_OFF = 2 * X2_BUF;              // 98304
+constexpr int D2_SLOT = 4 * 4096;               // 16384
+constexpr int T2_OFF = D2_OFF + 3 * D2_SLOT;    // 147456
+constexpr int T2P_OFF = T2_OFF;                 // u16 [128]  tile pixel -> patch row (tap 0,0)
+constexpr int T2T_OFF = T2_OFF + 256;           // u16 [128]  tile pixel -> ty<<8|tx, 0xffff outside the tile
+constexpr int T2R_OFF = T2_OFF + 512;           // u16 [192]  patch row -> py<<8|px, 0xffff unused
+constexpr int T2X_OFF = T2_OFF + 896;           // i32 [192]  patch row -> byte offset relative to the tile's first pixel
+constexpr int T2D_OFF = T2X_OFF + 768;          // i32 [128]  tile pixel -> byte offset of its dy row, relative likewise
+constexpr int LDS2_TOTAL = T2D_OFF + 512;       // 149632
+
+__global__ void __launch_bounds__(512)
+k_wgrad3x3_w64(W3Args a) {
+  constexpr int EB = 4;
+  constexpr unsigned REL_NONE = 0x40000000u;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wco = wave & 1, wci = (wave >> 1) & 1, kg = wave >> 2;
+  const int h = lane >> 5, g1 = (lane >> 4) & 1, t16 = lane & 15;
+  const int tq = t16 >> 2, tp = t16 & 3;
+
+  int bid = blockIdx.x;
+  {
+    const int nt = gridDim.x, q = nt / 8, r = nt % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + bid / 8;
+  }
+  const int pairs = a.co_tiles * a.ci_tiles;
+  const int split = bid / pairs;
+  const int pr = bid - split * pairs;
+  const int co0 = (pr / a.ci_tiles) * 64, ci0 = (pr % a.ci_tiles) * 64;
+  const int t_begin = split * a.tiles_per_split;
+  const int t_end = min(a.ntiles, t_begin + a.tiles_per_split);
+  const int PW = a.PW;
+  const int npix = a.TH * a.TW;
+
+  // ---- lookup tables -------------------------------------------------------------------------------------------
+  unsigned short* tabP = reinterpret_cast<unsigned short*>(smem + T2P_OFF);
+  unsigned short* tabT = reinterpret_cast<unsigned short*>(smem + T2T_OFF);
+  unsigned short* tabR = reinterpret_cast<unsigned short*>(smem + T2R_OFF);
+  unsigned* tabX = reinterpret_cast<unsigned*>(smem + T2X_OFF);
+  unsigned* tabD = reinterpret_cast<unsigned*>(smem + T2D_OFF);
+  if (threadIdx.x < 128) {
+    const int p = threadIdx.x;
+    if (p < npix) {
+      const int ty = p / a.TW, tx = p - ty * a.TW;
+      tabP[p] = (unsigned short)(ty * PW + tx);
+      tabT[p] = (unsigned short)((ty << 8) | tx);
+      tabD[p] = (unsigned)((ty * a.W + tx) * a.lddy * EB);
+    } else {
+      tabP[p] = 0;
+      tabT[p] = 0xffff;
+      tabD[p] = REL_NONE;
+    }
+  }
+  if (threadIdx.x < X2_ROWS) {
+    const int r = threadIdx.x;
+    const int py = r / PW, px = r - py * PW;
+    const bool ok = py < a.TH + 2;
+    tabR[r] = ok ? (unsigned short)((py << 8) | px) : (unsigned short)0xffff;
+    tabX[r] = ok ? (unsigned)(((py - 1) * a.W + (px - 1)) * a.Cin * EB) : REL_NONE;      // signed, see REL_NONE above
+  }
+  __syncthreads();
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.x, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.Cin * EB), 0x00020000);
+  const __amdgpu_buffer_rsrc_t dres = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)a.dy, (short)0, (int)min((int64_t)0x7fffffff, (int64_t)a.B * a.H * a.W * a.lddy * EB), 0x00020000);
+
+  // DMA pieces (1 KiB = 16 rows x 64 B of ONE plane).  x: 48 per patch, piece q = wave * 6 + k -> plane q / 12 = wave >> 1,
+  // row group q % 12 = (wave & 1) * 6 + k;  dy: 16 per chunk, piece q = wave * 2 + i -> plane wave >> 1, row group
+  // 2 * (wave & 1) + i.  Plane p = (32-channel fragment p >> 1, hi / lo p & 1): a lane takes the hi or the lo 16-byte
+  // chunk of the 8-channel group (lane & 3) of its pixel -- the de-interleaving DMA of the 64 x 32 kernel.
+  const int plane = wave >> 1;
+  int pr_col, dy_col;        // byte offset inside a pixel, -1: the lane never loads (channel tails)
+  {
+    const int cx = ci0 + (plane >> 1) * 32 + (lane & 3) * 8;
+    pr_col = (cx < a.Cin) ? (cx * 4 + (plane & 1) * 16) : -1;
+    const int cd = co0 + (plane >> 1) * 32 + (lane & 3) * 8;
+    dy_col = (cd + 8 <= a.lddy && cd < a.Cout) ? (cd * 4 + (plane & 1) * 16) : -1;
+  }
+  const unsigned colx = pr_col >= 0 ? (unsigned)pr_col : REL_NONE, cold = dy_col >= 0 ? (unsigned)dy_col : REL_NONE;
+  auto rel_off = [&](unsigned base, unsigned t, unsigned col) {
+    return (t == REL_NONE || col == REL_NONE) ? OOB_OFF : base + t + col;
+  };
+
+  struct Org { int b, y0, x0; unsigned base_x, base_dy; bool in_x, in_dy; };
+  auto finish = [&](Org o) {
+    const int pix = (o.b * a.H + o.y0) * a.W + o.x0;
+    o.base_dy = (unsigned)(pix * a.lddy * EB);
+    o.base_x = (unsigned)(pix * a.Cin * EB);
+    o.in_dy = (o.y0 + a.TH <= a.H) && (o.x0 + a.TW <= a.W);
+    o.in_x = o.in_dy && o.y0 >= 1 && o.x0 >= 1 && (o.y0 + a.TH + 1 <= a.H) && (o.x0 + a.TW + 1 <= a.W);
+    return o;
+  };
+  auto tile_origin = [&](int t) {
+    const int per = a.tiles_y * a.tiles_x;
+    Org o;
+    o.b = t / per;
+    const int r = t - o.b * per;
+    const int tyi = r / a.tiles_x;
+    o.y0 = tyi * a.TH;
+    o.x0 = (r - tyi * a.tiles_x) * a.TW;
+    return finish(o);
+  };
+  auto advance = [&](Org o) {
+    o.x0 += a.TW;
+    if (o.x0 >= a.tiles_x * a.TW) {
+      o.x0 = 0;
+      o.y0 += a.TH;
+      if (o.y0 >= a.tiles_y * a.TH) { o.y0 = 0; ++o.b; }
+    }
+    return finish(o);
+  };
+  auto patch_off = [&](int k, Org o) -> unsigned {
+    const int row = ((wave & 1) * 6 + k) * 16 + (lane >> 2);
+    if (o.in_x) return rel_off(o.base_x, tabX[row], colx);
+    const int pk = tabR[row];
+    const int py = pk >> 8, px = pk & 255;
+    const int iy = o.y0 - 1 + py, ix = o.x0 - 1 + px;
+    const bool ok = pk != 0xffff && pr_col >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    return ok ? (unsigned)(((o.b * a.H + iy) * a.W + ix) * a.Cin * EB + pr_col) : OOB_OFF;
+  };
+  auto issue_patch = [&](int k, Org o, int buf) {
+    bufload16(xres, patch_off(k, o), 0u, smem + buf * X2_BUF + (wave * 6 + k) * 1024);
+  };
+  // dy chunk c (0 / 1) of tile o into ring slot
+  auto issue_dy = [&](Org o, int c, int slot) {
+    unsigned offs[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = c * 64 + (2 * (wave & 1) + i) * 16 + (lane >> 2);
+      if (o.in_dy) {
+        offs[i] = rel_off(o.base_dy, tabD[row], cold);
+      } else {
+        const int tt = tabT[row];
+        const int ty = tt >> 8, tx = tt & 255;
+        const bool ok = tt != 0xffff && dy_col >= 0 && o.y0 + ty < a.H && o.x0 + tx < a.W;
+        offs[i] = ok ? (unsigned)(((o.b * a.H + o.y0 + ty) * a.W + o.x0 + tx) * a.lddy * EB + dy_col) : OOB_OFF;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) bufload16(dres, offs[i], 0u, smem + D2_OFF + slot * D2_SLOT + (wave * 2 + i) * 1024);
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  const int cbb = (g1 * 16 + 4 * tp) * 2;                          // byte column inside a 64-byte plane row
+  const int a_lane = (2 * wco) * 4096 + (8 * h + tq) * 64 + cbb;   // dy: hi plane of fragment wco (lo = + 4096), + 1024 per k-step
+  const int b_lane = (2 * wci) * X2_PLANE + cbb;                   // x : hi plane of fragment wci (lo = + X2_PLANE), + row * 64
+
+  // patch rows of this lane's two transposed reads (tile pixels p0, p0 + 4) for (chunk c, k-step 2 kg + sl), two per register
+  unsigned prow[4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int sl = 0; sl < 2; ++sl) {
+      const int p0 = c * 64 + (2 * kg + sl) * 16 + 8 * h + tq;
+      prow[c * 2 + sl] = (unsigned)tabP[p0] | ((unsigned)tabP[p0 + 4] << 16);
+    }
+
+  s16x4 qq[2][12];
+  auto issue_row = [&](s16x4* d, unsigned r0, unsigned r1) {
+    d[0] = tr_read<0>(r0);   d[1] = tr_read<0>(r1);
+    d[2] = tr_read<64>(r0);  d[3] = tr_read<64>(r1);
+    d[4] = tr_read<128>(r0); d[5] = tr_read<128>(r1);
+    d[6] = tr_read<X2_PLANE>(r0);       d[7] = tr_read<X2_PLANE>(r1);
+    d[8] = tr_read<X2_PLANE + 64>(r0);  d[9] = tr_read<X2_PLANE + 64>(r1);
+    d[10] = tr_read<X2_PLANE + 128>(r0); d[11] = tr_read<X2_PLANE + 128>(r1);
+  };
+  // One k-step (16 pixels x 9 taps) of chunk c.  Fragment rows alternate between qq[X] and qq[X ^ 1], X = sl: a k-step
+  // reads its filter rows 1 and 2 and the NEXT k-step's row 0 while the previous row's MFMAs run.  first: nothing was
+  // requested for this k-step yet (first k-step of a tile); more: request the next k-step's row 0 (not after the last
+  // k-step of a tile: the next patch may not be complete).  hook0 / hook1: DMA issue behind the first two MFMA groups.
+  auto kstep = [&](auto cc, auto slc, int xb_off, int dyb_off, auto&& hook0, auto&& hook1) {
+    constexpr int c = decltype(cc)::value, sl = decltype(slc)::value;
+    constexpr int X = sl;
+    constexpr bool first = (c == 0 && sl == 0), more = !(c == 1 && sl == 1);
+    unsigned pw = prow[c * 2 + sl];
+    asm volatile("" : "+v"(pw));       // keeps the fragment addresses of all four k-steps from being hoisted (VGPRs)
+    const unsigned rx0 = (unsigned)(xb_off + (int)(pw & 0xffffu) * 64 + b_lane);
+    const unsigned rx1 = (unsigned)(xb_off + (int)(pw >> 16) * 64 + b_lane);
+    const unsigned ra = (unsigned)(dyb_off + a_lane + (2 * kg + sl) * 1024);
+    const s16x4 a0h = tr_read<0>(ra), a1h = tr_read<256>(ra), a0l = tr_read<4096>(ra), a1l = tr_read<4096 + 256>(ra);
+    if constexpr (first) issue_row(qq[X], rx0, rx1);
+    auto mfma_row = [&](const s16x4* r, int ky) {
+      const bf16x8 ah = cat8(a0h, a1h), al = cat8(a0l, a1l);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const bf16x8 bh = cat8(r[2 * kx], r[2 * kx + 1]), bl = cat8(r[6 + 2 * kx], r[6 + 2 * kx + 1]);
+        f32x16 v = acc[ky * 3 + kx];
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, v, 0, 0, 0);
+        v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, v, 0, 0, 0);
+        acc[ky * 3 + kx] = v;
+      }
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_sched_barrier(0);     // see the 64 x 32 kernel: a sunk MFMA group keeps a third fragment row alive
+    };
+    issue_row(qq[X ^ 1], rx0 + PW * 64, rx1 + PW * 64);
+    wait_lgkm<12>();
+    mfma_row(qq[X], 0);
+    hook0();
+    issue_row(qq[X], rx0 + 2 * PW * 64, rx1 + 2 * PW * 64);
+    wait_lgkm<12>();
+    mfma_row(qq[X ^ 1], 1);
+    hook1();
+    if constexpr (more) {
+      constexpr int nidx = (sl == 0) ? c * 2 + 1 : (c + 1) * 2;     // next k-step: (c, 1) or (c + 1, 0), same patch
+      unsigned pn = prow[nidx & 3];
+      asm volatile("" : "+v"(pn));
+      const unsigned nx0 = (unsigned)(xb_off + (int)(pn & 0xffffu) * 64 + b_lane);
+      const unsigned nx1 = (unsigned)(xb_off + (int)(pn >> 16) * 64 + b_lane);
+      issue_row(qq[X ^ 1], nx0, nx1);
+      wait_lgkm<12>();
+    } else {
+      wait_lgkm<0>();
+    }
+    mfma_row(qq[X], 2);
+  };
+
+  if (t_begin < t_end) {
+    // ---- prologue: patch of the first tile, both dy chunks ---------------------------------------------------
+    Org cur = tile_origin(t_begin);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) issue_patch(k, cur, 0);
+    issue_dy(cur, 0, 0);
+    issue_dy(cur, 1, 1);
+    int gc = 0;  // global chunk counter (ring slot = gc % 3)
+    for (int t = t_begin; t < t_end; ++t, cur = advance(cur)) {
+      const Org nxt = advance(cur);
+      const bool last = (t == t_end - 1);
+      const int xbuf = (t - t_begin) & 1;
+      auto stage = [&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        // Per wave and stage the DMA order is patch x 3, dy x 2 (nothing in the last tile).  Stage 0 needs the patch and
+        // dy chunk 0: everything but the 2 dy pieces of chunk 1 issued last; stage 1 needs dy chunk 1: everything but
+        // stage 0's five (none in the last tile).
+        if constexpr (c == 0) wait_vm<2>();
+        else { if (last) wait_vm<0>(); else wait_vm<5>(); }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int slot = gc + 2;
+        slot -= (slot >= 3) ? 3 : 0;
+        const int xo = xbuf * X2_BUF, dyo = D2_OFF + gc * D2_SLOT;
+        kstep(cc, IC<0>{}, xo, dyo,
+              [&]() { if (!last) issue_patch(3 * c + 0, nxt, xbuf ^ 1); },
+              [&]() { if (!last) issue_patch(3 * c + 1, nxt, xbuf ^ 1); });
+        kstep(cc, IC<1>{}, xo, dyo,
+              [&]() { if (!last) issue_patch(3 * c + 2, nxt, xbuf ^ 1); },
+              [&]() { if (!last) issue_dy(nxt, c, slot); });
+        gc = (gc == 2) ? 0 : gc + 1;
+      };
+      stage(IC<0>{}); stage(IC<1>{});
+    }
+  }
+
+  // ---- write the partial block into this split's slab (two k-step groups -> two slabs per split) ---------------
+  float* out = a.slab + (int64_t)(split * 2 + kg) * a.Cout * 9 * a.Cin;
+  const int ci = ci0 + wci * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < a.Cout && ci < a.Cin) out[((int64_t)co * 9 + t) * a.Cin + ci] = acc[t][r];
+    }
+}
+
 // dw[i] (+)= sum_s slab[s][i], fixed order.  MODE 0: dw is the packed [Cout][9][Cin] gradient (accumulated into);
 // MODE 1 / 2: dw is the state-dict layout OIHW [Cout][Cin][3][3], overwritten (1) or accumulated into (2) -- the
 // unpack pass and the zero fill of a packed temporary are folded into this reduction.
@@ -628,11 +920,68 @@ k_wgrad_reduce(const float* __restrict__ slab, float* __restrict__ dw, int64_t n
 
 }  // namespace
 
+// A/B knob of the bf16x3 weight gradient (environment SFOD_W3_PIPE): 2 (default) the 64 x 64-block kernel on 128-pixel
+// tiles where Cin >= 64 (else 1), 1 the pipelined 64 x 32-block loop, 0 the round-2 loop.  1 and 0 give bit-identical
+// results; 2 sums the same products in a different grouping (other pixel tiles).
+static std::atomic<int> g_w3_pipe{-1};   // -1: not initialised (SFOD_W3_PIPE or 2)
+extern "C" int sfod_set_wgrad3x3_pipe(int on) {
+  g_w3_pipe.store((on < 0 || on > 2) ? 2 : on, std::memory_order_relaxed);
+  return 0;
+}
+static int w3_mode() {
+  int m = g_w3_pipe.load(std::memory_order_relaxed);
+  if (m < 0) {
+    const char* ev = getenv("SFOD_W3_PIPE");
+    m = ev ? atoi(ev) : 2;
+    if (m < 0 || m > 2) m = 2;
+    int expect = -1;
+    g_w3_pipe.compare_exchange_strong(expect, m, std::memory_order_relaxed);
+    m = g_w3_pipe.load(std::memory_order_relaxed);
+  }
+  return m;
+}
+
 // split != 0: SFOD_BF16X3 operands; Cin / Cout / lddy are LOGICAL channel counts in either case
 W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split) {
   W3Plan p;
   p.ok = 0;
+  p.w64 = 0;
   if (B < 1 || H < 1 || W < 1) return p;
+  if (split && w3_mode() == 2 && Cin >= 64 && Cin % 8 == 0 && Cout % 8 == 0 && lddy % 8 == 0 &&
+      (int64_t)B * H * W * Cin < ((int64_t)1 << 29) && (int64_t)B * H * W * lddy < ((int64_t)1 << 29)) {
+    // 128-pixel tiles, patch (TH + 2) x (TW + 2) <= 192 rows
+    double best = -1.0;
+    for (int tw = 4; tw <= 64 && tw <= W + 3; ++tw) {
+      int th = 128 / tw;
+      while (th > 1 && (th + 2) * (tw + 2) > X2_ROWS) --th;
+      if (th > H) th = H;
+      if (th < 1 || (th + 2) * (tw + 2) > X2_ROWS) continue;
+      const int ty = (H + th - 1) / th, tx = (W + tw - 1) / tw;
+      th = (H + ty - 1) / ty;
+      const double eff = (double)H * W / ((double)ty * tx * 128.0);
+      const double score = eff + 1e-6 * tw;
+      if (score > best) { best = score; p.TH = th; p.TW = tw; p.tiles_y = ty; p.tiles_x = tx; }
+    }
+    if (best >= 0.0) {
+      p.w64 = 1;
+      p.CO = 4;
+      p.co_tiles = (Cout + 63) / 64;
+      p.ci_tiles = (Cin + 63) / 64;
+      const int pairs = p.co_tiles * p.ci_tiles;
+      const int ntiles = B * p.tiles_y * p.tiles_x;
+      int ns = 256 / pairs;
+      if (ns < 1) ns = 1;
+      const int64_t slab_bytes = (int64_t)Cout * 9 * Cin * 4 * 2;       // two k-step groups
+      while (ns > 1 && ns * slab_bytes > ((int64_t)128 << 20)) --ns;
+      if (ns > ntiles) ns = ntiles;
+      p.tiles_per_split = (ntiles + ns - 1) / ns;
+      p.nsplit = (ntiles + p.tiles_per_split - 1) / p.tiles_per_split;
+      p.nslab = p.nsplit * 2;
+      p.ws_bytes = (int64_t)p.nslab * Cout * 9 * Cin * 4;
+      p.ok = 1;
+      return p;
+    }
+  }
   if (split) {
     if (Cin % 8 != 0 || Cout % 8 != 0 || lddy % 8 != 0) return p;
     if ((int64_t)B * H * W * Cin >= ((int64_t)1 << 29) || (int64_t)B * H * W * lddy >= ((int64_t)1 << 29)) return p;   // 32-bit byte offsets
@@ -674,13 +1023,6 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split)
   return p;
 }
 
-// A/B knob: 1 (default) the pipelined bf16x3 chunk loop, 0 the round-2 loop.  Same values either way.
-static std::atomic<int> g_w3_pipe{-1};   // -1: not initialised (SFOD_W3_PIPE or 1)
-extern "C" int sfod_set_wgrad3x3_pipe(int on) {
-  g_w3_pipe.store(on ? 1 : 0, std::memory_order_relaxed);
-  return 0;
-}
-
 // split != 0 (SFOD_BF16X3): x / dy hold (hi, lo) pairs; Cin / Cout / lddy are LOGICAL channel counts in either case
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split) {
@@ -699,19 +1041,13 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
       hipError_t e = hipFuncSetAttribute(ks[i], hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
       if (e != hipSuccess) return e;
     }
-    return hipSuccess;
+    return hipFuncSetAttribute((const void*)k_wgrad3x3_w64, hipFuncAttributeMaxDynamicSharedMemorySize, LDS2_TOTAL);
   }();
   if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute(w3): %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
   dim3 grid(p.co_tiles * p.ci_tiles * p.nsplit), blk(512);
-  int pipe = g_w3_pipe.load(std::memory_order_relaxed);
-  if (pipe < 0) {
-    const char* ev = getenv("SFOD_W3_PIPE");
-    pipe = (ev && atoi(ev) == 0) ? 0 : 1;
-    int expect = -1;
-    g_w3_pipe.compare_exchange_strong(expect, pipe, std::memory_order_relaxed);
-    pipe = g_w3_pipe.load(std::memory_order_relaxed);
-  }
-  if (split && pipe) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true, true>), grid, blk, LDS_TOTAL, s, a);
+  const int pipe = w3_mode();
+  if (split && p.w64) hipLaunchKernelGGL(k_wgrad3x3_w64, grid, blk, LDS2_TOTAL, s, a);
+  else if (split && pipe) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true, true>), grid, blk, LDS_TOTAL, s, a);
   else if (split) hipLaunchKernelGGL((k_wgrad3x3_patch<4, true>), grid, blk, LDS_TOTAL, s, a);
   else if (p.CO == 4) hipLaunchKernelGGL(k_wgrad3x3_patch<4>, grid, blk, LDS_TOTAL, s, a);
   else hipLaunchKernelGGL(k_wgrad3x3_patch<2>, grid, blk, LDS_TOTAL, s, a);

@@ -235,8 +235,9 @@ def set_conv_algo(algo):
 
 
 def set_wgrad3x3_pipe(on):
-    """Pipelined chunk loop of the bf16x3 halo-patch weight gradient (A/B knob, include/sfod_hip.h)."""
-    load().sfod_set_wgrad3x3_pipe(int(bool(on)))
+    """bf16x3 halo-patch weight gradient: 2 = 64 x 64-block kernel on 128-pixel tiles (default), 1 = pipelined 64 x 32-block
+    loop, 0 = the round-2 loop (A/B knob, include/sfod_hip.h)."""
+    load().sfod_set_wgrad3x3_pipe(int(on))
 
 
 def set_conv3x3_variant(variant):

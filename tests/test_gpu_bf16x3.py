@@ -188,12 +188,16 @@ def test_conv_dgrad_and_wgrad(native, shape, algo):
     (2, 9, 13, 16, 96),
     (1, 70, 150, 48, 80),
     (3, 5, 6, 256, 256),
+    (2, 30, 44, 72, 136),     # channel tails in both 64-wide blocks of the 64 x 64 kernel, tiles overhanging the map
+    (1, 64, 96, 192, 64),
 ])
-@pytest.mark.parametrize("pipe", [1, 0])
+@pytest.mark.parametrize("pipe", [2, 1, 0])
 def test_conv3x3_patch_wgrad(native, shape, pipe):
     """k_wgrad3x3_patch<4, SPLIT> (planes de-interleaved by the DMA, hi*lo + lo*hi + hi*hi per tap, four k-step slabs per
-    pixel split) + the slab reduction against fp64 autograd; ``pipe``: the round-3 pipelined chunk loop (default) and
-    the round-2 loop behind sfod_set_wgrad3x3_pipe."""
+    pixel split) + the slab reduction against fp64 autograd; ``pipe`` (sfod_set_wgrad3x3_pipe): 2 = the 64 x 64-block kernel
+    on 128-pixel tiles (k_wgrad3x3_w64, default; layers with Cin >= 64, otherwise it falls back to 1), 1 = the pipelined
+    64 x 32-block loop, 0 = the round-2 loop.  0 and 1 issue the same MFMA sequence per accumulator (bit-equal); 2 groups
+    the pixels differently (equal to fp32 summation order)."""
     B, H, W, Cin, Cout = shape
     native.set_wgrad3x3_pipe(pipe)
     g = torch.Generator().manual_seed(sum(shape) + 1)
@@ -212,16 +216,19 @@ def test_conv3x3_patch_wgrad(native, shape, pipe):
         native.conv_wgrad_oihw(xd, dyd, direct, accumulate=False)
         acc = torch.ones(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
         native.conv_wgrad_oihw(xd, dyd, acc, accumulate=True)
-        native.set_wgrad3x3_pipe(1 - pipe)
+        native.set_wgrad3x3_pipe((pipe + 1) % 3)
         other = native.conv_wgrad(xd, dyd, Cout, 3)
     finally:
         native.set_conv_algo(0)
-        native.set_wgrad3x3_pipe(1)
+        native.set_wgrad3x3_pipe(2)
     dw = torch.empty(Cout, Cin, 3, 3, dtype=torch.float32, device=DEV)
     native.unpack_conv_wgrad(dwp, dw)
     assert rel_err(dw.cpu(), w.grad) < TOL
     assert torch.equal(dwp, dwp2), "slab reduction must be deterministic"
-    assert torch.equal(dwp, other), "both chunk loops issue the same MFMA sequence per accumulator"
+    if {pipe, (pipe + 1) % 3} == {0, 1} or Cin < 64:
+        assert torch.equal(dwp, other), "both 64 x 32 chunk loops issue the same MFMA sequence per accumulator"
+    else:
+        assert rel_err(other.cpu(), dwp.cpu()) < 2e-6, "same products, other pixel grouping: fp32 summation order only"
     assert torch.equal(direct, dw)
     torch.testing.assert_close(acc, dw + 1.0, rtol=0, atol=1e-6)
 
@@ -471,6 +478,11 @@ def test_conv3x3_patch_wgrad_pipelined_loop_under_load(native):
         for _ in range(6):
             out = native.conv_wgrad(xd, dyd, Cout, 3)
             assert torch.equal(out, ref)
+        native.set_wgrad3x3_pipe(2)          # 64 x 64 blocks on 128-pixel tiles: deterministic, fp32-summation-order equal
+        first = native.conv_wgrad(xd, dyd, Cout, 3).clone()
+        assert rel_err(first.cpu(), ref.cpu()) < 2e-6
+        for _ in range(6):
+            assert torch.equal(native.conv_wgrad(xd, dyd, Cout, 3), first)
     finally:
         native.set_conv_algo(0)
-        native.set_wgrad3x3_pipe(1)
+        native.set_wgrad3x3_pipe(2)

@@ -54,7 +54,7 @@ def main():
                 continue
             dy = native.cast(torch.randn(B, H, W, Cout, device=dev, generator=g), odt)
             native.set_conv_algo(2)
-            ts, dws = {0: [], 1: []}, {}
+            ts, dws = {0: [], 1: [], 2: []}, {}
             for r in range(args.rounds + 1):
                 for v in ts:
                     native.set_wgrad3x3_pipe(v)
@@ -67,13 +67,14 @@ def main():
                     if r > 0:
                         ts[v].append(e0.elapsed_time(e1))
                     dws[v] = dw
-            native.set_wgrad3x3_pipe(1)
+            native.set_wgrad3x3_pipe(2)
             native.set_conv_algo(0)
             line = f"{name:9s} {B}x{H}x{W} {Cin:4d}->{Cout:4d} {flops / 1e9:8.1f} GF wgrad"
             for v in ts:
                 t = sorted(ts[v])[len(ts[v]) // 2]
-                line += f" | {'pipelined' if v else 'round 2 '} {t:6.3f} ms {flops / t / 1e9:6.0f} TF/s"
-            print(line + f" | equal {torch.equal(dws[0], dws[1])}", flush=True)
+                line += f" | {('round 2', 'pipelined', '64x64 block')[v]} {t:6.3f} ms {flops / t / 1e9:6.0f} TF/s"
+            d2 = ((dws[2] - dws[0]).double().norm() / dws[0].double().norm()).item()
+            print(line + f" | 0 == 1: {torch.equal(dws[0], dws[1])}, rel diff of 2: {d2:.1e}", flush=True)
             continue
         if args.variants:
             native.set_conv_algo(2)
