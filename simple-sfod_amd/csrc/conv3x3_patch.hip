@@ -30,6 +30,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// Knock-out switches for tools/experiments/conv_knockout.sh (time floors of the bf16x3 loop; results are WRONG by
+// construction, the product build defines none): P3_KO_MFMA no MFMAs, P3_KO_READS no LDS fragment reads, P3_KO_PATCHDMA /
+// P3_KO_WDMA no patch / weight LDS-DMA inside the K loop, P3_KO_EPI no epilogue (stores, statistics).
 namespace {
 
 template <int J> using IC = std::integral_constant<int, J>;
@@ -195,10 +198,16 @@ k_conv3x3_patch(P3Args a) {
   const int epair = (G == 2) ? (wave >> 2) : 0;  // which (tap, slice) pair of a stage this wave's B DMA feeds
 
   auto issue_patch = [&](int k, int slice, int buf) {
+#ifdef P3_KO_PATCHDMA
+    if (slice > 0) return;          // the first slice's patch is reused for every body
+#endif
     bufload16(xres, poff[k], (unsigned)slice * 64u, smem + buf * PATCH_BYTES + (wave * NPW + k) * 1024);
   };
   // weights of global stage sg (= body * 9 + j)
   auto issue_b = [&](int sg) {
+#ifdef P3_KO_WDMA
+    if (sg >= D) return;            // only the prologue's weight stages are ever loaded
+#endif
     const int gp = sg * G + epair;  // global pair index
     const int slice = gp / 9, tap = gp - slice * 9;
     bufload16(wres, boff, (unsigned)(tap * a.Cin + slice * 32) * 2u, smem + BRING_OFF + (sg % NBS) * BSLOT + wave * 1024);
@@ -259,6 +268,13 @@ k_conv3x3_patch(P3Args a) {
     }
     if constexpr (SPLIT) {
       bf16x8 ah[FM], al[FM], bh[FN], bl[FN];
+#ifdef P3_KO_READS
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" : "=v"(ah[i]), "=v"(al[i]));     // whatever the registers hold
+#pragma unroll
+      for (int j = 0; j < FN; ++j) asm volatile("" : "=v"(bh[j]), "=v"(bl[j]));
+      (void)addrA; (void)patch; (void)bsl;
+#else
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
         ah[i] = *reinterpret_cast<const bf16x8*>(patch + addrA[i]);
@@ -269,6 +285,15 @@ k_conv3x3_patch(P3Args a) {
         bh[j] = *reinterpret_cast<const bf16x8*>(bsl + offB[j]);
         bl[j] = *reinterpret_cast<const bf16x8*>(bsl + (offB[j] ^ 16));
       }
+#endif
+#ifdef P3_KO_MFMA
+#pragma unroll
+      for (int i = 0; i < FM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+      for (int j = 0; j < FN; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+      acc[0][0][0] += 1.0f;
+      return;
+#endif
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -353,6 +378,19 @@ k_conv3x3_patch(P3Args a) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------------
+#ifdef P3_KO_EPI
+  {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+    if (t == 1.2345e-30f) reinterpret_cast<float*>(a.y)[0] = t;       // keeps the accumulators alive, stores nothing
+    return;
+  }
+#endif
   float bcol[FN];
 #pragma unroll
   for (int j = 0; j < FN; ++j) {
