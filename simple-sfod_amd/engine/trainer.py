@@ -74,6 +74,16 @@ class EventStorage:
         dev_vals = [v for v in vals if v is not None]
         world = get_world_size() if reduce_over_ranks else 1
         host = []
+        if world > 1:
+            # every rank must bring the same number of device scalars (they follow from the config; a rank whose share
+            # of a tiny evaluation set is empty would not): agree on it first, and fall back to rank-local values
+            # rather than hang in a mismatched collective
+            dev = dev_vals[0].device if dev_vals else torch.device("cuda", torch.cuda.current_device()) \
+                if torch.cuda.is_available() else torch.device("cpu")
+            n = torch.tensor([len(dev_vals), -len(dev_vals)], dtype=torch.int64, device=dev)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            if int(n[0]) != -int(n[1]):
+                world = 1
         if dev_vals:
             stacked = torch.stack(dev_vals)
             if world > 1:

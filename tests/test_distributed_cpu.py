@@ -98,6 +98,11 @@ def _worker(rank, world, port, q):
     rec = st.flush(reduce_over_ranks=True)
     ok_sum = ok_sum and rec["loss_cls"] == 1.5 and rec["total_loss"] == 15.0 and rec["data_time"] == 0.5 \
         and rec["lr_note"] == 3.0 and st.flush(reduce_over_ranks=True) == {}
+    # a rank with a different number of scalars (e.g. an empty share of a tiny evaluation set): no mismatched collective,
+    # every rank keeps its own values
+    st.put_scalars(a=torch.tensor(float(rank)), **({"b": torch.tensor(5.0)} if rank == 0 else {}))
+    rec = st.flush(reduce_over_ranks=True)
+    ok_sum = ok_sum and rec["a"] == float(rank) and (("b" in rec) == (rank == 0))
     # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream
     s = iter(sfod.data.TrainingSampler(10, seed=7, rank=rank, world=world))
     mine = [next(s) for _ in range(10)]
