@@ -18,6 +18,9 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   python3 tools/bench_conv.py --dtype bf16x3 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bf16x3_conv_layers.txt
   python3 tools/bench_conv.py --dtype bf16x3 --wgrad 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bf16x3_conv_layers_wgrad.txt
 fi
+if [ "$WHAT" = all ] && [ -s $O/${TAG}_pmc_hbm_traffic_bf16x3.json ]; then
+  cp $O/${TAG}_pmc_hbm_traffic_bf16x3.json profiles/pmc_hbm_traffic_latest.json    # the bench lines below carry THIS capture
+fi
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   python3 bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
   python3 bench.py --kernel-table --steps 30 --no-cpu-baseline --no-secondary > /dev/null 2> $O/${TAG}_kernel_table.txt
