@@ -21,6 +21,12 @@
  *     of 8 consecutive channels is 32 bytes = 8 x bf16 hi followed by 8 x bf16 lo.  Convolutions / GEMMs take
  *     SFOD_BF16X3 operands and write fp32; the elementwise producers (preprocess, BatchNorm apply, BatchNorm
  *     backward, ROIAlign, cast) write the pairs.
+ *     SFOD_F16X3: the same storage and the same three-MFMA product with IEEE half pairs, hi = f16(v),
+ *     lo = f16(v - hi) (v_mfma_f32_32x32x16_f16; subnormal inputs are kept): 22 significand bits per operand for
+ *     |v| in [2^-3, 65504], an absolute 2^-25 below, +-65504 saturation above -- the operand format of the FORWARD
+ *     products of cfg.SFOD.COMPUTE_DTYPE = "f16x3" (activations and weights, whose magnitudes sit in that window;
+ *     gradients do not, the backward products of that mode use SFOD_BF16X3).  Served by the forward convolution /
+ *     GEMM entry points and by every producer of operand pairs; the weight-gradient entry points take SFOD_BF16X3.
  *   - per-image variable-length results live in fixed-capacity arrays plus an int32 count per
  *     image, so that no entry point needs a host round trip.
  */
@@ -34,6 +40,7 @@ extern "C" {
 #define SFOD_F32 0
 #define SFOD_BF16 1
 #define SFOD_BF16X3 2
+#define SFOD_F16X3 3
 
 int sfod_version(void);
 /* last error text of the calling thread ("" if none) */
@@ -74,6 +81,12 @@ int sfod_resize_bilinear_u8(const void* src, void* dst, int C, int H, int W, int
 int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
                   int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
                   void* stream);
+/* the same for SFOD_F16X3 weights packed with their per-tensor power-of-two scale (sfod_pack_*_ws below): w_absmax is the
+ * device word the packer published (bits of max|w|); the kernels multiply their accumulators by the inverse scale before
+ * bias / statistics / activation (exact).  w_absmax == NULL: unscaled weights (= sfod_conv_fwd). */
+int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B, int H,
+                     int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
+                     void* stream);
 /* number of statistics blocks nblk sfod_conv_fwd writes for this layer shape; `stats` holds
  * nblk * (2*Cout + 1) floats */
 int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
@@ -118,6 +131,9 @@ int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, in
 int sfod_conv_first_fused(const void* x, const void* w, const float* bias, const float* scale,
                           const float* shift, void* y, float* stats, int B, int H, int W, int ldy,
                           int act, int dt, void* stream);
+int sfod_conv_first_fused_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias,
+                             const float* scale, const float* shift, void* y, float* stats, int B, int H, int W,
+                             int ldy, int act, int dt, void* stream);
 
 /* weight gradient: dw[n][tap][c] += sum_m dy[m][n] * x[pix(m)+tap][c]  (fp32, packed layout, added
  * into the caller's (zero-initialised) buffer).  3x3 bf16 layers run the halo-patch kernel: pixel
@@ -140,12 +156,21 @@ int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oihw, int B, i
  * swaps in/out channels and flips the taps: the dgrad weight [Cin][KH*KW][Cout]. */
 int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Cout, int Cin, int ksize,
                           int CinPad, int rot180, int dt, void* stream);
+/* SFOD_F16X3 weights with a per-tensor scale: half pairs keep 22 bits only for |v| >= 2^-3 and weights are uniformly
+ * small, so the `_ws` packers first reduce max|w| of the fp32 source into the device word(s) `absmax` (bit pattern of a
+ * non-negative float; one word per tensor), then store w * s with s the power of two that puts max|w| * s into
+ * [2^13, 2^14).  The forward entry points (`sfod_conv_fwd_ws`, `sfod_conv_first_fused_ws`) take the same word and undo
+ * the scale on their accumulators.  absmax == NULL: unscaled (any dt). */
+int sfod_pack_conv_weight_ws(const float* w_oihw, void* w_packed, uint32_t* absmax, int Cout, int Cin, int ksize,
+                             int CinPad, int rot180, int dt, void* stream);
 /* every conv weight of a model in one launch.  desc (device, int64): n entries of 8 values
  * {src fp32 OIHW pointer, dst packed pointer, Cout, Cin, ksize, innerPad, rot180, first_block}, where
  * first_block is the running sum of sfod_pack_conv_weights_blocks over the preceding entries;
  * total_blocks = the sum over all entries.  Same layouts as sfod_pack_conv_weight. */
 int sfod_pack_conv_weights_blocks(int Cout, int Cin, int ksize, int innerPad, int rot180);
 int sfod_pack_conv_weights_multi(const int64_t* desc, int n, int total_blocks, int dt, void* stream);
+int sfod_pack_conv_weights_multi_ws(const int64_t* desc, int n, int total_blocks, int dt, uint32_t* absmax /* [n] */,
+                                    void* stream);
 /* packed fp32 grad [Cout][taps][CinPad] -> OIHW fp32 grad (accumulate=0: overwrite) */
 int sfod_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int Cout, int Cin, int ksize,
                            int CinPad, int accumulate, void* stream);
@@ -160,6 +185,8 @@ int sfod_unpack_fc_wgrad(const float* dw_packed, float* dw, int N, int K, int ch
  * that every row is a whole number of 16-byte chunks, e.g. the 41 predictor outputs -> 48) */
 int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose, int ld,
                            int dt, void* stream);
+int sfod_pack_fc_weight_ld_ws(const float* w, void* out, uint32_t* absmax, int N, int K, int chw_c, int transpose,
+                              int ld, int dt, void* stream);
 int sfod_unpack_fc_wgrad_ld(const float* dw_packed, float* dw, int N, int K, int chw_c, int ld,
                             int accumulate, void* stream);
 /* column sums of a [M, ld] matrix's first N columns: bias gradients.  db[n] (+)= sum_m dy[m][n] */
@@ -185,13 +212,19 @@ int sfod_bn_finalize_ws_floats(int C);
 int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
                           const float* gamma, const float* beta, void* z, int B, int H, int W,
                           int C, int pool, int dt, int out_dt, void* stream);
+/* the same with a second output: out_dt SFOD_F16X3 (z: half pairs, the next convolution's forward operand) and z2 (may be
+ * NULL) the same values as SFOD_BF16X3 pairs (that convolution's weight-gradient operand) -- "f16x3" mode, student pass */
+int sfod_bn_relu_pool_fwd2(const void* y, const float* mean, const float* invstd,
+                           const float* gamma, const float* beta, void* z, void* z2, int B, int H, int W,
+                           int C, int pool, int dt, int out_dt, void* stream);
 /* Bottleneck tail of the ResNet path (d2 BottleneckBlock.forward, reached through build_resnet_backbone of the r101
  * yaml): z = relu(bn(y) + residual) in one pass over [rows, C]; same statistics / affine inputs as above.
- * z_pairs (may be NULL; dt SFOD_F32, C % 8 == 0): additionally the same values as SFOD_BF16X3 operand pairs -- the
- * block output is both the fp32 residual stream and the next convolution's MFMA operand. */
+ * z_pairs (may be NULL; dt SFOD_F32, C % 8 == 0): additionally the same values as operand pairs of type pairs_dt
+ * (SFOD_BF16X3 / SFOD_F16X3) -- the block output is both the fp32 residual stream and the next convolution's MFMA
+ * operand. */
 int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
                          const float* beta, const void* residual, void* z, void* z_pairs, int64_t rows, int C,
-                         int dt, void* stream);
+                         int dt, int pairs_dt, void* stream);
 /* backward of the block above.  dz: grad w.r.t. block output; y: saved conv output; returns dy
  * (grad w.r.t. conv output), dgamma, dbeta.  ws: fp32 workspace [nblk*2*C] (see ws query).
  * dgamma_acc / dbeta_acc (may be NULL): the parameters' gradient accumulators (+= this call's dgamma /
@@ -208,8 +241,9 @@ int sfod_bn_bwd_ws_floats(int M, int C);
 /* ---- ResNet-101-C4 backbone helpers (d2 build_resnet_backbone selected by the r101 yaml's missing
  * BACKBONE.NAME, configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28) ----
  * out = act(a + b), act 0/1: residual join of BottleneckBlock (relu(conv3(x) + shortcut(x))); out_pairs (may be NULL,
- * fp32 data, n % 8 == 0 with 8-channel groups): the same values as SFOD_BF16X3 operand pairs */
-int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, int64_t n, int act, int dt, void* stream);
+ * fp32 data, n % 8 == 0 with 8-channel groups): the same values as operand pairs of type pairs_dt */
+int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, int64_t n, int act, int dt, int pairs_dt,
+                 void* stream);
 /* backward=0: dst [B,ceil(H/2),ceil(W/2),C] = src [B,H,W,C] at even pixels (data movement of a 1x1
  * stride-2 conv, STRIDE_IN_1X1); backward=1: the adjoint (dst [B,H,W,C] zero except even pixels) */
 int sfod_subsample2(const void* src, void* dst, int B, int H, int W, int C, int backward, int dt,
@@ -418,6 +452,10 @@ int sfod_teacher_metrics(const float* det_scores, const int* det_count, int D, c
                          const int* rpn_count, int P, const int* gt_count, int B, float thr, float* out,
                          void* stream);
 
+/* fp32 [n] (n % 8 == 0) -> SFOD_F16X3 pairs and SFOD_BF16X3 pairs of the same values in one pass ("f16x3" mode: a tensor
+ * that is the operand of a forward product and of a weight gradient; replaces the reference's single fp32 tensor at
+ * every such site, e.g. the RPN head input daod/modeling/proposal_generator/rpn.py:25-56) */
+int sfod_cast_pairs_both(const float* src, void* dst_f16x3, void* dst_bf16x3, int64_t n, void* stream);
 /* utilities */
 int sfod_fill_f32(float* p, int64_t n, float v, void* stream);
 int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int dst_dt, void* stream);

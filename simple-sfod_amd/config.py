@@ -371,7 +371,14 @@ def add_native_config(cfg):
                           2^-24 per product), fp32 activations / statistics / losses elsewhere.  NOT fp32 arithmetic:
                           it is gated at 1e-4 (losses, decoded boxes) on the VGG16 yamls at 600x1200
                           (tests/test_gpu_fullsize.py); on the 101-layer ResNet-C4 yaml it only reaches ~1e-3 and
-                          long trajectories can drift -- use "fp32" there.
+                          long trajectories can drift -- use "f16x3" or "fp32" there.
+                          "f16x3": the same three-MFMA product with the FORWARD operands as IEEE half pairs (22
+                          significand bits each; activations and weights sit inside half's exponent window, see
+                          include/sfod_hip.h) -- forward error at the level of the fp32 MFMA path, at the bf16x3 price
+                          (half MFMAs draw ~6 % more power per product); the BACKWARD products (data / weight gradients:
+                          magnitudes far below half's range, no loss scaling here) stay on bf16 pairs, so activations that
+                          feed a weight gradient are written in both formats by their producer.  Gated like "fp32" on
+                          both yamls (tests/test_gpu_fullsize.py); the parity mode bench.py --model r101 reports.
                           "fp32": v_mfma_f32_32x32x2_f32, bit-exact fp32 FMA chains (1/16 of the bf16 rate): the exact
                           parity mode of every config.  "bf16": one bf16 pass, bf16 activations (reduced precision,
                           NOT a parity mode: losses within a few % of the oracle).

@@ -60,6 +60,33 @@ __device__ __forceinline__ void split_store8(split_t* p, const float* in) {
   reinterpret_cast<uint4*>(p)[0] = hi.v;
   reinterpret_cast<uint4*>(p)[1] = lo.v;
 }
+// ---- SFOD_F16X3 storage: the same layout with IEEE half pairs, hi = f16(v), lo = f16(v - hi) (include/sfod_hip.h).
+// |v| beyond the half range saturates at +-65504 per component (NaN stays NaN).
+typedef _Float16 f16_t;
+struct splith_t { uint32_t raw; };
+
+__device__ __forceinline__ void f16_pair(float v, f16_t& h, f16_t& l) {
+  const float lim = 65504.f;
+  const float c = (fabsf(v) > lim) ? copysignf(lim, v) : v;       // NaN compares false: passes through
+  h = (f16_t)c;
+  const float r = v - (float)h;
+  l = (f16_t)((fabsf(r) > lim) ? copysignf(lim, r) : r);
+}
+__device__ __forceinline__ void split_load8(const splith_t* p, float* out) {
+  union { uint4 v; f16_t h[8]; } hi, lo;
+  hi.v = reinterpret_cast<const uint4*>(p)[0];
+  lo.v = reinterpret_cast<const uint4*>(p)[1];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = (float)hi.h[i] + (float)lo.h[i];
+}
+__device__ __forceinline__ void split_store8(splith_t* p, const float* in) {
+  union { f16_t h[8]; uint4 v; } hi, lo;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) f16_pair(in[i], hi.h[i], lo.h[i]);
+  reinterpret_cast<uint4*>(p)[0] = hi.v;
+  reinterpret_cast<uint4*>(p)[1] = lo.v;
+}
+
 // scalar access to logical element idx of a split tensor whose 8-groups start at `base`
 __device__ __forceinline__ void split_put(split_t* base, int64_t idx, float v) {
   bf16_t* b = reinterpret_cast<bf16_t*>(base) + (idx >> 3) * 16 + (idx & 7);
@@ -71,11 +98,51 @@ __device__ __forceinline__ float split_get(const split_t* base, int64_t idx) {
   const bf16_t* b = reinterpret_cast<const bf16_t*>(base) + (idx >> 3) * 16 + (idx & 7);
   return (float)b[0] + (float)b[8];
 }
+__device__ __forceinline__ void split_put(splith_t* base, int64_t idx, float v) {
+  f16_t* b = reinterpret_cast<f16_t*>(base) + (idx >> 3) * 16 + (idx & 7);
+  f16_pair(v, b[0], b[8]);
+}
+__device__ __forceinline__ float split_get(const splith_t* base, int64_t idx) {
+  const f16_t* b = reinterpret_cast<const f16_t*>(base) + (idx >> 3) * 16 + (idx & 7);
+  return (float)b[0] + (float)b[8];
+}
 // out[idx] = v for any storage type (fp32 / bf16: plain element; split: the (hi, lo) pair)
 template <typename T> __device__ __forceinline__ void put_elem(T* base, int64_t idx, float v) { base[idx] = from_f32<T>(v); }
 template <> __device__ __forceinline__ void put_elem<split_t>(split_t* base, int64_t idx, float v) { split_put(base, idx, v); }
+template <> __device__ __forceinline__ void put_elem<splith_t>(splith_t* base, int64_t idx, float v) { split_put(base, idx, v); }
 template <typename T> __device__ __forceinline__ float get_elem(const T* base, int64_t idx) { return to_f32(base[idx]); }
 template <> __device__ __forceinline__ float get_elem<split_t>(const split_t* base, int64_t idx) { return split_get(base, idx); }
+template <> __device__ __forceinline__ float get_elem<splith_t>(const splith_t* base, int64_t idx) { return split_get(base, idx); }
+
+// the split-precision product's MFMA on either pair format (FMT: 1 = bf16 pairs, 2 = f16 pairs; same registers, same rate)
+typedef __attribute__((ext_vector_type(8))) __bf16 sfod_bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 sfod_f16x8;
+typedef __attribute__((ext_vector_type(16))) float sfod_f32x16;
+template <int FMT>
+__device__ __forceinline__ sfod_f32x16 mfma_pairs(sfod_bf16x8 a, sfod_bf16x8 b, sfod_f32x16 c) {
+  if constexpr (FMT == 2)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(sfod_f16x8, a), __builtin_bit_cast(sfod_f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+// SFOD_F16X3 weights are stored multiplied by a power of two s chosen per packed tensor so that max|w| * s lands in
+// [2^13, 2^14): half's full 22-bit pair precision needs |v| >= 2^-3 (below, lo is a subnormal with absolute spacing 2^-24),
+// and weights are uniformly small (kaiming: 0.02 ... 0.09).  The packer publishes the bit pattern of max|w| in a device
+// word; the packing kernels derive s from it, the forward kernels derive 1 / s and apply it to their accumulators (exact:
+// powers of two).  Zero / non-finite maxima leave the tensor unscaled.
+__device__ __forceinline__ int wscale_biased_exp(unsigned absmax_bits) {
+  const int e = (int)(absmax_bits >> 23) & 0xff;
+  if (e == 0 || e == 255) return 127;
+  const int se = 127 + 13 - (e - 127);
+  return se < 8 ? 8 : (se > 246 ? 246 : se);
+}
+__device__ __forceinline__ float wscale_from_absmax(unsigned absmax_bits) {
+  return __uint_as_float((unsigned)wscale_biased_exp(absmax_bits) << 23);
+}
+__device__ __forceinline__ float winv_from_absmax(unsigned absmax_bits) {
+  return __uint_as_float((unsigned)(254 - wscale_biased_exp(absmax_bits)) << 23);
+}
+static inline bool sfod_is_pairs(int dt) { return dt == SFOD_BF16X3 || dt == SFOD_F16X3; }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 

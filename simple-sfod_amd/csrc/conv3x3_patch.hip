@@ -84,6 +84,7 @@ struct P3Args {
   const float* red_gamma;
   const float* red_beta;
   float* red_ws;
+  const unsigned* wamax;    // SFOD_F16X3: bits of max|w| of the scaled packed weights (common.h), or nullptr
 };
 
 // 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16), through a raw buffer
@@ -133,11 +134,12 @@ template <> struct WaitTab<2, 1> {   // 3 patch pieces per slice (stages 0-2 / 5
   static constexpr int NL[9] = {1, 2, 2, 2, 1, 1, 1, 1, 0};
 };
 
-// SPLIT (SFOD_BF16X3, fp32-equivalent): x and w hold (hi, lo) bf16 pairs -- per 8 logical channels 8 hi then 8 lo
+// SPLIT (1: SFOD_BF16X3, 2: SFOD_F16X3 -- the MFMA opcode is the only difference): x and w hold (hi, lo) pairs -- per 8
+// logical channels 8 hi then 8 lo
 // values, so the kernel sees 2 * Cin "physical" bf16 channels and its DMA / LDS side is unchanged; a 64-byte patch
 // row is then 16 logical channels as chunks (hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15), ONE MFMA k-step, fed as
 // hi*lo + lo*hi + hi*hi: the same four fragment reads as two bf16 k-steps, three MFMAs instead of two.
-template <int G, int FM, typename OutT, bool SPLIT = false, bool RED = false>
+template <int G, int FM, typename OutT, int SPLIT = 0, bool RED = false>
 __global__ void __launch_bounds__(512, (Lay<G, FM>::SMALL ? 4 : 2))   // 2nd arg: waves per SIMD (small tiles: 2 workgroups / CU)
 k_conv3x3_patch(P3Args a) {
   using L = Lay<G, FM>;
@@ -298,17 +300,17 @@ k_conv3x3_patch(P3Args a) {
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_pairs<SPLIT>(ah[i], bl[j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_pairs<SPLIT>(al[i], bh[j], acc[i][j]);
 #pragma unroll
       for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int j = 0; j < FN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+          acc[i][j] = mfma_pairs<SPLIT>(ah[i], bh[j], acc[i][j]);
       return;
     }
 #pragma unroll
@@ -396,6 +398,17 @@ k_conv3x3_patch(P3Args a) {
   for (int j = 0; j < FN; ++j) {
     const int n = n0 + wn * 64 + j * 32 + (lane & 31);
     bcol[j] = (a.bias != nullptr && n < a.Cout) ? a.bias[n] : 0.f;
+  }
+  if constexpr (SPLIT == 2) {     // undo the packed weights' power-of-two scale (exact)
+    if (a.wamax != nullptr) {
+      const float inv = winv_from_absmax(*a.wamax);
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+    }
   }
   __syncthreads();  // every wave is done reading operands; LDS is reused below
   const ActP actp = act_params(a.act);
@@ -715,7 +728,7 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   return p;
 }
 
-template <int G, int FM, typename OutT, bool SPLIT = false, bool RED = false>
+template <int G, int FM, typename OutT, int SPLIT = 0, bool RED = false>
 static int p3_launch_one(const P3Args& a, hipStream_t s) {
   auto kern = k_conv3x3_patch<G, FM, OutT, SPLIT, RED>;
   constexpr int LDS = Lay<G, FM>::TOTAL;
@@ -727,11 +740,12 @@ static int p3_launch_one(const P3Args& a, hipStream_t s) {
   return sfod_check_launch("conv3x3_patch");
 }
 
-// split != 0: SFOD_BF16X3 operands; Cin is then the PHYSICAL bf16 channel count (2 x logical), the output is fp32
+// split 1 / 2: SFOD_BF16X3 / SFOD_F16X3 operands; Cin is then the PHYSICAL 16-bit channel count (2 x logical), the output is fp32
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
                    int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split,
-                   const P3BnRed* red) {
+                   const P3BnRed* red, const unsigned* wamax) {
   P3Args a;
+  a.wamax = wamax;
   a.red_y = nullptr; a.red_mean = a.red_invstd = a.red_gamma = a.red_beta = nullptr; a.red_ws = nullptr;
   if (red != nullptr) {
     if (!out_f32 || ldy != Cout || Cout % 4 != 0) { sfod_set_error("conv3x3_patch: BatchNorm-backward epilogue needs a dense fp32 output"); return SFOD_EBADARG; }
@@ -749,17 +763,24 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
   a.ntiles = B * p.tiles_y * p.tiles_x * p.tiles_n;
   a.nblk = p.nblk;
   if (split) {
-    if (!out_f32) { sfod_set_error("conv3x3_patch: bf16x3 operands write fp32"); return SFOD_EBADARG; }
+    if (!out_f32) { sfod_set_error("conv3x3_patch: operand pairs write fp32"); return SFOD_EBADARG; }
     if (red != nullptr) {
-      if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, true, true>(a, s);
-      if (p.G == 1) return p3_launch_one<1, 4, float, true, true>(a, s);
-      if (p.FM == 2) return p3_launch_one<2, 2, float, true, true>(a, s);
-      return p3_launch_one<2, 1, float, true, true>(a, s);
+      if (split != 1) { sfod_set_error("conv3x3_patch: the BatchNorm-backward epilogue runs on bf16x3 operands"); return SFOD_EBADARG; }
+      if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, 1, true>(a, s);
+      if (p.G == 1) return p3_launch_one<1, 4, float, 1, true>(a, s);
+      if (p.FM == 2) return p3_launch_one<2, 2, float, 1, true>(a, s);
+      return p3_launch_one<2, 1, float, 1, true>(a, s);
     }
-    if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, true>(a, s);
-    if (p.G == 1) return p3_launch_one<1, 4, float, true>(a, s);
-    if (p.FM == 2) return p3_launch_one<2, 2, float, true>(a, s);
-    return p3_launch_one<2, 1, float, true>(a, s);
+    if (split == 2) {
+      if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, 2>(a, s);
+      if (p.G == 1) return p3_launch_one<1, 4, float, 2>(a, s);
+      if (p.FM == 2) return p3_launch_one<2, 2, float, 2>(a, s);
+      return p3_launch_one<2, 1, float, 2>(a, s);
+    }
+    if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, 1>(a, s);
+    if (p.G == 1) return p3_launch_one<1, 4, float, 1>(a, s);
+    if (p.FM == 2) return p3_launch_one<2, 2, float, 1>(a, s);
+    return p3_launch_one<2, 1, float, 1>(a, s);
   }
   if (p.G == 1 && p.FM == 2) return out_f32 ? p3_launch_one<1, 2, float>(a, s) : p3_launch_one<1, 2, bf16_t>(a, s);
   if (p.G == 1) return out_f32 ? p3_launch_one<1, 4, float>(a, s) : p3_launch_one<1, 4, bf16_t>(a, s);

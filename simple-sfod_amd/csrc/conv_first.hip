@@ -9,6 +9,7 @@
 // Epilogue as in conv3x3_patch.hip: bias, per-wave LDS staging for 16-byte stores, BatchNorm (sum, M2,
 // count) per workgroup.
 #include "conv_internal.h"
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -40,6 +41,7 @@ struct F1Args {
   float* stats;
   int B, H, W, ldy, act;
   int tiles_y, tiles_x, ntiles;
+  const unsigned* wamax;   // SFOD_F16X3: bits of max|w| of the scaled packed weights (common.h), or nullptr
 };
 
 __global__ void __launch_bounds__(256)
@@ -230,8 +232,12 @@ k_conv_first(F1Args a) {
 // pass: the BatchNorm backward needs it), or -- with the affine of a second, recomputing pass (teacher) -- the next
 // layer's operand pairs z = relu(scale * (conv + bias) + shift) directly; per wave 32 rows at a time are staged in LDS
 // and stored as whole 256-byte pixels.
+template <int FMT>      // 1: bf16 pairs (SFOD_BF16X3), 2: f16 pairs (SFOD_F16X3): MFMA opcode and the z pairs it writes
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3)))
 k_conv_first_x3(F1Args a) {
+  using pair_t = typename std::conditional<FMT == 2, splith_t, split_t>::type;
+  // SFOD_F16X3 weights carry a per-tensor power-of-two scale (common.h): undone on the accumulators (exact)
+  const float winv = (FMT == 2 && a.wamax != nullptr) ? winv_from_absmax(*a.wamax) : 1.0f;
   __shared__ __attribute__((aligned(16))) unsigned char smem[X3_LDS_BYTES];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -305,9 +311,9 @@ k_conv_first_x3(F1Args a) {
           const bf16x8 bl = __builtin_bit_cast(
               bf16x8, *reinterpret_cast<const uint4*>(smem + X3_W_OFF + (((s * 2 + j) * 2 + 1) * 64 + lane) * 16));
           f32x16 c = acc[i][j];
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+          c = mfma_pairs<FMT>(ah, bl, c);
+          c = mfma_pairs<FMT>(al, bh, c);
+          c = mfma_pairs<FMT>(ah, bh, c);
           acc[i][j] = c;
         }
       }
@@ -333,7 +339,7 @@ k_conv_first_x3(F1Args a) {
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += bcol[j];
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = acc[i][j][r] * winv + bcol[j];
     if (a.y != nullptr) {
       unsigned char* stg = smem + X3_STG_OFF + wave * (16 * X3_FP);
 #pragma unroll
@@ -360,7 +366,7 @@ k_conv_first_x3(F1Args a) {
                 const float4 v0 = *reinterpret_cast<const float4*>(stg + row * X3_FP + gch * 32);
                 const float4 v1 = *reinterpret_cast<const float4*>(stg + row * X3_FP + gch * 32 + 16);
                 const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                split_store8(reinterpret_cast<split_t*>(a.y) + (((int64_t)b * a.H + iy) * a.W + ix) * a.ldy + gch * 8, f);
+                split_store8(reinterpret_cast<pair_t*>(a.y) + (((int64_t)b * a.H + iy) * a.W + ix) * a.ldy + gch * 8, f);
               }
             }
           } else {
@@ -433,10 +439,11 @@ k_conv_first_x3(F1Args a) {
 
 int sfod_f1_nblk(int B, int H, int W) { return B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW); }
 
-// split != 0: SFOD_BF16X3 operands; y is fp32 (scale == nullptr) or operand pairs (scale / shift given)
+// split 1 / 2: SFOD_BF16X3 / SFOD_F16X3 operands; y is fp32 (scale == nullptr) or operand pairs (scale / shift given)
 int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int B, int H, int W,
-                   int ldy, int act, hipStream_t s, const float* scale, const float* shift, int split) {
+                   int ldy, int act, hipStream_t s, const float* scale, const float* shift, int split, const unsigned* wamax) {
   F1Args a;
+  a.wamax = wamax;
   a.x = (const bf16_t*)x; a.w = (const bf16_t*)w; a.bias = bias; a.y = y; a.stats = stats;
   a.scale = scale; a.shift = shift;
   a.B = B; a.H = H; a.W = W; a.ldy = ldy; a.act = act;
@@ -444,7 +451,8 @@ int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, flo
   a.ntiles = B * a.tiles_y * a.tiles_x;
   const int resident = split ? 256 * 3 : 256 * 8;      // bf16x3: 3 workgroups per CU (LDS), each stages the weights once
   int grid = a.ntiles < resident ? a.ntiles : resident;
-  if (split) hipLaunchKernelGGL(k_conv_first_x3, dim3(grid), dim3(256), 0, s, a);
+  if (split == 2) hipLaunchKernelGGL(k_conv_first_x3<2>, dim3(grid), dim3(256), 0, s, a);
+  else if (split) hipLaunchKernelGGL(k_conv_first_x3<1>, dim3(grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(k_conv_first, dim3(grid), dim3(256), 0, s, a);
   return sfod_check_launch("conv_first");
 }

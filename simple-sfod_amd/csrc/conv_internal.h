@@ -26,7 +26,7 @@ struct P3BnRed {
 };
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
                    int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split = 0,
-                   const P3BnRed* red = nullptr);
+                   const P3BnRed* red = nullptr, const unsigned* wamax = nullptr);
 
 // BatchNorm statistics buffer layout shared by every conv kernel:
 //   stats[blk][0][c] = sum over the block's valid rows, stats[blk][1][c] = sum of squared deviations
@@ -51,4 +51,5 @@ int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, vo
 int sfod_f1_nblk(int B, int H, int W);
 // y == nullptr: statistics only (no stores); scale / shift: optional per-channel affine before the activation
 int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, float* stats, int B, int H, int W,
-                   int ldy, int act, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, int split = 0);
+                   int ldy, int act, hipStream_t s, const float* scale = nullptr, const float* shift = nullptr, int split = 0,
+                   const unsigned* wamax = nullptr);

@@ -20,6 +20,10 @@ template <> struct VecT<split_t> {
   static constexpr int N = 8;
   typedef uint4 raw;
 };
+template <> struct VecT<splith_t> {
+  static constexpr int N = 8;
+  typedef uint4 raw;
+};
 
 template <typename T> __device__ __forceinline__ void load_vec(const T* p, float* out);
 template <> __device__ __forceinline__ void load_vec<float>(const float* p, float* out) {
@@ -36,8 +40,10 @@ template <> __device__ __forceinline__ void load_vec<bf16_t>(const bf16_t* p, fl
   }
 }
 template <> __device__ __forceinline__ void load_vec<split_t>(const split_t* p, float* out) { split_load8(p, out); }
+template <> __device__ __forceinline__ void load_vec<splith_t>(const splith_t* p, float* out) { split_load8(p, out); }
 template <typename T> __device__ __forceinline__ void store_vec(T* p, const float* in);
 template <> __device__ __forceinline__ void store_vec<split_t>(split_t* p, const float* in) { split_store8(p, in); }
+template <> __device__ __forceinline__ void store_vec<splith_t>(splith_t* p, const float* in) { split_store8(p, in); }
 template <> __device__ __forceinline__ void store_vec<float>(float* p, const float* in) {
   *reinterpret_cast<float4*>(p) = make_float4(in[0], in[1], in[2], in[3]);
 }
@@ -104,13 +110,16 @@ extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes
   SFOD_REQUIRE(Cpad >= 3, "Cpad < 3");
   dim3 grid(cdiv(Wp, 256), Hp, B);
   hipStream_t s = (hipStream_t)stream;
-  if (dt == SFOD_BF16X3) SFOD_REQUIRE(Cpad % 8 == 0, "preprocess: bf16x3 output needs Cpad % 8 == 0");
+  if (sfod_is_pairs(dt)) SFOD_REQUIRE(Cpad % 8 == 0, "preprocess: operand-pair output needs Cpad % 8 == 0");
   if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_preprocess<float>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
                        Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (float*)out);
   else if (dt == SFOD_BF16X3)
     hipLaunchKernelGGL(k_preprocess<split_t>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
                        Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (split_t*)out);
+  else if (dt == SFOD_F16X3)
+    hipLaunchKernelGGL(k_preprocess<splith_t>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
+                       Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (splith_t*)out);
   else
     hipLaunchKernelGGL(k_preprocess<bf16_t>, grid, dim3(256), 0, s, (const uint8_t* const*)img_ptrs, sizes,
                        Hp, Wp, Cpad, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2], (bf16_t*)out);
@@ -376,11 +385,13 @@ extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
 // ---------------------------------------------------------------------------------------------
 // K3/K4 forward: z = relu(gamma * (y - mean) * invstd + beta), optional 2x2/2 max-pool
 // ---------------------------------------------------------------------------------------------
-template <typename T, int POOL, int RELU, typename TO = T>
+// DUAL: the same values once more as SFOD_BF16X3 pairs (z2) -- "f16x3" mode, student pass: the forward products read
+// half pairs, the weight gradient of the consuming layer reads bf16 pairs of the same activation
+template <typename T, int POOL, int RELU, typename TO = T, bool DUAL = false>
 __global__ void __launch_bounds__(256)
 k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
                    const float* __restrict__ gamma, const float* __restrict__ beta, TO* __restrict__ z,
-                   int B, int H, int W, int C) {
+                   int B, int H, int W, int C, split_t* __restrict__ z2 = nullptr) {
   constexpr int V = VecW<T, TO>::N;
   const int Ho = POOL ? H / 2 : H, Wo = POOL ? W / 2 : W;
   const int cv = C / V;
@@ -413,6 +424,10 @@ k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, cons
         }
         store_n<TO, V>(z + t * V, v0);
         if (two) store_n<TO, V>(z + (t + stride) * V, v1);
+        if constexpr (DUAL) {
+          store_n<split_t, V>(z2 + t * V, v0);
+          if (two) store_n<split_t, V>(z2 + (t + stride) * V, v1);
+        }
       }
       return;
     }
@@ -447,6 +462,7 @@ k_bn_relu_pool_fwd(const T* __restrict__ y, const float* __restrict__ mean, cons
         for (int i = 0; i < V; ++i) r[i] = fmaxf(r[i], (v[i] - mu[i]) * sc[i] + sh[i]);
       }
     store_n<TO, V>(z + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, r);
+    if constexpr (DUAL) store_n<split_t, V>(z2 + (((int64_t)b * Ho + oy) * Wo + ox) * C + c0, r);
   }
 }
 
@@ -476,10 +492,11 @@ k_bn_add_relu_fwd(const T* __restrict__ y, const float* __restrict__ mean, const
 // fp32 in / out plus the same values as SFOD_BF16X3 operand pairs (the next convolution's input): the bottleneck output
 // feeds both the residual stream (fp32) and conv1 of the next block, whose operand would otherwise be made by a separate
 // conversion pass re-reading the tensor
+template <typename PT>
 __global__ void __launch_bounds__(256)
 k_bn_add_relu_fwd_dual(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
                        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
-                       float* __restrict__ z, split_t* __restrict__ zp, int64_t rows, int C) {
+                       float* __restrict__ z, PT* __restrict__ zp, int64_t rows, int C) {
   constexpr int V = 8;
   const int cv = C / V;
   const int64_t total = rows * cv;
@@ -493,13 +510,14 @@ k_bn_add_relu_fwd_dual(const float* __restrict__ y, const float* __restrict__ me
     for (int i = 0; i < V; ++i)
       v[i] = fmaxf((v[i] - mean[c0 + i]) * (invstd[c0 + i] * gamma[c0 + i]) + beta[c0 + i] + r[i], 0.f);
     store_n<float, V>(z + t * V, v);
-    store_n<split_t, V>(zp + t * V, v);
+    store_n<PT, V>(zp + t * V, v);
   }
 }
 
+template <typename PT>
 __global__ void __launch_bounds__(256)
 k_add_act_dual(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
-               split_t* __restrict__ op, int64_t nvec, int act) {
+               PT* __restrict__ op, int64_t nvec, int act) {
   constexpr int V = 8;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -512,7 +530,7 @@ k_add_act_dual(const float* __restrict__ a, const float* __restrict__ b, float* 
       x[i] = act ? fmaxf(v, 0.f) : v;
     }
     store_n<float, V>(o + t * V, x);
-    store_n<split_t, V>(op + t * V, x);
+    store_n<PT, V>(op + t * V, x);
   }
 }
 
@@ -525,16 +543,20 @@ static inline int ew_grid(int64_t total) {
 
 extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, const void* residual, void* z, void* z_pairs, int64_t rows,
-                                    int C, int dt, void* stream) {
+                                    int C, int dt, int pairs_dt, void* stream) {
   const int V = (dt == SFOD_F32 && z_pairs == nullptr) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "bn_add_relu: C not a multiple of the vector width");
-  SFOD_REQUIRE(z_pairs == nullptr || dt == SFOD_F32, "bn_add_relu: the operand-pair copy is made from fp32 data");
+  SFOD_REQUIRE(z_pairs == nullptr || (dt == SFOD_F32 && sfod_is_pairs(pairs_dt)),
+               "bn_add_relu: the operand-pair copy (SFOD_BF16X3 / SFOD_F16X3) is made from fp32 data");
   if (rows == 0) return 0;
   const int grid = ew_grid(rows * (C / V));
   hipStream_t s = (hipStream_t)stream;
-  if (z_pairs != nullptr)
-    hipLaunchKernelGGL(k_bn_add_relu_fwd_dual, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma, beta,
-                       (const float*)residual, (float*)z, (split_t*)z_pairs, rows, C);
+  if (z_pairs != nullptr && pairs_dt == SFOD_F16X3)
+    hipLaunchKernelGGL(k_bn_add_relu_fwd_dual<splith_t>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
+                       beta, (const float*)residual, (float*)z, (splith_t*)z_pairs, rows, C);
+  else if (z_pairs != nullptr)
+    hipLaunchKernelGGL(k_bn_add_relu_fwd_dual<split_t>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
+                       beta, (const float*)residual, (float*)z, (split_t*)z_pairs, rows, C);
   else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_bn_add_relu_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
                        beta, (const float*)residual, (float*)z, rows, C);
@@ -544,32 +566,47 @@ extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const floa
   return sfod_check_launch("bn_add_relu_fwd");
 }
 
-extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
-                                     const float* gamma, const float* beta, void* z, int B, int H, int W,
-                                     int C, int pool_flags, int dt, int out_dt, void* stream) {
+extern "C" int sfod_bn_relu_pool_fwd2(const void* y, const float* mean, const float* invstd,
+                                      const float* gamma, const float* beta, void* z, void* z2, int B, int H, int W,
+                                      int C, int pool_flags, int dt, int out_dt, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
-  SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && out_dt == SFOD_BF16X3),
-               "bn: output type must equal the input type, or fp32 -> bf16x3");
-  SFOD_REQUIRE(dt != SFOD_BF16X3, "bn: reads fp32 or bf16 (convolutions write fp32 in bf16x3 mode)");
+  SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && sfod_is_pairs(out_dt)),
+               "bn: output type must equal the input type, or fp32 -> operand pairs");
+  SFOD_REQUIRE(!sfod_is_pairs(dt), "bn: reads fp32 or bf16 (convolutions on operand pairs write fp32)");
+  SFOD_REQUIRE(z2 == nullptr || out_dt == SFOD_F16X3, "bn: the second (bf16-pair) output accompanies SFOD_F16X3 pairs");
   const int V = (out_dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "bn: C not a multiple of the vector width");
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   const int grid = ew_grid((int64_t)B * Ho * Wo * (C / V));
 #define LAUNCH(T, P, R, TO)                                                                                  \
   hipLaunchKernelGGL((k_bn_relu_pool_fwd<T, P, R, TO>), dim3(grid), dim3(256), 0, s, (const T*)y, mean, invstd, \
-                     gamma, beta, (TO*)z, B, H, W, C)
+                     gamma, beta, (TO*)z, B, H, W, C, (split_t*)nullptr)
+#define LAUNCH_DUAL(P, R)                                                                                            \
+  hipLaunchKernelGGL((k_bn_relu_pool_fwd<float, P, R, splith_t, true>), dim3(grid), dim3(256), 0, s, (const float*)y, \
+                     mean, invstd, gamma, beta, (splith_t*)z, B, H, W, C, (split_t*)z2)
 #define LAUNCH4(T, TO)                                                           \
   do {                                                                           \
     if (norelu) { if (pool) LAUNCH(T, 1, 0, TO); else LAUNCH(T, 0, 0, TO); }     \
     else { if (pool) LAUNCH(T, 1, 1, TO); else LAUNCH(T, 0, 1, TO); }            \
   } while (0)
-  if (out_dt == SFOD_BF16X3) LAUNCH4(float, split_t);
+  if (z2 != nullptr) {
+    if (norelu) { if (pool) LAUNCH_DUAL(1, 0); else LAUNCH_DUAL(0, 0); }
+    else { if (pool) LAUNCH_DUAL(1, 1); else LAUNCH_DUAL(0, 1); }
+  } else if (out_dt == SFOD_BF16X3) LAUNCH4(float, split_t);
+  else if (out_dt == SFOD_F16X3) LAUNCH4(float, splith_t);
   else if (dt == SFOD_F32) LAUNCH4(float, float);
   else LAUNCH4(bf16_t, bf16_t);
 #undef LAUNCH4
+#undef LAUNCH_DUAL
 #undef LAUNCH
   return sfod_check_launch("bn_relu_pool_fwd");
+}
+
+extern "C" int sfod_bn_relu_pool_fwd(const void* y, const float* mean, const float* invstd,
+                                     const float* gamma, const float* beta, void* z, int B, int H, int W,
+                                     int C, int pool_flags, int dt, int out_dt, void* stream) {
+  return sfod_bn_relu_pool_fwd2(y, mean, invstd, gamma, beta, z, nullptr, B, H, W, C, pool_flags, dt, out_dt, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1069,14 +1106,18 @@ __global__ void k_add_act(const T* __restrict__ a, const T* __restrict__ b, T* _
 }
 
 extern "C" int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, int64_t n, int act, int dt,
-                            void* stream) {
+                            int pairs_dt, void* stream) {
   const int V = (dt == SFOD_F32 && out_pairs == nullptr) ? 4 : 8;
   SFOD_REQUIRE(n % V == 0, "add_act: n not a multiple of the vector width");
-  SFOD_REQUIRE(out_pairs == nullptr || dt == SFOD_F32, "add_act: the operand-pair copy is made from fp32 data");
+  SFOD_REQUIRE(out_pairs == nullptr || (dt == SFOD_F32 && sfod_is_pairs(pairs_dt)),
+               "add_act: the operand-pair copy (SFOD_BF16X3 / SFOD_F16X3) is made from fp32 data");
   const int64_t nvec = n / V;
   if (nvec == 0) return 0;
-  if (out_pairs != nullptr)
-    hipLaunchKernelGGL(k_add_act_dual, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+  if (out_pairs != nullptr && pairs_dt == SFOD_F16X3)
+    hipLaunchKernelGGL(k_add_act_dual<splith_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
+                       (const float*)b, (float*)out, (splith_t*)out_pairs, nvec, act);
+  else if (out_pairs != nullptr)
+    hipLaunchKernelGGL(k_add_act_dual<split_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
                        (const float*)b, (float*)out, (split_t*)out_pairs, nvec, act);
   else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_add_act<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
@@ -1174,7 +1215,7 @@ __global__ void k_im2col_stem(const T* __restrict__ x, TO* __restrict__ out, int
 extern "C" int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, int out_dt,
                                 void* stream) {
   SFOD_REQUIRE(Kpad >= 152 && Kpad % 8 == 0 && Cp >= 3, "im2col_stem: Kpad must be a multiple of 8 >= 152");
-  SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && out_dt == SFOD_BF16X3), "im2col_stem: output is the input type, or bf16x3 from fp32");
+  SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && sfod_is_pairs(out_dt)), "im2col_stem: output is the input type, or operand pairs from fp32");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int64_t total = (int64_t)B * Ho * Wo * (Kpad / 8);
   if (total == 0) return 0;
@@ -1182,6 +1223,9 @@ extern "C" int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, i
   if (out_dt == SFOD_BF16X3)
     hipLaunchKernelGGL((k_im2col_stem<float, split_t>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x,
                        (split_t*)out, B, H, W, Cp, Kpad);
+  else if (out_dt == SFOD_F16X3)
+    hipLaunchKernelGGL((k_im2col_stem<float, splith_t>), dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x,
+                       (splith_t*)out, B, H, W, Cp, Kpad);
   else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_im2col_stem<float>, dim3(ew_grid(total)), dim3(256), 0, s, (const float*)x, (float*)out, B, H,
                        W, Cp, Kpad);
@@ -1239,9 +1283,38 @@ extern "C" int sfod_maxpool3s2(const void* x, void* y, int B, int H, int W, int 
 // ---------------------------------------------------------------------------------------------
 // weight packing
 // ---------------------------------------------------------------------------------------------
+// max|w| of fp32 tensors as the bit pattern of a non-negative float (orders like an unsigned; a NaN wins), combined
+// with atomicMax into amax[blockIdx.y] (zeroed by the caller): the per-tensor scale of SFOD_F16X3 weights (common.h).
+// desc == nullptr: one tensor (w, count); else entry blockIdx.y of a sfod_pack_conv_weights_multi table.
+__global__ void __launch_bounds__(256)
+k_weight_absmax(const float* __restrict__ w, int64_t count, const long long* __restrict__ desc, unsigned* __restrict__ amax) {
+  if (desc != nullptr) {
+    const int e = blockIdx.y;
+    w = reinterpret_cast<const float*>(desc[e * 8 + 0]);
+    count = (int64_t)desc[e * 8 + 2] * desc[e * 8 + 3] * desc[e * 8 + 4] * desc[e * 8 + 4];
+  }
+  unsigned m = 0;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += stride)
+    m = max(m, __float_as_uint(w[i]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m != 0) atomicMax(amax + blockIdx.y, m);
+}
+static int launch_weight_absmax(const float* w, int64_t count, const long long* desc, int n, unsigned* amax, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(amax, 0, sizeof(unsigned) * n, s);
+  if (e != hipSuccess) { sfod_set_error("weight absmax: %s", hipGetErrorString(e)); return -(int)e; }
+  int gx = desc != nullptr ? 32 : (int)((count + 256 * 64 - 1) / (256 * 64));      // >= 64 elements per thread
+  if (gx > 512) gx = 512;
+  if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(k_weight_absmax, dim3(gx, n), dim3(256), 0, s, w, count, desc, amax);
+  return sfod_check_launch("weight_absmax");
+}
+
 template <typename T>
 __global__ void k_pack_conv_weight(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin,
-                                   int ks, int innerPad, int rot180) {
+                                   int ks, int innerPad, int rot180, const unsigned* __restrict__ amax) {
+  const float ws = amax != nullptr ? wscale_from_absmax(*amax) : 1.0f;     // SFOD_F16X3: per-tensor power of two (common.h)
   // normal : out[co][tap][ci]  (inner = Cin  -> innerPad)
   // rot180 : out[ci][tap'][co] (inner = Cout -> innerPad), tap' = flipped tap
   const int taps = ks * ks;
@@ -1259,25 +1332,40 @@ __global__ void k_pack_conv_weight(const float* __restrict__ w, T* __restrict__ 
       const int st = rot180 ? (taps - 1 - tap) : tap;
       v = w[((int64_t)co * Cin + ci) * taps + st];
     }
-    put_elem<T>(out, t, v);
+    put_elem<T>(out, t, v * ws);
   }
+}
+
+extern "C" int sfod_pack_conv_weight_ws(const float* w_oihw, void* w_packed, uint32_t* absmax, int Cout, int Cin,
+                                        int ksize, int CinPad, int rot180, int dt, void* stream) {
+  const int rows = rot180 ? Cin : Cout;
+  const int64_t total = (int64_t)rows * ksize * ksize * CinPad;
+  hipStream_t s = (hipStream_t)stream;
+  SFOD_REQUIRE(absmax == nullptr || dt == SFOD_F16X3, "pack_conv_weight: the per-tensor scale belongs to SFOD_F16X3");
+  if (absmax != nullptr) {
+    const int rc = launch_weight_absmax(w_oihw, (int64_t)Cout * Cin * ksize * ksize, nullptr, 1, absmax, s);
+    if (rc) return rc;
+  }
+  if (sfod_is_pairs(dt)) {
+    SFOD_REQUIRE(CinPad % 8 == 0, "pack_conv_weight: operand pairs need an inner size that is a multiple of 8");
+    if (dt == SFOD_F16X3)
+      hipLaunchKernelGGL(k_pack_conv_weight<splith_t>, dim3(ew_grid(total)), dim3(256), 0, s,
+                         w_oihw, (splith_t*)w_packed, Cout, Cin, ksize, CinPad, rot180, (const unsigned*)absmax);
+    else
+      hipLaunchKernelGGL(k_pack_conv_weight<split_t>, dim3(ew_grid(total)), dim3(256), 0, s,
+                         w_oihw, (split_t*)w_packed, Cout, Cin, ksize, CinPad, rot180, (const unsigned*)nullptr);
+  } else if (dt == SFOD_F32)
+    hipLaunchKernelGGL(k_pack_conv_weight<float>, dim3(ew_grid(total)), dim3(256), 0, s,
+                       w_oihw, (float*)w_packed, Cout, Cin, ksize, CinPad, rot180, (const unsigned*)nullptr);
+  else
+    hipLaunchKernelGGL(k_pack_conv_weight<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s,
+                       w_oihw, (bf16_t*)w_packed, Cout, Cin, ksize, CinPad, rot180, (const unsigned*)nullptr);
+  return sfod_check_launch("pack_conv_weight");
 }
 
 extern "C" int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Cout, int Cin, int ksize,
                                      int CinPad, int rot180, int dt, void* stream) {
-  const int rows = rot180 ? Cin : Cout;
-  const int64_t total = (int64_t)rows * ksize * ksize * CinPad;
-  if (dt == SFOD_BF16X3) {
-    SFOD_REQUIRE(CinPad % 8 == 0, "pack_conv_weight: bf16x3 needs an inner size that is a multiple of 8");
-    hipLaunchKernelGGL(k_pack_conv_weight<split_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, (split_t*)w_packed, Cout, Cin, ksize, CinPad, rot180);
-  } else if (dt == SFOD_F32)
-    hipLaunchKernelGGL(k_pack_conv_weight<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, (float*)w_packed, Cout, Cin, ksize, CinPad, rot180);
-  else
-    hipLaunchKernelGGL(k_pack_conv_weight<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, (bf16_t*)w_packed, Cout, Cin, ksize, CinPad, rot180);
-  return sfod_check_launch("pack_conv_weight");
+  return sfod_pack_conv_weight_ws(w_oihw, w_packed, nullptr, Cout, Cin, ksize, CinPad, rot180, dt, stream);
 }
 
 // All conv weights of a model in ONE launch.  desc: n entries of 8 int64
@@ -1289,7 +1377,7 @@ extern "C" int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Co
 #define PACK_T 32
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_pack_conv_weights_multi(const long long* __restrict__ desc, int n) {
+k_pack_conv_weights_multi(const long long* __restrict__ desc, int n, const unsigned* __restrict__ amax) {
   __shared__ float tile[PACK_T][PACK_T * 9 + 1];
   // the entry that owns this workgroup: last e with first_block[e] <= blockIdx.x (binary search over uniform scalar
   // loads; the linear scan cost ResNet-101's 200-entry table 3 ms per launch)
@@ -1302,6 +1390,7 @@ k_pack_conv_weights_multi(const long long* __restrict__ desc, int n) {
   T* __restrict__ out = reinterpret_cast<T*>(desc[e * 8 + 1]);
   const int Cout = (int)desc[e * 8 + 2], Cin = (int)desc[e * 8 + 3], ks = (int)desc[e * 8 + 4];
   const int innerPad = (int)desc[e * 8 + 5], rot180 = (int)desc[e * 8 + 6];
+  const float ws = amax != nullptr ? wscale_from_absmax(amax[e]) : 1.0f;   // SFOD_F16X3: per-tensor power of two (common.h)
   // tile grid: rows of the packed tensor x inner (padded) axis
   const int rowsN = rot180 ? Cin : Cout;
   const int tiles_inner = (innerPad + PACK_T - 1) / PACK_T;
@@ -1327,7 +1416,7 @@ k_pack_conv_weights_multi(const long long* __restrict__ desc, int n) {
       if (row >= rowsN || inner >= innerPad) continue;
       const int col = rot180 ? il : rl, cl = rot180 ? rl : il;
       const int st = rot180 ? (taps - 1 - tap) : tap;
-      put_elem<T>(out, ((int64_t)row * taps + tap) * innerPad + inner, tile[col][cl * taps + st]);
+      put_elem<T>(out, ((int64_t)row * taps + tap) * innerPad + inner, tile[col][cl * taps + st] * ws);
     }
   };
   if (ks == 3) body(std::integral_constant<int, 9>{});
@@ -1340,18 +1429,30 @@ extern "C" int sfod_pack_conv_weights_blocks(int Cout, int Cin, int ksize, int i
   return ((rowsN + PACK_T - 1) / PACK_T) * ((innerPad + PACK_T - 1) / PACK_T);
 }
 
-extern "C" int sfod_pack_conv_weights_multi(const int64_t* desc, int n, int total_blocks, int dt, void* stream) {
+extern "C" int sfod_pack_conv_weights_multi_ws(const int64_t* desc, int n, int total_blocks, int dt, uint32_t* absmax,
+                                               void* stream) {
   SFOD_REQUIRE(n >= 1 && total_blocks >= 1, "pack_multi: empty table (kernel sizes 1 and 3 only)");
+  SFOD_REQUIRE(absmax == nullptr || dt == SFOD_F16X3, "pack_multi: the per-tensor scales belong to SFOD_F16X3");
+  hipStream_t s = (hipStream_t)stream;
+  if (absmax != nullptr) {
+    const int rc = launch_weight_absmax(nullptr, 0, (const long long*)desc, n, absmax, s);
+    if (rc) return rc;
+  }
+  const unsigned* am = absmax;
+  const unsigned* none = nullptr;
   if (dt == SFOD_BF16X3)    // every innerPad of the table must be a multiple of 8 (caller's contract)
-    hipLaunchKernelGGL(k_pack_conv_weights_multi<split_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)desc, n);
+    hipLaunchKernelGGL(k_pack_conv_weights_multi<split_t>, dim3(total_blocks), dim3(256), 0, s, (const long long*)desc, n, none);
+  else if (dt == SFOD_F16X3)
+    hipLaunchKernelGGL(k_pack_conv_weights_multi<splith_t>, dim3(total_blocks), dim3(256), 0, s, (const long long*)desc, n, am);
   else if (dt == SFOD_F32)
-    hipLaunchKernelGGL(k_pack_conv_weights_multi<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)desc, n);
+    hipLaunchKernelGGL(k_pack_conv_weights_multi<float>, dim3(total_blocks), dim3(256), 0, s, (const long long*)desc, n, none);
   else
-    hipLaunchKernelGGL(k_pack_conv_weights_multi<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                       (const long long*)desc, n);
+    hipLaunchKernelGGL(k_pack_conv_weights_multi<bf16_t>, dim3(total_blocks), dim3(256), 0, s, (const long long*)desc, n, none);
   return sfod_check_launch("pack_conv_weights_multi");
+}
+
+extern "C" int sfod_pack_conv_weights_multi(const int64_t* desc, int n, int total_blocks, int dt, void* stream) {
+  return sfod_pack_conv_weights_multi_ws(desc, n, total_blocks, dt, nullptr, stream);
 }
 
 __global__ void k_unpack_conv_wgrad(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
@@ -1379,7 +1480,8 @@ extern "C" int sfod_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, in
 // nn.Linear weight [N][K]; K axis optionally permuted (c,p)->(p,c); optional transpose.
 template <typename T>
 __global__ void k_pack_fc_weight(const float* __restrict__ w, T* __restrict__ out, int N, int K, int chw_c,
-                                 int transpose, int ld) {
+                                 int transpose, int ld, const unsigned* __restrict__ amax) {
+  const float ws = amax != nullptr ? wscale_from_absmax(*amax) : 1.0f;
   const int rows = transpose ? K : N;
   const int64_t total = (int64_t)rows * ld;
   const int PP = chw_c > 0 ? K / chw_c : 1;
@@ -1395,7 +1497,7 @@ __global__ void k_pack_fc_weight(const float* __restrict__ w, T* __restrict__ ou
       if (chw_c > 0) { const int p = kp / chw_c, c = kp % chw_c; k = c * PP + p; }
       v = w[(int64_t)n * K + k];
     }
-    put_elem<T>(out, t, v);
+    put_elem<T>(out, t, v * ws);
   }
 }
 
@@ -1407,7 +1509,9 @@ extern "C" int sfod_pack_fc_weight(const float* w, void* out, int N, int K, int 
 // (contiguous (c, p) runs of one output row) and the write (contiguous c / contiguous n) are coalesced.
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_pack_fc_chw(const float* __restrict__ w, T* __restrict__ out, int N, int C, int PP, int ld) {
+k_pack_fc_chw(const float* __restrict__ w, T* __restrict__ out, int N, int C, int PP, int ld,
+              const unsigned* __restrict__ amax) {
+  const float ws = amax != nullptr ? wscale_from_absmax(*amax) : 1.0f;
   // block = (row n, 64 channels): tile[c][p], out[n][p*C + c]
   extern __shared__ float tile[];     // [64][PP]
   const int n = blockIdx.y, c0 = blockIdx.x * 64;
@@ -1418,13 +1522,15 @@ k_pack_fc_chw(const float* __restrict__ w, T* __restrict__ out, int N, int C, in
   T* dst = out + (int64_t)n * ld;
   for (int j = threadIdx.x; j < PP * 64; j += 256) {
     const int p = j >> 6, cl = j & 63;
-    if (cl < cw) put_elem<T>(dst, (int64_t)p * C + c0 + cl, tile[cl * PP + p]);
+    if (cl < cw) put_elem<T>(dst, (int64_t)p * C + c0 + cl, tile[cl * PP + p] * ws);
   }
 }
 
 template <typename T>
 __global__ void __launch_bounds__(256)
-k_pack_fc_chw_t(const float* __restrict__ w, T* __restrict__ out, int N, int C, int PP, int ld) {
+k_pack_fc_chw_t(const float* __restrict__ w, T* __restrict__ out, int N, int C, int PP, int ld,
+                const unsigned* __restrict__ amax) {
+  const float ws = amax != nullptr ? wscale_from_absmax(*amax) : 1.0f;
   // block = (64 rows n, 4 channels): tile[n][c][p], out[(p*C + c)][n]
   extern __shared__ float tile[];     // [64][4*PP + 1]
   const int n0 = blockIdx.y * 64, c0 = blockIdx.x * 4;
@@ -1439,45 +1545,58 @@ k_pack_fc_chw_t(const float* __restrict__ w, T* __restrict__ out, int N, int C, 
     const int r = j >> 6, nl = j & 63;          // r = cl * PP + p
     if (nl < nw) {
       const int cl = r / PP, p = r - cl * PP;
-      put_elem<T>(out, ((int64_t)p * C + c0 + cl) * ld + n0 + nl, tile[nl * pitch + r]);
+      put_elem<T>(out, ((int64_t)p * C + c0 + cl) * ld + n0 + nl, tile[nl * pitch + r] * ws);
     }
   }
 }
 
-extern "C" int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose,
-                                      int ld, int dt, void* stream) {
+extern "C" int sfod_pack_fc_weight_ld_ws(const float* w, void* out, uint32_t* absmax, int N, int K, int chw_c,
+                                         int transpose, int ld, int dt, void* stream) {
   SFOD_REQUIRE(ld >= (transpose ? N : K), "pack_fc_weight: ld too small");
-  SFOD_REQUIRE(dt != SFOD_BF16X3 || ld % 8 == 0, "pack_fc_weight: bf16x3 needs ld % 8 == 0");
+  SFOD_REQUIRE(!sfod_is_pairs(dt) || ld % 8 == 0, "pack_fc_weight: operand pairs need ld % 8 == 0");
+  SFOD_REQUIRE(absmax == nullptr || dt == SFOD_F16X3, "pack_fc_weight: the per-tensor scale belongs to SFOD_F16X3");
+  hipStream_t s = (hipStream_t)stream;
+  if (absmax != nullptr) {
+    const int rc = launch_weight_absmax(w, (int64_t)N * K, nullptr, 1, absmax, s);
+    if (rc) return rc;
+  }
+  const unsigned* am = absmax;
+  const unsigned* none = nullptr;
   if (chw_c > 0 && K % chw_c == 0 && K / chw_c <= 64 && (int64_t)N * K >= (1 << 20) &&
       ld == (transpose ? N : K)) {
     const int C = chw_c, PP = K / chw_c;
-    hipStream_t s = (hipStream_t)stream;
     if (!transpose) {
       const dim3 grid(cdiv(C, 64), N);
       const size_t lds = (size_t)64 * PP * 4;
-      if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld);
-      else if (dt == SFOD_BF16X3) hipLaunchKernelGGL(k_pack_fc_chw<split_t>, grid, dim3(256), lds, s, w, (split_t*)out, N, C, PP, ld);
-      else hipLaunchKernelGGL(k_pack_fc_chw<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld);
+      if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld, none);
+      else if (dt == SFOD_BF16X3) hipLaunchKernelGGL(k_pack_fc_chw<split_t>, grid, dim3(256), lds, s, w, (split_t*)out, N, C, PP, ld, none);
+      else if (dt == SFOD_F16X3) hipLaunchKernelGGL(k_pack_fc_chw<splith_t>, grid, dim3(256), lds, s, w, (splith_t*)out, N, C, PP, ld, am);
+      else hipLaunchKernelGGL(k_pack_fc_chw<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld, none);
     } else {
       const dim3 grid(cdiv(C, 4), cdiv(N, 64));
       const size_t lds = (size_t)64 * (4 * PP + 1) * 4;
-      if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw_t<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld);
-      else if (dt == SFOD_BF16X3) hipLaunchKernelGGL(k_pack_fc_chw_t<split_t>, grid, dim3(256), lds, s, w, (split_t*)out, N, C, PP, ld);
-      else hipLaunchKernelGGL(k_pack_fc_chw_t<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld);
+      if (dt == SFOD_F32) hipLaunchKernelGGL(k_pack_fc_chw_t<float>, grid, dim3(256), lds, s, w, (float*)out, N, C, PP, ld, none);
+      else if (dt == SFOD_BF16X3) hipLaunchKernelGGL(k_pack_fc_chw_t<split_t>, grid, dim3(256), lds, s, w, (split_t*)out, N, C, PP, ld, none);
+      else if (dt == SFOD_F16X3) hipLaunchKernelGGL(k_pack_fc_chw_t<splith_t>, grid, dim3(256), lds, s, w, (splith_t*)out, N, C, PP, ld, am);
+      else hipLaunchKernelGGL(k_pack_fc_chw_t<bf16_t>, grid, dim3(256), lds, s, w, (bf16_t*)out, N, C, PP, ld, none);
     }
     return sfod_check_launch("pack_fc_weight(chw)");
   }
   const int64_t total = (int64_t)(transpose ? K : N) * ld;
   if (dt == SFOD_BF16X3)
-    hipLaunchKernelGGL(k_pack_fc_weight<split_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
-                       (split_t*)out, N, K, chw_c, transpose, ld);
+    hipLaunchKernelGGL(k_pack_fc_weight<split_t>, dim3(ew_grid(total)), dim3(256), 0, s, w, (split_t*)out, N, K, chw_c, transpose, ld, none);
+  else if (dt == SFOD_F16X3)
+    hipLaunchKernelGGL(k_pack_fc_weight<splith_t>, dim3(ew_grid(total)), dim3(256), 0, s, w, (splith_t*)out, N, K, chw_c, transpose, ld, am);
   else if (dt == SFOD_F32)
-    hipLaunchKernelGGL(k_pack_fc_weight<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
-                       (float*)out, N, K, chw_c, transpose, ld);
+    hipLaunchKernelGGL(k_pack_fc_weight<float>, dim3(ew_grid(total)), dim3(256), 0, s, w, (float*)out, N, K, chw_c, transpose, ld, none);
   else
-    hipLaunchKernelGGL(k_pack_fc_weight<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, w,
-                       (bf16_t*)out, N, K, chw_c, transpose, ld);
+    hipLaunchKernelGGL(k_pack_fc_weight<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, s, w, (bf16_t*)out, N, K, chw_c, transpose, ld, none);
   return sfod_check_launch("pack_fc_weight");
+}
+
+extern "C" int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose,
+                                      int ld, int dt, void* stream) {
+  return sfod_pack_fc_weight_ld_ws(w, out, nullptr, N, K, chw_c, transpose, ld, dt, stream);
 }
 
 extern "C" int sfod_pack_fc_weight(const float* w, void* out, int N, int K, int chw_c, int transpose,
@@ -1723,21 +1842,42 @@ __global__ void k_cast8(const S* __restrict__ s, D* __restrict__ d, int64_t n8) 
     store_n<D, 8>(d + i * 8, v);
   }
 }
+// fp32 -> SFOD_F16X3 pairs AND SFOD_BF16X3 pairs in one pass ("f16x3" mode: forward operand + weight-gradient operand)
+__global__ void k_cast8_both(const float* __restrict__ s, splith_t* __restrict__ dh, split_t* __restrict__ db, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    float v[8];
+    load_n<float, 8>(s + i * 8, v);
+    store_n<splith_t, 8>(dh + i * 8, v);
+    store_n<split_t, 8>(db + i * 8, v);
+  }
+}
+extern "C" int sfod_cast_pairs_both(const float* src, void* dst_f16x3, void* dst_bf16x3, int64_t n, void* stream) {
+  SFOD_REQUIRE(n % 8 == 0, "cast_pairs_both: operand-pair tensors hold whole 8-element groups");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_cast8_both, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, src, (splith_t*)dst_f16x3,
+                     (split_t*)dst_bf16x3, n / 8);
+  return sfod_check_launch("cast_pairs_both");
+}
+
 extern "C" int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int dst_dt, void* stream) {
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 g(ew_grid(n)), b(256);
-  if (src_dt == SFOD_BF16X3 || dst_dt == SFOD_BF16X3) {
-    SFOD_REQUIRE(n % 8 == 0, "cast: bf16x3 tensors hold whole 8-element groups");
+  if (sfod_is_pairs(src_dt) || sfod_is_pairs(dst_dt)) {
+    SFOD_REQUIRE(n % 8 == 0, "cast: operand-pair tensors hold whole 8-element groups");
     const dim3 g8(ew_grid(n / 8));
-    if (src_dt == SFOD_F32 && dst_dt == SFOD_BF16X3)
-      hipLaunchKernelGGL((k_cast8<float, split_t>), g8, b, 0, s, (const float*)src, (split_t*)dst, n / 8);
-    else if (src_dt == SFOD_BF16X3 && dst_dt == SFOD_F32)
-      hipLaunchKernelGGL((k_cast8<split_t, float>), g8, b, 0, s, (const split_t*)src, (float*)dst, n / 8);
-    else if (src_dt == SFOD_BF16X3 && dst_dt == SFOD_BF16X3)
-      hipLaunchKernelGGL((k_cast8<split_t, split_t>), g8, b, 0, s, (const split_t*)src, (split_t*)dst, n / 8);
+#define CAST8(S, D) hipLaunchKernelGGL((k_cast8<S, D>), g8, b, 0, s, (const S*)src, (D*)dst, n / 8)
+    if (src_dt == SFOD_F32 && dst_dt == SFOD_BF16X3) CAST8(float, split_t);
+    else if (src_dt == SFOD_F32 && dst_dt == SFOD_F16X3) CAST8(float, splith_t);
+    else if (src_dt == SFOD_BF16X3 && dst_dt == SFOD_F32) CAST8(split_t, float);
+    else if (src_dt == SFOD_F16X3 && dst_dt == SFOD_F32) CAST8(splith_t, float);
+    else if (src_dt == SFOD_BF16X3 && dst_dt == SFOD_BF16X3) CAST8(split_t, split_t);
+    else if (src_dt == SFOD_F16X3 && dst_dt == SFOD_F16X3) CAST8(splith_t, splith_t);
+    else if (src_dt == SFOD_F16X3 && dst_dt == SFOD_BF16X3) CAST8(splith_t, split_t);   // re-split of hi + lo
+    else if (src_dt == SFOD_BF16X3 && dst_dt == SFOD_F16X3) CAST8(split_t, splith_t);
     else
-      SFOD_REQUIRE(false, "cast: bf16x3 converts from / to fp32 only");
+      SFOD_REQUIRE(false, "cast: operand pairs convert from / to fp32 and each other only");
+#undef CAST8
     return sfod_check_launch("cast");
   }
   if (src_dt == SFOD_F32 && dst_dt == SFOD_BF16)

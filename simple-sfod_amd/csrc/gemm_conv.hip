@@ -38,6 +38,7 @@ struct ConvArgs {
   int kchunks;    // total 16-byte chunks along K = taps * Cin * sizeof(T) / 16
   int ldy;        // row stride of y
   int act;        // 0 none, 1 relu, 2 leaky relu 0.2
+  const unsigned* wamax;   // SFOD_F16X3 weights packed with a per-tensor power-of-two scale (common.h): max|w| bits, or nullptr
 };
 
 template <typename T> struct Chunk { static constexpr int E = 16 / sizeof(T); };
@@ -68,13 +69,14 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 // NST = LDS stages: 2 = load(t+1) || compute(t) with a full drain per K tile; 3 = two K tiles in
 // flight across raw s_barriers with a counted s_waitcnt vmcnt (the DMA queue is never drained
 // inside the loop).
-// SPLIT (SFOD_BF16X3): T = bf16 over 2 * Cin physical channels holding (8 hi | 8 lo) groups; a 128-byte LDS row is
-// then 32 logical channels = two k-steps, each fed as hi*lo + lo*hi + hi*hi (fp32-equivalent product, see sfod_hip.h).
+// SPLIT (1: SFOD_BF16X3, 2: SFOD_F16X3): T = 16-bit words over 2 * Cin physical channels holding (8 hi | 8 lo) groups; a
+// 128-byte LDS row is then 32 logical channels = two k-steps, each fed as hi*lo + lo*hi + hi*hi (see sfod_hip.h); the two
+// pair formats differ in the MFMA opcode only.
 // BKB = bytes per LDS row (K extent of a stage): 128 (8 chunks), or 64 (4 chunks; bf16x3: ONE k-step per stage) for the
 // 256 x 256 tile (WN = 4: wave tile 64 x 128) whose three stages of 128-byte rows would not fit LDS.  The wide tile moves
 // 1/3 fewer operand bytes L2 -> LDS per MFMA than 256 x 128 -- the bound of the long-K linear layers in bf16x3, whose
 // operands are 4 bytes per element.
-template <typename T, typename OutT, int WM, int WN, bool UT, int WR, int NST, bool SPLIT = false, int BKB = 128>
+template <typename T, typename OutT, int WM, int WN, bool UT, int WR, int NST, int SPLIT = 0, int BKB = 128>
 __global__ void __launch_bounds__(WR * 128)
 k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __restrict__ bias,
            OutT* __restrict__ y, float* __restrict__ stats, ConvArgs a, int tiles_n, int ntiles) {
@@ -256,17 +258,17 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_pairs<SPLIT>(ah[i], bl[j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_pairs<SPLIT>(al[i], bh[j], acc[i][j]);
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
           for (int j = 0; j < WN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+            acc[i][j] = mfma_pairs<SPLIT>(ah[i], bh[j], acc[i][j]);
       }
     } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -343,6 +345,17 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
     }
   }
 
+  if constexpr (SPLIT == 2) {     // undo the packed weights' power-of-two scale (exact)
+    if (a.wamax != nullptr) {
+      const float inv = winv_from_absmax(*a.wamax);
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+    }
+  }
   // ---- epilogue: bias + activation + store; optional per-block BN partial statistics ----------
   float bcol[WN];
   for (int j = 0; j < WN; ++j) {
@@ -467,8 +480,10 @@ extern "C" int sfod_set_conv_algo(int algo) { g_conv_algo_v.store(algo, std::mem
 
 // SFOD_BF16X3 tensors are bf16 tensors with twice the channels (8 hi | 8 lo groups) as far as DMA, LDS layout and
 // tile plans are concerned: the kernels below are planned / launched on the PHYSICAL channel count.
-static inline bool is_bf16_storage(int dt) { return dt == SFOD_BF16 || dt == SFOD_BF16X3; }
-static inline int phys_ch(int dt, int c) { return dt == SFOD_BF16X3 ? 2 * c : c; }
+// SFOD_F16X3: the same with half pairs -- only the MFMA opcode of the forward kernels differs (split_code).
+static inline bool is_bf16_storage(int dt) { return dt == SFOD_BF16 || sfod_is_pairs(dt); }
+static inline int phys_ch(int dt, int c) { return sfod_is_pairs(dt) ? 2 * c : c; }
+static inline int split_code(int dt) { return dt == SFOD_BF16X3 ? 1 : (dt == SFOD_F16X3 ? 2 : 0); }
 
 static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, int dt) {
   if (ksize != 3 || !is_bf16_storage(dt) || !p.ok || g_conv_algo == 1) return false;
@@ -480,7 +495,7 @@ static bool use_patch_kernel(const P3Plan& p, int B, int H, int W, int ksize, in
 
 // first VGG layer: 3 real channels in one 8-wide chunk, 64 outputs; bf16 in / bf16 out, or bf16x3 pairs in / fp32 out
 static bool use_first_kernel(int B, int H, int W, int Cin, int Cout, int ksize, int dt, int ldy, int out_dt) {
-  const bool types = (dt == SFOD_BF16 && out_dt == SFOD_BF16) || (dt == SFOD_BF16X3 && out_dt == SFOD_F32);
+  const bool types = (dt == SFOD_BF16 && out_dt == SFOD_BF16) || (sfod_is_pairs(dt) && out_dt == SFOD_F32);
   return ksize == 3 && types && Cin == 8 && Cout == 64 && ldy % 8 == 0 &&
          g_conv_algo != 1 && (int64_t)B * H * W >= 4096;
 }
@@ -488,20 +503,20 @@ static bool use_first_kernel(int B, int H, int W, int Cin, int Cout, int ksize, 
 static bool use_wide_gemm(int M, int Cout, int ks);
 
 extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
-  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, dt == SFOD_BF16X3 ? SFOD_F32 : SFOD_BF16)) return 3;
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16)) return 3;
   const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return 2;
-  return (dt == SFOD_BF16X3 && use_wide_gemm(B * H * W, Cout, ksize)) ? 4 : 1;     // (fp32 output assumed: bf16x3 has no other)
+  return (sfod_is_pairs(dt) && use_wide_gemm(B * H * W, Cout, ksize)) ? 4 : 1;     // (fp32 output assumed: bf16x3 has no other)
 }
 
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
-  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, dt == SFOD_BF16X3 ? SFOD_F32 : SFOD_BF16)) return sfod_f1_nblk(B, H, W);
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16)) return sfod_f1_nblk(B, H, W);
   const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;
   return (B * H * W + 127) / 128;
 }
 
-template <typename T, typename OutT, int WN, bool UT, int WR, int NST, bool SPLIT = false, int BKB = 128>
+template <typename T, typename OutT, int WN, bool UT, int WR, int NST, int SPLIT = 0, int BKB = 128>
 static int launch_one(const void* x, const void* w, const float* bias, void* y, float* stats,
                       const ConvArgs& a, hipStream_t s) {
   constexpr int BM = WR * 64, BN = 64 * WN;
@@ -533,7 +548,7 @@ static bool use_wide_gemm(int M, int Cout, int ks) {
   return wide == 2 || (t256 >= 200 && r256 * 0.80 <= r128);
 }
 
-template <typename T, typename OutT, bool UT, bool SPLIT = false>
+template <typename T, typename OutT, bool UT, int SPLIT = 0>
 static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
                               const ConvArgs& a, hipStream_t s) {
   if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
@@ -573,7 +588,7 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
   return launch_one<T, OutT, 2, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
 }
 
-template <typename T, typename OutT, bool SPLIT = false>
+template <typename T, typename OutT, int SPLIT = 0>
 static int launch_conv_fwd(const void* x, const void* w, const float* bias, void* y, float* stats,
                            const ConvArgs& a, hipStream_t s) {
   const int cpt = a.Cin / Chunk<T>::E;
@@ -583,40 +598,56 @@ static int launch_conv_fwd(const void* x, const void* w, const float* bias, void
 }
 
 extern "C" int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, int ldy) {
-  return use_first_kernel(B, H, W, Cin, Cout, 3, dt, ldy, dt == SFOD_BF16X3 ? SFOD_F32 : SFOD_BF16) ? 1 : 0;
+  return use_first_kernel(B, H, W, Cin, Cout, 3, dt, ldy, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16) ? 1 : 0;
 }
 
 extern "C" int sfod_conv_first_fused(const void* x, const void* w, const float* bias, const float* scale,
                                      const float* shift, void* y, float* stats, int B, int H, int W, int ldy,
                                      int act, int dt, void* stream) {
+  return sfod_conv_first_fused_ws(x, w, nullptr, bias, scale, shift, y, stats, B, H, W, ldy, act, dt, stream);
+}
+
+extern "C" int sfod_conv_first_fused_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias,
+                                        const float* scale, const float* shift, void* y, float* stats, int B, int H,
+                                        int W, int ldy, int act, int dt, void* stream) {
+  SFOD_REQUIRE(w_absmax == nullptr || dt == SFOD_F16X3, "conv_first: scaled weights are an SFOD_F16X3 format");
   SFOD_REQUIRE(sfod_conv_first_supported(B, H, W, 8, 64, dt, ldy),
                "conv_first_fused: shape not served by the first-layer kernel (sfod_conv_first_supported)");
   SFOD_REQUIRE(y != nullptr || stats != nullptr, "conv_first_fused: nothing to produce");
   SFOD_REQUIRE((scale == nullptr) == (shift == nullptr), "conv_first_fused: scale and shift come together");
-  return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, (hipStream_t)stream, scale, shift, dt == SFOD_BF16X3);
+  return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, (hipStream_t)stream, scale, shift, split_code(dt), w_absmax);
 }
 
 extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
                              int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
                              int out_dt, void* stream) {
+  return sfod_conv_fwd_ws(x, w, nullptr, bias, y, B, H, W, Cin, Cout, ksize, ldy, act, stats, dt, out_dt, stream);
+}
+
+extern "C" int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B,
+                                int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
+                                int out_dt, void* stream) {
+  SFOD_REQUIRE(w_absmax == nullptr || dt == SFOD_F16X3, "conv: scaled weights are an SFOD_F16X3 format");
   SFOD_REQUIRE(ksize == 1 || ksize == 3, "conv: ksize must be 1 or 3");
   SFOD_REQUIRE(ldy >= Cout, "conv: ldy < Cout");
   const int E = (dt == SFOD_F32) ? 4 : 8;
-  SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || dt == SFOD_BF16X3, "conv: unknown dt");
-  SFOD_REQUIRE(Cin % E == 0, "conv: Cin must be a multiple of the 16-byte chunk (bf16x3: of 8)");
-  SFOD_REQUIRE(dt != SFOD_BF16X3 || out_dt == SFOD_F32, "conv: bf16x3 operands write fp32");
+  SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || sfod_is_pairs(dt), "conv: unknown dt");
+  SFOD_REQUIRE(Cin % E == 0, "conv: Cin must be a multiple of the 16-byte chunk (operand pairs: of 8)");
+  SFOD_REQUIRE(!sfod_is_pairs(dt) || out_dt == SFOD_F32, "conv: operand pairs write fp32");
   if ((int64_t)B * H * W == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, ldy, out_dt))
-    return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, s, nullptr, nullptr, dt == SFOD_BF16X3);
-  const int split = (dt == SFOD_BF16X3);
+    return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, s, nullptr, nullptr, split_code(dt), w_absmax);
+  const int split = split_code(dt);
   Cin = phys_ch(dt, Cin);           // from here on: bf16 channels as stored
   if (ksize == 3 && is_bf16_storage(dt)) {
     const P3Plan p = sfod_p3_plan(B, H, W, Cin, Cout);
     if (use_patch_kernel(p, B, H, W, ksize, dt))
-      return sfod_p3_launch(p, x, w, bias, y, stats, B, H, W, Cin, Cout, ldy, act, out_dt == SFOD_F32, s, split);
+      return sfod_p3_launch(p, x, w, bias, y, stats, B, H, W, Cin, Cout, ldy, act, out_dt == SFOD_F32, s, split, nullptr,
+                            w_absmax);
   }
   ConvArgs a;
+  a.wamax = w_absmax;
   a.M = B * H * W; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ks = ksize; a.ldy = ldy; a.act = act;
   const int cpt = Cin / E;
   a.cpt_shift = 0;
@@ -629,7 +660,8 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
     SFOD_REQUIRE(out_dt == SFOD_F32, "conv: fp32 compute writes fp32");
     return launch_conv_fwd<float, float>(x, w, bias, y, stats, a, s);
   }
-  if (split) return launch_conv_fwd<bf16_t, float, true>(x, w, bias, y, stats, a, s);
+  if (split == 2) return launch_conv_fwd<bf16_t, float, 2>(x, w, bias, y, stats, a, s);
+  if (split) return launch_conv_fwd<bf16_t, float, 1>(x, w, bias, y, stats, a, s);
   if (out_dt == SFOD_F32) return launch_conv_fwd<bf16_t, float>(x, w, bias, y, stats, a, s);
   return launch_conv_fwd<bf16_t, bf16_t>(x, w, bias, y, stats, a, s);
 }
@@ -1099,7 +1131,7 @@ k_conv_wgrad_x3w(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, fl
 }
 
 static bool use_patch_wgrad(const W3Plan& p, int ksize, int dt) {
-  if (ksize != 3 || !is_bf16_storage(dt) || !p.ok || g_conv_algo == 1) return false;
+  if (ksize != 3 || !is_bf16_storage(dt) || dt == SFOD_F16X3 || !p.ok || g_conv_algo == 1) return false;
   if (g_conv_algo == 2) return true;
   // tiny problems: not enough pixel tiles to give every (co, ci) block a few tiles per split
   return p.nsplit * p.tiles_per_split >= 3;
@@ -1113,7 +1145,7 @@ static W3Plan w3_plan_chunked(int B, int H, int W, int Cin, int Cout, int ksize,
   nb = 0;
   W3Plan p;
   p.ok = 0;
-  if (ksize != 3 || !is_bf16_storage(dt) || (int64_t)B * H * W == 0) return p;
+  if (ksize != 3 || !is_bf16_storage(dt) || dt == SFOD_F16X3 || (int64_t)B * H * W == 0) return p;   // half pairs: forward only
   const int split = (dt == SFOD_BF16X3);
   for (int n = B; n >= 1; n = (n == 1) ? 0 : (n + 1) / 2) {
     p = sfod_w3_plan(n, H, W, Cin, Cout, lddy, split);

@@ -88,6 +88,11 @@ template <> struct RVec<split_t> {
   static __device__ __forceinline__ void load(const split_t* p, float* o) { split_load8(p, o); }
   static __device__ __forceinline__ void store(split_t* p, const float* o) { split_store8(p, o); }
 };
+template <> struct RVec<splith_t> {     // SFOD_F16X3: the same with half pairs
+  static constexpr int N = 8;
+  static __device__ __forceinline__ void load(const splith_t* p, float* o) { split_load8(p, o); }
+  static __device__ __forceinline__ void store(splith_t* p, const float* o) { split_store8(p, o); }
+};
 
 // Forward.  One workgroup per ROI; a lane owns one 16-byte channel vector (NHWC: a bilinear corner
 // is one contiguous row segment, so a wavefront reads 1 KiB per corner), the 49 bins are spread over
@@ -171,6 +176,9 @@ template <> struct Pair<bf16_t> {
 
 template <> struct Pair<split_t> {     // only used to zero-fill padding rows: two logical elements = 8 bytes
   static __device__ __forceinline__ void store(split_t* p, float, float) { *reinterpret_cast<uint2*>(p) = make_uint2(0u, 0u); }
+};
+template <> struct Pair<splith_t> {
+  static __device__ __forceinline__ void store(splith_t* p, float, float) { *reinterpret_cast<uint2*>(p) = make_uint2(0u, 0u); }
 };
 
 template <typename T, int P>
@@ -549,6 +557,9 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
     else if (dt == SFOD_BF16X3)
       hipLaunchKernelGGL((k_roi_align_fwd_sep<split_t, 7>), dim3(R), dim3(256), lds, s, (const split_t*)feat, H, W, C,
                          rois, scale, (split_t*)out);
+    else if (dt == SFOD_F16X3)
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<splith_t, 7>), dim3(R), dim3(256), lds, s, (const splith_t*)feat, H, W, C,
+                         rois, scale, (splith_t*)out);
     else
       hipLaunchKernelGGL((k_roi_align_fwd_sep<bf16_t, 7>), dim3(R), dim3(256), lds, s, (const bf16_t*)feat, H, W, C,
                          rois, scale, (bf16_t*)out);
@@ -560,6 +571,9 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
   else if (dt == SFOD_BF16X3)
     hipLaunchKernelGGL(k_roi_align_fwd<split_t>, dim3(R), dim3(256), 0, s, (const split_t*)feat, H, W, C, rois,
                        pooled, scale, (split_t*)out);
+  else if (dt == SFOD_F16X3)
+    hipLaunchKernelGGL(k_roi_align_fwd<splith_t>, dim3(R), dim3(256), 0, s, (const splith_t*)feat, H, W, C, rois,
+                       pooled, scale, (splith_t*)out);
   else
     hipLaunchKernelGGL(k_roi_align_fwd<bf16_t>, dim3(R), dim3(256), 0, s, (const bf16_t*)feat, H, W, C,
                        rois, pooled, scale, (bf16_t*)out);
@@ -572,7 +586,7 @@ extern "C" int sfod_roi_align_bwd(const void* dout, int B, int H, int W, int C, 
   SFOD_REQUIRE(C % 8 == 0, "roi_align_bwd: C must be a multiple of 8");
   SFOD_REQUIRE(pooled >= 1 && pooled <= ROI_MAXP, "roi_align_bwd: pooled size must be <= 8");
   hipStream_t s = (hipStream_t)stream;
-  SFOD_REQUIRE(dt != SFOD_BF16X3, "roi_align_bwd: the upstream gradient is fp32 in bf16x3 mode");
+  SFOD_REQUIRE(!sfod_is_pairs(dt), "roi_align_bwd: the upstream gradient is fp32 in the operand-pair modes");
   if (dt == SFOD_F32) return dispatch_roi_bwd<float>(dout, B, H, W, C, rois, R, pooled, scale, dfeat, s);
   return dispatch_roi_bwd<bf16_t>(dout, B, H, W, C, rois, R, pooled, scale, dfeat, s);
 }

@@ -170,7 +170,8 @@ class ResNet(nn.Module):
         # activations stay fp32 here (residual joins, stride-2 subsampling and the elementwise backward all work on
         # them) and are converted to (hi, lo) operand pairs at each convolution's input (native.as_operand); the VGG
         # trunk instead has its BatchNorm kernels write the pairs directly.
-        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
+        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)       # operands of the forward products
+        self.grad_dtype = native.grad_dtype_of(self.compute_dtype)          # operands of dgrad / wgrad ("f16x3": bf16 pairs)
         self.act_dtype = native.out_dtype_of(self.compute_dtype)
         self.bn_momentum = 0.1
         self._frozen_gen = 0                 # generation of the frozen stages' values (see _frozen_packed)
@@ -243,16 +244,17 @@ class ResNet(nn.Module):
         kpad = 192
         wk = torch.zeros(conv.out_channels, kpad, dtype=torch.float32, device=x.device)
         wk[:, :147] = w
-        cols = native.im2col_stem(x, kpad, out_dtype=self.compute_dtype if self.compute_dtype == native.SPLIT_DTYPE else None)
+        cols = native.im2col_stem(x, kpad, out_dtype=self.compute_dtype if native.is_pairs(self.compute_dtype) else None)
         B, Ho, Wo, _ = cols.shape
         wp = native.pack_fc_weight(wk, dt)
         y = native.conv_fwd(cols.view(B * Ho * Wo, kpad), wp, shift.contiguous(), conv.out_channels, 1, act=1)
         return native.maxpool3s2(y.view(B, Ho, Wo, conv.out_channels))
 
     def _pack_live_weights(self, dt, with_dgrad):
-        """Forward (and, for a backward, rotated) packed weights of every live conv in ONE launch per forward
-        (native.ConvWeightPacker) instead of two tiny launches per conv."""
+        """Forward (and, for a backward, rotated) packed weights of every live conv in ONE launch per forward and operand
+        format (native.ConvWeightPacker) instead of two tiny launches per conv."""
         key = (dt, bool(with_dgrad))
+        gdt = native.dt_of_dtype(self.grad_dtype)
         packers = self.__dict__.setdefault("_packers", {})
         ent = packers.get(key)
         if ent is None:
@@ -264,17 +266,20 @@ class ResNet(nn.Module):
                     for c in (blk.conv1, blk.conv2, blk.conv3, blk.shortcut):
                         if c is not None:
                             convs.append(c)
-            specs = [(c.weight, c.in_channels, False) for c in convs]
-            if with_dgrad:
-                specs += [(c.weight, c.out_channels, True) for c in convs]
-            ent = packers[key] = (native.ConvWeightPacker(specs, dt), convs)
-        pk, convs = ent
-        views = pk.pack()
+            fwd = [(c.weight, c.in_channels, False) for c in convs]
+            rot = [(c.weight, c.out_channels, True) for c in convs] if with_dgrad else []
+            if gdt == dt or not rot:
+                pks = (native.ConvWeightPacker(fwd + rot, dt), None)
+            else:
+                pks = (native.ConvWeightPacker(fwd, dt), native.ConvWeightPacker(rot, gdt))
+            ent = packers[key] = (pks, convs)
+        pks, convs = ent
+        views = list(pks[0].pack()) + (list(pks[1].pack()) if pks[1] is not None else [])
         n = len(convs)
         self._wp = {id(c): views[i] for i, c in enumerate(convs)}
         self._wr = {id(c): views[n + i] for i, c in enumerate(convs)} if with_dgrad else {}
 
-    def _live_conv_bn(self, x, conv, relu, dt, residual=None, z_operand=False, dual=False):
+    def _live_conv_bn(self, x, conv, relu, dt, residual=None, z_operand=False, dual=False, z_grad=False):
         """conv + train-mode BatchNorm (+ ReLU / residual join).  ``x``: an MFMA operand tensor (bf16x3: pairs) or an
         activation-dtype tensor (converted by conv_fwd).  ``z_operand``: write the output directly as the next
         convolution's operand (bf16x3: the BatchNorm kernel emits the pairs; no separate conversion pass)."""
@@ -295,17 +300,20 @@ class ResNet(nn.Module):
         if residual is not None:      # bottleneck tail: relu(bn(y) + shortcut) without materialising bn(y)
             # dual: z = (fp32 block output, the same as operand pairs for the next block's conv1 / shortcut)
             z = native.bn_add_relu_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual,
-                                       with_operand=dual)
+                                       with_operand=self.compute_dtype if dual else None)
         else:
+            # z_grad (a pass that will be differentiated): z = (forward operand, the operand of the consuming
+            # convolution's weight gradient) from one launch -- the same tensor unless the mode splits them (f16x3)
             z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False, relu=relu,
-                                        out_dtype=self.compute_dtype if z_operand else None)
+                                        out_dtype=self.compute_dtype if z_operand else None,
+                                        with_grad_operand=z_grad and z_operand)
         return y, mean, invstd, z
 
-    def _block_forward(self, blk, x, live, dt, x_op=None, want_op=False):
+    def _block_forward(self, blk, x, live, dt, x_op=None, want_op=False, save=False):
         """-> (block output, its operand-pair copy or None, saved activations or None).  ``x_op``: the block input as
         MFMA operand when the producer already wrote it (bf16x3: the previous block's join kernel emits the fp32
         residual stream AND the pairs in one pass); ``want_op``: do the same for the next block."""
-        dual = want_op and self.dual_join and self.compute_dtype == native.SPLIT_DTYPE and x.shape[-1] % 8 == 0
+        dual = want_op and self.dual_join and native.is_pairs(self.compute_dtype) and x.shape[-1] % 8 == 0
         if blk.stride == 2:
             xs, x_op = native.subsample2(x), None
         else:
@@ -319,13 +327,18 @@ class ResNet(nn.Module):
             o = self._frozen_conv(o, blk.conv2, 1, dt)
             o = self._frozen_conv(o, blk.conv3, 0, dt)
             if dual:
-                out, out_op = native.add_act(o, sc, 1, with_operand=True)
+                out, out_op = native.add_act(o, sc, 1, with_operand=self.compute_dtype)
                 return out, out_op, None
             return native.add_act(o, sc, 1), None, None
-        # a1 / a2 only feed convolutions, so their BatchNorm kernels write pairs directly
+        # a1 / a2 only feed convolutions, so their BatchNorm kernels write pairs directly (a differentiated pass: also the
+        # weight-gradient operands a1g / a2g -- the same tensors except in f16x3 mode)
         xs_act, xs = xs, xs_op
-        y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt, z_operand=True)
-        y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt, z_operand=True)
+        split_g = save and self.grad_dtype != self.compute_dtype
+        xs_g = native.as_operand(xs_act, self.grad_dtype) if split_g else xs
+        y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt, z_operand=True, z_grad=split_g)
+        a1, a1g = a1 if split_g else (a1, a1)
+        y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt, z_operand=True, z_grad=split_g)
+        a2, a2g = a2 if split_g else (a2, a2)
         if blk.shortcut is not None:
             ys, ms, is_, ts = self._live_conv_bn(xs, blk.shortcut, False, dt)
         else:
@@ -339,10 +352,10 @@ class ResNet(nn.Module):
                 out, out_op = out
         else:
             y3, m3, i3, t3 = self._live_conv_bn(a2, blk.conv3, False, dt)
-            out = native.add_act(t3, ts, 1, with_operand=dual)
+            out = native.add_act(t3, ts, 1, with_operand=self.compute_dtype if dual else None)
             if dual:
                 out, out_op = out
-        return out, out_op, (x.shape, xs, y1, m1, i1, a1, y2, m2, i2, a2, y3, m3, i3, ys, ms, is_, out)
+        return out, out_op, (x.shape, xs_g, y1, m1, i1, a1g, y2, m2, i2, a2g, y3, m3, i3, ys, ms, is_, out)
 
     def _forward_impl(self, x, save=True):
         dt = native.dt_of_dtype(self.compute_dtype)
@@ -357,7 +370,7 @@ class ResNet(nn.Module):
             live = name not in self.frozen
             # the next block reads this output as a convolution operand unless it subsamples first (stride 2)
             want_op = bi + 1 < len(blocks) and blocks[bi + 1][1].stride != 2
-            x, x_op, sv = self._block_forward(blk, x, live, dt, x_op=x_op, want_op=want_op)
+            x, x_op, sv = self._block_forward(blk, x, live, dt, x_op=x_op, want_op=want_op, save=save)
             if live and save:
                 saved.append(sv)
             if name in self._out_features and (bi + 1 == len(blocks) or blocks[bi + 1][0] != name):
@@ -373,16 +386,16 @@ class ResNet(nn.Module):
         dy, dgamma, dbeta = native.bn_relu_pool_bwd(g, y, mean, invstd, bn.weight.detach(), bn.bias.detach(), False,
                                                     relu=relu, dgamma_acc=gsink if direct_bn else None,
                                                     dbeta_acc=bsink if direct_bn else None,
-                                                    out_dtype=self.compute_dtype)   # dy only feeds wgrad / dgrad MFMAs
+                                                    out_dtype=self.grad_dtype)   # dy only feeds wgrad / dgrad MFMAs
         if direct_bn:
             dgamma = dbeta = None
-        dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.compute_dtype)
+        dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.grad_dtype)
         dx = None
         if need_dx:
             wr = self.__dict__.get("_wr", {}).get(id(conv))      # packed with the forward weights (same step, same values)
             if wr is None:
                 wr = native.pack_conv_weight(conv.weight.detach(), conv.out_channels,
-                                             native.dt_of_dtype(self.compute_dtype), rot180=True)
+                                             native.dt_of_dtype(self.grad_dtype), rot180=True)
             dx = native.conv_fwd(dy, wr, None, conv.in_channels, k)
         return dx, [dw, dgamma, dbeta]
 

@@ -63,7 +63,7 @@ class _VGGFn(torch.autograd.Function):
         ctx.module = module
         ctx.saved = saved
         ctx.need_dx = False
-        if module.compute_dtype == native.SPLIT_DTYPE:
+        if native.is_pairs(module.compute_dtype):
             # bf16x3: between the layers activations are (hi, lo) operand pairs; what leaves the trunk (and meets
             # autograd, whose gradients are fp32) is fp32 -- converted for the stages somebody consumes only
             # (``needed_features``; vgg4 is 1/1024 of vgg0's pixels), the others are not returned
@@ -102,7 +102,8 @@ class vgg_backbone(nn.Module):
         # the heads' IN_FEATURES); the other modes return zero-copy views of all five
         self.needed_features = set(self._stage_names)
         del self.vgg
-        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)
+        self.compute_dtype = native.mode_dtype(cfg.SFOD.COMPUTE_DTYPE)      # operands of the forward products
+        self.grad_dtype = native.grad_dtype_of(self.compute_dtype)         # operands of dgrad / wgrad ("f16x3": bf16 pairs)
         self.bn_momentum, self.bn_eps = 0.1, 1e-5
         # momentum updates of the running statistics per training-mode forward.  The reference's student passes the same
         # batch through its backbone three times per step when the (zero-weighted) domain branch is on; with
@@ -157,7 +158,7 @@ class vgg_backbone(nn.Module):
         """x: [N,3,H,W] normalised image batch (NCHW logical).  Returns {"vgg0".."vgg4"} as NCHW (channels-last)
         views -- the Detectron2 Backbone surface (fp32 tensors in fp32 and bf16x3 mode)."""
         dt = native.dt_of_dtype(self.compute_dtype)
-        if dt == native.BF16X3:     # fp32 NHWC padded to one 8-channel group, then converted to (hi, lo) pairs
+        if native.is_pairs(self.compute_dtype):     # fp32 NHWC padded to one 8-channel group, then converted to (hi, lo) pairs
             xn = native.cast(nhwc_from_nchw_view(x, torch.float32, native.chunk_elems(dt)), self.compute_dtype)
             return self.forward_nhwc(xn)
         xn = nhwc_from_nchw_view(x, self.compute_dtype, native.chunk_elems(dt))
@@ -183,25 +184,28 @@ class vgg_backbone(nn.Module):
 
     def _packed_weights(self, dt, cin0_pad, with_dgrad):
         """Packed forward weights of all layers (+ the rotated dgrad weights of layers 1.. when a backward
-        follows), refreshed from the fp32 master weights by ONE launch per call."""
+        follows), refreshed from the fp32 master weights by ONE launch per call (one per operand format: "f16x3" packs
+        the forward weights as half pairs and the rotated ones as bf16 pairs)."""
+        gdt = native.dt_of_dtype(native.grad_dtype_of(native.torch_dtype(dt)))
         if os.environ.get("SFOD_NO_MULTIPACK"):   # A/B hook: one launch per layer
             f = [native.pack_conv_weight(c.weight.detach(), cin0_pad if i == 0 else c.in_channels, dt)
                  for i, (c, _, _, _) in enumerate(self._plan)]
-            r = ([None] + [native.pack_conv_weight(c.weight.detach(), c.out_channels, dt, rot180=True)
+            r = ([None] + [native.pack_conv_weight(c.weight.detach(), c.out_channels, gdt, rot180=True)
                            for c, _, _, _ in self._plan[1:]]) if with_dgrad else None
             return f, r
         key = (dt, cin0_pad, bool(with_dgrad))
         packers = self.__dict__.setdefault("_packers", {})
         pk = packers.get(key)
         if pk is None:
-            specs = []
-            for li, (conv, _, _, _) in enumerate(self._plan):
-                specs.append((conv.weight, cin0_pad if li == 0 else conv.in_channels, False))
-            if with_dgrad:
-                for conv, _, _, _ in self._plan[1:]:
-                    specs.append((conv.weight, conv.out_channels, True))
-            pk = packers[key] = native.ConvWeightPacker(specs, dt)
-        views = pk.pack()
+            fwd = [(conv.weight, cin0_pad if li == 0 else conv.in_channels, False)
+                   for li, (conv, _, _, _) in enumerate(self._plan)]
+            rot = [(conv.weight, conv.out_channels, True) for conv, _, _, _ in self._plan[1:]] if with_dgrad else []
+            if gdt == dt or not rot:
+                pk = (native.ConvWeightPacker(fwd + rot, dt), None)
+            else:
+                pk = (native.ConvWeightPacker(fwd, dt), native.ConvWeightPacker(rot, gdt))
+            packers[key] = pk
+        views = list(pk[0].pack()) + (list(pk[1].pack()) if pk[1] is not None else [])
         n = len(self._plan)
         return views[:n], ([None] + list(views[n:]) if with_dgrad else None)
 
@@ -211,6 +215,7 @@ class vgg_backbone(nn.Module):
         saved, outs = [], []
         fwd_w, rot_w = self._packed_weights(dt, x.shape[-1], save)
         self._rot_w = rot_w
+        x_g = native.as_operand(x, self.grad_dtype) if save else None      # conv1_1's weight-gradient operand (8 channels)
         for li, (conv, bn, pool, stage_end) in enumerate(self._plan):
             cout = conv.out_channels
             wp = fwd_w[li]
@@ -237,11 +242,14 @@ class vgg_backbone(nn.Module):
                 y = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3)
                 mean = bn.running_mean
                 invstd = torch.rsqrt(bn.running_var + self.bn_eps)
-            z = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool,
-                                        out_dtype=x.dtype)       # bf16x3: y is fp32, z is written as (hi, lo) pairs
+            # bf16x3 / f16x3: y is fp32, z is written as (hi, lo) pairs; a pass that will be differentiated also gets
+            # the operand of the next layer's weight gradient from the same launch (f16x3: bf16 pairs; else z itself)
+            zz = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool,
+                                         out_dtype=x.dtype, with_grad_operand=save)
+            z, z_g = zz if save else (zz, None)
             if save:
-                saved.append((x, y, mean, invstd))
-            x = z
+                saved.append((x_g, y, mean, invstd))
+            x, x_g = z, z_g
             if stage_end:
                 outs.append(z)
         return saved, outs
@@ -251,7 +259,7 @@ class vgg_backbone(nn.Module):
         hook = getattr(self, "_pre_backward", None)
         if hook is not None:
             hook()   # e.g. GradientReducer.launch_early: the heads' gradients are final now
-        dtype = self.compute_dtype
+        dtype = self.grad_dtype
         pgrads = [None] * (4 * len(self._plan))
         stage_of = []
         s = 0

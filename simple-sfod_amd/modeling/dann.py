@@ -82,7 +82,7 @@ class _DCImgLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         dc, acts, logits = ctx.dc, ctx.acts, ctx.logits
-        dtype = dc.compute_dtype
+        dtype = native.grad_dtype_of(dc.compute_dtype)      # operands of the backward products ("f16x3": bf16 pairs)
         dt = native.dt_of_dtype(dtype)
         E = native.chunk_elems(dt)
         adt = native.out_dtype_of(dtype)       # dtype gradients flow in (fp32 in bf16x3 mode: converted at the MFMA)
@@ -189,7 +189,7 @@ class _DCInsLossFn(torch.autograd.Function):
     def backward(ctx, g):
         heads, head, st, rois, masks = ctx.heads, ctx.head, ctx.st, ctx.rois, ctx.masks
         r1, z1, r2, z2, z, live, n_live = ctx.acts
-        dtype = heads.compute_dtype
+        dtype = native.grad_dtype_of(heads.compute_dtype)
         dt = native.dt_of_dtype(dtype)
         E = native.chunk_elems(dt)
         fc1 = getattr(head, head.da_ins_fc1_layers[0])

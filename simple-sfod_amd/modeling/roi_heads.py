@@ -278,7 +278,7 @@ class StandardROIHeads(nn.Module):
         return {"x0": x0, "h1": h1, "h2": h2, "pred": pred, "wp": wp, "feat_shape": tuple(feat.shape)}
 
     def _box_backward(self, st, rois, d_pred, feat_shape_nchw):
-        dtype = self.compute_dtype
+        dtype = native.grad_dtype_of(self.compute_dtype)      # operands of the backward products ("f16x3": bf16 pairs)
         dt = native.dt_of_dtype(dtype)
         bh = self.box_head
         K = self.num_classes
@@ -297,7 +297,7 @@ class StandardROIHeads(nn.Module):
     def _box_head_backward(self, st, rois, dh2):
         """grad wrt the box-head output (``box_features`` = relu(fc2), consumed in place) -> (grad wrt the feature
         map as an NCHW view, [dw1, db1, dw2, db2]); dw1 is None when it went straight into the flat gradient."""
-        dtype = self.compute_dtype
+        dtype = native.grad_dtype_of(self.compute_dtype)      # operands of the backward products ("f16x3": bf16 pairs)
         dt = native.dt_of_dtype(dtype)
         bh = self.box_head
         C = self.channels

@@ -156,7 +156,7 @@ class RPN(nn.Module):
         w1p = native.pack_fc_weight(w1, dt)
         B, Hf, Wf, _ = feat.shape
         rpn_out = native.conv_fwd(t.view(B * Hf * Wf, C), w1p, b1, 5 * A, 1, out_dtype=torch.float32, ldy=self.ld)
-        return {"feat": feat, "t": t, "rpn_out": rpn_out, "w1": w1, "shape": (B, Hf, Wf)}
+        return {"feat": feat, "feat_src": feat_nchw, "t": t, "rpn_out": rpn_out, "w1": w1, "shape": (B, Hf, Wf)}
 
     def _sizes_dev(self, image_sizes, device):
         return native.dev_const(tuple((int(s[0]), int(s[1])) for s in image_sizes), torch.int32, device)
@@ -200,7 +200,7 @@ class RPN(nn.Module):
         B, Hf, Wf = st["shape"]
         cell = self._cell()
         C, A = self.channels, self.num_anchors
-        dtype = self.compute_dtype
+        dtype = native.grad_dtype_of(self.compute_dtype)      # operands of the backward products ("f16x3": bf16 pairs)
         dt = native.dt_of_dtype(dtype)
         _, d_out = native.rpn_loss(st["rpn_out"], cell, B, Hf, Wf, self.stride, labels, matched, gt.boxes,
                                    gt.count, self.batch_size_per_image, grad_scale=grad_scale)
@@ -216,7 +216,8 @@ class RPN(nn.Module):
         # 3x3 conv
         h = self.rpn_head
         dt4 = dt_.view(B, Hf, Wf, C)
-        dw0 = native.conv_weight_grad(st["feat"], dt4, h.conv.weight, operand=dtype)
+        feat_g = st["feat"] if st["feat"].dtype == dtype else native.nhwc_operand(st["feat_src"], dtype)
+        dw0 = native.conv_weight_grad(feat_g, dt4, h.conv.weight, operand=dtype)
         db0 = native.bias_grad(dt_, C)
         wr = native.pack_conv_weight(h.conv.weight.detach(), C, dt, rot180=True)
         dfeat = native.conv_fwd(dt4, wr, None, C, 3)

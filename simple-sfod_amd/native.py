@@ -21,7 +21,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "sfod_hip.h")
 SO_PATH = os.environ.get("SFOD_HIP_LIB", os.path.join(_HERE, "lib", "libsfod_hip.so"))   # override: kernel A/B builds
 
-F32, BF16, BF16X3 = 0, 1, 2
+F32, BF16, BF16X3, F16X3 = 0, 1, 2, 3
 
 # Storage tag of SFOD_BF16X3 ("split") tensors (include/sfod_hip.h): 4 bytes per logical element -- a (hi, lo) bf16
 # pair, stored per 8 channels as 8 hi then 8 lo.  torch never does arithmetic on them (only empty / zeros / view /
@@ -29,8 +29,15 @@ F32, BF16, BF16X3 = 0, 1, 2
 # shapes stay the LOGICAL shapes and every wrapper below dispatches on ``dt_of(t)``.  Conversions go through
 # ``cast`` (sfod_cast), never through ``Tensor.to``.
 SPLIT_DTYPE = torch.complex32
+# SFOD_F16X3 tensors -- the same storage with IEEE half pairs -- carry their own 4-byte tag, so that a tensor of one pair
+# format can never reach a kernel instantiated for the other (the weight-gradient entry points reject SFOD_F16X3).
+SPLITH_DTYPE = torch.uint32
+PAIR_DTYPES = (SPLIT_DTYPE, SPLITH_DTYPE)
 
-COMPUTE_MODES = {"fp32": F32, "bf16": BF16, "bf16x3": BF16X3}
+# cfg.SFOD.COMPUTE_DTYPE -> operand type of the FORWARD products.  "f16x3": forward products on half pairs (22-bit
+# operands; activations and weights sit inside half's exponent range), backward products (data and weight gradients:
+# tiny values, no loss scaling) on bf16 pairs -- ``grad_dtype_of``.
+COMPUTE_MODES = {"fp32": F32, "bf16": BF16, "bf16x3": BF16X3, "f16x3": F16X3}
 
 
 def mode_dt(name):
@@ -48,7 +55,17 @@ def mode_dtype(name):
 
 def out_dtype_of(dtype):
     """dtype convolutions / GEMMs write (and elementwise gradients flow in) for operands of ``dtype``."""
-    return torch.float32 if dtype == SPLIT_DTYPE else dtype
+    return torch.float32 if dtype in PAIR_DTYPES else dtype
+
+
+def grad_dtype_of(dtype):
+    """operand dtype of the BACKWARD products (data gradient, weight gradient) of a model whose forward operands are
+    ``dtype``: half pairs hold activations and weights, not gradients (range) -> bf16 pairs."""
+    return SPLIT_DTYPE if dtype == SPLITH_DTYPE else dtype
+
+
+def is_pairs(dtype):
+    return dtype in PAIR_DTYPES
 
 
 class NativeLibraryError(RuntimeError):
@@ -145,15 +162,17 @@ def dt_of(t):
         return BF16
     if t.dtype == SPLIT_DTYPE:
         return BF16X3
+    if t.dtype == SPLITH_DTYPE:
+        return F16X3
     raise TypeError(f"unsupported dtype {t.dtype}")
 
 
 def dt_of_dtype(dtype):
-    return {torch.float32: F32, torch.bfloat16: BF16, SPLIT_DTYPE: BF16X3}[dtype]
+    return {torch.float32: F32, torch.bfloat16: BF16, SPLIT_DTYPE: BF16X3, SPLITH_DTYPE: F16X3}[dtype]
 
 
 def torch_dtype(dt):
-    return {F32: torch.float32, BF16: torch.bfloat16, BF16X3: SPLIT_DTYPE}[dt]
+    return {F32: torch.float32, BF16: torch.bfloat16, BF16X3: SPLIT_DTYPE, F16X3: SPLITH_DTYPE}[dt]
 
 
 def chunk_elems(dt):
@@ -166,15 +185,34 @@ def nhwc_operand(x_nchw, dtype):
     p = x_nchw.permute(0, 2, 3, 1)
     if p.dtype == dtype:
         return p.contiguous()
-    if dtype == SPLIT_DTYPE or p.dtype == SPLIT_DTYPE:
+    if dtype in PAIR_DTYPES or p.dtype in PAIR_DTYPES:
         return cast(p.contiguous(), dtype)
     return p.to(dtype).contiguous()
 
 
 def as_operand(t, dtype):
     """t as an MFMA operand of ``dtype``: unchanged if it already is, else converted by sfod_cast (fp32 -> bf16 /
-    bf16x3 pairs).  The trunk's producers write operand tensors directly; the heads' small fp32 tensors pass here."""
+    operand pairs; half pairs -> bf16 pairs for a weight gradient whose producer did not write both).  The trunk's
+    producers write operand tensors directly; the heads' small fp32 tensors pass here."""
     return t if t.dtype == dtype else cast(t, dtype)
+
+
+def operands_for(t, dtype, need_grad):
+    """fp32 ``t`` -> (forward operand of ``dtype``, the operand the weight gradient will read or None).  One pass over
+    ``t`` also when the two differ ("f16x3": half pairs + bf16 pairs)."""
+    gdt = grad_dtype_of(dtype)
+    if not need_grad:
+        return as_operand(t, dtype), None
+    if gdt == dtype:
+        op = as_operand(t, dtype)
+        return op, op
+    if t.dtype == torch.float32 and dtype == SPLITH_DTYPE and gdt == SPLIT_DTYPE:
+        t = t.contiguous()
+        a = torch.empty(t.shape, dtype=SPLITH_DTYPE, device=t.device)
+        b = torch.empty(t.shape, dtype=SPLIT_DTYPE, device=t.device)
+        call("sfod_cast_pairs_both", t, a, b, t.numel())
+        return a, b
+    return as_operand(t, dtype), as_operand(t, gdt)
 
 
 class KernelTimer:
@@ -427,11 +465,28 @@ def hflip_u8(img):
     return out
 
 
+def _wscale_slots(n, dev):
+    """device words the `_ws` packers publish max|w| in (SFOD_F16X3 weights carry a per-tensor power-of-two scale,
+    include/sfod_hip.h); a packed tensor keeps its word as ``.wscale`` and the forward wrappers hand it to the kernels"""
+    return torch.empty(n, dtype=torch.int32, device=dev)
+
+
+def wscale_of(w_packed):
+    ws = getattr(w_packed, "wscale", None)
+    if w_packed.dtype == SPLITH_DTYPE and ws is None:
+        raise NativeLibraryError("an SFOD_F16X3 weight tensor lost its scale word (.wscale): pass the packer's own tensor, "
+                                 "not a view of it")
+    return ws
+
+
 def pack_conv_weight(w_oihw, cin_pad, dt, rot180=False):
     cout, cin, ks, _ = w_oihw.shape
     rows = cin if rot180 else cout
     out = torch.empty(rows, ks * ks, cin_pad, dtype=torch_dtype(dt), device=w_oihw.device)
-    call("sfod_pack_conv_weight", w_oihw.contiguous(), out, cout, cin, ks, cin_pad, int(rot180), dt)
+    ws = _wscale_slots(1, w_oihw.device) if dt == F16X3 else None
+    call("sfod_pack_conv_weight_ws", w_oihw.contiguous(), out, ws, cout, cin, ks, cin_pad, int(rot180), dt)
+    if ws is not None:
+        out.wscale = ws
     return out
 
 
@@ -470,6 +525,10 @@ class ConvWeightPacker:
             tot += (r * t * p_ + 127) // 128 * 128          # keep every packed tensor 256-byte aligned
         self._buf = torch.empty(tot, dtype=tdt, device=dev)
         self.views = [self._buf[o:o + r * t * p_].view(r, t, p_) for o, (r, t, p_) in zip(offs, sizes)]
+        self._amax = _wscale_slots(len(self.specs), dev) if self.dt == F16X3 else None
+        if self._amax is not None:
+            for i, v in enumerate(self.views):
+                v.wscale = self._amax[i:i + 1]
         rows, first = [], 0
         for (w, pad, rot), v, nb in zip(self.specs, self.views, blocks):
             cout, cin, ks, _ = w.shape
@@ -486,7 +545,7 @@ class ConvWeightPacker:
             for w, _, _ in self.specs:
                 assert w.is_contiguous() and w.dtype == torch.float32
             self._build()
-        call("sfod_pack_conv_weights_multi", self._desc, len(self.specs), self._total, self.dt)
+        call("sfod_pack_conv_weights_multi_ws", self._desc, len(self.specs), self._total, self.dt, self._amax)
         return self.views
 
 
@@ -500,7 +559,10 @@ def pack_fc_weight(w, dt, chw_c=0, transpose=False, ld=None):
     inner = n if transpose else k
     ld = ld or inner
     out = torch.empty(k if transpose else n, ld, dtype=torch_dtype(dt), device=w.device)
-    call("sfod_pack_fc_weight_ld", w.contiguous(), out, n, k, chw_c, int(transpose), ld, dt)
+    ws = _wscale_slots(1, w.device) if dt == F16X3 else None
+    call("sfod_pack_fc_weight_ld_ws", w.contiguous(), out, ws, n, k, chw_c, int(transpose), ld, dt)
+    if ws is not None:
+        out.wscale = ws
     return out
 
 
@@ -532,14 +594,14 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
     if _timer is not None:
         _pending_tag = ":patch3x3" if query("sfod_conv_fwd_algo", B, H, W, cin, cout, ksize, dt) == 2 else ":gemm"
-    call("sfod_conv_fwd", x, w_packed, bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
-         dt_of_dtype(out_dtype))
+    call("sfod_conv_fwd_ws", x, w_packed, wscale_of(w_packed), bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
+         dt_of_dtype(out_dtype), timer_name="sfod_conv_fwd")
     _pending_tag = ""
     return (y, stats) if want_stats else y
 
 
 def conv_first_supported(x, cout):
-    if x.dim() != 4 or x.dtype not in (torch.bfloat16, SPLIT_DTYPE):
+    if x.dim() != 4 or x.dtype not in (torch.bfloat16,) + PAIR_DTYPES:
         return False
     B, H, W, cin = x.shape
     return bool(query("sfod_conv_first_supported", B, H, W, cin, cout, dt_of(x), cout))
@@ -551,7 +613,8 @@ def conv_first_stats(x, w_packed, bias):
     nb = query("sfod_conv_stats_blocks", B, H, W, cin, 64, 3, dt_of(x))
     stats = torch.empty(nb * (2 * 64 + 1), dtype=torch.float32, device=x.device)
     stats.nblk = nb
-    call("sfod_conv_first_fused", x, w_packed, bias, None, None, None, stats, B, H, W, 64, 0, dt_of(x))
+    call("sfod_conv_first_fused_ws", x, w_packed, wscale_of(w_packed), bias, None, None, None, stats, B, H, W, 64, 0,
+         dt_of(x))
     return stats
 
 
@@ -561,7 +624,8 @@ def conv_first_apply(x, w_packed, bias, scale, shift, relu=True):
     B, H, W, cin = x.shape
     z = torch.empty(B, H, W, 64, dtype=x.dtype, device=x.device)
     global _pending_flops
-    call("sfod_conv_first_fused", x, w_packed, bias, scale, shift, z, None, B, H, W, 64, 1 if relu else 0, dt_of(x))
+    call("sfod_conv_first_fused_ws", x, w_packed, wscale_of(w_packed), bias, scale, shift, z, None, B, H, W, 64,
+         1 if relu else 0, dt_of(x))
     return z
 
 
@@ -590,7 +654,7 @@ def conv_wgrad(x, dy, cout, ksize, dw_packed=None, operand=None):
         B, H, W, cin = x.shape
     lddy = dy.shape[-1]
     # bf16x3 rows come in whole 8-channel groups: compute ceil8(cout) rows (dy's padding columns are zero)
-    cout_k = (cout + 7) // 8 * 8 if dt == BF16X3 else cout
+    cout_k = (cout + 7) // 8 * 8 if dt in (BF16X3, F16X3) else cout
     assert cout_k <= lddy, "dy narrower than the padded output-channel count"
     if dw_packed is None or cout_k != cout:
         assert dw_packed is None, "accumulating bf16x3 weight gradients needs Cout % 8 == 0"
@@ -671,24 +735,32 @@ def bn_finalize(stats, M, C, running_mean, running_var, momentum=0.1, eps=1e-5, 
     return mean, invstd
 
 
-def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True, out_dtype=None):
-    """``out_dtype``: y.dtype, or SPLIT_DTYPE from an fp32 y (the next convolution's operand, written directly)."""
+def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True, out_dtype=None, with_grad_operand=False):
+    """``out_dtype``: y.dtype, or a pair dtype from an fp32 y (the next convolution's operand, written directly).
+    ``with_grad_operand`` (out_dtype SPLITH_DTYPE): -> (z, the same values as bf16 pairs: the operand of that
+    convolution's weight gradient), both written by the one pass."""
     B, H, W, C = y.shape
     Ho, Wo = (H // 2, W // 2) if pool else (H, W)
     z = torch.empty(B, Ho, Wo, C, dtype=out_dtype or y.dtype, device=y.device)
+    if with_grad_operand and z.dtype == SPLITH_DTYPE:
+        z2 = torch.empty(B, Ho, Wo, C, dtype=SPLIT_DTYPE, device=y.device)
+        call("sfod_bn_relu_pool_fwd2", y, mean, invstd, gamma, beta, z, z2, B, H, W, C,
+             int(pool) | (0 if relu else 2), dt_of(y), dt_of(z))
+        return z, z2
     call("sfod_bn_relu_pool_fwd", y, mean, invstd, gamma, beta, z, B, H, W, C, int(pool) | (0 if relu else 2),
          dt_of(y), dt_of(z))
-    return z
+    return (z, z) if with_grad_operand else z
 
 
-def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual, with_operand=False):
-    """relu(bn(y) + residual) in one pass (bottleneck tail).  ``with_operand`` (fp32 data of a bf16x3 model): also return
-    the same values as (hi, lo) operand pairs -> (z, z_pairs)."""
+def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual, with_operand=None):
+    """relu(bn(y) + residual) in one pass (bottleneck tail).  ``with_operand`` (a pair dtype; fp32 data of a bf16x3 /
+    f16x3 model): also return the same values as (hi, lo) operand pairs of that type -> (z, z_pairs)."""
     assert residual.shape == y.shape and residual.dtype == y.dtype
     z = torch.empty_like(y)
     C = y.shape[-1]
-    zp = torch.empty(y.shape, dtype=SPLIT_DTYPE, device=y.device) if with_operand else None
-    call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, zp, y.numel() // C, C, dt_of(y))
+    zp = torch.empty(y.shape, dtype=with_operand, device=y.device) if with_operand else None
+    call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, zp, y.numel() // C, C, dt_of(y),
+         dt_of(zp) if zp is not None else BF16X3)
     return (z, zp) if with_operand else z
 
 
@@ -763,11 +835,12 @@ def mul_mask_(a, mask_u8, scale):
     return a
 
 
-def add_act(a, b, act=1, with_operand=False):
-    """act(a + b); ``with_operand`` (fp32 data of a bf16x3 model): also the (hi, lo) operand pairs -> (out, out_pairs)."""
+def add_act(a, b, act=1, with_operand=None):
+    """act(a + b); ``with_operand`` (a pair dtype; fp32 data of a bf16x3 / f16x3 model): also the (hi, lo) operand pairs
+    of that type -> (out, out_pairs)."""
     out = torch.empty_like(a)
-    op = torch.empty(a.shape, dtype=SPLIT_DTYPE, device=a.device) if with_operand else None
-    call("sfod_add_act", a, b, out, op, a.numel(), int(act), dt_of(a))
+    op = torch.empty(a.shape, dtype=with_operand, device=a.device) if with_operand else None
+    call("sfod_add_act", a, b, out, op, a.numel(), int(act), dt_of(a), dt_of(op) if op is not None else BF16X3)
     return (out, op) if with_operand else out
 
 
