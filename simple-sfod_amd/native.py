@@ -758,6 +758,7 @@ def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual, with_operand=None):
     assert residual.shape == y.shape and residual.dtype == y.dtype
     z = torch.empty_like(y)
     C = y.shape[-1]
+    with_operand = SPLIT_DTYPE if with_operand is True else with_operand
     zp = torch.empty(y.shape, dtype=with_operand, device=y.device) if with_operand else None
     call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, zp, y.numel() // C, C, dt_of(y),
          dt_of(zp) if zp is not None else BF16X3)
@@ -839,6 +840,7 @@ def add_act(a, b, act=1, with_operand=None):
     """act(a + b); ``with_operand`` (a pair dtype; fp32 data of a bf16x3 / f16x3 model): also the (hi, lo) operand pairs
     of that type -> (out, out_pairs)."""
     out = torch.empty_like(a)
+    with_operand = SPLIT_DTYPE if with_operand is True else with_operand
     op = torch.empty(a.shape, dtype=with_operand, device=a.device) if with_operand else None
     call("sfod_add_act", a, b, out, op, a.numel(), int(act), dt_of(a), dt_of(op) if op is not None else BF16X3)
     return (out, op) if with_operand else out

@@ -145,7 +145,8 @@ def test_linear_kernels_wide_and_tall(native, shape):
     rows = torch.randint(0, M, (64,), generator=g)
     ref = x[rows].double() @ w.double().t() + b.double()
     y = native.conv_fwd(x.to(DEV), native.pack_fc_weight(w.to(DEV), native.F16X3), b.to(DEV), N, 1)
-    assert rel_err(y[rows.to(DEV)].cpu(), ref) < TOL
+    # long K: the fp32 accumulation's own error grows with sqrt(K) (fp32 MFMA at K = 25 088: 2e-6)
+    assert rel_err(y[rows.to(DEV)].cpu(), ref) < TOL * max(1.0, math.sqrt(K / 4608.0))
 
 
 @pytest.mark.parametrize("shape", [
