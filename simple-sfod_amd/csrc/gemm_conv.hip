@@ -551,6 +551,17 @@ static bool use_wide_gemm(int M, int Cout, int ks) {
 template <typename T, typename OutT, bool UT, int SPLIT = 0>
 static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
                               const ConvArgs& a, hipStream_t s) {
+  // SFOD_GEMM_TILE = 1..5: force a tile shape where it exists (A/B runs: 1 128x64, 2 128x128, 3 256x128, 4 256x64, 5 256x256)
+  static const int forced = []() { const char* e = getenv("SFOD_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  if constexpr (UT) {
+    if (forced == 1) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
+    if (forced == 2) return launch_one<T, OutT, 2, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
+    if (forced == 3) return launch_one<T, OutT, 2, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);
+    if (forced == 4) return launch_one<T, OutT, 1, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);
+    if constexpr (SPLIT && sizeof(OutT) == 4) {
+      if (forced == 5) return launch_one<T, OutT, 4, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
+    }
+  }
   if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
   // long-K linear layers with few rows (the student's fc1: 4096 x 25088 -> 1024): 256 x 64 tiles, 8 waves, 3-stage
   // pipeline -- one 8-wave workgroup per CU instead of one 4-wave one (0.35 -> 0.30 ms; SFOD_GEMM_TALL=0 disables)

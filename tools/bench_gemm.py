@@ -4,7 +4,8 @@ import argparse, importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 ap = argparse.ArgumentParser()
-ap.add_argument("--dtype", choices=["bf16", "bf16x3", "fp32"], default="bf16x3")
+ap.add_argument("--dtype", choices=["bf16", "bf16x3", "f16x3", "fp32"], default="bf16x3")
+ap.add_argument("--only", default="", help="substring filter on the shape names")
 args = ap.parse_args()
 sfod = importlib.import_module("simple-sfod_amd"); native = sfod.native; native.load()
 dev = "cuda"
@@ -16,12 +17,18 @@ SHAPES = [("vgg fc1 teacher", 16000, 25088, 1024), ("vgg fc1 student", 4096, 250
           ("r101 res2 64->256", 360000, 64, 256), ("r101 res2 256->64", 360000, 256, 64),
           ("r101 res4 1024->1024 (shortcut-like)", 22800, 1024, 1024), ("r101 rpn 1x1 1024->60", 22800, 1024, 60)]
 split = args.dtype == "bf16x3"
+SHAPES += [("r101 res3 256->512 (shortcut)", 90000, 256, 512), ("r101 res4 512->1024 (shortcut)", 22800, 512, 1024),
+           ("r101 res2 64->64", 360000, 64, 64), ("r101 fc2 teacher", 16000, 2048, 2048), ("r101 predictor", 16000, 2048, 48)]
 for (name, M, K, N) in SHAPES:
+    if args.only and args.only not in name:
+        continue
     g = torch.Generator(device=dev).manual_seed(1)
     a = torch.randn(M, K, device=dev, generator=g)
     w = torch.randn(N, K, device=dev, generator=g) / K ** 0.5
     if split:
         a, w = native.cast(a, native.SPLIT_DTYPE), native.cast(w, native.SPLIT_DTYPE)
+    elif args.dtype == "f16x3":       # half pairs; the weights under their per-tensor scale
+        a, w = native.cast(a, native.SPLITH_DTYPE), native.pack_fc_weight(w, native.F16X3)
     elif args.dtype == "bf16":
         a, w = a.bfloat16(), w.bfloat16()
     ts = []
