@@ -53,7 +53,7 @@ def make_inputs(B, H, W, ngt, seed=0, with_gt=True):
     return out
 
 
-@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32", "f16x3"])
 def test_backbone_matches_reference_golden(sfod, native, dtype):
     """build_vgg_backbone under the same seed reproduces the reference's weights draw for draw and,
     on the HIP kernels, its forward outputs and train-mode BN running statistics (vgg.py)."""
@@ -298,7 +298,7 @@ def _student_vs_oracle(sfod, B, H, W, ngt, dtype, seed):
     return model, sd, losses, losses_ref
 
 
-@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32", "f16x3"])
 def test_student_losses_and_gradients_match_oracle(sfod, native, dtype):
     model, sd, losses, losses_ref = _student_vs_oracle(sfod, 2, 160, 224, [3, 5], dtype, 3)
     for k, v in losses_ref.items():
@@ -343,7 +343,7 @@ def test_student_losses_and_gradients_match_oracle(sfod, native, dtype):
             assert buf.item() == sd[name].item() == 1
 
 
-@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32", "f16x3"])
 def test_student_ragged_batch_and_image_without_gt(sfod, native, dtype):
     """Edge cases of the batch contract: images of different sizes (zero-padded to the batch maximum, boxes
     clipped to each image's own size) and an image with no (pseudo-)ground truth at all."""
@@ -367,7 +367,7 @@ def test_student_bf16_mode_tracks_the_fp32_oracle(sfod, native):
         assert torch.isfinite(p.grad).all(), name
 
 
-@pytest.mark.parametrize("dtype", ["bf16x3", "fp32"])
+@pytest.mark.parametrize("dtype", ["bf16x3", "fp32", "f16x3"])
 def test_teacher_pseudo_label_pipeline_matches_oracle(sfod, native, dtype):
     cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", dtype])
     torch.manual_seed(11)

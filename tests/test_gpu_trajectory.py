@@ -47,7 +47,7 @@ R101_YAML = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "r101_c4_cs_f
 
 
 @pytest.mark.parametrize("model,dtype,elide", [("vgg", "fp32", True), ("vgg", "bf16x3", True), ("vgg", "fp32", False),
-                                               ("r101", "fp32", True), ("vgg", "f16x3", True), ("r101", "f16x3", True)])
+                                               ("r101", "fp32", True), ("vgg", "f16x3", True), ("r101", "f16x3", True), ("vgg", "f16x3", False)])
 def test_three_steps_match_the_oracle_trajectory(sfod, native, model, dtype, elide):
     """``r101``: BASELINE config #5 (r101_c4_cs_foggy_adaptive_teacher_source_free.yaml) in its parity mode -- frozen
     stem / res2 (never move, no momentum), live BatchNorm res3 / res4 refreshed by teacher and student (AdaBN), no
