@@ -500,8 +500,43 @@ k_bn_add_relu_fwd_dual(const float* __restrict__ y, const float* __restrict__ me
   constexpr int V = 8;
   const int cv = C / V;
   const int64_t total = rows * cv;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
-       t += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (stride % cv == 0) {
+    // a thread keeps ONE channel group for its whole grid-stride walk: the affine lives in registers (as in
+    // k_bn_relu_pool_fwd), two rows in flight per iteration
+    const int c0 = (int)(t % cv) * V;
+    float sc[V], mu[V], be[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      sc[i] = invstd[c0 + i] * gamma[c0 + i];
+      mu[i] = mean[c0 + i];
+      be[i] = beta[c0 + i];
+    }
+    for (; t < total; t += 2 * stride) {
+      const bool two = t + stride < total;
+      float v0[V], r0[V], v1[V], r1[V];
+      load_n<float, V>(y + t * V, v0);
+      load_n<float, V>(res + t * V, r0);
+      if (two) {
+        load_n<float, V>(y + (t + stride) * V, v1);
+        load_n<float, V>(res + (t + stride) * V, r1);
+      }
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        v0[i] = fmaxf((v0[i] - mu[i]) * sc[i] + be[i] + r0[i], 0.f);
+        if (two) v1[i] = fmaxf((v1[i] - mu[i]) * sc[i] + be[i] + r1[i], 0.f);
+      }
+      store_n<float, V>(z + t * V, v0);
+      store_n<PT, V>(zp + t * V, v0);
+      if (two) {
+        store_n<float, V>(z + (t + stride) * V, v1);
+        store_n<PT, V>(zp + (t + stride) * V, v1);
+      }
+    }
+    return;
+  }
+  for (; t < total; t += stride) {
     const int c0 = (int)(t % cv) * V;
     float v[V], r[V];
     load_n<float, V>(y + t * V, v);

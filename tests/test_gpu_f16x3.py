@@ -246,8 +246,9 @@ def test_resnet_join_kernels_emit_half_pairs(native):
     z = native.bn_add_relu_fwd(y, mean, invstd, gamma, beta, res)
     for dtype, view in ((native.SPLITH_DTYPE, torch.float16), (native.SPLIT_DTYPE, torch.bfloat16)):
         z2, zp = native.bn_add_relu_fwd(y, mean, invstd, gamma, beta, res, with_operand=dtype)
-        assert zp.dtype == dtype and torch.equal(z2, z)
-        assert torch.equal(zp.view(view), native.cast(z, dtype).view(view))
+        assert zp.dtype == dtype
+        torch.testing.assert_close(z2, z, rtol=2e-7, atol=1e-7)       # (the two instantiations may contract a*b+c differently)
+        assert torch.equal(zp.view(view), native.cast(z2, dtype).view(view))      # the pairs: the exact split of that fp32 half
         o = native.add_act(y, res, 1)
         o2, op = native.add_act(y, res, 1, with_operand=dtype)
         assert torch.equal(o, o2) and torch.equal(op.view(view), native.cast(o, dtype).view(view))
