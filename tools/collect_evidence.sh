@@ -24,20 +24,22 @@ fi
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   python3 bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
   python3 bench.py --kernel-table --steps 30 --no-cpu-baseline --no-secondary > /dev/null 2> $O/${TAG}_kernel_table.txt
-  for cfg in "--trainer base" "--trainer base --res full --steps 40" "--res full --steps 40" "--batch 1 --steps 200" "--model r101 --steps 40" "--opts SFOD.ELIDE_DEAD_BRANCHES False"; do
+  for cfg in "--trainer base" "--trainer base --res full --steps 40" "--res full --steps 40" "--batch 1 --steps 200" "--opts SFOD.ELIDE_DEAD_BRANCHES False" "--dtype f16x3"; do
     name=$(echo $cfg | tr -d ' -' | tr '.' '_')
     python3 bench.py $cfg --no-cpu-baseline --no-secondary > $O/${TAG}_bench_${name}.json 2> $O/${TAG}_bench_${name}.err
   done
+  # config #5 with its labelled blocks (other parity mode fp32; reduced-precision bf16x3 / bf16) from child processes
+  python3 bench.py --model r101 --steps 40 --no-cpu-baseline > $O/${TAG}_bench_modelr101steps40.json 2> $O/${TAG}_bench_modelr101steps40.err
 fi
 if [ "$WHAT" = r101 ] || [ "$WHAT" = all ]; then
-  # config #5 in its parity mode (fp32): kernel trace of single-stream steps, GPU busy fraction (union of kernel intervals
+  # config #5 in its parity mode (f16x3): kernel trace of single-stream steps, GPU busy fraction (union of kernel intervals
   # over the span of the timed steps, and the un-profiled step time of the bench line beside the profiled kernel-time sum)
   rm -rf $O/prof_r101
-  rocprofv3 --kernel-trace --stats -d $O/prof_r101 -o r101 -- python3 bench.py --model r101 --no-overlap --steps 12 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timer > $O/${TAG}_r101_fp32_profiled_bench.json 2> $O/${TAG}_r101_prof.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_r101 -o r101 -- python3 bench.py --model r101 --no-overlap --steps 12 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timer > $O/${TAG}_r101_f16x3_profiled_bench.json 2> $O/${TAG}_r101_prof.err
   DB=$(find $O/prof_r101 -name "*.db" | head -1)
-  python3 tools/rocpd_stats.py $DB 15 > $O/${TAG}_r101_fp32_kernel_stats.csv
-  python3 tools/busy_fraction.py $DB 0.3 > $O/${TAG}_r101_fp32_busy_fraction.txt
+  python3 tools/rocpd_stats.py $DB 15 > $O/${TAG}_r101_f16x3_kernel_stats.csv
+  python3 tools/busy_fraction.py $DB 0.3 > $O/${TAG}_r101_f16x3_busy_fraction.txt
   rm -rf $O/prof_r101
-  python3 bench.py --model r101 --no-overlap --steps 20 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_r101_fp32_single_stream.json 2> /dev/null
+  python3 bench.py --model r101 --no-overlap --steps 20 --no-cpu-baseline --no-secondary > $O/${TAG}_bench_r101_f16x3_single_stream.json 2> /dev/null
 fi
 ls -la $O | grep ${TAG}_ | awk '{print $5, $9}'
