@@ -456,6 +456,11 @@ int sfod_teacher_metrics(const float* det_scores, const int* det_count, int D, c
  * that is the operand of a forward product and of a weight gradient; replaces the reference's single fp32 tensor at
  * every such site, e.g. the RPN head input daod/modeling/proposal_generator/rpn.py:25-56) */
 int sfod_cast_pairs_both(const float* src, void* dst_f16x3, void* dst_bf16x3, int64_t n, void* stream);
+/* SFOD_F16X3 range report: every producer of half pairs raises a device flag when a FINITE value beyond +-65504 had to be
+ * clamped (activations or scaled weights outside the window the mode assumes).  This call ORs the flags into the caller's
+ * device word (zeroed by the caller once) and clears them; no host synchronisation -- the trainer reads the word at its
+ * metrics period, beside the RPN's non-finite flag (d2 raises FloatingPointError inside predict_proposals). */
+int sfod_f16x3_poll(uint32_t* word, void* stream);
 /* utilities */
 int sfod_fill_f32(float* p, int64_t n, float v, void* stream);
 int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int dst_dt, void* stream);

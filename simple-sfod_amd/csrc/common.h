@@ -65,8 +65,18 @@ __device__ __forceinline__ void split_store8(split_t* p, const float* in) {
 typedef _Float16 f16_t;
 struct splith_t { uint32_t raw; };
 
+// Saturation is REPORTED: a finite value beyond half's range raises this word (one copy per translation unit that
+// produces half pairs; sfod_f16x3_poll ORs them into the caller's device word and clears them), so that a model whose
+// activations or scaled weights leave the window the mode assumes fails loudly at the trainer's next metrics flush
+// instead of training on clamped values.
+static __device__ unsigned g_f16_sat;
+#define SFOD_DEFINE_F16_POLL(fn)                                                                            \
+  static __global__ void fn##_k(unsigned* out) { if (g_f16_sat) { atomicOr(out, 1u); g_f16_sat = 0u; } }    \
+  void fn(unsigned* out, hipStream_t s) { hipLaunchKernelGGL(fn##_k, dim3(1), dim3(1), 0, s, out); }
+
 __device__ __forceinline__ void f16_pair(float v, f16_t& h, f16_t& l) {
   const float lim = 65504.f;
+  if (fabsf(v) > lim && fabsf(v) <= 3.0e38f) g_f16_sat = 1u;      // finite and out of range (inf / NaN: the finite checks' business)
   const float c = (fabsf(v) > lim) ? copysignf(lim, v) : v;       // NaN compares false: passes through
   h = (f16_t)c;
   const float r = v - (float)h;

@@ -456,3 +456,5 @@ int sfod_f1_launch(const void* x, const void* w, const float* bias, void* y, flo
   else hipLaunchKernelGGL(k_conv_first, dim3(grid), dim3(256), 0, s, a);
   return sfod_check_launch("conv_first");
 }
+
+SFOD_DEFINE_F16_POLL(sfod_f16_poll_first)

@@ -47,6 +47,11 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split 
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split = 0);
 
+// ---- SFOD_F16X3 saturation words of the translation units that produce half pairs (common.h) -----------------------
+void sfod_f16_poll_elementwise(unsigned* out, hipStream_t s);
+void sfod_f16_poll_roi(unsigned* out, hipStream_t s);
+void sfod_f16_poll_first(unsigned* out, hipStream_t s);
+
 // ---- first layer (Cin = one padded chunk of 8, Cout = 64), bf16 / bf16x3 ------------------------------------------
 int sfod_f1_nblk(int B, int H, int W);
 // y == nullptr: statistics only (no stores); scale / shift: optional per-channel affine before the activation

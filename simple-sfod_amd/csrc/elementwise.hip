@@ -3,7 +3,7 @@
 //
 // Activations are NHWC; every kernel reads/writes 16 bytes per lane along the channel axis
 // (4 x fp32 or 8 x bf16) so a wavefront covers 1 KiB of contiguous channels per instruction.
-#include "common.h"
+#include "conv_internal.h"
 #include <type_traits>
 
 template <typename T> struct VecT;
@@ -1934,4 +1934,15 @@ extern "C" int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int 
   else
     hipLaunchKernelGGL((k_cast<bf16_t, bf16_t>), g, b, 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
   return sfod_check_launch("cast");
+}
+
+// ---- SFOD_F16X3 saturation report (common.h: g_f16_sat) -----------------------------------------------------------------
+SFOD_DEFINE_F16_POLL(sfod_f16_poll_elementwise)
+extern "C" int sfod_f16x3_poll(uint32_t* word, void* stream) {
+  SFOD_REQUIRE(word != nullptr, "f16x3_poll: null word");
+  hipStream_t s = (hipStream_t)stream;
+  sfod_f16_poll_elementwise(word, s);
+  sfod_f16_poll_roi(word, s);
+  sfod_f16_poll_first(word, s);
+  return sfod_check_launch("f16x3_poll");
 }

@@ -5,7 +5,7 @@
 // Forward: one workgroup per ROI, 16-byte channel vectors across the lanes; the feature map of the
 // hot config is 37x75x512 (2.8 MB in bf16) and stays L2-resident, so the [R,49,C] output writes are the
 // HBM traffic.  Backward: tiled gather (one owner per gradient element, no atomics) for pooled == 7.
-#include "common.h"
+#include "conv_internal.h"
 
 struct Sample {
   int y_low, x_low, y_high, x_high;
@@ -590,3 +590,5 @@ extern "C" int sfod_roi_align_bwd(const void* dout, int B, int H, int W, int C, 
   if (dt == SFOD_F32) return dispatch_roi_bwd<float>(dout, B, H, W, C, rois, R, pooled, scale, dfeat, s);
   return dispatch_roi_bwd<bf16_t>(dout, B, H, W, C, rois, R, pooled, scale, dfeat, s);
 }
+
+SFOD_DEFINE_F16_POLL(sfod_f16_poll_roi)

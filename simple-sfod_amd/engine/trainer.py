@@ -409,6 +409,8 @@ class BaseTrainer:
         rpn = getattr(self.model, "proposal_generator", None)
         if rpn is not None:
             rpn.check_finite()
+        if str(self.cfg.SFOD.COMPUTE_DTYPE).lower() == "f16x3":     # half pairs: clamped values are reported, not silent
+            native.check_f16x3_range(torch.device(self.device))
         rec = self.storage.flush(reduce_over_ranks=True)
         rec["lr"] = self.optimizer.param_groups[0]["lr"]
         if get_rank() == 0 and self.cfg.OUTPUT_DIR:

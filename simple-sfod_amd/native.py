@@ -479,6 +479,23 @@ def wscale_of(w_packed):
     return ws
 
 
+_f16_words = {}
+
+
+def check_f16x3_range(device):
+    """Raise if any producer of half pairs on ``device`` had to clamp a finite value beyond +-65504 since the last call
+    (sfod_f16x3_poll).  One host synchronisation: call it where the step synchronises anyway (the metrics flush)."""
+    w = _f16_words.get(device)
+    if w is None:
+        w = _f16_words[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    call("sfod_f16x3_poll", w)
+    if w.item() != 0:
+        w.zero_()
+        raise FloatingPointError(
+            "SFOD.COMPUTE_DTYPE f16x3: a finite activation or scaled weight beyond half's range (|v| > 65504) was clamped "
+            "since the last check -- the model leaves the exponent window this mode assumes; use \"fp32\" (or \"bf16x3\").")
+
+
 def pack_conv_weight(w_oihw, cin_pad, dt, rot180=False):
     cout, cin, ks, _ = w_oihw.shape
     rows = cin if rot180 else cout

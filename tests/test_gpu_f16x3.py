@@ -359,3 +359,38 @@ def test_conv_first_layer_kernel(native, hw):
     assert rel_err(nchw(zf), zref) < TOL
     z2 = native.bn_relu_pool_fwd(y, mean, invstd, gamma.to(DEV), beta.to(DEV), False, out_dtype=native.SPLITH_DTYPE)
     assert rel_err(zf, native.cast(z2, torch.float32).cpu()) < 1e-6
+
+
+def test_values_beyond_half_range_are_reported(native):
+    """A finite value that had to be clamped at +-65504 raises the library's flag; the trainer polls it at its metrics
+    period (native.check_f16x3_range) -- saturation is loud, not silent.  inf / NaN are the finite checks' business."""
+    dev = torch.device(DEV)
+    try:
+        native.check_f16x3_range(dev)          # whatever earlier tests left behind
+    except FloatingPointError:
+        pass
+    x = torch.randn(64, 64, device=DEV) * 100.0
+    to_pairs(native, x)
+    native.pack_fc_weight(x, native.F16X3)
+    y = torch.randn(2, 8, 8, 64, device=DEV)
+    m, i = y.mean(dim=(0, 1, 2)), torch.rsqrt(y.var(dim=(0, 1, 2)) + 1e-5)
+    native.bn_relu_pool_fwd(y, m, i, torch.ones(64, device=DEV), torch.zeros(64, device=DEV), False, out_dtype=native.SPLITH_DTYPE)
+    native.check_f16x3_range(dev)              # in range: silent
+    x[3, 5] = float("inf")
+    x[4, 5] = float("nan")
+    to_pairs(native, x)
+    native.check_f16x3_range(dev)              # non-finite values are not range errors
+    x[3, 5], x[4, 5] = 70000.0, 0.0
+    to_pairs(native, x)
+    with pytest.raises(FloatingPointError):
+        native.check_f16x3_range(dev)
+    native.check_f16x3_range(dev)              # reported once, then clear
+    feat = torch.full((1, 8, 8, 64), 1.0e5, device=DEV)        # the ROIAlign producer (its own translation unit)
+    rois = torch.tensor([[0.0, 0.0, 0.0, 100.0, 100.0]], device=DEV)
+    fp = native.cast(feat, native.SPLITH_DTYPE)
+    with pytest.raises(FloatingPointError):    # the conversion itself clamps 1e5's lo part? no: 65504 + 34496 -- but hi saturates
+        native.check_f16x3_range(dev)
+    native.roi_align_fwd(fp, rois, 7, 1.0 / 32)                 # pooled values 1e5 again: reported by THAT kernel's flag
+    with pytest.raises(FloatingPointError):
+        native.check_f16x3_range(dev)
+    native.check_f16x3_range(dev)
