@@ -178,6 +178,10 @@ class ResNet(nn.Module):
         self.bn_updates_per_forward = 1      # see backbone_vgg: momentum updates folded into one forward
         self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
         self.dual_join = os.environ.get("SFOD_NO_DUAL_JOIN", "0") != "1"           # A/B hook: join kernels also emit the operand pairs
+        # weight gradients of the live bottleneck convolutions on a second HIP stream beside the data-gradient chain: at this
+        # config's sizes (res4: 22 800 rows) one 1x1 kernel fills 70 % of the CUs for 60 us, so the two independent
+        # GEMMs of a layer's backward share the chip (SFOD_RESNET_WGRAD_STREAM=0: everything on one stream)
+        self.wgrad_stream = os.environ.get("SFOD_RESNET_WGRAD_STREAM", "1") != "0"
 
     # ---- Detectron2 Backbone surface -----------------------------------------------------------------
     @property
@@ -389,7 +393,18 @@ class ResNet(nn.Module):
                                                     out_dtype=self.grad_dtype)   # dy only feeds wgrad / dgrad MFMAs
         if direct_bn:
             dgamma = dbeta = None
-        dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.grad_dtype)
+        side = self.__dict__.get("_side")
+        if side is not None:
+            # dy is complete on the main stream; the weight gradient reads (x_in, dy) on the side stream while the main
+            # stream goes on with the data gradient.  Both tensors stay referenced until the join at the end of the backward.
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.grad_dtype)
+            self._side_keep.append((x_in, dy, dw))
+        else:
+            dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.grad_dtype)
         dx = None
         if need_dx:
             wr = self.__dict__.get("_wr", {}).get(id(conv))      # packed with the forward weights (same step, same values)
@@ -429,6 +444,12 @@ class ResNet(nn.Module):
             hook()   # e.g. GradientReducer.launch_early: the heads' gradients are final now
         blocks = self._live_blocks()
         assert len(saved) == len(blocks)
+        self._side, self._side_keep = None, []
+        if self.wgrad_stream and torch.cuda.is_available():
+            st = self.__dict__.get("_side_stream")
+            if st is None:
+                st = self.__dict__["_side_stream"] = torch.cuda.Stream()
+            self._side = st
         # only the last requested feature feeds the heads on the C4 path; earlier ones would add here
         live_names = [n for n in self.stage_names if n not in self.frozen]
         block_stage = [n for n in live_names for _ in getattr(self, n)]
@@ -454,6 +475,13 @@ class ResNet(nn.Module):
             dx, pg[bi], masked = self._block_backward(blk, saved[bi], dx, need_dx=bi > 0,   # first live block: frozen input
                                                       masked=masked, below_out=below)
             saved[bi] = None
+        if self._side is not None:      # every weight gradient is in its buffer before anyone (all-reduce, SGD, autograd) reads it
+            main = torch.cuda.current_stream()
+            main.wait_stream(self._side)
+            for _, _, dw in self._side_keep:      # a gradient tensor made on the side stream is consumed on the main one
+                if dw is not None:
+                    dw.record_stream(main)
+            self._side, self._side_keep = None, []
         out = []
         for bi, blk in enumerate(blocks):
             if bi in pg:
