@@ -1217,6 +1217,23 @@ extern "C" int sfod_subsample2(const void* src, void* dst, int B, int H, int W, 
 // im2col of the 7x7 stride-2 pad-3 stem convolution: out [B,Ho,Wo,Kpad], k = (ky*7+kx)*3 + c for the
 // first 147 columns, zeros up to Kpad.  The stem is frozen (FREEZE_AT=2), so only the forward exists;
 // the GEMM itself (K = Kpad, N = 64, FrozenBN folded into the weights, ReLU) runs on sfod_conv_fwd.
+// column k -> (ky, kx, c) packed as ky | kx << 8 | c << 16 (0xffffffff: padding column), built at compile time: the
+// per-element divisions were the kernel's cost (8 scattered 4-byte loads per thread otherwise hit L1 / L2)
+struct StemLut { unsigned v[200]; };
+static constexpr StemLut make_stem_lut() {
+  StemLut t{};
+  for (int k = 0; k < 200; ++k) {
+    if (k < 147) {
+      const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+      t.v[k] = (unsigned)ky | ((unsigned)kx << 8) | ((unsigned)c << 16);
+    } else {
+      t.v[k] = 0xffffffffu;
+    }
+  }
+  return t;
+}
+__constant__ StemLut c_stem_lut = make_stem_lut();
+
 template <typename T, typename TO = T>
 __global__ void k_im2col_stem(const T* __restrict__ x, TO* __restrict__ out, int B, int H, int W, int Cp, int Kpad) {
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -1230,16 +1247,16 @@ __global__ void k_im2col_stem(const T* __restrict__ x, TO* __restrict__ out, int
     pix /= Wo;
     const int oy = (int)(pix % Ho);
     const int b = (int)(pix / Ho);
+    const T* xb = x + (int64_t)b * H * W * Cp;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = g * 8 + e;
+      const unsigned code = k < 200 ? c_stem_lut.v[k] : 0xffffffffu;
       float val = 0.f;
-      if (k < 147) {
-        const int tap = k / 3, c = k - tap * 3;
-        const int ky = tap / 7, kx = tap - ky * 7;
-        const int iy = 2 * oy - 3 + ky, ix = 2 * ox - 3 + kx;
-        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = to_f32(x[(((int64_t)b * H + iy) * W + ix) * Cp + c]);
+      if (code != 0xffffffffu) {
+        const int iy = 2 * oy - 3 + (int)(code & 0xffu), ix = 2 * ox - 3 + (int)((code >> 8) & 0xffu);
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = to_f32(xb[((int64_t)iy * W + ix) * Cp + (code >> 16)]);
       }
       v[e] = val;
     }

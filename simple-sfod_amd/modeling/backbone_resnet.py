@@ -245,7 +245,8 @@ class ResNet(nn.Module):
         assert isinstance(conv.norm, FrozenBatchNorm2d), "the stem is frozen on the hot path (FREEZE_AT >= 1)"
         scale, shift = conv.norm.scale_shift()
         w = (conv.weight.detach() * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).reshape(conv.out_channels, 147)
-        kpad = 192
+        # 147 columns padded to whole K tiles of the GEMM's uniform-tap path (8 x 16-byte chunks): 160 (5 tiles) for fp32 / pairs, 192 (3) for bf16
+        kpad = 192 if self.compute_dtype == torch.bfloat16 else 160
         wk = torch.zeros(conv.out_channels, kpad, dtype=torch.float32, device=x.device)
         wk[:, :147] = w
         cols = native.im2col_stem(x, kpad, out_dtype=self.compute_dtype if native.is_pairs(self.compute_dtype) else None)

@@ -18,7 +18,7 @@ SHAPES = [("vgg fc1 teacher", 16000, 25088, 1024), ("vgg fc1 student", 4096, 250
           ("r101 res4 1024->1024 (shortcut-like)", 22800, 1024, 1024), ("r101 rpn 1x1 1024->60", 22800, 1024, 60)]
 split = args.dtype == "bf16x3"
 SHAPES += [("r101 res3 256->512 (shortcut)", 90000, 256, 512), ("r101 res4 512->1024 (shortcut)", 22800, 512, 1024),
-           ("r101 res2 64->64", 360000, 64, 64), ("r101 fc2 teacher", 16000, 2048, 2048), ("r101 predictor", 16000, 2048, 48)]
+           ("r101 res2 64->64", 360000, 64, 64), ("r101 stem im2col 160->64", 1440000, 160, 64), ("r101 fc2 teacher", 16000, 2048, 2048), ("r101 predictor", 16000, 2048, 48)]
 for (name, M, K, N) in SHAPES:
     if args.only and args.only not in name:
         continue
