@@ -185,6 +185,7 @@ def build_trainer(sfod, args, dtype, world, rank, local_rank):
         opts += ["SOLVER.IMS_PER_BATCH_TARGET", str(args.batch * world)]
     if args.no_overlap:
         opts += ["SFOD.OVERLAP_TEACHER", "False"]
+        os.environ["SFOD_RESNET_WGRAD_STREAM"] = "0"      # ... and the ResNet backward's weight gradients too: ONE stream
     if args.res == "full":
         opts += ["INPUT.MIN_SIZE_TRAIN", "(1024,)", "INPUT.MAX_SIZE_TRAIN", "2048"]
     yaml = YAML["vgg_base"] if args.trainer == "base" else YAML[args.model]
@@ -286,6 +287,11 @@ def main():
     if not args.no_kernel_timer and overlapped:
         rl_steps = max(1, min(5, args.steps))
         trainer.overlap_teacher = False
+        bbs = [m.backbone for m in (trainer.model, getattr(trainer, "model_teacher", None)) if m is not None]
+        ws_saved = [getattr(b, "wgrad_stream", None) for b in bbs]
+        for b in bbs:                       # (ResNet: the backward's weight gradients run on a side stream otherwise)
+            if hasattr(b, "wgrad_stream"):
+                b.wgrad_stream = False
         run_steps(trainer, args.warmup + args.steps, 1)   # one untimed step to settle the allocator in this mode
         timer = sfod.native.KernelTimer()
         sfod.native.set_timer(timer)
@@ -296,6 +302,9 @@ def main():
         rl_elapsed = time.perf_counter() - t1
         sfod.native.set_timer(None)
         trainer.overlap_teacher = None
+        for b, w in zip(bbs, ws_saved):
+            if w is not None:
+                b.wgrad_stream = w
         rl_segment = (f"{rl_steps} single-stream steps after the timed region ({1000.0 * rl_elapsed / rl_steps:.2f} ms/step): "
                       "the timed steps run the teacher on a second stream, where a kernel's event duration includes "
                       "time shared with concurrent kernels")

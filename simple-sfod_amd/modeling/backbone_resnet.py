@@ -325,7 +325,12 @@ class ResNet(nn.Module):
             xs = x
         # the block input becomes an operand ONCE, shared by conv1, the shortcut conv and (live blocks) both weight
         # gradients
-        xs_op = x_op if x_op is not None else native.as_operand(xs, self.compute_dtype)
+        split_g = live and save and self.grad_dtype != self.compute_dtype
+        xs_g = None
+        if x_op is not None:
+            xs_op = x_op
+        else:       # (f16x3, differentiated pass: half pairs AND the weight gradient's bf16 pairs from one pass over xs)
+            xs_op, xs_g = native.operands_for(xs, self.compute_dtype, need_grad=split_g)
         if not live:
             sc = x if blk.shortcut is None else self._frozen_conv(xs_op, blk.shortcut, 0, dt)
             o = self._frozen_conv(xs_op, blk.conv1, 1, dt)
@@ -338,8 +343,10 @@ class ResNet(nn.Module):
         # a1 / a2 only feed convolutions, so their BatchNorm kernels write pairs directly (a differentiated pass: also the
         # weight-gradient operands a1g / a2g -- the same tensors except in f16x3 mode)
         xs_act, xs = xs, xs_op
-        split_g = save and self.grad_dtype != self.compute_dtype
-        xs_g = native.as_operand(xs_act, self.grad_dtype) if split_g else xs
+        if not split_g:
+            xs_g = xs
+        elif xs_g is None:
+            xs_g = native.as_operand(xs_act, self.grad_dtype)
         y1, m1, i1, a1 = self._live_conv_bn(xs, blk.conv1, True, dt, z_operand=True, z_grad=split_g)
         a1, a1g = a1 if split_g else (a1, a1)
         y2, m2, i2, a2 = self._live_conv_bn(a1, blk.conv2, True, dt, z_operand=True, z_grad=split_g)

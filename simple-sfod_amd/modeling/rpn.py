@@ -95,7 +95,7 @@ class _RPNLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rpn, feat_nchw, gt, keys, *params):
-        st = rpn._head_forward(feat_nchw)
+        st = rpn._head_forward(feat_nchw, need_grad=True)
         loss, lab_state = rpn._loss_forward(st, gt, keys)
         ctx.rpn, ctx.st, ctx.lab_state, ctx.gt = rpn, st, lab_state, gt
         rpn._last_head_state = st
@@ -142,11 +142,17 @@ class RPN(nn.Module):
     def _cell(self):
         return self.anchor_generator.cell_anchors._buffers["0"]
 
-    def _head_forward(self, feat_nchw):
-        """feat (NCHW view of NHWC memory) -> dict(feat, t, rpn_out)"""
+    def _head_forward(self, feat_nchw, need_grad=False):
+        """feat (NCHW view of NHWC memory) -> dict(feat, t, rpn_out).  ``need_grad``: a backward follows -- the input is also
+        kept as the operand the 3x3 convolution's weight gradient reads (f16x3: bf16 pairs, from the same pass)"""
         dtype = self.compute_dtype
         dt = native.dt_of_dtype(dtype)
-        feat = native.nhwc_operand(feat_nchw, dtype)
+        nhwc = feat_nchw.permute(0, 2, 3, 1)
+        if nhwc.dtype == torch.float32 and native.is_pairs(dtype):
+            feat, feat_g = native.operands_for(nhwc.contiguous(), dtype, need_grad)
+        else:
+            feat = native.nhwc_operand(feat_nchw, dtype)
+            feat_g = feat if need_grad else None
         h = self.rpn_head
         C, A = self.channels, self.num_anchors
         wp = native.pack_conv_weight(h.conv.weight.detach(), C, dt)
@@ -156,7 +162,7 @@ class RPN(nn.Module):
         w1p = native.pack_fc_weight(w1, dt)
         B, Hf, Wf, _ = feat.shape
         rpn_out = native.conv_fwd(t.view(B * Hf * Wf, C), w1p, b1, 5 * A, 1, out_dtype=torch.float32, ldy=self.ld)
-        return {"feat": feat, "feat_src": feat_nchw, "t": t, "rpn_out": rpn_out, "w1": w1, "shape": (B, Hf, Wf)}
+        return {"feat": feat, "feat_g": feat_g, "t": t, "rpn_out": rpn_out, "w1": w1, "shape": (B, Hf, Wf)}
 
     def _sizes_dev(self, image_sizes, device):
         return native.dev_const(tuple((int(s[0]), int(s[1])) for s in image_sizes), torch.int32, device)
@@ -216,8 +222,7 @@ class RPN(nn.Module):
         # 3x3 conv
         h = self.rpn_head
         dt4 = dt_.view(B, Hf, Wf, C)
-        feat_g = st["feat"] if st["feat"].dtype == dtype else native.nhwc_operand(st["feat_src"], dtype)
-        dw0 = native.conv_weight_grad(feat_g, dt4, h.conv.weight, operand=dtype)
+        dw0 = native.conv_weight_grad(st["feat_g"], dt4, h.conv.weight, operand=dtype)
         db0 = native.bias_grad(dt_, C)
         wr = native.pack_conv_weight(h.conv.weight.detach(), C, dt, rot180=True)
         dfeat = native.conv_fwd(dt4, wr, None, C, 3)
