@@ -1217,25 +1217,21 @@ extern "C" int sfod_subsample2(const void* src, void* dst, int B, int H, int W, 
 // im2col of the 7x7 stride-2 pad-3 stem convolution: out [B,Ho,Wo,Kpad], k = (ky*7+kx)*3 + c for the
 // first 147 columns, zeros up to Kpad.  The stem is frozen (FREEZE_AT=2), so only the forward exists;
 // the GEMM itself (K = Kpad, N = 64, FrozenBN folded into the weights, ReLU) runs on sfod_conv_fwd.
-// column k -> (ky, kx, c) packed as ky | kx << 8 | c << 16 (0xffffffff: padding column), built at compile time: the
-// per-element divisions were the kernel's cost (8 scattered 4-byte loads per thread otherwise hit L1 / L2)
-struct StemLut { unsigned v[200]; };
-static constexpr StemLut make_stem_lut() {
-  StemLut t{};
-  for (int k = 0; k < 200; ++k) {
-    if (k < 147) {
-      const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
-      t.v[k] = (unsigned)ky | ((unsigned)kx << 8) | ((unsigned)c << 16);
-    } else {
-      t.v[k] = 0xffffffffu;
-    }
-  }
-  return t;
-}
-__constant__ StemLut c_stem_lut = make_stem_lut();
-
+// column k -> (ky, kx, c) packed as ky | kx << 8 | c << 16 (0xffffffff: padding column): a per-workgroup LDS table -- the
+// per-element divisions were the kernel's cost (8 scattered 4-byte loads per thread otherwise hit L1 / L2); lanes of a
+// wave index it at different k, which a __constant__ table serialises (tried: 630 -> 760 us)
 template <typename T, typename TO = T>
 __global__ void k_im2col_stem(const T* __restrict__ x, TO* __restrict__ out, int B, int H, int W, int Cp, int Kpad) {
+  __shared__ unsigned lut[256];
+  for (int k = threadIdx.x; k < 256; k += blockDim.x) {
+    unsigned code = 0xffffffffu;
+    if (k < 147) {
+      const int tap = k / 3, c = k - tap * 3, ky = tap / 7, kx = tap - ky * 7;
+      code = (unsigned)ky | ((unsigned)kx << 8) | ((unsigned)c << 16);
+    }
+    lut[k] = code;
+  }
+  __syncthreads();
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
   const int kv = Kpad / 8;   // 8-element groups per row
   const int64_t total = (int64_t)B * Ho * Wo * kv;
@@ -1252,7 +1248,7 @@ __global__ void k_im2col_stem(const T* __restrict__ x, TO* __restrict__ out, int
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int k = g * 8 + e;
-      const unsigned code = k < 200 ? c_stem_lut.v[k] : 0xffffffffu;
+      const unsigned code = k < 256 ? lut[k] : 0xffffffffu;
       float val = 0.f;
       if (code != 0xffffffffu) {
         const int iy = 2 * oy - 3 + (int)(code & 0xffu), ix = 2 * ox - 3 + (int)((code >> 8) & 0xffu);
