@@ -76,12 +76,12 @@ def test_backbone_matches_reference_golden(sfod, native, dtype):
         assert list(f.shape) == list(fx[f"vgg{i}_shape"])
         got = f if i >= 2 else f[:, ::8, ::4, ::4]
         # 13 conv + BatchNorm layers deep: fp32 MFMA 2e-5; bf16x3 (4e-6 per dot product, see test_gpu_bf16x3.py) 1e-4 (measured 5.5e-5 at vgg4)
-        assert rel_err(got, torch.from_numpy(fx[f"vgg{i}"])) < (2e-5 if dtype == "fp32" else 1e-4)
+        assert rel_err(got, torch.from_numpy(fx[f"vgg{i}"])) < (2e-5 if dtype in ("fp32", "f16x3") else 1e-4)     # f16x3: forward products on 22-bit operands, held to fp32's gate
     sd = bb.state_dict()
     for k in fx.files:
         if k.startswith("after/"):
             torch.testing.assert_close(sd[k[len("after/"):]].cpu(), torch.from_numpy(fx[k]), rtol=1e-4,
-                                       atol=1e-6 if dtype == "fp32" else 2e-5)
+                                       atol=1e-6 if dtype in ("fp32", "f16x3") else 2e-5)
 
 
 def test_dann_modules_match_reference_golden(sfod, native):
@@ -338,7 +338,7 @@ def test_student_losses_and_gradients_match_oracle(sfod, native, dtype):
     # BN running statistics refreshed identically
     for name, buf in model.state_dict().items():
         if "running" in name:
-            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6 if dtype == "fp32" else 2e-5)
+            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6 if dtype in ("fp32", "f16x3") else 2e-5)
         if "num_batches_tracked" in name:
             assert buf.item() == sd[name].item() == 1
 
@@ -411,7 +411,7 @@ def test_teacher_pseudo_label_pipeline_matches_oracle(sfod, native, dtype):
     # (bf16x3: a channel mean is a sum of cancelling terms; its error is ~1e-6 of the channel's standard deviation)
     for name, buf in model.state_dict().items():
         if "running" in name:
-            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6 if dtype == "fp32" else 2e-5)
+            torch.testing.assert_close(buf.cpu(), sd[name].detach(), rtol=1e-4, atol=1e-6 if dtype in ("fp32", "f16x3") else 2e-5)
 
 
 def test_eval_mode_inference_and_trainer_test_match_oracle(sfod, native, tmp_path):

@@ -244,7 +244,7 @@ def test_bf16x3_stays_with_fp32_over_a_longer_horizon(sfod, native):
     stay a small fraction of the distance the weights travelled."""
     B, H, W, STEPS = 2, 256, 384, 16
     runs = {}
-    for tag, dtype, eps in (("fp32", "fp32", 0.0), ("fp32_perturbed", "fp32", 1e-7), ("bf16x3", "bf16x3", 0.0)):
+    for tag, dtype, eps in (("fp32", "fp32", 0.0), ("fp32_perturbed", "fp32", 1e-7), ("bf16x3", "bf16x3", 0.0), ("f16x3", "f16x3", 0.0)):
         cfg = sfod.config.setup_cfg(HOT_YAML, [
             "OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", dtype, "SOLVER.IMS_PER_BATCH_TARGET", str(B),
             "SFOD.SYNTHETIC.HEIGHT", str(H), "SFOD.SYNTHETIC.WIDTH", str(W), "SFOD.SYNTHETIC.NUM_IMAGES", "8",
@@ -285,3 +285,6 @@ def test_bf16x3_stays_with_fp32_over_a_longer_horizon(sfod, native):
           f"bf16x3 {med['bf16x3']}")
     assert d_x3 < 0.5 * moved
     assert d_x3 < 4.0 * d_fp32 + 0.02 * moved
+    d_h3 = (runs["f16x3"][1] - p32).norm().item()
+    print(f"[longer horizon] f16x3 distance / moved {d_h3 / moved:.3f}")
+    assert d_h3 < 0.5 * moved and d_h3 < 4.0 * d_fp32 + 0.02 * moved
