@@ -326,22 +326,25 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
     }
     stage_compute(cur);
   } else {
-    // 3 stages: K tiles t+1 and t+2 are in flight while tile t feeds the MFMAs.  Per wave and stage
-    // exactly AI+BI DMA instructions are issued, so "all but the newest AI+BI" == "tile t landed".
-    stage_load(0, 0);
-    if (KT > 1) stage_load(1, 1);
-    int cur = 0, nxt = 2;
+    // NST >= 3 stages: K tiles t+1 .. t+NST-1 are in flight while tile t feeds the MFMAs.  Per wave and stage
+    // exactly AI+BI DMA instructions are issued, so "all but the newest (NST-2) x (AI+BI)" == "tile t landed".
+    static_assert(NST >= 3 && NST <= 4 && (NST - 2) * (AI + BI) <= 63, "counted vmcnt immediate");
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+      if (p < KT) stage_load(p, p);
+    int cur = 0, nxt = NST - 1;
     for (int kt = 0; kt < KT; ++kt) {
       // lgkmcnt(0): this wave's fragment reads of tile kt-1 have returned before anyone's DMA may overwrite
       // that buffer (the compiler sinks the last reads + MFMAs below the barrier otherwise)
-      if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AI + BI) : "memory");
+      if (NST == 4 && kt + 2 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(2 * (AI + BI)) : "memory");
+      else if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(AI + BI) : "memory");
       else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // tile kt landed for every wave; everyone is done with tile kt-1
       asm volatile("" ::: "memory");
-      if (kt + 2 < KT) stage_load(kt + 2, nxt);
+      if (kt + NST - 1 < KT) stage_load(kt + NST - 1, nxt);
       stage_compute(cur);
-      cur = (cur == 2) ? 0 : cur + 1;
-      nxt = (nxt == 2) ? 0 : nxt + 1;
+      cur = (cur == NST - 1) ? 0 : cur + 1;
+      nxt = (nxt == NST - 1) ? 0 : nxt + 1;
     }
   }
 
@@ -573,6 +576,7 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
   // bf16x3 linear layers / 1x1 convolutions with wide outputs: 256 x 256 tiles (64-byte K stages) when their rounds of
   // 256 workgroups (one per CU) are filled well enough to beat 256 x 128 (profiles/r2d_bench_gemm.txt)
   if constexpr (UT && SPLIT && sizeof(OutT) == 4) {
+    // (a 4-stage form of this pipeline -- three K tiles in flight -- measured the same: profiles/r3_rejected_experiments.txt)
     if (use_wide_gemm(a.M, a.Cout, a.ks)) return launch_one<T, OutT, 4, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
   }
   // fp32 (MFMA-bound at 1/16 of the bf16 rate: a tile's time is its FLOPs, the operand stream is never the limit): pick
