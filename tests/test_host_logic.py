@@ -298,3 +298,41 @@ def test_reads_checkpoints_in_the_reference_stacks_formats(sfod, tmp_path):
         assert torch.equal(opt.mom[o:o + k].view(shp), m), n
     with pytest.raises(ValueError, match="does not fit this model"):
         opt.load_state_dict({"state": {}, "param_groups": [{"lr": 0.1, "params": [0, 1, 2]}]})
+
+
+def test_compute_modes_and_operand_formats(sfod):
+    """SFOD.COMPUTE_DTYPE -> operand formats, host side only: every mode name resolves, the yamls select the mode their
+    600x1200 gate passes in (VGG16: bf16x3; ResNet-101: f16x3), f16x3 pairs half-pair forward operands with bf16-pair
+    backward operands, and the two pair formats carry distinct storage tags (a tensor of one can never be taken for the other)."""
+    native = sfod.native
+    assert set(native.COMPUTE_MODES) == {"fp32", "bf16", "bf16x3", "f16x3"}
+    assert [native.mode_dt(n) for n in ("fp32", "bf16", "bf16x3", "f16x3")] == [native.F32, native.BF16, native.BF16X3, native.F16X3]
+    assert native.mode_dt("F16X3") == native.F16X3
+    with pytest.raises(ValueError):
+        native.mode_dt("fp16")
+    assert native.mode_dtype("bf16x3") == native.SPLIT_DTYPE and native.mode_dtype("f16x3") == native.SPLITH_DTYPE
+    assert native.SPLIT_DTYPE != native.SPLITH_DTYPE
+    assert torch.empty(0, dtype=native.SPLIT_DTYPE).element_size() == torch.empty(0, dtype=native.SPLITH_DTYPE).element_size() == 4
+    for dtype in (torch.float32, torch.bfloat16, native.SPLIT_DTYPE, native.SPLITH_DTYPE):
+        assert native.torch_dtype(native.dt_of_dtype(dtype)) == dtype
+    # forward operands -> backward operands / dtype the convolutions write
+    assert native.grad_dtype_of(native.SPLITH_DTYPE) == native.SPLIT_DTYPE          # gradients do not fit half's range
+    assert native.grad_dtype_of(native.SPLIT_DTYPE) == native.SPLIT_DTYPE
+    assert native.grad_dtype_of(torch.float32) == torch.float32 and native.grad_dtype_of(torch.bfloat16) == torch.bfloat16
+    assert native.out_dtype_of(native.SPLITH_DTYPE) == native.out_dtype_of(native.SPLIT_DTYPE) == torch.float32
+    assert native.is_pairs(native.SPLITH_DTYPE) and native.is_pairs(native.SPLIT_DTYPE) and not native.is_pairs(torch.float32)
+    assert native.chunk_elems(native.F16X3) == native.chunk_elems(native.BF16X3) == 8
+    # the header's codes are the wrapper's
+    hdr = open(native.HEADER).read()
+    for name, code in (("SFOD_F32", native.F32), ("SFOD_BF16", native.BF16), ("SFOD_BF16X3", native.BF16X3), ("SFOD_F16X3", native.F16X3)):
+        assert f"#define {name} {code}\n" in hdr
+    # which mode each yaml runs in
+    cfgs = os.path.join(ROOT, "configs")
+    hot = sfod.config.setup_cfg(os.path.join(cfgs, "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"))
+    r101 = sfod.config.setup_cfg(os.path.join(cfgs, "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml"))
+    assert hot.SFOD.COMPUTE_DTYPE == "bf16x3" and r101.SFOD.COMPUTE_DTYPE == "f16x3"
+    over = sfod.config.setup_cfg(os.path.join(cfgs, "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml"), ["SFOD.COMPUTE_DTYPE", "fp32"])
+    assert over.SFOD.COMPUTE_DTYPE == "fp32"
+    import importlib
+    bench = importlib.import_module("bench")
+    assert bench.PARITY_DTYPE == {"vgg": hot.SFOD.COMPUTE_DTYPE, "r101": r101.SFOD.COMPUTE_DTYPE}
