@@ -296,8 +296,11 @@ def test_bf16x3_stays_with_fp32_over_a_longer_horizon(sfod, native):
     print(f"\n[{STEPS} free-running steps] student distance from the fp32 run / distance travelled: another fp32 run "
           f"{d_fp32 / moved:.3f}, bf16x3 {d_x3 / moved:.3f}; median relative loss difference per key: fp32' {med['fp32_perturbed']}, "
           f"bf16x3 {med['bf16x3']}")
-    assert d_x3 < 0.5 * moved
-    assert d_x3 < 4.0 * d_fp32 + 0.02 * moved
     d_h3 = (runs["f16x3"][1] - p32).norm().item()
     print(f"[longer horizon] f16x3 distance / moved {d_h3 / moved:.3f}")
-    assert d_h3 < 0.5 * moved and d_h3 < 4.0 * d_fp32 + 0.02 * moved
+    # all three distances are outcomes of the same chaotic process (seen: 0.34 ... 0.41 of the distance travelled, any of
+    # them the largest): the modes may not drift more than twice as far as the second fp32 run does, nor leave the
+    # neighbourhood of the fp32 trajectory altogether
+    for d in (d_x3, d_h3):
+        assert d < 2.0 * d_fp32 + 0.05 * moved, (d / moved, d_fp32 / moved)
+        assert d < 0.9 * moved, d / moved
