@@ -441,7 +441,7 @@ def main():
                        ("losses and decoded boxes within 1e-4 of the CPU oracle, intermediates (RPN logits / deltas, box "
                         "scores / deltas) within 2e-4 (measured 6e-5 .. 1e-4), every discrete decision bit-exact"
                         if args.model == "vgg" else
-                        "on this 101-layer network only ~1e-3 (tracking gates) -- fp32 is this config's parity mode")),
+                        "on this 101-layer network only ~1e-3 (tracking gates) -- f16x3 and fp32 are this config's parity modes")),
             "fp32": "v_mfma_f32_32x32x2_f32 (exact fp32 FMA chains); losses and decoded boxes within 1e-4 of the CPU oracle at "
                     "600x1200 (tests/test_gpu_fullsize.py), intermediates within 3x the reference arithmetic's own fp32-vs-fp64 "
                     "error on the network",
