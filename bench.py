@@ -53,8 +53,10 @@ PARITY_DTYPE = {"vgg": "bf16x3", "r101": "f16x3"}
 OTHER_PARITY = {"vgg": {"bf16x3": ["f16x3"]}, "r101": {"f16x3": ["fp32"]}}
 # "planted-label" scale on cls_score: 10-30 teacher detections per image clear the 0.8 threshold
 PLANT = {"vgg": 60.0, "r101": 3.0}
-# the committed PMC capture (profiles/pmc_hbm_traffic_latest.json) was taken on exactly this run configuration
-PMC_CAPTURE = {"model": "vgg", "trainer": "source_free", "res": "r600", "batch": 8}
+# the committed PMC captures (profiles/pmc_hbm_traffic_latest.json: VGG16 bf16x3; pmc_hbm_traffic_r101_latest.json: R101 f16x3)
+# were taken on exactly these run configurations
+PMC_CAPTURE = {"trainer": "source_free", "res": "r600", "batch": 8,
+               "files": {"vgg": ("bf16x3", "pmc_hbm_traffic_latest.json"), "r101": ("f16x3", "pmc_hbm_traffic_r101_latest.json")}}
 
 
 def step_flops(res, model="vgg", trainer="source_free"):
@@ -140,12 +142,13 @@ def cpu_baseline(res, planted, model="vgg"):
             "seconds_per_stage": {k: round(v, 3) for k, v in stages.items()}}
 
 
-def pmc_traffic(*kernel_substrs):
+def pmc_traffic(model, *kernel_substrs):
     """HBM bytes per launch of the dominant kernel family from the committed PMC passes (rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs, gfx950 corrections applied by tools/pmc_summary.py): the
     launch-weighted mean over the family's template instantiations (tile shapes, with / without the BatchNorm-backward
     epilogue), i.e. per launch over the same set of launches as `achieved`.  bench.py cannot collect counters itself."""
-    path = os.path.join(ROOT, "profiles", "pmc_hbm_traffic_latest.json")
+    fname = PMC_CAPTURE["files"][model][1]
+    path = os.path.join(ROOT, "profiles", fname)
     if not os.path.exists(path):
         return None
     try:
@@ -157,14 +160,15 @@ def pmc_traffic(*kernel_substrs):
             return None
         return {"hbm_read_MB_per_launch": round(sum(r["hbm_read_MB_per_launch"] * r["launches"] for r in rows) / n, 3),
                 "hbm_write_MB_per_launch": round(sum(r["hbm_write_MB_per_launch"] * r["launches"] for r in rows) / n, 3),
-                "kernels": len(rows), "launches_counted": n, "source": "profiles/pmc_hbm_traffic_latest.json"}
+                "kernels": len(rows), "launches_counted": n, "source": "profiles/" + fname}
     except Exception:
         return None
 
 
 def pmc_matches(args):
-    return (args.model == PMC_CAPTURE["model"] and args.trainer == PMC_CAPTURE["trainer"] and args.res == PMC_CAPTURE["res"]
-            and args.batch == PMC_CAPTURE["batch"] and not args.opts)
+    return (args.model in PMC_CAPTURE["files"] and args.dtype == PMC_CAPTURE["files"][args.model][0] and
+            args.trainer == PMC_CAPTURE["trainer"] and args.res == PMC_CAPTURE["res"] and args.batch == PMC_CAPTURE["batch"]
+            and not args.opts)
 
 
 def _launcher():
@@ -501,8 +505,11 @@ def main():
             "frac_of_bf16_peak_algorithmic": round(ach / PEAK["bf16"], 4),
             # HBM bytes per launch from the committed PMC passes of THIS mode's kernel (tools/pmc_hbm_run.sh); null otherwise
             # only when THIS run is the configuration the counters were captured on (else null)
-            "traffic": (pmc_traffic("k_conv3x3_patch<", {"bf16x3": ("float, true", "float, 1,"), "bf16": ("__bf16, false", "__bf16, 0,")}.get(args.dtype, "-"))
-                        if key.endswith("patch3x3") and pmc_matches(args) else None),
+            "traffic": ((pmc_traffic(args.model, "k_conv3x3_patch<", {"bf16x3": ("float, true", "float, 1,"), "f16x3": ("float, 2,",),
+                                                                      "bf16": ("__bf16, false", "__bf16, 0,")}.get(args.dtype, "-"))
+                         if key.endswith("patch3x3") else
+                         pmc_traffic(args.model, "k_conv_fwd<", {"bf16x3": (", 1, 64>", ", 1, 128>"), "f16x3": (", 2, 64>", ", 2, 128>")}.get(args.dtype, "-")))
+                        if pmc_matches(args) else None),
             "launches_per_step": k["launches"] // max(rl_steps, 1),
             "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
             "algorithmic_gflop_per_launch": round(k["flops"] / max(k["launches"], 1) / 1e9, 3),
