@@ -6,6 +6,7 @@
 // hot config is 37x75x512 (2.8 MB in bf16) and stays L2-resident, so the [R,49,C] output writes are the
 // HBM traffic.  Backward: tiled gather (one owner per gradient element, no atomics) for pooled == 7.
 #include "conv_internal.h"
+#include <cstdlib>
 
 struct Sample {
   int y_low, x_low, y_high, x_high;
@@ -184,14 +185,23 @@ template <> struct Pair<splith_t> {
 template <typename T, int P>
 __global__ void __launch_bounds__(256)
 k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois, float scale,
-                    T* __restrict__ out) {
+                    T* __restrict__ out, int R, int ncb) {
   extern __shared__ __attribute__((aligned(16))) float sw[];   // Ay [P][H], Ax [P][W], then int sup[2 * P][2]
-  const int r = blockIdx.x;
+  // grid = ncb channel blocks x R boxes, channel-block major: at any time the chip works on ONE slice of C / ncb channels of
+  // the feature map (38 x 75 x 256 channels x 4 B = 2.9 MB per image), which stays in an XCD's 4 MB L2 across the boxes
+  // that share it -- with all 1024 channels per workgroup the 16 000 boxes of a teacher pass re-read the 93 MB map ~80x
+  // past L2 (7.5 GB: profiles/r3_pmc_hbm_traffic_r101_f16x3.json).  Measured: 1.91 -> 1.84 ms at 1024 channels, nothing at
+  // 512 (tools/experiments/time_roi_align.py, SFOD_ROI_CBLOCKS=0 / 1): the re-reads were not what bounds the kernel.
+  const int r = blockIdx.x % R, cb = blockIdx.x / R;
   const float* roi = rois + (int64_t)r * 5;
   const int tid = threadIdx.x;
   T* orow = out + (int64_t)r * P * P * C;
+  const int cblk = C / ncb;          // channels of this workgroup: [cb * cblk, (cb + 1) * cblk)
   if (roi[0] < 0.f) {  // padding row
-    for (int i = tid; i < P * P * C / 2; i += blockDim.x) Pair<T>::store(orow + 2 * i, 0.f, 0.f);
+    for (int i = tid; i < P * P * cblk / 2; i += blockDim.x) {
+      const int e = 2 * i, bin = e / cblk, c = e - bin * cblk;
+      Pair<T>::store(orow + (int64_t)bin * C + cb * cblk + c, 0.f, 0.f);
+    }
     return;
   }
   const RoiGeom g = roi_geom(roi, scale, P);
@@ -232,12 +242,13 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
   // a lane owns one 16-byte channel vector (a wavefront reads 1 KiB per pixel); the bin rows are spread over the
   // remaining thread groups like the bins of the sample-by-sample kernel
   constexpr int V = RVec<T>::N;
-  const int cv = C / V;
+  const int cv = cblk / V;
   const int clanes = min(cv, (int)blockDim.x);
   const int groups = blockDim.x / clanes;
   const int cl = tid % clanes, grp = tid / clanes;
   if (grp >= groups) return;
-  for (int c = cl; c < cv; c += clanes) {
+  for (int cc = cl; cc < cv; cc += clanes) {
+    const int c = cb * cv + cc;
     const T* fc = fb + c * V;
     for (int ph = grp; ph < P; ph += groups) {
       // a bin row only sees the few feature rows its samples touch: contract those with Ay, then spread over pw
@@ -551,18 +562,22 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)pooled * (H + W) * 4 + 4 * pooled * 4;
   if (pooled == 7 && lds <= 48 * 1024) {       // the configs' POOLER_RESOLUTION: separable form
+    // channel blocks of 256 (one L2-resident slice of the feature map at a time): 1024 channels -> 4, 512 -> 2
+    static const int cblocks = []() { const char* e = getenv("SFOD_ROI_CBLOCKS"); return e ? atoi(e) : 1; }();    // 0: one workgroup per box (A/B)
+    const int ncb = (cblocks && C % 256 == 0 && C > 256) ? C / 256 : 1;
+    const dim3 grid((unsigned)R * ncb);
     if (dt == SFOD_F32)
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<float, 7>), dim3(R), dim3(256), lds, s, (const float*)feat, H, W, C,
-                         rois, scale, (float*)out);
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<float, 7>), grid, dim3(256), lds, s, (const float*)feat, H, W, C,
+                         rois, scale, (float*)out, R, ncb);
     else if (dt == SFOD_BF16X3)
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<split_t, 7>), dim3(R), dim3(256), lds, s, (const split_t*)feat, H, W, C,
-                         rois, scale, (split_t*)out);
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<split_t, 7>), grid, dim3(256), lds, s, (const split_t*)feat, H, W, C,
+                         rois, scale, (split_t*)out, R, ncb);
     else if (dt == SFOD_F16X3)
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<splith_t, 7>), dim3(R), dim3(256), lds, s, (const splith_t*)feat, H, W, C,
-                         rois, scale, (splith_t*)out);
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<splith_t, 7>), grid, dim3(256), lds, s, (const splith_t*)feat, H, W, C,
+                         rois, scale, (splith_t*)out, R, ncb);
     else
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<bf16_t, 7>), dim3(R), dim3(256), lds, s, (const bf16_t*)feat, H, W, C,
-                         rois, scale, (bf16_t*)out);
+      hipLaunchKernelGGL((k_roi_align_fwd_sep<bf16_t, 7>), grid, dim3(256), lds, s, (const bf16_t*)feat, H, W, C,
+                         rois, scale, (bf16_t*)out, R, ncb);
     return sfod_check_launch("roi_align_fwd_sep");
   }
   if (dt == SFOD_F32)
