@@ -221,10 +221,11 @@ int sfod_bn_relu_pool_fwd2(const void* y, const float* mean, const float* invstd
  * yaml): z = relu(bn(y) + residual) in one pass over [rows, C]; same statistics / affine inputs as above.
  * z_pairs (may be NULL; dt SFOD_F32, C % 8 == 0): additionally the same values as operand pairs of type pairs_dt
  * (SFOD_BF16X3 / SFOD_F16X3) -- the block output is both the fp32 residual stream and the next convolution's MFMA
- * operand. */
+ * operand; z_pairs2 (may be NULL; pairs_dt SFOD_F16X3): once more as SFOD_BF16X3 pairs -- that convolution's
+ * weight-gradient operand in "f16x3" mode. */
 int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
-                         const float* beta, const void* residual, void* z, void* z_pairs, int64_t rows, int C,
-                         int dt, int pairs_dt, void* stream);
+                         const float* beta, const void* residual, void* z, void* z_pairs, void* z_pairs2, int64_t rows,
+                         int C, int dt, int pairs_dt, void* stream);
 /* backward of the block above.  dz: grad w.r.t. block output; y: saved conv output; returns dy
  * (grad w.r.t. conv output), dgamma, dbeta.  ws: fp32 workspace [nblk*2*C] (see ws query).
  * dgamma_acc / dbeta_acc (may be NULL): the parameters' gradient accumulators (+= this call's dgamma /
@@ -241,9 +242,10 @@ int sfod_bn_bwd_ws_floats(int M, int C);
 /* ---- ResNet-101-C4 backbone helpers (d2 build_resnet_backbone selected by the r101 yaml's missing
  * BACKBONE.NAME, configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28) ----
  * out = act(a + b), act 0/1: residual join of BottleneckBlock (relu(conv3(x) + shortcut(x))); out_pairs (may be NULL,
- * fp32 data, n % 8 == 0 with 8-channel groups): the same values as operand pairs of type pairs_dt */
-int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, int64_t n, int act, int dt, int pairs_dt,
-                 void* stream);
+ * fp32 data, n % 8 == 0 with 8-channel groups): the same values as operand pairs of type pairs_dt; out_pairs2 (may be NULL;
+ * pairs_dt SFOD_F16X3): once more as SFOD_BF16X3 pairs */
+int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, void* out_pairs2, int64_t n, int act, int dt,
+                 int pairs_dt, void* stream);
 /* backward=0: dst [B,ceil(H/2),ceil(W/2),C] = src [B,H,W,C] at even pixels (data movement of a 1x1
  * stride-2 conv, STRIDE_IN_1X1); backward=1: the adjoint (dst [B,H,W,C] zero except even pixels) */
 int sfod_subsample2(const void* src, void* dst, int B, int H, int W, int C, int backward, int dt,

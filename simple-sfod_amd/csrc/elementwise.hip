@@ -496,7 +496,9 @@ template <typename PT>
 __global__ void __launch_bounds__(256)
 k_bn_add_relu_fwd_dual(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
                        const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ res,
-                       float* __restrict__ z, PT* __restrict__ zp, int64_t rows, int C) {
+                       float* __restrict__ z, PT* __restrict__ zp, int64_t rows, int C, split_t* __restrict__ zg) {
+  // zg (may be null; f16x3, differentiated pass): the same values once more as bf16 pairs -- the next block's conv1 /
+  // shortcut weight gradients read those
   constexpr int V = 8;
   const int cv = C / V;
   const int64_t total = rows * cv;
@@ -529,9 +531,11 @@ k_bn_add_relu_fwd_dual(const float* __restrict__ y, const float* __restrict__ me
       }
       store_n<float, V>(z + t * V, v0);
       store_n<PT, V>(zp + t * V, v0);
+      if (zg != nullptr) store_n<split_t, V>(zg + t * V, v0);
       if (two) {
         store_n<float, V>(z + (t + stride) * V, v1);
         store_n<PT, V>(zp + (t + stride) * V, v1);
+        if (zg != nullptr) store_n<split_t, V>(zg + (t + stride) * V, v1);
       }
     }
     return;
@@ -546,13 +550,14 @@ k_bn_add_relu_fwd_dual(const float* __restrict__ y, const float* __restrict__ me
       v[i] = fmaxf((v[i] - mean[c0 + i]) * (invstd[c0 + i] * gamma[c0 + i]) + beta[c0 + i] + r[i], 0.f);
     store_n<float, V>(z + t * V, v);
     store_n<PT, V>(zp + t * V, v);
+    if (zg != nullptr) store_n<split_t, V>(zg + t * V, v);
   }
 }
 
 template <typename PT>
 __global__ void __launch_bounds__(256)
 k_add_act_dual(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o,
-               PT* __restrict__ op, int64_t nvec, int act) {
+               PT* __restrict__ op, int64_t nvec, int act, split_t* __restrict__ og) {
   constexpr int V = 8;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nvec;
        t += (int64_t)gridDim.x * blockDim.x) {
@@ -566,6 +571,7 @@ k_add_act_dual(const float* __restrict__ a, const float* __restrict__ b, float* 
     }
     store_n<float, V>(o + t * V, x);
     store_n<PT, V>(op + t * V, x);
+    if (og != nullptr) store_n<split_t, V>(og + t * V, x);
   }
 }
 
@@ -577,8 +583,10 @@ static inline int ew_grid(int64_t total) {
 }
 
 extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
-                                    const float* beta, const void* residual, void* z, void* z_pairs, int64_t rows,
-                                    int C, int dt, int pairs_dt, void* stream) {
+                                    const float* beta, const void* residual, void* z, void* z_pairs, void* z_pairs2,
+                                    int64_t rows, int C, int dt, int pairs_dt, void* stream) {
+  SFOD_REQUIRE(z_pairs2 == nullptr || (z_pairs != nullptr && pairs_dt == SFOD_F16X3),
+               "bn_add_relu: the second (bf16-pair) copy accompanies SFOD_F16X3 pairs");
   const int V = (dt == SFOD_F32 && z_pairs == nullptr) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "bn_add_relu: C not a multiple of the vector width");
   SFOD_REQUIRE(z_pairs == nullptr || (dt == SFOD_F32 && sfod_is_pairs(pairs_dt)),
@@ -588,10 +596,10 @@ extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const floa
   hipStream_t s = (hipStream_t)stream;
   if (z_pairs != nullptr && pairs_dt == SFOD_F16X3)
     hipLaunchKernelGGL(k_bn_add_relu_fwd_dual<splith_t>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
-                       beta, (const float*)residual, (float*)z, (splith_t*)z_pairs, rows, C);
+                       beta, (const float*)residual, (float*)z, (splith_t*)z_pairs, rows, C, (split_t*)z_pairs2);
   else if (z_pairs != nullptr)
     hipLaunchKernelGGL(k_bn_add_relu_fwd_dual<split_t>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
-                       beta, (const float*)residual, (float*)z, (split_t*)z_pairs, rows, C);
+                       beta, (const float*)residual, (float*)z, (split_t*)z_pairs, rows, C, (split_t*)nullptr);
   else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_bn_add_relu_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)y, mean, invstd, gamma,
                        beta, (const float*)residual, (float*)z, rows, C);
@@ -1140,8 +1148,10 @@ __global__ void k_add_act(const T* __restrict__ a, const T* __restrict__ b, T* _
   }
 }
 
-extern "C" int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, int64_t n, int act, int dt,
-                            int pairs_dt, void* stream) {
+extern "C" int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, void* out_pairs2, int64_t n, int act,
+                            int dt, int pairs_dt, void* stream) {
+  SFOD_REQUIRE(out_pairs2 == nullptr || (out_pairs != nullptr && pairs_dt == SFOD_F16X3),
+               "add_act: the second (bf16-pair) copy accompanies SFOD_F16X3 pairs");
   const int V = (dt == SFOD_F32 && out_pairs == nullptr) ? 4 : 8;
   SFOD_REQUIRE(n % V == 0, "add_act: n not a multiple of the vector width");
   SFOD_REQUIRE(out_pairs == nullptr || (dt == SFOD_F32 && sfod_is_pairs(pairs_dt)),
@@ -1150,10 +1160,10 @@ extern "C" int sfod_add_act(const void* a, const void* b, void* out, void* out_p
   if (nvec == 0) return 0;
   if (out_pairs != nullptr && pairs_dt == SFOD_F16X3)
     hipLaunchKernelGGL(k_add_act_dual<splith_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
-                       (const float*)b, (float*)out, (splith_t*)out_pairs, nvec, act);
+                       (const float*)b, (float*)out, (splith_t*)out_pairs, nvec, act, (split_t*)out_pairs2);
   else if (out_pairs != nullptr)
     hipLaunchKernelGGL(k_add_act_dual<split_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
-                       (const float*)b, (float*)out, (split_t*)out_pairs, nvec, act);
+                       (const float*)b, (float*)out, (split_t*)out_pairs, nvec, act, (split_t*)nullptr);
   else if (dt == SFOD_F32)
     hipLaunchKernelGGL(k_add_act<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, (const float*)a,
                        (const float*)b, (float*)out, nvec, act);

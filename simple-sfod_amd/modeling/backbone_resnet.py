@@ -284,7 +284,7 @@ class ResNet(nn.Module):
         self._wp = {id(c): views[i] for i, c in enumerate(convs)}
         self._wr = {id(c): views[n + i] for i, c in enumerate(convs)} if with_dgrad else {}
 
-    def _live_conv_bn(self, x, conv, relu, dt, residual=None, z_operand=False, dual=False, z_grad=False):
+    def _live_conv_bn(self, x, conv, relu, dt, residual=None, z_operand=False, dual=False, z_grad=False, dual_g=False):
         """conv + train-mode BatchNorm (+ ReLU / residual join).  ``x``: an MFMA operand tensor (bf16x3: pairs) or an
         activation-dtype tensor (converted by conv_fwd).  ``z_operand``: write the output directly as the next
         convolution's operand (bf16x3: the BatchNorm kernel emits the pairs; no separate conversion pass)."""
@@ -305,7 +305,7 @@ class ResNet(nn.Module):
         if residual is not None:      # bottleneck tail: relu(bn(y) + shortcut) without materialising bn(y)
             # dual: z = (fp32 block output, the same as operand pairs for the next block's conv1 / shortcut)
             z = native.bn_add_relu_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), residual,
-                                       with_operand=self.compute_dtype if dual else None)
+                                       with_operand=self.compute_dtype if dual else None, with_grad_operand=dual and dual_g)
         else:
             # z_grad (a pass that will be differentiated): z = (forward operand, the operand of the consuming
             # convolution's weight gradient) from one launch -- the same tensor unless the mode splits them (f16x3)
@@ -314,19 +314,24 @@ class ResNet(nn.Module):
                                         with_grad_operand=z_grad and z_operand)
         return y, mean, invstd, z
 
-    def _block_forward(self, blk, x, live, dt, x_op=None, want_op=False, save=False):
+    def _block_forward(self, blk, x, live, dt, x_op=None, want_op=False, save=False, want_g=False):
         """-> (block output, its operand-pair copy or None, saved activations or None).  ``x_op``: the block input as
         MFMA operand when the producer already wrote it (bf16x3: the previous block's join kernel emits the fp32
-        residual stream AND the pairs in one pass); ``want_op``: do the same for the next block."""
+        residual stream AND the pairs in one pass), or the tuple (forward operand, weight-gradient operand) when it wrote
+        both (f16x3, differentiated pass); ``want_op`` / ``want_g``: do the same for the next block."""
         dual = want_op and self.dual_join and native.is_pairs(self.compute_dtype) and x.shape[-1] % 8 == 0
+        want_g = want_g and dual and self.grad_dtype != self.compute_dtype and os.environ.get("SFOD_NO_JOIN_G", "0") != "1"   # A/B hook
+        x_g_in = None
+        if isinstance(x_op, tuple):
+            x_op, x_g_in = x_op
         if blk.stride == 2:
-            xs, x_op = native.subsample2(x), None
+            xs, x_op, x_g_in = native.subsample2(x), None, None
         else:
             xs = x
         # the block input becomes an operand ONCE, shared by conv1, the shortcut conv and (live blocks) both weight
         # gradients
         split_g = live and save and self.grad_dtype != self.compute_dtype
-        xs_g = None
+        xs_g = x_g_in
         if x_op is not None:
             xs_op = x_op
         else:       # (f16x3, differentiated pass: half pairs AND the weight gradient's bf16 pairs from one pass over xs)
@@ -336,6 +341,9 @@ class ResNet(nn.Module):
             o = self._frozen_conv(xs_op, blk.conv1, 1, dt)
             o = self._frozen_conv(o, blk.conv2, 1, dt)
             o = self._frozen_conv(o, blk.conv3, 0, dt)
+            if dual and want_g:
+                out, out_op, out_g = native.add_act(o, sc, 1, with_operand=self.compute_dtype, with_grad_operand=True)
+                return out, (out_op, out_g), None
             if dual:
                 out, out_op = native.add_act(o, sc, 1, with_operand=self.compute_dtype)
                 return out, out_op, None
@@ -359,13 +367,17 @@ class ResNet(nn.Module):
         del xs_act
         out_op = None
         if self.fuse_residual:
-            y3, m3, i3, out = self._live_conv_bn(a2, blk.conv3, False, dt, residual=ts, dual=dual)
-            if dual:
+            y3, m3, i3, out = self._live_conv_bn(a2, blk.conv3, False, dt, residual=ts, dual=dual, dual_g=want_g)
+            if dual and want_g:
+                out, out_op = out[0], (out[1], out[2])
+            elif dual:
                 out, out_op = out
         else:
             y3, m3, i3, t3 = self._live_conv_bn(a2, blk.conv3, False, dt)
-            out = native.add_act(t3, ts, 1, with_operand=self.compute_dtype if dual else None)
-            if dual:
+            out = native.add_act(t3, ts, 1, with_operand=self.compute_dtype if dual else None, with_grad_operand=want_g)
+            if dual and want_g:
+                out, out_op = out[0], (out[1], out[2])
+            elif dual:
                 out, out_op = out
         return out, out_op, (x.shape, xs_g, y1, m1, i1, a1g, y2, m2, i2, a2g, y3, m3, i3, ys, ms, is_, out)
 
@@ -382,7 +394,9 @@ class ResNet(nn.Module):
             live = name not in self.frozen
             # the next block reads this output as a convolution operand unless it subsamples first (stride 2)
             want_op = bi + 1 < len(blocks) and blocks[bi + 1][1].stride != 2
-            x, x_op, sv = self._block_forward(blk, x, live, dt, x_op=x_op, want_op=want_op, save=save)
+            # ... and, in a differentiated f16x3 pass, a live next block also wants the bf16 pairs for its weight gradients
+            want_g = want_op and save and blocks[bi + 1][0] not in self.frozen
+            x, x_op, sv = self._block_forward(blk, x, live, dt, x_op=x_op, want_op=want_op, save=save, want_g=want_g)
             if live and save:
                 saved.append(sv)
             if name in self._out_features and (bi + 1 == len(blocks) or blocks[bi + 1][0] != name):

@@ -769,16 +769,20 @@ def bn_relu_pool_fwd(y, mean, invstd, gamma, beta, pool, relu=True, out_dtype=No
     return (z, z) if with_grad_operand else z
 
 
-def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual, with_operand=None):
+def bn_add_relu_fwd(y, mean, invstd, gamma, beta, residual, with_operand=None, with_grad_operand=False):
     """relu(bn(y) + residual) in one pass (bottleneck tail).  ``with_operand`` (a pair dtype; fp32 data of a bf16x3 /
-    f16x3 model): also return the same values as (hi, lo) operand pairs of that type -> (z, z_pairs)."""
+    f16x3 model): also return the same values as (hi, lo) operand pairs of that type -> (z, z_pairs);
+    ``with_grad_operand`` (half pairs only): -> (z, z_pairs, the same as bf16 pairs), all from the one pass."""
     assert residual.shape == y.shape and residual.dtype == y.dtype
     z = torch.empty_like(y)
     C = y.shape[-1]
     with_operand = SPLIT_DTYPE if with_operand is True else with_operand
     zp = torch.empty(y.shape, dtype=with_operand, device=y.device) if with_operand else None
-    call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, zp, y.numel() // C, C, dt_of(y),
+    zg = torch.empty(y.shape, dtype=SPLIT_DTYPE, device=y.device) if (with_grad_operand and with_operand == SPLITH_DTYPE) else None
+    call("sfod_bn_add_relu_fwd", y, mean, invstd, gamma, beta, residual.contiguous(), z, zp, zg, y.numel() // C, C, dt_of(y),
          dt_of(zp) if zp is not None else BF16X3)
+    if with_grad_operand:
+        return z, zp, (zg if zg is not None else zp)
     return (z, zp) if with_operand else z
 
 
@@ -853,13 +857,16 @@ def mul_mask_(a, mask_u8, scale):
     return a
 
 
-def add_act(a, b, act=1, with_operand=None):
+def add_act(a, b, act=1, with_operand=None, with_grad_operand=False):
     """act(a + b); ``with_operand`` (a pair dtype; fp32 data of a bf16x3 / f16x3 model): also the (hi, lo) operand pairs
-    of that type -> (out, out_pairs)."""
+    of that type -> (out, out_pairs); ``with_grad_operand``: -> (out, out_pairs, the same as bf16 pairs)."""
     out = torch.empty_like(a)
     with_operand = SPLIT_DTYPE if with_operand is True else with_operand
     op = torch.empty(a.shape, dtype=with_operand, device=a.device) if with_operand else None
-    call("sfod_add_act", a, b, out, op, a.numel(), int(act), dt_of(a), dt_of(op) if op is not None else BF16X3)
+    og = torch.empty(a.shape, dtype=SPLIT_DTYPE, device=a.device) if (with_grad_operand and with_operand == SPLITH_DTYPE) else None
+    call("sfod_add_act", a, b, out, op, og, a.numel(), int(act), dt_of(a), dt_of(op) if op is not None else BF16X3)
+    if with_grad_operand:
+        return out, op, (og if og is not None else op)
     return (out, op) if with_operand else out
 
 

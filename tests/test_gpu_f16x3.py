@@ -252,6 +252,15 @@ def test_resnet_join_kernels_emit_half_pairs(native):
         o = native.add_act(y, res, 1)
         o2, op = native.add_act(y, res, 1, with_operand=dtype)
         assert torch.equal(o, o2) and torch.equal(op.view(view), native.cast(o, dtype).view(view))
+        # three outputs from one pass: fp32 stream, forward operand, weight-gradient operand (bf16 pairs; the same tensor
+        # when the forward operand already is one)
+        z3, zp3, zg3 = native.bn_add_relu_fwd(y, mean, invstd, gamma, beta, res, with_operand=dtype, with_grad_operand=True)
+        assert torch.equal(z3, z2) and torch.equal(zp3.view(view), zp.view(view)) and zg3.dtype == native.SPLIT_DTYPE
+        assert torch.equal(zg3.view(torch.bfloat16), native.cast(z2, native.SPLIT_DTYPE).view(torch.bfloat16))
+        assert (zg3 is zp3) == (dtype == native.SPLIT_DTYPE)
+        o3, op3, og3 = native.add_act(y, res, 1, with_operand=dtype, with_grad_operand=True)
+        assert torch.equal(o3, o) and torch.equal(op3.view(view), op.view(view))
+        assert torch.equal(og3.view(torch.bfloat16), native.cast(o, native.SPLIT_DTYPE).view(torch.bfloat16))
 
 
 def test_roi_align_preprocess_packers_im2col(native):
