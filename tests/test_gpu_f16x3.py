@@ -403,3 +403,27 @@ def test_values_beyond_half_range_are_reported(native):
     with pytest.raises(FloatingPointError):
         native.check_f16x3_range(dev)
     native.check_f16x3_range(dev)
+
+
+@pytest.mark.parametrize("fmt", ["f16", "bf16"])
+@pytest.mark.parametrize("shape", [(700, 256, 96), (513, 1024, 264), (300, 4608, 64)])
+def test_kernels_compute_the_product_they_are_defined_to_compute(native, fmt, shape):
+    """The device result against oracle/split_precision.py -- the definition of the mode (hi*hi + hi*lo + lo*hi on the
+    rounded pairs, weights under their power-of-two scale), accumulated in fp64: what is left is the fp32 accumulation
+    order (1.1e-8 * sqrt(K)) -- for bf16 pairs an order of magnitude below the mode's own distance from the exact product (4.5e-6),
+    for half pairs the whole of it (the definition itself sits 8e-8 from exact)."""
+    from oracle import split_precision as sp
+    M, K, N = shape
+    g = torch.Generator().manual_seed(M + K)
+    x = torch.relu(torch.randn(M, K, generator=g)) + 0.01 * torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) * (2.0 / K) ** 0.5
+    dt = native.F16X3 if fmt == "f16" else native.BF16X3
+    y = native.conv_fwd(x.to(DEV), native.pack_fc_weight(w.to(DEV), dt), None, N, 1).cpu()
+    defined = sp.linear(x, w, fmt)
+    exact = x.double() @ w.double().t()
+    e_def, e_exact = rel_err(y, defined), rel_err(y, exact)
+    print(f"[{fmt} pairs, M={M} K={K} N={N}] device vs its definition {e_def:.2e}, vs the exact product {e_exact:.2e}, "
+          f"definition vs exact {rel_err(defined, exact):.2e}")
+    assert e_def < 2.5e-7 * math.sqrt(K / 256.0), (e_def, e_exact)      # fp32 accumulation: ~1.1e-8 * sqrt(K) (seen 1.8e-7 / 3.5e-7 / 7.7e-7)
+    if fmt == "bf16":
+        assert e_def < 0.2 * e_exact        # the bf16-pair mode's error IS its definition's, not the kernel's
