@@ -1,4 +1,5 @@
 """Host-side mirror of the reference's config / registry / structures surface (no GPU needed)."""
+import math
 import os
 
 import pytest
@@ -336,3 +337,29 @@ def test_compute_modes_and_operand_formats(sfod):
     import importlib
     bench = importlib.import_module("bench")
     assert bench.PARITY_DTYPE == {"vgg": hot.SFOD.COMPUTE_DTYPE, "r101": r101.SFOD.COMPUTE_DTYPE}
+
+
+def test_split_precision_definitions_and_their_own_error():
+    """oracle/split_precision.py (what the pair modes are defined to compute) on the CPU: the pairs are exact splits, the
+    weight scale is the packers' power of two, and the definitions sit where DESIGN.md 1a says they do relative to the exact
+    product -- bf16 pairs ~4.5e-6 (16-bit operands), half pairs ~8e-8 (22-bit operands under the weight scale), and half pairs
+    WITHOUT the scale 4x worse on kaiming-sized weights (lo falls into half's subnormals)."""
+    from oracle import split_precision as sp
+    g = torch.Generator().manual_seed(0)
+    x = torch.relu(torch.randn(128, 1024, generator=g)) + 0.01 * torch.randn(128, 1024, generator=g)
+    w = torch.randn(64, 1024, generator=g) * (2.0 / 1024) ** 0.5
+    for fmt, bits in (("bf16", 16), ("f16", 22)):
+        hi, lo = sp.split_pairs(x, fmt)
+        assert ((hi + lo - x.double()).abs() <= x.double().abs() * 2.0 ** -bits + 2.0 ** -25).all()
+        assert torch.equal(hi.float().double(), hi) and torch.equal(lo.float().double(), lo)      # 16-bit values: exact in fp32
+    s = sp.weight_scale(w)
+    assert math.log2(s) == int(math.log2(s)) and 2.0 ** 13 <= float(w.abs().max()) * s < 2.0 ** 14
+    assert sp.weight_scale(torch.zeros(4, 4)) == 1.0
+    exact = x.double() @ w.double().t()
+    err = lambda y: ((y - exact).norm() / exact.norm()).item()
+    e_bf, e_h = err(sp.linear(x, w, "bf16")), err(sp.linear(x, w, "f16"))
+    xh, xl = sp.split_pairs(x, "f16")
+    wh, wl = sp.split_pairs(w, "f16")                     # unscaled weights
+    e_h_unscaled = err(xh @ wh.t() + xh @ wl.t() + xl @ wh.t())
+    assert 2e-6 < e_bf < 8e-6 and e_h < 2e-7 and e_h < e_bf / 20, (e_bf, e_h)
+    assert e_h_unscaled > 2.5 * e_h, (e_h_unscaled, e_h)
