@@ -108,8 +108,14 @@ int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, 
                           const float* y, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, float* red_ws, void* stream);
 /* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
- * 4 = 512 x 64 (applied where the channel counts allow it).  For A/B runs and parity tests. */
+ * 4 = 512 x 64 (applied where the channel counts allow it), 5 = 256 x 128 on v_mfma_f32_16x16x32 (operand pairs with
+ * Cin % 32 == 0; otherwise as 2: 8 waves x (64 px x 64 ch), four waves per SIMD), 6 = the same with 4 waves x (128 px x
+ * 64 ch), two per SIMD (leaves registers for a co-resident kernel; tools/experiments/corun_conv_bn.py).  For A/B runs and
+ * parity tests. */
 int sfod_set_conv3x3_variant(int variant);
+/* whether the automatic choice runs shape 2 as shape 5 (default 1; environment SFOD_P3_M16).  Same tiles, same products,
+ * another fp32 summation order inside a 32-deep k-step. */
+int sfod_set_conv3x3_m16(int on);
 /* A/B knob of the bf16x3 halo-patch weight gradient (environment SFOD_W3_PIPE): 2 (default) the 64 co x 64 ci block on
  * 128-pixel tiles (k_wgrad3x3_w64; layers with Cin >= 64, else as 1), 1 the pipelined 64 x 32-block loop
  * (k_wgrad3x3_patch<4, true, true>), 0 the round-2 loop.  0 and 1 give bit-identical results, 2 sums the same products over

@@ -27,9 +27,11 @@
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
+// (k_conv3x3_m16 has its own set for tools/experiments/m16_knockout.sh: M16_KO_{MFMA,WDMA,PDMA,BAR,EPI}, M16_V_LATEW.)
 // Knock-out switches for tools/experiments/conv_knockout.sh (time floors of the bf16x3 loop; results are WRONG by
 // construction, the product build defines none): P3_KO_MFMA no MFMAs, P3_KO_READS no LDS fragment reads, P3_KO_PATCHDMA /
 // P3_KO_WDMA no patch / weight LDS-DMA inside the K loop, P3_KO_EPI no epilogue (stores, statistics).
@@ -640,6 +642,517 @@ k_conv3x3_patch(P3Args a) {
   }
 }
 
+
+// =====================================================================================================================
+// k_conv3x3_m16 (round 4): the 256-pixel x 128-channel workgroup shape on v_mfma_f32_16x16x32_{bf16,f16}, operand pairs only.
+//
+// Why: back to back on random operands the halo-patch kernel is bound by the power the chip may draw, not by its
+// instruction stream -- the same launch on all-zero operands runs 40 % faster (conv4_2, B = 8: 0.98 -> 0.70 ms,
+// profiles/r4_conv_power_bound.txt) -- and per FLOP the 16x16x32 shape moves less accumulator data through the register
+// file than 32x32x16 (1 KiB read + written per 16 K MACs at K = 32 instead of 4 KiB per 32 K MACs at K = 16): in a bare
+// LDS-read + MFMA loop of this kernel's shape it sustains 1.17x the FLOP/s under the cap
+// (tools/experiments/mfma_shape_power.hip).  Measured on this kernel (profiles/r4_m16_*): it holds 1.88 GHz where the
+// 32x32x16 form holds 1.65, with the matrix pipe 70 % instead of 75 % busy: +2 ... 6 % per layer back to back, ~1 % inside
+// the training step (where BatchNorm passes between the convolutions let the chip clock higher anyway).
+//
+// K = 32 per instruction = TWO (tap, 16-logical-channel slice) pairs: lane group q = lane >> 4 feeds k = 8q .. 8q+7 from
+// pair (q & 1), channels 8 (q >> 1) .. +7, for both operands.  So a stage is two consecutive pairs (u = 2j, 2j+1 of the 18
+// pairs of a "super-body" = two 32-physical-channel input slices), 9 stages per super-body, ONE barrier per 48 MFMAs per
+// wave (the 32x32x16 form: one per 12).  The patch image, its swizzle and the weight rows are the 32x32x16 kernel's; a
+// fragment read is one ds_read_b128 whose lanes address two different taps (pixel operand) / two 8 KiB weight blocks.
+//   LDS   patch[2]   2 x 384 rows x 64 B      slice 2*sb -> buffer 0, slice 2*sb+1 -> buffer 1
+//         weights[2] 2 x (2 pairs x 128 rows x 64 B): stage g reads slot g & 1 while the DMA fills the other one
+//         = 80 KiB exactly = two workgroups per CU; the epilogue's scratch overlays the operands
+//   MFMA  A = weight fragment (rows = output channels), B = pixel fragment (columns = pixels): a lane then owns 4
+//         consecutive channels of one pixel per tile -> 16-byte stores straight from the accumulators, no LDS staging
+//   waves <NW, NIP>: NW = (NW / 2) (pixels) x 2 (channels) waves, each NIP 16-pixel tiles x 64 channels.
+//         <8, 4> (shape 5, the default): wave tile 64 x 64, 124 VGPRs, four waves per SIMD, 16 fragment reads per 48 MFMAs;
+//         <4, 8> (shape 6): wave tile 128 x 64, 206 VGPRs, two waves per SIMD, 24 reads per 96 MFMAs, pixel fragments
+//         double-buffered -- 1-2 % slower, but leaves 96 registers per SIMD lane for a co-resident kernel
+//   loop  ONE rolled body per stage: every per-stage constant (tap offsets, ring slot, which patch pieces go out) is a
+//         scalar value and the patch DMA offsets are recomputed (~15 VALU beside 48 MFMAs) -- the nine-stage unrolled form
+//         of the 32x32x16 kernel made hipcc rotate accumulators through temporaries and spill at this register budget
+//   DMA   weights of stage g+1 go out right behind stage g's weight-fragment reads (16 / NW per wave), the <= 2 patch
+//         pieces of a stage behind its first MFMA groups; the stage wait allows exactly those patch pieces to be
+//         outstanding (slice 1 of this super-body streams in during stages 0-2, slice 0 of the next during 5-7)
+//   Tried and dropped (profiles/r4_m16_rejected.txt): a 512-pixel tile with one workgroup per CU, a 4-slot weight ring
+//         (three stages ahead) and the two wave halves half a stage apart -- twice the barriers cost more than the stagger
+//         and the deeper prefetch returned; in-kernel stamps show no dominant stall in the loop (DMA wait 6 %, barrier 2 %,
+//         fragment reads + DMA issue 18 % of a wave's stage, covered by the SIMD's other waves)
+template <int FMT>
+__device__ __forceinline__ f32x4_t mfma16(bf16x8 a, bf16x8 b, f32x4_t c) {
+  if constexpr (FMT == 2)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(sfod_f16x8, a), __builtin_bit_cast(sfod_f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+// sum over the 16 lanes of a DPP row (every lane of the row ends up with the total)
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));  // row_half_mirror
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));  // row_mirror
+  return v;
+}
+
+// counted wait with a run-time (wave-uniform) count: at most n of this wave's DMAs may still be in flight (n > 15: 15)
+__device__ __forceinline__ void wait_vm_dyn(int n) {
+  switch (n) {
+    case 0: wait_vm<0>(); break;   case 1: wait_vm<1>(); break;   case 2: wait_vm<2>(); break;   case 3: wait_vm<3>(); break;
+    case 4: wait_vm<4>(); break;   case 5: wait_vm<5>(); break;   case 6: wait_vm<6>(); break;   case 7: wait_vm<7>(); break;
+    case 8: wait_vm<8>(); break;   case 9: wait_vm<9>(); break;   case 10: wait_vm<10>(); break; case 11: wait_vm<11>(); break;
+    case 12: wait_vm<12>(); break; case 13: wait_vm<13>(); break; case 14: wait_vm<14>(); break; default: wait_vm<15>(); break;
+  }
+}
+
+template <int NW, int NIP> struct M16Lay {
+  static constexpr int PIX = (NW / 2) * NIP * 16;           // pixels per workgroup: 256 | 512
+  static constexpr int PR = (PIX == 256) ? 384 : 640;       // patch rows (pixels incl. halo) per buffer
+  static constexpr int NPW = PR / 16 / NW;                  // 1 KiB patch pieces per wave and slice
+  static constexpr int PPS = (NPW + 2) / 3;                 // ... issued per stage (stages 0-2 / 5-7)
+  static constexpr int WPW = 16 / NW;                       // 1 KiB weight pieces per wave and stage: 4 | 2
+  static constexpr int PATCH_BYTES = PR * 64;
+  static constexpr int WR_OFF = 2 * PATCH_BYTES;
+  static constexpr int WSLOT = 16384;
+  static constexpr int LDS = WR_OFF + 2 * WSLOT;            // 81920 (256 pixels) | 114688
+};
+
+#ifdef M16_STAMP
+// diagnostic build (tools/experiments/m16_knockout.sh, variant STAMP): cycle sums of wave 0 of every workgroup:
+// [0] DMA wait, [1] barrier, [2] fragment reads + DMA issue, [3] MFMA phase, [4] stages, [5] kernel cycles, [6] workgroups
+__device__ unsigned long long g_m16_stamps[8];
+#endif
+
+template <int NW, int NIP, int FMT, bool RED>
+__global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::LDS)) / 4) k_conv3x3_m16(P3Args a) {
+  using L = M16Lay<NW, NIP>;
+#ifdef M16_STAMP
+  const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
+#endif
+  constexpr int PR = L::PR, NPW = L::NPW, WPW = L::WPW, PATCH_BYTES = L::PATCH_BYTES, WR_OFF = L::WR_OFF, WSLOT = L::WSLOT;
+  constexpr int NWM = NW / 2;            // waves along the pixel axis
+  constexpr int WPX = NIP * 16;          // pixels per wave (NIP 16-pixel tiles)
+  constexpr int XB = (NIP >= 8) ? 2 : 1; // pixel fragment register sets: the 128-register shape has room for one only
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = lane >> 4, r16 = lane & 15;
+  const int pb = q & 1, chh = q >> 1;        // which pair of the stage / which 8-channel half this lane group feeds
+
+  // ---- tile decode (as k_conv3x3_patch) ----------------------------------------------------------------------------
+  int bid = blockIdx.x;
+  {
+    const int qq = a.ntiles / 8, r = a.ntiles % 8, xcd = bid % 8;
+    bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + bid / 8;
+  }
+  int t = (int)fdiv((unsigned)bid, (unsigned)a.tiles_n, a.m_tn);
+  const int tn = bid - t * a.tiles_n;
+  int t2 = (int)fdiv((unsigned)t, (unsigned)a.tiles_x, a.m_tx);
+  const int txi = t - t2 * a.tiles_x;
+  const int b = (int)fdiv((unsigned)t2, (unsigned)a.tiles_y, a.m_ty);
+  const int tyi = t2 - b * a.tiles_y;
+  const int mtile = (b * a.tiles_y + tyi) * a.tiles_x + txi;
+  const int x0 = txi * a.TW, y0 = tyi * a.TH, n0 = tn * 128;
+  const int PW = a.PW;
+  const int npix = a.TH * a.TW;
+  const bf16_t* ximg = a.x + (int64_t)b * a.H * a.W * a.Cin;
+  const int Ktot = 9 * a.Cin;
+
+  const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc((void*)ximg, (short)0, a.H * a.W * a.Cin * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wres = __builtin_amdgcn_make_buffer_rsrc((void*)a.w, (short)0, a.Cout * Ktot * 2, 0x00020000);
+  // byte offset inside the image of this lane's 16-byte chunk of patch piece k (slice 0), or OOB_OFF.  Recomputed at every
+  // use (~15 VALU instructions beside 96 MFMAs) instead of living in NPW registers: the stage loop below is ONE rolled
+  // loop body whose patch piece index is a run-time value
+  auto patch_off = [&](int k) -> unsigned {
+    const int row = (wave * NPW + k) * 16 + (lane >> 2);
+    const int lc = (lane & 3) ^ ((row >> 2) & 3);
+    const int py = (int)fdiv((unsigned)row, (unsigned)PW, a.m_pw), px = row - py * PW;
+    const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+    const bool ok = (py < a.TH + 2) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+    return ok ? (unsigned)(((iy * a.W + ix) * a.Cin + lc * 8) * 2) : OOB_OFF;
+  };
+  // weight pieces of a stage: 16 x 1 KiB = (pair a: 128 rows, pair b: 128 rows); wave w issues pieces w*WPW .. +WPW-1
+  unsigned boff[WPW];
+#pragma unroll
+  for (int k = 0; k < WPW; ++k) {
+    const int n = ((wave * WPW + k) & 7) * 16 + (lane >> 2);
+    const int lc = (lane & 3) ^ ((n >> 2) & 3);
+    boff[k] = (n0 + n < a.Cout) ? (unsigned)(((n0 + n) * Ktot + lc * 8) * 2) : OOB_OFF;
+  }
+  const int wpair = (wave * WPW) >> 3;       // which pair of a stage this wave's weight pieces belong to
+  auto issue_patch = [&](int k, int slice, int buf) {
+    bufload16(xres, patch_off(k), (unsigned)__builtin_amdgcn_readfirstlane(slice * 64),
+              smem + buf * PATCH_BYTES + (wave * NPW + k) * 1024);
+  };
+  // (tap, slice) of pair u (0 .. 17) of super-body sb: u < 9: (u, 2 sb), else (u - 9, 2 sb + 1)
+  // this wave's share of the weights of global pair index gu = 18 * sb + u (its pair of the stage) -> stage slot `slot`
+  auto issue_w = [&](int sbi, int u0, int slot) {
+    const int u = u0 + wpair;
+    const int sl = (u >= 9) ? 1 : 0, tap = u - 9 * sl;
+    const unsigned so = (unsigned)__builtin_amdgcn_readfirstlane((tap * a.Cin + (2 * sbi + sl) * 32) * 2);
+#pragma unroll
+    for (int k = 0; k < WPW; ++k)
+      bufload16(wres, boff[k], so, smem + WR_OFF + slot * WSLOT + (wave * WPW + k) * 1024);
+  };
+
+  // ---- prologue ----------------------------------------------------------------------------------------------------
+  const int nsb = a.nbody;          // Cin / 64
+  const int nst = nsb * 9;          // stages
+#pragma unroll
+  for (int k = 0; k < NPW; ++k) issue_patch(k, 0, 0);
+  issue_w(0, 0, 0);
+
+  // ---- fragment addressing -----------------------------------------------------------------------------------------
+  int rowA[NIP];
+#pragma unroll
+  for (int i = 0; i < NIP; ++i) {
+    const int p = wm * WPX + i * 16 + r16;
+    const int ty = (int)fdiv((unsigned)p, (unsigned)a.TW, a.m_tw);
+    rowA[i] = (p < npix) ? (ty * PW + (p - ty * a.TW)) : 0;
+    asm volatile("" : "+v"(rowA[i]));       // materialised here, not re-derived from spilled 64-bit products inside the K loop
+  }
+  // weight fragment of channel tile ic: + ic * 1024; lo = ^ 16   ((n >> 2) & 3 == (r16 >> 2) & 3 for n = 16 m + r16)
+  const int offW = pb * 8192 + (wn * 64 + r16) * 64 + (((2 * chh) ^ ((r16 >> 2) & 3)) << 4);
+
+  f32x4_t acc[4][NIP];     // [channel tile][pixel tile]: channel = wn*64 + ic*16 + q*4 + r, pixel = wm*128 + ip*16 + r16
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NIP; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+
+  // patch row offset of this lane group's pair in stage j of a super-body: buffer * PR rows + tap shift (PR % 16 == 0: the
+  // swizzle of the buffer-relative row is the swizzle of the global row).  Pairs ua = 2j, ub = 2j + 1.
+  auto stage_offq = [&](int j) -> int {
+    const int ua = 2 * j, ub = 2 * j + 1;
+    const int sa = (ua >= 9) ? 1 : 0, ta = ua - 9 * sa, sbb = (ub >= 9) ? 1 : 0, tb = ub - 9 * sbb;
+    const int kya = (ta * 11) >> 5, kyb = (tb * 11) >> 5;            // t / 3 for t < 9
+    const int dta = sa * PR + kya * PW + (ta - 3 * kya), dtb = sbb * PR + kyb * PW + (tb - 3 * kyb);
+    return pb ? dtb : dta;
+  };
+
+  {
+  // ---- K loop: one rolled body per stage (j = stage inside the super-body sb; all stage constants are scalar values)
+  int sb = 0, j = 0, par = 0, nprev = 0;      // nprev: patch pieces the previous stage issued behind its weights
+#ifdef M16_STAMP
+  unsigned long long stamp_sum[4] = {0, 0, 0, 0};
+#endif
+#pragma unroll 1
+  for (int g = 0; g < nst; ++g) {
+    const bool last = (sb == nsb - 1);
+    // the DMAs of the previous stage: weights (needed now) first, then its patch pieces (may stay in flight)
+#ifdef M16_STAMP
+    const unsigned long long st_a = __builtin_amdgcn_s_memtime();
+#endif
+#ifndef M16_KO_BAR
+    if (nprev == 0) wait_vm<0>();
+    else if (nprev == 1) wait_vm<1>();
+    else wait_vm<2>();
+#ifdef M16_STAMP
+    const unsigned long long st_a2 = __builtin_amdgcn_s_memtime();
+#endif
+    __builtin_amdgcn_s_barrier();
+#endif
+    asm volatile("" ::: "memory");
+#ifdef M16_STAMP
+    const unsigned long long st_b = __builtin_amdgcn_s_memtime();
+#endif
+
+    const unsigned char* wsl = smem + WR_OFF + par * WSLOT;
+    bf16x8 wh[4], wl[4];
+#pragma unroll
+    for (int ic = 0; ic < 4; ++ic) {
+      wh[ic] = *reinterpret_cast<const bf16x8*>(wsl + ic * 1024 + offW);
+      wl[ic] = *reinterpret_cast<const bf16x8*>(wsl + ic * 1024 + (offW ^ 16));
+    }
+    const int offq = stage_offq(j);
+    bf16x8 xh[XB], xl[XB];
+    auto read_x = [&](int ip, int slot) {
+      const int row = rowA[ip] + offq;
+      const int ad = row * 64 + (((2 * chh) ^ ((row >> 2) & 3)) << 4);
+      xh[slot] = *reinterpret_cast<const bf16x8*>(smem + ad);
+      xl[slot] = *reinterpret_cast<const bf16x8*>(smem + (ad ^ 16));
+    };
+    read_x(0, 0);
+    // the next stage's weights: behind the fragment reads (their LDS latency covers the issue)
+#if !defined(M16_KO_WDMA) && !defined(M16_V_LATEW)
+    if (j < 8) issue_w(sb, 2 * j + 2, par ^ 1);
+    else if (!last) issue_w(sb + 1, 0, par ^ 1);
+#endif
+    // patch pieces of this stage (<= PPS): slice 1 of this super-body -> buffer 1 in stages 0-2, slice 0 of the next -> buffer 0 in 5-7
+    int np = 0, pslice = 0, pbuf = 0, pk = 0;
+    if (j < 3) { pk = L::PPS * j; np = min(L::PPS, NPW - pk); pslice = 2 * sb + 1; pbuf = 1; }
+    else if (j >= 5 && j < 8 && !last) { pk = L::PPS * (j - 5); np = min(L::PPS, NPW - pk); pslice = 2 * sb + 2; pbuf = 0; }
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef M16_STAMP
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long st_c = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ip = 0; ip < NIP; ++ip) {
+      if constexpr (XB == 2) { if (ip + 1 < NIP) read_x(ip + 1, (ip + 1) & 1); }
+      else { if (ip > 0) read_x(ip, 0); }
+      const bf16x8 ch = xh[ip % XB], cl = xl[ip % XB];
+#ifdef M16_KO_MFMA
+#pragma unroll
+      for (int ic = 0; ic < 4; ++ic) asm volatile("" ::"v"(wh[ic]), "v"(wl[ic]));
+      asm volatile("" ::"v"(ch), "v"(cl));
+      acc[0][ip][0] += 1.0f;
+#else
+#pragma unroll
+      for (int ic = 0; ic < 4; ++ic) acc[ic][ip] = mfma16<FMT>(wh[ic], cl, acc[ic][ip]);
+#pragma unroll
+      for (int ic = 0; ic < 4; ++ic) acc[ic][ip] = mfma16<FMT>(wl[ic], ch, acc[ic][ip]);
+#pragma unroll
+      for (int ic = 0; ic < 4; ++ic) acc[ic][ip] = mfma16<FMT>(wh[ic], ch, acc[ic][ip]);
+#endif
+#ifndef M16_KO_PDMA
+      if (ip < L::PPS) { if (ip < np) issue_patch(pk + ip, pslice, pbuf); }
+#endif
+#if defined(M16_V_LATEW) && !defined(M16_KO_WDMA)
+      if (ip == 2) {
+        if (j < 8) issue_w(sb, 2 * j + 2, par ^ 1);
+        else if (!last) issue_w(sb + 1, 0, par ^ 1);
+      }
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+#ifdef M16_STAMP
+    {
+      // all MFMAs of the stage issued (the last one may still be in the pipe): stamp and accumulate the four phases
+      const unsigned long long st_d = __builtin_amdgcn_s_memtime();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      stamp_sum[0] += st_a2 - st_a;      // own DMA wait (+ own LDS reads)
+      stamp_sum[1] += st_b - st_a2;      // barrier
+      stamp_sum[2] += st_c - st_b;       // weight + first pixel fragment reads, DMA issue
+      stamp_sum[3] += st_d - st_c;       // 96 MFMAs with the streamed fragment reads and the patch DMA issue
+    }
+#endif
+    nprev = np;
+    par ^= 1;
+    if (++j == 9) { j = 0; ++sb; }
+  }
+#ifdef M16_STAMP
+  if (threadIdx.x == 0) {
+    atomicAdd(&g_m16_stamps[0], stamp_sum[0]); atomicAdd(&g_m16_stamps[1], stamp_sum[1]);
+    atomicAdd(&g_m16_stamps[2], stamp_sum[2]); atomicAdd(&g_m16_stamps[3], stamp_sum[3]);
+    atomicAdd(&g_m16_stamps[4], (unsigned long long)nst);
+    atomicAdd(&g_m16_stamps[5], __builtin_amdgcn_s_memtime() - stamp_t0);
+    atomicAdd(&g_m16_stamps[6], 1ull);
+  }
+#endif
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------
+#ifdef M16_KO_EPI
+  {
+    float tt = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NIP; ++jj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tt += acc[i][jj][r];
+    if (tt == 1.2345e-30f) reinterpret_cast<float*>(a.y)[0] = tt;       // keeps the accumulators alive, stores nothing
+    return;
+  }
+#endif
+  if constexpr (FMT == 2) {       // undo the packed weights' power-of-two scale (exact)
+    if (a.wamax != nullptr) {
+      const float inv = winv_from_absmax(*a.wamax);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < NIP; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] *= inv;
+    }
+  }
+  const ActP actp = act_params(a.act);
+  const int64_t ybase = (int64_t)b * a.H * a.W;
+  int pix[NIP];          // pixel index inside the image of this lane's pixel of tile ip, -1: not an output pixel
+#pragma unroll
+  for (int ip = 0; ip < NIP; ++ip) {
+    const int p = wm * WPX + ip * 16 + r16;
+    int v = -1;
+    if (p < npix) {
+      const int ty = (int)fdiv((unsigned)p, (unsigned)a.TW, a.m_tw), tx = p - ty * a.TW;
+      if (y0 + ty < a.H && x0 + tx < a.W) v = (y0 + ty) * a.W + (x0 + tx);
+    }
+    pix[ip] = v;
+  }
+  const int cb = n0 + wn * 64 + q * 4;          // first of this lane's 4 channels in channel tile 0 (+ ic * 16)
+  float* yo = reinterpret_cast<float*>(a.y);
+  // every channel of this wave's 64 exists and rows are 16-byte aligned (wave-uniform; the common case): 32 x dwordx4
+  // per lane, back to back -- a lane group of 16 lanes x 4 rows writes 64 contiguous bytes of each of its 16 pixels
+  const bool fast = (a.ldy % 4) == 0 && (n0 + wn * 64 + 64 <= a.Cout);
+  float bv[4][4];
+#pragma unroll
+  for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int c = cb + ic * 16 + r;
+      bv[ic][r] = (a.bias != nullptr && c < a.Cout) ? a.bias[c] : 0.f;
+    }
+  int64_t rowoff[NIP];
+#pragma unroll
+  for (int ip = 0; ip < NIP; ++ip) rowoff[ip] = (ybase + max(pix[ip], 0)) * a.ldy;
+#pragma unroll
+  for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+    for (int ip = 0; ip < NIP; ++ip)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ic][ip][r] += bv[ic][r];          // pre-activation value: what the statistics are taken of
+  if (fast) {
+#pragma unroll
+    for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+      for (int ip = 0; ip < NIP; ++ip) {
+        float4 o;
+        o.x = act_f(acc[ic][ip][0], actp); o.y = act_f(acc[ic][ip][1], actp);
+        o.z = act_f(acc[ic][ip][2], actp); o.w = act_f(acc[ic][ip][3], actp);
+        if (pix[ip] >= 0) *reinterpret_cast<float4*>(yo + rowoff[ip] + (cb + ic * 16)) = o;
+      }
+  } else {
+#pragma unroll
+    for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+      for (int ip = 0; ip < NIP; ++ip)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = cb + ic * 16 + r;
+          if (pix[ip] >= 0 && c < a.Cout) yo[rowoff[ip] + c] = act_f(acc[ic][ip][r], actp);
+        }
+  }
+
+  if constexpr (!RED) { if (a.stats == nullptr) return; }
+  __syncthreads();       // every wave is done reading operands: LDS is reused below
+  float* sred = reinterpret_cast<float*>(smem);        // [wave][64 channels][2]
+  float* scnt = sred + NW * 64 * 2;                    // [wave]
+
+  if constexpr (RED) {
+    // BatchNorm-backward partial sums of the tensor this launch writes (see P3Args): g = dz * [bn(y) > 0], (sum g, sum g xhat)
+    const float* __restrict__ yb = a.red_y + ybase * a.ldy;
+#pragma unroll
+    for (int ic = 0; ic < 4; ++ic) {
+      const int c = cb + ic * 16;
+      float mu[4], is[4], sc[4], sh[4], sbv[4], sgv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int nc = min(c + r, a.Cout - 1);
+        mu[r] = a.red_mean[nc]; is[r] = a.red_invstd[nc]; sc[r] = is[r] * a.red_gamma[nc]; sh[r] = a.red_beta[nc];
+        sbv[r] = 0.f; sgv[r] = 0.f;
+      }
+      const int cc = min(c, a.Cout - 4);             // dense fp32 output, Cout % 4 == 0 (checked at launch)
+#pragma unroll
+      for (int ip = 0; ip < NIP; ++ip) {
+        const float4 yv4 = *reinterpret_cast<const float4*>(yb + (unsigned)(max(pix[ip], 0) * a.ldy + cc));
+        const float* yv = &yv4.x;
+        const bool ok = pix[ip] >= 0 && c < a.Cout;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float d = yv[r] - mu[r];
+          const float g = (ok && d * sc[r] + sh[r] > 0.f) ? acc[ic][ip][r] : 0.f;      // the mask k_bn_bwd_apply recomputes
+          sbv[r] += g;
+          sgv[r] = fmaf(g, d * is[r], sgv[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float s1 = row16_sum(sbv[r]), s2 = row16_sum(sgv[r]);
+        if (r16 == 0) {
+          sred[(wave * 64 + ic * 16 + q * 4 + r) * 2 + 0] = s1;
+          sred[(wave * 64 + ic * 16 + q * 4 + r) * 2 + 1] = s2;
+        }
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int col = threadIdx.x, cwn = col >> 6, cl = col & 63;
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int k = 0; k < NWM; ++k) {
+        s1 += sred[((k * 2 + cwn) * 64 + cl) * 2 + 0];
+        s2 += sred[((k * 2 + cwn) * 64 + cl) * 2 + 1];
+      }
+      const int n = n0 + col;
+      if (n < a.Cout) {
+        a.red_ws[(int64_t)mtile * 2 * a.Cout + n] = s1;
+        a.red_ws[(int64_t)mtile * 2 * a.Cout + a.Cout + n] = s2;
+      }
+    }
+    if (a.stats == nullptr) return;
+    __syncthreads();
+  }
+
+  {
+    // per-wave (count, sum, M2 about the wave's mean) of the pre-activation values, combined over the workgroup in fp64
+    int cnt = 0;
+#pragma unroll
+    for (int ip = 0; ip < NIP; ++ip) cnt += (pix[ip] >= 0) ? 1 : 0;
+    cnt = (int)row16_sum((float)cnt);                       // <= 128: exact
+    const float inv = 1.f / (float)(cnt > 0 ? cnt : 1);
+#pragma unroll
+    for (int ic = 0; ic < 4; ++ic)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float s = 0.f;
+#pragma unroll
+        for (int ip = 0; ip < NIP; ++ip) s += (pix[ip] >= 0) ? acc[ic][ip][r] : 0.f;
+        s = row16_sum(s);
+        const float mean = s * inv;
+        float m2 = 0.f;
+#pragma unroll
+        for (int ip = 0; ip < NIP; ++ip) {
+          const float d = acc[ic][ip][r] - mean;
+          m2 += (pix[ip] >= 0) ? d * d : 0.f;
+        }
+        m2 = row16_sum(m2);
+        if (r16 == 0) {
+          sred[(wave * 64 + ic * 16 + q * 4 + r) * 2 + 0] = s;
+          sred[(wave * 64 + ic * 16 + q * 4 + r) * 2 + 1] = m2;
+        }
+      }
+    if (lane == 0) scnt[wave] = (float)cnt;
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int col = threadIdx.x, cwn = col >> 6, cl = col & 63;
+      double n_tot = 0.0, s_tot = 0.0;
+#pragma unroll
+      for (int k = 0; k < NWM; ++k) {
+        const int wv = k * 2 + cwn;
+        n_tot += (double)scnt[wv];
+        s_tot += (double)sred[(wv * 64 + cl) * 2 + 0];
+      }
+      const double mu = n_tot > 0.0 ? s_tot / n_tot : 0.0;
+      double m2 = 0.0;
+#pragma unroll
+      for (int k = 0; k < NWM; ++k) {
+        const int wv = k * 2 + cwn;
+        const double nk = (double)scnt[wv];
+        if (nk > 0.0) {
+          const double d = (double)sred[(wv * 64 + cl) * 2 + 0] / nk - mu;
+          m2 += (double)sred[(wv * 64 + cl) * 2 + 1] + nk * d * d;
+        }
+      }
+      const int n = n0 + col;
+      if (n < a.Cout) {
+        a.stats[((int64_t)mtile * 2 + 0) * a.Cout + n] = (float)s_tot;
+        a.stats[((int64_t)mtile * 2 + 1) * a.Cout + n] = (float)m2;
+      }
+      if (col == 0 && tn == 0) a.stats[(int64_t)a.nblk * 2 * a.Cout + mtile] = (float)n_tot;
+    }
+  }
+}
+
 }  // namespace
 
 // Workgroup shape + tile shape.  Variants (all 8 waves):
@@ -647,6 +1160,10 @@ k_conv3x3_patch(P3Args a) {
 //   2  G=1 FM=2  256 px x 128 ch, wave tile  64 x 64, two workgroups per CU (72 KiB, 114 VGPRs)
 //   3  G=2 FM=1  256 px x  64 ch, wave tile  32 x 64, two workgroups per CU (76 KiB,  72 VGPRs)
 //   4  G=2 FM=2  512 px x  64 ch, wave tile  64 x 64, one workgroup per CU
+//   5  shape 2 on v_mfma_f32_16x16x32 (k_conv3x3_m16<8, 4>: 8 waves, wave tile 64 x 64, two workgroups per CU; operand pairs
+//      with Cin % 32 == 0 only, everything else runs as 2).  The automatic choice takes it wherever it picks shape 2
+//      (SFOD_P3_M16=0 / sfod_set_conv3x3_m16(0): the 32x32x16 kernel everywhere, for A/B runs)
+//   6  the same on 4 waves per workgroup (k_conv3x3_m16<4, 8>, wave tile 128 x 64)
 // Measured per layer (tools/bench_conv.py, interleaved A/B; profiles/r1q_conv_variants.txt): two resident
 // workgroups overlap each other's prologue / epilogue / barrier stalls, which beats the larger tiles' lower
 // L2 -> LDS traffic on every VGG shape; between the two small shapes the 64 x 64 wave tile needs one LDS
@@ -657,8 +1174,25 @@ k_conv3x3_patch(P3Args a) {
 // initialised (SFOD_P3_VARIANT or 0 = auto).  It selects among kernels that compute the same values.
 static std::atomic<int> g_p3_variant{-1};
 
+// 16x16x32 form of the 256 x 128 shape for operand pairs (k_conv3x3_m16): -1 not initialised (SFOD_P3_M16, default on)
+static std::atomic<int> g_p3_m16{-1};
+extern "C" int sfod_set_conv3x3_m16(int on) {
+  g_p3_m16.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+static bool p3_m16_enabled() {
+  int v = g_p3_m16.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* ev = getenv("SFOD_P3_M16");
+    int want = ev ? (atoi(ev) != 0) : 1, expect = -1;
+    g_p3_m16.compare_exchange_strong(expect, want, std::memory_order_relaxed);
+    v = g_p3_m16.load(std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+
 extern "C" int sfod_set_conv3x3_variant(int variant) {
-  g_p3_variant.store((variant >= 1 && variant <= 4) ? variant : 0, std::memory_order_relaxed);
+  g_p3_variant.store((variant >= 1 && variant <= 6) ? variant : 0, std::memory_order_relaxed);
   return 0;
 }
 
@@ -688,6 +1222,7 @@ static bool p3_best_tile(int H, int W, int BM, int cap, int& TH, int& TW, int& t
 P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   P3Plan p;
   p.ok = 0;
+  p.m16 = 0;
   if (H < 1 || W < 1 || B < 1) return p;
   int variant = g_p3_variant.load(std::memory_order_relaxed);
   if (variant < 0) {
@@ -697,6 +1232,8 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
     g_p3_variant.compare_exchange_strong(expect, variant, std::memory_order_relaxed);   // a concurrent setter wins
     variant = g_p3_variant.load(std::memory_order_relaxed);
   }
+  p.m16 = (variant == 5) ? 1 : (variant == 6 ? 2 : ((variant < 1 || variant > 6) ? (p3_m16_enabled() ? 1 : 0) : 0));
+  if (variant == 5 || variant == 6) variant = 2;
   if (variant < 1 || variant > 4) {
     const int64_t mt = ((int64_t)B * H * W + 255) / 256;          // 256-pixel tiles (lower bound)
     const int64_t wg128 = mt * ((Cout + 127) / 128);
@@ -726,6 +1263,27 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
   p.nblk = B * p.tiles_y * p.tiles_x;
   p.ok = 1;
   return p;
+}
+
+#ifdef M16_STAMP
+extern "C" int sfod_debug_m16_stamps(unsigned long long* out8, int reset) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_m16_stamps), 64);
+  if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_m16_stamps), z, 64); }
+  return 0;
+}
+#endif
+
+template <int NW, int NIP, int FMT, bool RED>
+static int p3_launch_m16(P3Args a, hipStream_t s) {
+  auto kern = k_conv3x3_m16<NW, NIP, FMT, RED>;
+  constexpr int LDS = M16Lay<NW, NIP>::LDS;
+  static const hipError_t attr_rc =
+      hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+  if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute(m16): %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
+  a.nbody = a.Cin / 64;
+  hipLaunchKernelGGL(kern, dim3(a.ntiles), dim3(NW * 64), LDS, s, a);
+  return sfod_check_launch("conv3x3_m16");
 }
 
 template <int G, int FM, typename OutT, int SPLIT = 0, bool RED = false>
@@ -764,6 +1322,15 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
   a.nblk = p.nblk;
   if (split) {
     if (!out_f32) { sfod_set_error("conv3x3_patch: operand pairs write fp32"); return SFOD_EBADARG; }
+    // the 256 x 128 shape on 16x16x32 MFMAs: same tile plan (statistics blocks, reduction rows), two slices per super-body
+    if (p.m16 && p.G == 1 && p.FM == 2 && Cin % 64 == 0 && (red == nullptr || split == 1)) {
+      if (p.m16 == 2) {                 // shape 6: 4 waves x (128 px x 64 ch), 2 x 208 of a SIMD lane's 512 registers
+        if (red != nullptr) return p3_launch_m16<4, 8, 1, true>(a, s);
+        return split == 2 ? p3_launch_m16<4, 8, 2, false>(a, s) : p3_launch_m16<4, 8, 1, false>(a, s);
+      }
+      if (red != nullptr) return p3_launch_m16<8, 4, 1, true>(a, s);
+      return split == 2 ? p3_launch_m16<8, 4, 2, false>(a, s) : p3_launch_m16<8, 4, 1, false>(a, s);
+    }
     if (red != nullptr) {
       if (split != 1) { sfod_set_error("conv3x3_patch: the BatchNorm-backward epilogue runs on bf16x3 operands"); return SFOD_EBADARG; }
       if (p.G == 1 && p.FM == 2) return p3_launch_one<1, 2, float, 1, true>(a, s);

@@ -13,6 +13,7 @@ struct P3Plan {
   int TH, TW;            // output pixels per tile (TH*TW <= 512 | 256, (TH+2)*(TW+2) <= 640 | 384)
   int tiles_y, tiles_x, tiles_n;
   int nblk;              // BatchNorm statistics blocks = B * tiles_y * tiles_x
+  int m16;               // G = 1, FM = 2 only: operand-pair launches with Cin % 64 == 0 run k_conv3x3_m16 (same tiles)
 };
 P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout);
 // BatchNorm-backward reduction folded into a data-gradient launch (fp32 output [B,H,W,Cout] dense): see P3Args

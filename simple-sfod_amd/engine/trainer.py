@@ -48,60 +48,74 @@ def get_rank():
 
 
 class EventStorage:
-    """Scalars are kept as device tensors until ``flush`` (one host sync per writer period)."""
+    """Scalars are kept as device tensors until ``flush`` (one host sync per writer period).
+
+    Two kinds of scalars, as in the reference: the step's ``metrics_dict`` (``_write_metrics``, base.py:198-209:
+    gathered from every rank, logged as the mean over ranks, ``data_time`` as the max) is put with ``rank_mean=True``;
+    everything else a trainer or a hook puts (``roi_head/mean_confidence``, ``acc_thres/*``, ``calibration/bpc_loss``,
+    the ValLossHook's ``*_val`` keys, evaluation results) is rank-local there -- each rank has its own storage and only
+    the main process writes -- so the record carries this rank's value and rank 0's is what reaches ``metrics.json``."""
 
     def __init__(self, start_iter=0):
         self.iter = start_iter
         self._pending = {}
+        self._rank_mean = set()
         self.history = []
 
-    def put_scalar(self, name, value):
+    def put_scalar(self, name, value, rank_mean=False):
         self._pending[name] = value
+        (self._rank_mean.add if rank_mean else self._rank_mean.discard)(name)
 
-    def put_scalars(self, **kw):
-        self._pending.update(kw)
+    def put_scalars(self, rank_mean=False, **kw):
+        for k, v in kw.items():
+            self.put_scalar(k, v, rank_mean=rank_mean)
 
     def flush(self, reduce_over_ranks=False):
-        """-> the record of this writer period.  ``reduce_over_ranks``: the reference gathers every rank's metrics dict
-        each step and logs the mean (``data_time``: the max) over ranks (daod/engine/trainers/base.py:198-209,
-        ``comm.gather`` + ``np.mean``); here the device scalars of the period are stacked and averaged with ONE small
-        all-reduce per writer period (+ one MAX all-reduce for ``data_time``).  Every rank must call it with the same
-        tensor-valued keys (they follow from the config, not from the data)."""
+        """-> the record of this writer period.  ``reduce_over_ranks``: the ``rank_mean`` keys of the period are stacked
+        and averaged with ONE small all-reduce (+ one MAX all-reduce for ``data_time``); every rank must call it with
+        the same ``rank_mean`` keys (they follow from the config, not from the data).  If the ranks disagree on their
+        number anyway, nothing is exchanged (a mismatched collective would hang), every rank keeps its own values and
+        says so once on stderr."""
         if not self._pending:
             return {}
         names = list(self._pending)
         vals = [v.detach().float().reshape(()) if isinstance(v, torch.Tensor) else None for v in self._pending.values()]
-        dev_vals = [v for v in vals if v is not None]
+        dev_idx = [i for i, v in enumerate(vals) if v is not None]
         world = get_world_size() if reduce_over_ranks else 1
-        host = []
+        shared = [i for i in dev_idx if names[i] in self._rank_mean] if world > 1 else []
+        has_dt = world > 1 and "data_time" in self._rank_mean and "data_time" in self._pending
         if world > 1:
-            # every rank must bring the same number of device scalars (they follow from the config; a rank whose share
-            # of a tiny evaluation set is empty would not): agree on it first, and fall back to rank-local values
-            # rather than hang in a mismatched collective
-            dev = dev_vals[0].device if dev_vals else torch.device("cuda", torch.cuda.current_device()) \
-                if torch.cuda.is_available() else torch.device("cpu")
-            n = torch.tensor([len(dev_vals), -len(dev_vals)], dtype=torch.int64, device=dev)
+            dev = vals[dev_idx[0]].device if dev_idx else (torch.device("cuda", torch.cuda.current_device())
+                                                        if torch.cuda.is_available() else torch.device("cpu"))
+            n = torch.tensor([len(shared), -len(shared), int(has_dt), -int(has_dt)], dtype=torch.int64, device=dev)
             dist.all_reduce(n, op=dist.ReduceOp.MAX)
-            if int(n[0]) != -int(n[1]):
-                world = 1
-        if dev_vals:
-            stacked = torch.stack(dev_vals)
-            if world > 1:
-                dist.all_reduce(stacked)
-                stacked = stacked / world
-            host = stacked.cpu().tolist()
-        out, j = {"iteration": self.iter}, 0
-        for n, v in zip(names, vals):
-            if v is None:
-                out[n] = float(self._pending[n])
-            else:
-                out[n] = host[j]
-                j += 1
-        if world > 1 and "data_time" in out and dev_vals:
-            t = torch.tensor([out["data_time"]], dtype=torch.float32, device=dev_vals[0].device)
+            if int(n[0]) != -int(n[1]) or int(n[2]) != -int(n[3]):
+                if not getattr(self, "_warned_mismatch", False):
+                    import sys
+                    print("[EventStorage] rank {}: the ranks bring different numbers of rank-mean scalars ({} here, up to "
+                          "{} elsewhere); logging rank-local values".format(get_rank(), len(shared), int(n[0])),
+                          file=sys.stderr)
+                    self._warned_mismatch = True
+                shared, has_dt = [], False
+        host = {}
+        if dev_idx:
+            stacked = torch.stack([vals[i] for i in dev_idx])
+            if shared:
+                pos = {i: j for j, i in enumerate(dev_idx)}
+                sel = torch.tensor([pos[i] for i in shared], dtype=torch.int64, device=stacked.device)
+                part = stacked[sel]
+                dist.all_reduce(part)
+                stacked = stacked.index_copy(0, sel, part / world)
+            host = dict(zip(dev_idx, stacked.cpu().tolist()))
+        out = {"iteration": self.iter}
+        for i, n_ in enumerate(names):
+            out[n_] = host[i] if i in host else float(self._pending[n_])
+        if has_dt:
+            t = torch.tensor([out["data_time"]], dtype=torch.float32, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             out["data_time"] = t.item()
         self._pending = {}
+        self._rank_mean = set()
         self.history.append(out)
         return out
 
@@ -320,9 +334,9 @@ class BaseTrainer:
         loss_keys = [k for k in metrics_dict if k[:4] == "loss"]
         if loss_keys:
             self.storage.put_scalar("total_loss", total if total is not None
-                                    else sum(metrics_dict[k].detach() for k in loss_keys))
-        self.storage.put_scalars(**{k: (v.detach() if isinstance(v, torch.Tensor) else v)
-                                    for k, v in metrics_dict.items()})
+                                    else sum(metrics_dict[k].detach() for k in loss_keys), rank_mean=True)
+        self.storage.put_scalars(rank_mean=True, **{k: (v.detach() if isinstance(v, torch.Tensor) else v)
+                                                    for k, v in metrics_dict.items()})
 
     def after_step(self):
         """d2 hook order (source_free_adaptive_teacher.py:622-679 ``build_hooks``): LRScheduler, PeriodicCheckpointer,
@@ -384,7 +398,8 @@ class BaseTrainer:
                     acc[k] = acc[k] + v if k in acc else v
                 nb += 1
             losses = {k: v / max(nb, 1) for k, v in acc.items() if k[:4] == "loss"}
-            if losses:     # every rank logs its share of the test set; the flush averages over ranks
+            if losses:     # rank-local like the reference's (val_loss.py:64-66 writes on the main process only): the
+                           # record of rank 0 -- its share of the test set -- is what reaches metrics.json
                 self.storage.put_scalar("total_loss" + name + "_val", sum(losses.values()))
                 if len(losses) > 1:
                     self.storage.put_scalars(**{k + name + "_val": v for k, v in losses.items()})

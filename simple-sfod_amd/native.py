@@ -279,8 +279,13 @@ def set_wgrad3x3_pipe(on):
 
 
 def set_conv3x3_variant(variant):
-    """Workgroup shape of the halo-patch kernel: 0 auto, 1..4 see include/sfod_hip.h (A/B runs, tests)."""
+    """Workgroup shape of the halo-patch kernel: 0 auto, 1..5 see include/sfod_hip.h (A/B runs, tests)."""
     load().sfod_set_conv3x3_variant(int(variant))
+
+
+def set_conv3x3_m16(on):
+    """Automatic shape choice: run the 256 x 128 shape on 16x16x32 MFMAs (default on; include/sfod_hip.h)."""
+    load().sfod_set_conv3x3_m16(int(bool(on)))
 
 
 # =================================================================================================

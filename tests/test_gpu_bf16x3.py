@@ -110,7 +110,7 @@ def test_conv_fwd_generic_kernel(native, shape, act):
     (3, 5, 6, 256, 256),
 ])
 @pytest.mark.parametrize("variant", ["plain", "relu_stats", "ldy"])
-@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4, 5, 6])
 def test_conv3x3_patch_kernel(native, shape, variant, wg):
     B, H, W, Cin, Cout = shape
     g = torch.Generator().manual_seed(sum(shape))
@@ -359,8 +359,36 @@ def test_conv_first_layer_kernel_split(native, hw):
     assert rel_err(zf, native.cast(z2, torch.float32).cpu()) < 1e-6
 
 
+@pytest.mark.parametrize("wg", [2, 5, 6])
+def test_conv3x3_pairs_under_load_is_deterministic(native, wg):
+    """Full-chip launch on operand pairs (two workgroups per CU): the 32x32x16 kernel (2) and the 16x16x32 kernel (5) must
+    each be run-to-run bit-identical -- guards the counted-wait DMA pipelines, whose hazards (a fragment read still queued
+    when another wave's DMA overwrites its slot; a stage read before its DMA landed) only show under load -- and agree
+    with each other to fp32 summation order."""
+    B, H, W, Cin, Cout = 8, 150, 300, 256, 256
+    g = torch.Generator(device=DEV).manual_seed(1)
+    x = to_split(native, torch.randn(B, H, W, Cin, device=DEV, generator=g))
+    w = to_split(native, torch.randn(Cout, 9, Cin, device=DEV, generator=g) / (3 * Cin ** 0.5))
+    bias = torch.randn(Cout, device=DEV, generator=g)
+    try:
+        native.set_conv_algo(2)
+        native.set_conv3x3_variant(2)
+        ref, ref_stats = native.conv_fwd(x, w, bias, Cout, 3, want_stats=True)
+        native.set_conv3x3_variant(wg)
+        outs = [native.conv_fwd(x, w, bias, Cout, 3, want_stats=True) for _ in range(6)]
+        torch.cuda.synchronize()
+    finally:
+        native.set_conv_algo(0)
+        native.set_conv3x3_variant(0)
+    for y, st in outs[1:]:
+        assert torch.equal(outs[0][0], y), "pair conv is not run-to-run deterministic"
+        assert torch.equal(outs[0][1], st), "pair conv statistics are not run-to-run deterministic"
+    assert rel_err(outs[0][0], ref) < 2e-6
+    torch.testing.assert_close(outs[0][1], ref_stats, rtol=2e-4, atol=2e-3)
+
+
 @pytest.mark.parametrize("shape", [(2, 37, 75, 64, 128), (1, 40, 64, 128, 64), (2, 18, 25, 256, 256), (1, 33, 31, 64, 64)])
-@pytest.mark.parametrize("variant", [0, 1, 4])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6])
 def test_dgrad_with_fused_batchnorm_backward_reduction(native, shape, variant):
     """sfod_conv_dgrad_bnred: the data-gradient kernel's epilogue also makes the (dbeta, dgamma) partial sums of the layer
     below.  dz must be bit-identical to the plain kernel's, and BatchNorm backward fed with the pre-reduced workspace must

@@ -86,7 +86,7 @@ def test_conv_fwd(native, dtype, shape, act):
     (3, 5, 6, 256, 256),      # tiny maps, 8 slices
 ])
 @pytest.mark.parametrize("variant", ["plain", "relu_stats", "f32out"])
-@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4])   # workgroup shape: auto, 512x128, 256x128, 256x64, 512x64
+@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4, 5, 6])   # workgroup shape: auto, 512x128, 256x128, 256x64, 512x64, 256x128 on 16x16x32 (8 / 4 waves; pairs only)
 def test_conv3x3_patch_kernel(native, shape, variant, wg):
     """k_conv3x3_patch (forced) against F.conv2d on bf16-rounded operands and against the generic
     implicit-GEMM kernel; BatchNorm partial statistics through sfod_bn_finalize."""

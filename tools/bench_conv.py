@@ -23,6 +23,9 @@ def main():
     ap.add_argument("--dtype", choices=["bf16", "bf16x3"], default="bf16x3")
     ap.add_argument("--variants", action="store_true",
                     help="time the halo-patch kernel's workgroup shapes 1..4 (and auto = 0) instead of algo 1 vs 2")
+    ap.add_argument("--data", choices=["randn", "zeros", "relu"], default="randn",
+                    help="operand values: zeros shows how much of a kernel's time is the clock the chip holds under load "
+                         "(same instruction stream, less switching power); relu = half of x's entries zero like a ReLU output")
     ap.add_argument("--w3pipe", action="store_true",
                     help="halo-patch weight gradient: round-2 chunk loop vs the pipelined one, interleaved (sfod_set_wgrad3x3_pipe)")
     args = ap.parse_args()
@@ -48,6 +51,11 @@ def main():
         x = native.cast(torch.randn(B, H, W, Cin, device=dev, generator=g), odt)
         w = native.cast(torch.randn(Cout, 9, Cin, device=dev, generator=g) / (3 * Cin ** 0.5), odt)
         bias = torch.randn(Cout, device=dev, generator=g)
+        if args.data == "zeros":
+            x.view(torch.uint8).zero_()
+            w.view(torch.uint8).zero_()
+        elif args.data == "relu":
+            x = native.cast(torch.relu(torch.randn(B, H, W, Cin, device=dev, generator=g)), odt)
         flops = 2.0 * B * H * W * Cout * 9 * Cin
         if args.w3pipe:
             if name == "conv1_1":
@@ -78,7 +86,7 @@ def main():
             continue
         if args.variants:
             native.set_conv_algo(2)
-            vt = {v: [] for v in (0, 1, 2, 3, 4)}
+            vt = {v: [] for v in (0, 1, 2, 3, 4, 5, 6)}
             for r in range(args.rounds + 1):
                 for v in vt:
                     native.set_conv3x3_variant(v)
@@ -91,7 +99,7 @@ def main():
                         vt[v].append(e0.elapsed_time(e1))
             native.set_conv3x3_variant(0)
             native.set_conv_algo(0)
-            names = {0: "auto", 1: "512x128", 2: "256x128", 3: "256x64", 4: "512x64"}
+            names = {0: "auto", 1: "512x128", 2: "256x128", 3: "256x64", 4: "512x64", 5: "256x128 m16", 6: "256x128 m16 4w"}
             line = f"{name:9s} {B}x{H}x{W} {Cin:4d}->{Cout:4d} {flops / 1e9:8.1f} GF"
             for v in vt:
                 t = sorted(vt[v])[len(vt[v]) // 2]
