@@ -13,8 +13,8 @@ bf16 matrix pipe, about 16 significand bits per operand: losses and boxes within
 for ``--model r101`` (the same three-MFMA product with the forward operands as IEEE half pairs, 22 bits each: gated like
 fp32) -- on that 101-layer network bf16x3 reaches only ~1e-3 (the test says so), so it is NOT reported as ``value`` there.
 Other modes are measured afterwards by child processes and reported in labelled blocks, never as ``value``: faster, less
-exact ones under ``reduced_precision_mode``; the tighter parity modes of the same config (VGG16: ``f16x3``; r101: ``fp32``)
-under ``other_parity_modes``.
+exact ones under ``reduced_precision_mode``; the tighter parity modes of the same config (VGG16: ``f16x3`` and ``fp32``, the
+reference's own arithmetic; r101: ``fp32``) under ``other_parity_modes``.
 
 Contract: ``python bench.py --gpus N --steps K --warmup W``; rank 0 prints ONE JSON line.  N > 1: either started under
 ``python -m torch.distributed.run`` (RANK / WORLD_SIZE in the environment), or plainly -- then the script starts the N
@@ -50,7 +50,8 @@ PEAK = {"bf16": 2500.0, "fp32": 157.3, "bf16x3": 2500.0 / 3.0, "f16x3": 2500.0 /
 # the mode test_gpu_fullsize.py gates at the north star's 1e-4 for each model = what `value` is measured in
 PARITY_DTYPE = {"vgg": "bf16x3", "r101": "f16x3"}
 # further modes that pass the same fullsize gates on the config (reported beside `value`, measured by child processes)
-OTHER_PARITY = {"vgg": {"bf16x3": ["f16x3"]}, "r101": {"f16x3": ["fp32"]}}
+# (fp32 = the reference's own arithmetic: every default line carries one number in it)
+OTHER_PARITY = {"vgg": {"bf16x3": ["f16x3", "fp32"], "f16x3": ["fp32"]}, "r101": {"f16x3": ["fp32"]}}
 # "planted-label" scale on cls_score: 10-30 teacher detections per image clear the 0.8 threshold
 PLANT = {"vgg": 60.0, "r101": 3.0}
 # the committed PMC captures (profiles/pmc_hbm_traffic_latest.json: VGG16 bf16x3; pmc_hbm_traffic_r101_latest.json: R101 f16x3)
@@ -402,7 +403,9 @@ def main():
         n2 = max(5, min(40, args.steps))
         secondary = []
         for dt2 in list(faster) + list(others):
-            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt2, "--steps", str(n2), "--warmup", "5",
+            # fp32 runs at 1/16 of the matrix rate: fewer steps keep the default run within its few minutes
+            n_dt = max(5, n2 // 3) if dt2 == "fp32" else n2
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt2, "--steps", str(n_dt), "--warmup", "3" if dt2 == "fp32" else "5",
                    "--batch", str(args.batch), "--res", args.res, "--model", args.model, "--trainer", args.trainer,
                    "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"]
             cmd += (["--no-planted"] if args.no_planted else []) + (["--no-overlap"] if args.no_overlap else [])

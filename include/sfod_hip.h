@@ -113,6 +113,13 @@ int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, 
  * 64 ch), two per SIMD (leaves registers for a co-resident kernel; tools/experiments/corun_conv_bn.py).  For A/B runs and
  * parity tests. */
 int sfod_set_conv3x3_variant(int variant);
+/* Deterministic gradients (default 0; environment SFOD_DETERMINISTIC, config SFOD.DETERMINISTIC): the generic weight-gradient
+ * kernels (1x1 / linear / first layer / fp32) store every pixel split's partial tile into a slab of the workspace
+ * (sfod_conv_wgrad_ws_bytes grows accordingly) and sum the slabs in split order instead of combining them with float atomics,
+ * the bias gradient runs one workgroup per 64 columns: bit-identical results from run to run (the halo-patch 3x3 weight
+ * gradient, BatchNorm and ROIAlign backward are always order-fixed).  sfod_get_deterministic: the current setting. */
+int sfod_set_deterministic(int on);
+int sfod_get_deterministic(void);
 /* whether the automatic choice runs shape 2 as shape 5 (default 1; environment SFOD_P3_M16).  Same tiles, same products,
  * another fp32 summation order inside a 32-deep k-step. */
 int sfod_set_conv3x3_m16(int on);
@@ -464,7 +471,7 @@ int sfod_teacher_metrics(const float* det_scores, const int* det_count, int D, c
  * that is the operand of a forward product and of a weight gradient; replaces the reference's single fp32 tensor at
  * every such site, e.g. the RPN head input daod/modeling/proposal_generator/rpn.py:25-56) */
 int sfod_cast_pairs_both(const float* src, void* dst_f16x3, void* dst_bf16x3, int64_t n, void* stream);
-/* SFOD_F16X3 range report: every producer of half pairs raises a device flag when a FINITE value beyond +-65504 had to be
+/* SFOD_F16X3 range report: every producer of half pairs raises a device flag when a value beyond +-65504 (an infinity included; NaN stays NaN) had to be
  * clamped (activations or scaled weights outside the window the mode assumes).  This call ORs the flags into the caller's
  * device word (zeroed by the caller once) and clears them; no host synchronisation -- the trainer reads the word at its
  * metrics period, beside the RPN's non-finite flag (d2 raises FloatingPointError inside predict_proposals). */

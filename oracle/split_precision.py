@@ -20,8 +20,9 @@ def split_pairs(v, fmt):
         hi = v.bfloat16().float()
         lo = (v - hi).bfloat16().float()
     elif fmt == "f16":
-        hi = v.clamp(-65504.0, 65504.0).half().float()
-        lo = (v - hi).clamp(-65504.0, 65504.0).half().float()
+        c = v.clamp(-65504.0, 65504.0)          # beyond half's range (infinities too): exactly +-65504, lo = 0; NaN stays NaN
+        hi = c.half().float()
+        lo = (c - hi).half().float()
     else:
         raise ValueError(fmt)
     return hi.double(), lo.double()

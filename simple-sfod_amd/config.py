@@ -385,6 +385,10 @@ def add_native_config(cfg):
     SFOD.ELIDE_DEAD_BRANCHES  skip the zero-weighted 2nd ROI pass / BPC / domain branch.
     SFOD.OVERLAP_TEACHER  run the teacher's pseudo-labelling pass on a second HIP stream beside the
                           student's backbone forward (they are independent until the student's RPN loss).
+    SFOD.DETERMINISTIC    no float atomics in weight / bias gradients (sfod_set_deterministic): the pixel splits of the
+                          generic weight-gradient kernels are summed through slabs in a fixed order, so a step is
+                          bit-identical from run to run (the reference on CUDA is not: cuDNN / atomicAdd); costs one
+                          more pass over the split partials of the 1x1 / linear gradients (fc1: 2 x 103 MB).
     """
     _C = cfg
     _C.SFOD = CN()
@@ -394,6 +398,7 @@ def add_native_config(cfg):
     _C.SFOD.COMPUTE_DTYPE = "bf16x3"
     _C.SFOD.ELIDE_DEAD_BRANCHES = True
     _C.SFOD.OVERLAP_TEACHER = True
+    _C.SFOD.DETERMINISTIC = False
     # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass
     # that stores the activated output directly; sfod_conv_first_fused)
     _C.SFOD.FUSE_FIRST_LAYER = True

@@ -61,7 +61,7 @@ __device__ __forceinline__ void split_store8(split_t* p, const float* in) {
   reinterpret_cast<uint4*>(p)[1] = lo.v;
 }
 // ---- SFOD_F16X3 storage: the same layout with IEEE half pairs, hi = f16(v), lo = f16(v - hi) (include/sfod_hip.h).
-// |v| beyond the half range saturates at +-65504 per component (NaN stays NaN).
+// |v| beyond the half range (infinities included) saturates at exactly +-65504, lo = 0 (NaN stays NaN).
 typedef _Float16 f16_t;
 struct splith_t { uint32_t raw; };
 
@@ -71,16 +71,16 @@ struct splith_t { uint32_t raw; };
 // instead of training on clamped values.
 static __device__ unsigned g_f16_sat;
 #define SFOD_DEFINE_F16_POLL(fn)                                                                            \
-  static __global__ void fn##_k(unsigned* out) { if (g_f16_sat) { atomicOr(out, 1u); g_f16_sat = 0u; } }    \
+  static __global__ void fn##_k(unsigned* out) { if (atomicExch(&g_f16_sat, 0u)) atomicOr(out, 1u); }       \
   void fn(unsigned* out, hipStream_t s) { hipLaunchKernelGGL(fn##_k, dim3(1), dim3(1), 0, s, out); }
 
 __device__ __forceinline__ void f16_pair(float v, f16_t& h, f16_t& l) {
   const float lim = 65504.f;
-  if (fabsf(v) > lim && fabsf(v) <= 3.0e38f) g_f16_sat = 1u;      // finite and out of range (inf / NaN: the finite checks' business)
-  const float c = (fabsf(v) > lim) ? copysignf(lim, v) : v;       // NaN compares false: passes through
+  const bool over = fabsf(v) > lim;                 // NaN compares false: passes through as NaN in both halves
+  if (over) g_f16_sat = 1u;                         // finite or infinite: the value left half's range -- reported
+  const float c = over ? copysignf(lim, v) : v;
   h = (f16_t)c;
-  const float r = v - (float)h;
-  l = (f16_t)((fabsf(r) > lim) ? copysignf(lim, r) : r);
+  l = (f16_t)(c - (float)h);                        // residual of the CLAMPED value: a saturated element is exactly +-65504
 }
 __device__ __forceinline__ void split_load8(const splith_t* p, float* out) {
   union { uint4 v; f16_t h[8]; } hi, lo;

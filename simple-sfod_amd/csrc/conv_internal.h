@@ -48,6 +48,9 @@ W3Plan sfod_w3_plan(int B, int H, int W, int Cin, int Cout, int lddy, int split 
 int sfod_w3_launch(const W3Plan& p, const void* x, const void* dy, float* dw, void* ws, int B, int H, int W,
                    int Cin, int Cout, int lddy, int out_mode, hipStream_t s, int split = 0);
 
+// ---- deterministic mode (gemm_conv.hip: sfod_set_deterministic / SFOD_DETERMINISTIC) -----------------------------------
+bool sfod_deterministic();
+
 // ---- SFOD_F16X3 saturation words of the translation units that produce half pairs (common.h) -----------------------
 void sfod_f16_poll_elementwise(unsigned* out, hipStream_t s);
 void sfod_f16_poll_roi(unsigned* out, hipStream_t s);

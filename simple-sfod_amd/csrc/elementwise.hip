@@ -1751,6 +1751,7 @@ extern "C" int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, i
   if (M == 0) return 0;
   int slices = (M + 63) / 64;
   if (slices > BG_SLICES) slices = BG_SLICES;
+  if (sfod_deterministic()) slices = 1;      // one workgroup per 64 columns walks every row: a single add per address
   const int rps = (M + slices - 1) / slices;
   dim3 grid(cdiv(N, 64), cdiv(M, rps));
   if (dt == SFOD_F32)

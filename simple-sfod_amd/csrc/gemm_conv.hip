@@ -722,7 +722,15 @@ struct WgradArgs {
   int Ntot;      // taps * Cin (row stride of dw)
   int pix_per_split;
   int tiles_n, tiles_m;
+  // deterministic mode (sfod_set_deterministic): > 0 = every pixel split STORES its partial tile into its own slab
+  // dw + split * slab_stride (workspace), summed afterwards in split order by k_wgrad_slab_sum; 0 = float atomics into dw
+  int64_t slab_stride;
 };
+// one element of a pixel split's partial weight-gradient tile
+__device__ __forceinline__ void wg_emit(float* dw, const WgradArgs& a, int split, int co, int n, float v) {
+  if (a.slab_stride > 0) dw[(int64_t)split * a.slab_stride + (int64_t)co * a.Ntot + n] = v;
+  else atomicAdd(dw + (int64_t)co * a.Ntot + n, v);
+}
 
 // SPLIT (SFOD_BF16X3 operands; T = bf16, WgradArgs in LOGICAL channels): the workgroup tile is 64 output channels x 64
 // flattened (tap, ci) columns.  The DMA de-interleaves the (8 hi | 8 lo) groups -- a 256-byte LDS row is the 64 hi values
@@ -954,7 +962,7 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
       const int ln = e & 63, r = (e >> 6) & 15, t = e >> 10;
       const int co = co0 + (t >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5);
       const int n = n0 + (t & 1) * 32 + (ln & 31);
-      if (co < a.Cout && n < a.Ntot) atomicAdd(dw + (int64_t)co * a.Ntot + n, v);
+      if (co < a.Cout && n < a.Ntot) wg_emit(dw, a, split, co, n, v);
     }
     return;
   }
@@ -966,7 +974,7 @@ k_conv_wgrad(const T* __restrict__ x, const T* __restrict__ dy, float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wr * 32 * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < a.Cout && n < a.Ntot) atomicAdd(dw + (int64_t)co * a.Ntot + n, acc[i][j][r]);
+        if (co < a.Cout && n < a.Ntot) wg_emit(dw, a, split, co, n, acc[i][j][r]);
       }
     }
 }
@@ -1140,7 +1148,7 @@ k_conv_wgrad_x3w(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, fl
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < a.Cout && n < a.Ntot) atomicAdd(dw + (int64_t)co * a.Ntot + n, acc[i][j][r]);
+        if (co < a.Cout && n < a.Ntot) wg_emit(dw, a, split, co, n, acc[i][j][r]);
       }
     }
 }
@@ -1191,12 +1199,106 @@ static int w3_launch_chunked(const void* x, const void* dy, float* dw, void* ws,
   return 0;
 }
 
+// ---- deterministic mode (SFOD.DETERMINISTIC / SFOD_DETERMINISTIC=1): no float atomics in any weight / bias gradient -----
+// The halo-patch 3x3 weight gradient always sums its pixel splits through slabs in a fixed order; the generic kernels (1x1,
+// linear, first layer, fp32) combine theirs with float atomics, whose arrival order differs from run to run.  In this mode
+// they store each split's partial tile into a slab of the workspace instead and k_wgrad_slab_sum adds the slabs in split
+// order: run-to-run bit-identical gradients (tests/test_gpu_trajectory.py), for one more pass over splits x |dw| floats.
+static std::atomic<int> g_deterministic{-1};
+extern "C" int sfod_set_deterministic(int on) {
+  g_deterministic.store(on ? 1 : 0, std::memory_order_relaxed);
+  return 0;
+}
+bool sfod_deterministic() {
+  int v = g_deterministic.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* ev = getenv("SFOD_DETERMINISTIC");
+    int want = (ev && atoi(ev) != 0) ? 1 : 0, expect = -1;
+    g_deterministic.compare_exchange_strong(expect, want, std::memory_order_relaxed);
+    v = g_deterministic.load(std::memory_order_relaxed);
+  }
+  return v != 0;
+}
+extern "C" int sfod_get_deterministic(void) { return sfod_deterministic() ? 1 : 0; }
+
+__global__ void __launch_bounds__(256) k_wgrad_slab_sum(const float* __restrict__ ws, float* __restrict__ dw, int64_t n,
+                                                       int nslab, int64_t stride) {
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 4 <= n && (stride & 3) == 0) {
+      float4 acc = *reinterpret_cast<const float4*>(dw + i);
+      for (int sl = 0; sl < nslab; ++sl) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + sl * stride + i);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(dw + i) = acc;
+    } else {
+      for (int64_t e = i; e < n && e < i + 4; ++e) {
+        float acc = dw[e];
+        for (int sl = 0; sl < nslab; ++sl) acc += ws[sl * stride + e];
+        dw[e] = acc;
+      }
+    }
+  }
+}
+
+// pixel splits + tile counts of the generic weight-gradient launch (the one rule for the launch and the workspace query)
+struct GenWgradPlan { int wide, tiles_n, tiles_m, splits, pps; };
+static GenWgradPlan gen_wgrad_plan(int M, int Cout, int Ntot, int dt) {
+  GenWgradPlan g;
+  const int split = (dt == SFOD_BF16X3);
+  // wide tiles pay off when the OUTPUT is big (fc1: 1024 x 25088 -> 784 tiles; 1.29 -> 1.02 ms); a small output with a
+  // long pixel axis (1x1 bottleneck convolutions, fc2) needs many pixel splits either way and the 64 x 64 kernel's
+  // shorter prologue wins there (profiles/r2d_bench_wgrad.txt).  algo 3: A/B hook, always the 64 x 64 kernel
+  g.wide = split && Cout >= 128 && Ntot >= 256 && g_conv_algo != 3 &&
+           (g_conv_algo == 4 || (int64_t)((Ntot + 255) / 256) * ((Cout + 127) / 128) >= 256);
+  if (g.wide) {
+    // wide layers: 128 x 256 tiles, one 8-wave workgroup per CU.  Pixel splits: the fewest that fill >= 85 % of the
+    // last round of 256 workgroups (more splits = more float-atomic traffic), each at least 8 stages long
+    constexpr int BKP = 32;
+    g.tiles_n = (Ntot + 255) / 256; g.tiles_m = (Cout + 127) / 128;
+    const int tiles = g.tiles_n * g.tiles_m;
+    const int max_splits = std::max(1, M / (8 * BKP));
+    int best = 1;
+    double best_eff = 0.0;
+    for (int sp = 1; sp <= std::min(max_splits, 512); ++sp) {
+      const int64_t wgs = (int64_t)tiles * sp;
+      const double eff = (double)wgs / (double)((wgs + 255) / 256 * 256);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+      if (eff >= 0.85 && wgs >= 512) { best = sp; break; }
+      if (wgs >= 4096) break;
+    }
+    int pps = (M + best - 1) / best;
+    pps = (pps + BKP - 1) / BKP * BKP;
+    g.pps = pps;
+    g.splits = (M + pps - 1) / pps;
+    return g;
+  }
+  const int BKP = (dt == SFOD_F32) ? 32 : 64;
+  const int TILE = split ? 64 : 128;        // bf16x3: 64 logical channels x 64 logical columns per workgroup
+  g.tiles_n = (Ntot + TILE - 1) / TILE; g.tiles_m = (Cout + TILE - 1) / TILE;
+  // split the pixel axis so that the grid has ~4 workgroups per CU
+  int splits = (1024 + g.tiles_n * g.tiles_m - 1) / (g.tiles_n * g.tiles_m);
+  const int max_splits = (M + BKP - 1) / BKP;
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int pps = (M + splits - 1) / splits;
+  pps = (pps + BKP - 1) / BKP * BKP;
+  g.pps = pps;
+  g.splits = (M + pps - 1) / pps;
+  return g;
+}
+
 extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
-  if (dt == SFOD_F32) return 0;
-  int nb;
-  const W3Plan p = w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
-  if (nb > 0) return p.ws_bytes;      // the first sub-batch is the largest
-  return 0;      // the generic kernel accumulates with float atomics straight into dw
+  int nb = 0;
+  if (dt != SFOD_F32) {
+    const W3Plan p = w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
+    if (nb > 0) return p.ws_bytes;      // the first sub-batch is the largest
+  }
+  // the generic kernel accumulates with float atomics straight into dw -- unless the deterministic mode wants slabs
+  if (!sfod_deterministic() || (int64_t)B * H * W == 0) return 0;
+  const int Ntot = ksize * ksize * Cin;
+  const GenWgradPlan g = gen_wgrad_plan(B * H * W, Cout, Ntot, dt);
+  return g.splits > 1 ? (int64_t)g.splits * Cout * Ntot * 4 : 0;
 }
 
 extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
@@ -1243,62 +1345,48 @@ extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, 
   a.nchunks = ksize * ksize * cpt;
   a.Ntot = ksize * ksize * Cin;
   if (a.M == 0) return 0;
-  // wide tiles pay off when the OUTPUT is big (fc1: 1024 x 25088 -> 784 tiles; 1.29 -> 1.02 ms); a small output with a
-  // long pixel axis (1x1 bottleneck convolutions, fc2) needs many pixel splits either way and the 64 x 64 kernel's
-  // shorter prologue wins there (profiles/r2d_bench_wgrad.txt).  algo 3: A/B hook, always the 64 x 64 kernel
-  const bool wide = split && Cout >= 128 && a.Ntot >= 256 && g_conv_algo != 3 &&
-                    (g_conv_algo == 4 || (int64_t)((a.Ntot + 255) / 256) * ((Cout + 127) / 128) >= 256);
-  if (wide) {
-    // wide layers: 128 x 256 tiles, one 8-wave workgroup per CU.  Pixel splits: the fewest that fill >= 85 % of the
-    // last round of 256 workgroups (more splits = more float-atomic traffic), each at least 8 stages long
-    constexpr int BKP = 32, LDS = 3 * 32 * (128 + 256) * 4;
-    const int tiles_n = (a.Ntot + 255) / 256, tiles_m = (Cout + 127) / 128, tiles = tiles_n * tiles_m;
-    const int max_splits = std::max(1, a.M / (8 * BKP));
-    int best = 1;
-    double best_eff = 0.0;
-    for (int sp = 1; sp <= std::min(max_splits, 512); ++sp) {
-      const int64_t wgs = (int64_t)tiles * sp;
-      const double eff = (double)wgs / (double)((wgs + 255) / 256 * 256);
-      if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
-      if (eff >= 0.85 && wgs >= 512) { best = sp; break; }
-      if (wgs >= 4096) break;
+  const GenWgradPlan g = gen_wgrad_plan(a.M, Cout, a.Ntot, dt);
+  a.pix_per_split = g.pps;
+  a.tiles_n = g.tiles_n;
+  a.tiles_m = g.tiles_m;
+  // deterministic mode: every split but a lone one stores into its slab; the slabs are summed into dw in split order
+  a.slab_stride = 0;
+  const bool slabs = sfod_deterministic() && g.splits > 1;
+  if (slabs) {
+    const int64_t need = (int64_t)g.splits * Cout * a.Ntot * 4;
+    if (ws == nullptr || ws_bytes < need) {
+      sfod_set_error("wgrad: deterministic mode needs the workspace of sfod_conv_wgrad_ws_bytes");
+      return SFOD_EBADARG;
     }
-    int pps = (a.M + best - 1) / best;
-    pps = (pps + BKP - 1) / BKP * BKP;
-    const int splits = (a.M + pps - 1) / pps;
-    a.pix_per_split = pps;
-    a.tiles_n = tiles_n;
-    a.tiles_m = tiles_m;
+    a.slab_stride = (int64_t)Cout * a.Ntot;
+    dw_out = (float*)ws;
+  }
+  const int tiles = g.tiles_n * g.tiles_m;
+  if (g.wide) {
+    constexpr int LDS = 3 * 32 * (128 + 256) * 4;
     static const hipError_t attr_rc = hipFuncSetAttribute(reinterpret_cast<const void*>(k_conv_wgrad_x3w),
                                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
     SFOD_REQUIRE(attr_rc == hipSuccess, "wgrad: cannot raise the dynamic LDS limit");
-    hipLaunchKernelGGL(k_conv_wgrad_x3w, dim3(tiles * splits), dim3(512), LDS, s, (const bf16_t*)x, (const bf16_t*)dy,
+    hipLaunchKernelGGL(k_conv_wgrad_x3w, dim3(tiles * g.splits), dim3(512), LDS, s, (const bf16_t*)x, (const bf16_t*)dy,
                        dw_out, a);
-    return sfod_check_launch("conv_wgrad_x3w");
+  } else {
+    dim3 grid(tiles * g.splits);
+    if (dt == SFOD_F32)
+      hipLaunchKernelGGL((k_conv_wgrad<float, 2, 2>), grid, dim3(256), 2 * 2 * 32 * 512, s, (const float*)x,
+                         (const float*)dy, dw_out, a);
+    else if (split)
+      hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2, true>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
+                         (const bf16_t*)dy, dw_out, a);
+    else
+      hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
+                         (const bf16_t*)dy, dw_out, a);
   }
-  const int BKP = (dt == SFOD_F32) ? 32 : 64;
-  const int TILE = split ? 64 : 128;        // bf16x3: 64 logical channels x 64 logical columns per workgroup
-  const int tiles_n = (a.Ntot + TILE - 1) / TILE, tiles_m = (Cout + TILE - 1) / TILE;
-  // split the pixel axis so that the grid has ~4 workgroups per CU
-  int splits = (1024 + tiles_n * tiles_m - 1) / (tiles_n * tiles_m);
-  const int max_splits = (a.M + BKP - 1) / BKP;
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int pps = (a.M + splits - 1) / splits;
-  pps = (pps + BKP - 1) / BKP * BKP;
-  splits = (a.M + pps - 1) / pps;
-  a.pix_per_split = pps;
-  a.tiles_n = tiles_n;
-  a.tiles_m = tiles_m;
-  dim3 grid(tiles_n * tiles_m * splits);
-  if (dt == SFOD_F32)
-    hipLaunchKernelGGL((k_conv_wgrad<float, 2, 2>), grid, dim3(256), 2 * 2 * 32 * 512, s, (const float*)x,
-                       (const float*)dy, dw_out, a);
-  else if (split)
-    hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2, true>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
-                       (const bf16_t*)dy, dw_out, a);
-  else
-    hipLaunchKernelGGL((k_conv_wgrad<bf16_t, 2, 2>), grid, dim3(256), 2 * 2 * 64 * 256, s, (const bf16_t*)x,
-                       (const bf16_t*)dy, dw_out, a);
-  return sfod_check_launch("conv_wgrad");
+  int rc = sfod_check_launch(g.wide ? "conv_wgrad_x3w" : "conv_wgrad");
+  if (rc == 0 && slabs) {
+    const int64_t n = (int64_t)Cout * a.Ntot;
+    hipLaunchKernelGGL(k_wgrad_slab_sum, dim3(cdiv(n, 1024) > 4096 ? 4096 : cdiv(n, 1024)), dim3(256), 0, s,
+                       (const float*)ws, dw, n, g.splits, a.slab_stride);
+    rc = sfod_check_launch("wgrad_slab_sum");
+  }
+  return rc;
 }

@@ -5,8 +5,8 @@ Cityscapes-to-COCO converter writes the json files) and reads 
 ``load_coco_json`` / ``utils.read_image(file_name, format="BGR")``.  This module is the same thing without
 Detectron2 / pycocotools: ``register_coco_instances(name, json_file, image_root)``, ``load_coco_json`` with d2's
 conventions (category ids sorted and mapped to contiguous 0..K-1, ``bbox`` kept XYWH_ABS in the records,
-``iscrowd`` carried, images without annotations kept), and ``CocoTargetDataset``: frames decoded once with Pillow,
-kept resident on the device as uint8 CHW BGR tensors at their native size (288 GB of HBM hold the Cityscapes
+``iscrowd`` carried, images without annotations kept), and ``CocoTargetDataset``: frames decoded once with Pillow
+(by a pool of ``DATALOADER.NUM_WORKERS`` threads working ahead of the ordered consumer), kept resident on the device as uint8 CHW BGR tensors at their native size (288 GB of HBM hold the Cityscapes
 training set ~15 times), resized / flipped / augmented per iteration by the same device mapper as the
 synthetic set.  Frames of different sizes are handled per item; the loaders group batches by aspect ratio like
 ``AspectRatioGroupedSemiSupDatasetTwoCropSourceFree`` (``daod/data/common.py:199-228``).
@@ -127,8 +127,40 @@ class CocoTargetDataset:
             assert self.class_names in (None, cls), "datasets of one loader must share their categories"
             self.class_names = cls
             self._dicts += dicts
-        for rec in self._dicts:
+        # Decode off the constructing thread: the reference decodes in DATALOADER.NUM_WORKERS loader processes
+        # (daod/data/build.py:289-367 -> torch DataLoader; two_crop_augmentation_mapper.py:73-157 reads the file there).  Here
+        # a frame is decoded ONCE and stays resident, so the pool works ahead of the (ordered) consumer below: Pillow
+        # releases the GIL inside its decoders, a few threads keep as many cores busy, at most 2 x workers decoded frames
+        # wait in host memory, and on a CUDA device each goes through a pinned staging buffer so that the upload is
+        # asynchronous to the next decode.  NUM_WORKERS 0: decode inline (the order and every value are the same).
+        workers = int(cfg.DATALOADER.NUM_WORKERS) if "DATALOADER" in cfg else 0
+        on_cuda = torch.device(device).type == "cuda"
+
+        def decode(rec):
             img = torch.from_numpy(read_image_bgr(rec["file_name"])).permute(2, 0, 1).contiguous()
+            return img.pin_memory() if on_cuda else img
+
+        def decoded_in_order():
+            if workers <= 0 or len(self._dicts) < 2:
+                for rec in self._dicts:
+                    yield rec, decode(rec)
+                return
+            from collections import deque
+            from concurrent.futures import ThreadPoolExecutor
+            with ThreadPoolExecutor(max_workers=workers, thread_name_prefix="sfod-decode") as pool:
+                pending, it = deque(), iter(self._dicts)
+                for rec in it:
+                    pending.append((rec, pool.submit(decode, rec)))
+                    if len(pending) >= 2 * workers:
+                        break
+                while pending:
+                    rec, fut = pending.popleft()
+                    nxt = next(it, None)
+                    if nxt is not None:
+                        pending.append((nxt, pool.submit(decode, nxt)))
+                    yield rec, fut.result()
+
+        for rec, img in decoded_in_order():
             h, w = int(img.shape[1]), int(img.shape[2])
             newh, neww = resize_shortest_edge_shape(h, w, short, max_size)
             if (newh, neww) != (h, w) and not self.device_resize:
@@ -141,9 +173,11 @@ class CocoTargetDataset:
             boxes[:, 1::2].clamp_(0, newh)
             classes = torch.tensor([a["category_id"] for a in keep], dtype=torch.int64)
             nonempty = ((boxes[:, 2] - boxes[:, 0]) > 1e-5) & ((boxes[:, 3] - boxes[:, 1]) > 1e-5)   # filter_empty_instances
-            self.items.append({"image": img.to(device), "boxes": boxes[nonempty].to(device),
+            self.items.append({"image": img.to(device, non_blocking=on_cuda), "boxes": boxes[nonempty].to(device),
                                "classes": classes[nonempty].to(device), "height": h, "width": w,
                                "image_id": rec["image_id"], "file_name": rec["file_name"], "size": (newh, neww)})
+        if on_cuda:
+            torch.cuda.synchronize(device)          # the pinned staging buffers may go once every upload has finished
         self.size = self.items[0]["size"] if self.items else (0, 0)
 
     def __len__(self):

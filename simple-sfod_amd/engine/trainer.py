@@ -124,10 +124,11 @@ class GradientReducer:
     """Sum all-reduce of the flat gradient buffer in phases so that communication overlaps the backbone
     backward.  ``launch_early()`` (called when the backbone's backward starts, i.e. when every gradient of the
     heads is final) starts an asynchronous all-reduce of the contiguous heads slice on the collective's own
-    stream; ``launch_mid()`` (called by the VGG backward once the gradients of stages vgg2..vgg4 are written:
-    96 % of the trunk's parameters, with the two most expensive stages of the backward still to run) does the
-    same for that slice; ``finish()`` waits for both and reduces what is left (vgg0/vgg1 + the norm parameters,
-    < 1 MB).  xGMI is point-to-point, so few large messages (not 25 MB DDP buckets) keep every link busy."""
+    stream; ``launch_mid()`` (called by the backbone's backward once the slice it named in ``reduce_schedule`` is
+    written -- VGG16: stages vgg2..vgg4 = 96 % of the trunk's parameters, with the two most expensive stages of the
+    backward still to run; ResNet-C4: res4 = 95 % of the live trunk, res3 still to run) does the same for that slice;
+    ``finish()`` waits for both and reduces what is left (VGG: vgg0/vgg1, < 1 MB; R101: res3, 4.9 MB).  xGMI is
+    point-to-point, so few large messages (not 25 MB DDP buckets) keep every link busy."""
 
     def __init__(self, flat, prefixes=("proposal_generator.", "roi_heads."),
                  mid_prefixes=("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4.")):
@@ -166,7 +167,10 @@ class GradientReducer:
             self.work_mid = dist.all_reduce(self.flat.grad[self.mlo:self.mhi], async_op=True)
 
     def finish(self):
-        g = self.flat.grad
+        # parameters that are not optimised (frozen stages, a disabled domain classifier) sit behind ``n_norm_end`` in the
+        # flat buffer with zero gradients on every rank: nothing to exchange there
+        end = int(getattr(self.flat, "n_norm_end", self.flat.grad.numel()))
+        g = self.flat.grad[:end] if 0 < end < self.flat.grad.numel() else self.flat.grad
         if "final" not in self.phases:       # timing variant: only what was launched asynchronously
             for w in (self.work, self.work_mid):
                 if w is not None:
@@ -189,12 +193,19 @@ class GradientReducer:
         self.work = self.work_mid = None
 
 
+def _apply_process_knobs(cfg):
+    """Config keys that are process-wide library settings: applied when a trainer is constructed."""
+    if "DETERMINISTIC" in cfg.SFOD and torch.device(cfg.MODEL.DEVICE).type == "cuda":
+        native.set_deterministic(bool(cfg.SFOD.DETERMINISTIC))
+
+
 class BaseTrainer:
     """Source-only training (``TRAINER: "base"``)."""
 
     def __init__(self, cfg, data_loader=None):
         self.cfg = cfg
         self.device = torch.device(cfg.MODEL.DEVICE)
+        _apply_process_knobs(cfg)
         self.model = self.build_model(cfg)
         self.optimizer = self.build_optimizer(cfg, self.model)
         if cfg.MODEL.WEIGHTS:     # DetectionCheckpointer(model).resume_or_load(MODEL.WEIGHTS, resume=False), train_net_mt.py:75
@@ -231,18 +242,16 @@ class BaseTrainer:
                    (cfg.DOMAIN_CLASSIFIER.IMAGE or cfg.DOMAIN_CLASSIFIER.INSTANCE or not cfg.SFOD.ELIDE_DEAD_BRANCHES))
         self._reducer = None
         if get_world_size() > 1 and not dc_live:
-            # where the mid phase starts: with enough pixels per rank the backward of vgg0 alone (its two most expensive
-            # layers) hides the 57 MB message, so vgg1's weights ride in it too and the final phase shrinks to
-            # vgg0 + the norm parameters; the yaml's one 600x1200 frame per rank keeps the earlier launch point
+            # the mid phase: the backbone says which slice of its gradients is final while its backward still runs and calls
+            # ``_mid_backward`` there (VGG: the deep stages once vgg<s> is done; ResNet-C4: res4 once its first block is done)
             total = cfg.SOLVER.IMS_PER_BATCH if type(self) is BaseTrainer else cfg.SOLVER.IMS_PER_BATCH_TARGET
             b_local = max(1, int(total) // get_world_size())
             short = min(cfg.INPUT.MIN_SIZE_TRAIN) if len(cfg.INPUT.MIN_SIZE_TRAIN) else 600
-            stage = 1 if b_local * short * short * 2 >= 2 * 600 * 1200 else 2
-            mids = tuple("backbone.vgg{}.".format(i) for i in range(stage, 5))
+            bb = self.model.backbone
+            mids = tuple(bb.reduce_schedule(b_local * short * short * 2)) if hasattr(bb, "reduce_schedule") else ()
             self._reducer = GradientReducer(self.optimizer.flat, mid_prefixes=mids)
-            self.model.backbone._pre_backward = self._reducer.launch_early
-            self.model.backbone._mid_backward = self._reducer.launch_mid      # VGG: after stage vgg<stage>'s gradients
-            self.model.backbone._mid_stage = stage
+            bb._pre_backward = self._reducer.launch_early
+            bb._mid_backward = self._reducer.launch_mid if mids else None
 
     @classmethod
     def build_model(cls, cfg):
@@ -499,6 +508,7 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
     def __init__(self, cfg, data_loader=None):
         self.cfg = cfg
         self.device = torch.device(cfg.MODEL.DEVICE)
+        _apply_process_knobs(cfg)
         self.data_loader = data_loader or self.build_train_loader(cfg)
         self._data_loader_iter = iter(self.data_loader)
         # student, then teacher: both start from the same weights (:51-64).  With no checkpoint

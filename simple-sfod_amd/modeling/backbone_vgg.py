@@ -171,6 +171,16 @@ class vgg_backbone(nn.Module):
         return {n: o for n, o in zip(self._stage_names, outs) if o is not None}
 
     # ---- engine -------------------------------------------------------------------------------------
+    def reduce_schedule(self, pixels_per_rank):
+        """Which part of this backbone's gradients may be all-reduced while its backward is still running
+        (engine/trainer.py::GradientReducer): -> parameter-name prefixes of the slice that is final once stage
+        ``vgg<s>``'s gradients are written; ``_backward_impl`` calls ``_mid_backward`` right there.  With enough pixels per
+        rank the backward of vgg0 alone (its two most expensive layers) hides the 57 MB message, so vgg1's weights ride in it
+        too and the blocking rest shrinks to vgg0 + nothing else; one 600x1200 frame per rank keeps the earlier point."""
+        stage = 1 if pixels_per_rank >= 2 * 600 * 1200 else 2
+        self._mid_stage = stage
+        return tuple("backbone.vgg{}.".format(i) for i in range(stage, 5))
+
     def _first_layer_of_stage(self, stage):
         """index into ``_plan`` of the first conv of ``vgg<stage>``"""
         s, first = 0, 0

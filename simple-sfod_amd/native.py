@@ -283,6 +283,14 @@ def set_conv3x3_variant(variant):
     load().sfod_set_conv3x3_variant(int(variant))
 
 
+def set_deterministic(on):
+    """No float atomics in weight / bias gradients (include/sfod_hip.h: sfod_set_deterministic); -> previous setting."""
+    lib = load()
+    prev = bool(lib.sfod_get_deterministic())
+    lib.sfod_set_deterministic(int(bool(on)))
+    return prev
+
+
 def set_conv3x3_m16(on):
     """Automatic shape choice: run the 256 x 128 shape on 16x16x32 MFMAs (default on; include/sfod_hip.h)."""
     load().sfod_set_conv3x3_m16(int(bool(on)))
@@ -488,7 +496,7 @@ _f16_words = {}
 
 
 def check_f16x3_range(device):
-    """Raise if any producer of half pairs on ``device`` had to clamp a finite value beyond +-65504 since the last call
+    """Raise if any producer of half pairs on ``device`` had to clamp a value beyond +-65504 (infinities included) since the last call
     (sfod_f16x3_poll).  One host synchronisation: call it where the step synchronises anyway (the metrics flush)."""
     w = _f16_words.get(device)
     if w is None:
@@ -497,7 +505,7 @@ def check_f16x3_range(device):
     if w.item() != 0:
         w.zero_()
         raise FloatingPointError(
-            "SFOD.COMPUTE_DTYPE f16x3: a finite activation or scaled weight beyond half's range (|v| > 65504) was clamped "
+            "SFOD.COMPUTE_DTYPE f16x3: an activation or scaled weight beyond half's range (|v| > 65504) was clamped "
             "since the last check -- the model leaves the exponent window this mode assumes; use \"fp32\" (or \"bf16x3\").")
 
 

@@ -113,3 +113,27 @@ def test_reference_dataset_names_resolve_under_the_datasets_root(sfod, tmp_path,
     D.register_all_datasets(cfg)
     ds = D.TwoCropLoader(cfg, torch.device("cpu")).dataset
     assert isinstance(ds, D.CocoTargetDataset) and len(ds) == 2
+
+
+def test_decode_pool_keeps_order_and_values(sfod, tmp_path):
+    """The frames are decoded by DATALOADER.NUM_WORKERS threads working ahead of an ordered consumer (the reference: loader
+    worker processes, daod/data/build.py:289-367): whatever the worker count, the items come out in the json's image-id
+    order with identical tensors, boxes, classes and dict keys."""
+    D = sfod.data
+    sizes = [(40 + 3 * i, 80 - 2 * i) for i in range(13)]
+    jf, _ = _make_dataset(tmp_path, sizes)
+    D.register_coco_instances("tiny_pool", jf, str(tmp_path))
+    got = {}
+    for workers in (0, 1, 4):
+        cfg = sfod.config.setup_cfg(HOT, ["MODEL.DEVICE", "cpu", "DATASETS.TRAIN_TARGET", "('tiny_pool',)",
+                                          "INPUT.MIN_SIZE_TRAIN", "(32,)", "INPUT.MAX_SIZE_TRAIN", "64",
+                                          "DATALOADER.NUM_WORKERS", str(workers), "MODEL.ROI_HEADS.NUM_CLASSES", "3"])
+        got[workers] = D.CocoTargetDataset(cfg, torch.device("cpu"), ["tiny_pool"], train=True)
+    ref = got[0]
+    assert [it["image_id"] for it in ref.items] == [100 + i for i in range(13)]
+    for workers in (1, 4):
+        ds = got[workers]
+        assert len(ds) == len(ref)
+        for a, b in zip(ref.items, ds.items):
+            assert a.keys() == b.keys() and a["image_id"] == b["image_id"] and a["size"] == b["size"]
+            assert torch.equal(a["image"], b["image"]) and torch.equal(a["boxes"], b["boxes"]) and torch.equal(a["classes"], b["classes"])

@@ -78,6 +78,7 @@ def _worker(rank, world, port, q):
     bflat = sfod.engine.FlatModelState(big, frozen_prefixes=("DC_img.", "DC_ins."))
     g = torch.Generator().manual_seed(100 + rank)
     bflat.grad.copy_(torch.randn(bflat.grad.numel(), generator=g))
+    bflat.grad[bflat.n_norm_end:].zero_()     # not optimised (here: the domain classifier): no gradient is ever written, none exchanged
     mine_g = bflat.grad.clone()
     parts = [torch.zeros_like(mine_g) for _ in range(world)]
     dist.all_gather(parts, mine_g)
@@ -90,6 +91,32 @@ def _worker(rank, world, port, q):
                                                                       _reducer=redm))
     ok_sum = ok_sum and ok_model and torch.equal(bflat.grad, sum(parts))
     del big, bflat, parts
+    # BASELINE config #5 (an 8-GPU config): the ResNet-101-C4 layout.  The backbone names res4 for the mid phase; heads,
+    # res4 and the rest are disjoint, every element is reduced exactly once, and the blocking rest is res3 (< 10 MB)
+    cfg_r = sfod.config.setup_cfg(os.path.join(ROOT, "configs", "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml"), [])
+    torch.manual_seed(1)
+    r101 = sfod.registry.META_ARCH_REGISTRY.get(cfg_r.MODEL.META_ARCHITECTURE)(cfg_r)
+    rflat = sfod.engine.FlatModelState(r101, frozen_prefixes=("DC_img.", "DC_ins."))
+    g = torch.Generator().manual_seed(200 + rank)
+    rflat.grad.copy_(torch.randn(rflat.grad.numel(), generator=g))
+    rparts = [torch.zeros_like(rflat.grad) for _ in range(world)]
+    dist.all_gather(rparts, rflat.grad.clone())
+    mids = r101.backbone.reduce_schedule(2 * 600 * 1200)
+    redr = sfod.engine.trainer.GradientReducer(rflat, mid_prefixes=mids)
+    live = sum(p_.numel() for p_ in r101.backbone.parameters() if p_.requires_grad)
+    # (buffer order: weights, norm parameters, then everything that is not optimised -- the disabled domain classifier here)
+    rest = rflat.n_norm_end - (redr.hi - redr.lo) - (redr.mhi - redr.mlo)
+    ok_r101 = (tuple(mids) == ("backbone.res4.",) and (redr.mhi - redr.mlo) > 0.94 * live and redr.mhi <= redr.lo
+               and (redr.hi - redr.lo) > 100_000_000 and 0 < 4 * rest < 10_000_000 and rflat.n_norm_end < rflat.grad.numel())
+    rflat.grad[rflat.n_norm_end:].zero_()            # no gradient is ever written there
+    for t in rparts:
+        t[rflat.n_norm_end:].zero_()
+    redr.launch_early()
+    redr.launch_mid()
+    sfod.engine.trainer.BaseTrainer._reduce_gradients(SimpleNamespace(optimizer=SimpleNamespace(flat=rflat, grad_scale=1.0),
+                                                                      _reducer=redr))
+    ok_sum = ok_sum and ok_r101 and torch.equal(rflat.grad, sum(rparts))
+    del r101, rflat, rparts
     # logged metrics: mean over ranks of the period's device scalars with one small all-reduce, data_time = max over
     # ranks (reference base.py:198-209: comm.gather + np.mean / np.max)
     st = sfod.engine.trainer.EventStorage(0)

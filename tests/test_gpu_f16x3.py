@@ -34,10 +34,10 @@ def rel_err(a, b):
 
 def splith_ref(x):
     """fp32 [..., C] -> fp16 [..., 2C] in the documented layout (per 8 channels: 8 hi then 8 lo), saturating."""
-    hi = x.clamp(-65504.0, 65504.0).half()
-    hi = torch.where(torch.isnan(x), x.half(), hi)
-    r = x - hi.float()
-    lo = torch.where(torch.isnan(r), r.half(), r.clamp(-65504.0, 65504.0).half())
+    c = x.clamp(-65504.0, 65504.0)             # saturation: exactly +-65504 (lo = 0) beyond half's range, infinities included
+    hi = torch.where(torch.isnan(x), x.half(), c.half())
+    r = c - hi.float()
+    lo = r.half()                              # NaN stays NaN
     s = x.shape
     hi = hi.reshape(*s[:-1], s[-1] // 8, 1, 8)
     lo = lo.reshape(*s[:-1], s[-1] // 8, 1, 8)
@@ -71,7 +71,7 @@ def test_cast_layout_range_and_round_trip(native):
     assert ((back - x).abs()[inr] <= torch.maximum(x.abs()[inr] * 2.0 ** -22, torch.tensor(2.0 ** -25))).all()
     expect = ref.float().reshape(37, 5, 8, 2, 8).sum(-2).reshape(37, 5, 64)
     assert torch.equal(back[ok], expect[ok])
-    assert back[0, 0, 4] == -131008.0 and back[0, 1, 1] == 70000.0      # beyond half's range: hi and lo both saturate / carry
+    assert back[0, 0, 4] == -65504.0 and back[0, 1, 1] == 65504.0 and back[0, 1, 2] == -65504.0    # beyond half's range: saturated
     assert torch.isnan(back[0, 1, 0])
     assert torch.equal(native.cast(native.cast(back.to(DEV), native.SPLITH_DTYPE), torch.float32).cpu()[ok], back[ok])
     # pairs -> pairs: the bf16 split of hi + lo, as if converted through fp32
@@ -371,8 +371,8 @@ def test_conv_first_layer_kernel(native, hw):
 
 
 def test_values_beyond_half_range_are_reported(native):
-    """A finite value that had to be clamped at +-65504 raises the library's flag; the trainer polls it at its metrics
-    period (native.check_f16x3_range) -- saturation is loud, not silent.  inf / NaN are the finite checks' business."""
+    """A value that had to be clamped at +-65504 (finite or infinite) raises the library's flag; the trainer polls it at its
+    metrics period (native.check_f16x3_range) -- saturation is loud, not silent.  NaN stays NaN (the finite checks' business)."""
     dev = torch.device(DEV)
     try:
         native.check_f16x3_range(dev)          # whatever earlier tests left behind
@@ -385,10 +385,13 @@ def test_values_beyond_half_range_are_reported(native):
     m, i = y.mean(dim=(0, 1, 2)), torch.rsqrt(y.var(dim=(0, 1, 2)) + 1e-5)
     native.bn_relu_pool_fwd(y, m, i, torch.ones(64, device=DEV), torch.zeros(64, device=DEV), False, out_dtype=native.SPLITH_DTYPE)
     native.check_f16x3_range(dev)              # in range: silent
-    x[3, 5] = float("inf")
     x[4, 5] = float("nan")
     to_pairs(native, x)
-    native.check_f16x3_range(dev)              # non-finite values are not range errors
+    native.check_f16x3_range(dev)              # NaN is not a range error (it stays NaN in the pairs)
+    x[3, 5] = float("inf")
+    to_pairs(native, x)
+    with pytest.raises(FloatingPointError):    # an infinity is clamped like any other value beyond the range: reported
+        native.check_f16x3_range(dev)
     x[3, 5], x[4, 5] = 70000.0, 0.0
     to_pairs(native, x)
     with pytest.raises(FloatingPointError):
@@ -397,7 +400,7 @@ def test_values_beyond_half_range_are_reported(native):
     feat = torch.full((1, 8, 8, 64), 1.0e5, device=DEV)        # the ROIAlign producer (its own translation unit)
     rois = torch.tensor([[0.0, 0.0, 0.0, 100.0, 100.0]], device=DEV)
     fp = native.cast(feat, native.SPLITH_DTYPE)
-    with pytest.raises(FloatingPointError):    # the conversion itself clamps 1e5's lo part? no: 65504 + 34496 -- but hi saturates
+    with pytest.raises(FloatingPointError):    # the conversion itself saturates 1e5
         native.check_f16x3_range(dev)
     native.roi_align_fwd(fp, rois, 7, 1.0 / 32)                 # pooled values 1e5 again: reported by THAT kernel's flag
     with pytest.raises(FloatingPointError):

@@ -25,6 +25,9 @@ def rel_err(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+R101_YAML = os.path.join(os.path.dirname(HOT_YAML), "r101_c4_cs_foggy_adaptive_teacher_source_free.yaml")
+
+
 def make_cfg(sfod, yaml=HOT_YAML, opts=()):
     return sfod.config.setup_cfg(yaml, ["OUTPUT_DIR", ""] + list(opts))
 
@@ -923,11 +926,14 @@ def test_config1_source_training_step_matches_oracle(sfod, native):
     tr.after_step()
 
 
-def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native):
+@pytest.mark.parametrize("model", ["vgg", "r101"])
+def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native, model):
     """The N>1 code path on the one GPU a test box has: a 1-rank RCCL group, the world-size query patched to
     2 so that the trainer attaches the GradientReducer -- the heads' slice is all-reduced asynchronously from
-    the backbone's backward hook, the rest afterwards, 1/world folded into SGD.  Checks stream ordering and
-    bookkeeping (a 1-rank all-reduce is the identity), not the wire."""
+    the backbone's backward hook, the slice the backbone names in ``reduce_schedule`` from inside its backward, the rest
+    afterwards, 1/world folded into SGD.  Checks stream ordering and bookkeeping (a 1-rank all-reduce is the identity), not
+    the wire.  ``r101``: BASELINE config #5's yaml (an 8-GPU config): res4 rides in the mid phase (weight gradients come from
+    the backward's side stream), the blocking final slice is res3 -- asserted below 10 MB."""
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", str(29600 + os.getpid() % 300))
@@ -939,10 +945,13 @@ def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native):
     orig = T.get_world_size
     try:
         T.get_world_size = lambda: 2
-        cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "bf16", "SOLVER.IMS_PER_BATCH_TARGET", "2",
-                                   "SFOD.SYNTHETIC.HEIGHT", "256", "SFOD.SYNTHETIC.WIDTH", "512",
-                                   "SFOD.SYNTHETIC.NUM_IMAGES", "4", "INPUT.MIN_SIZE_TRAIN", "(192,)",
-                                   "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0"])
+        resnet = model == "r101"
+        cfg = make_cfg(sfod, yaml=R101_YAML if resnet else HOT_YAML,
+                       opts=["SFOD.COMPUTE_DTYPE", "f16x3" if resnet else "bf16", "SOLVER.IMS_PER_BATCH_TARGET", "2",
+                             "SFOD.SYNTHETIC.HEIGHT", "256", "SFOD.SYNTHETIC.WIDTH", "512",
+                             "SFOD.SYNTHETIC.NUM_IMAGES", "4", "INPUT.MIN_SIZE_TRAIN", "(192,)",
+                             "SOLVER.MAX_ITER", "2", "SOLVER.CHECKPOINT_PERIOD", "0", "TEST.EVAL_PERIOD", "0",
+                             "SFOD.EVAL_HOOK", "False"])
         torch.manual_seed(0)
         loader = sfod.data.TwoCropLoader(cfg, torch.device("cuda"), 0, 1)
         tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg, data_loader=loader)
@@ -950,11 +959,21 @@ def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native):
         assert red is not None and 0 < red.lo < red.hi <= tr.optimizer.flat.grad.numel()
         names = [n for n, (o, k, _) in tr.optimizer.flat.offsets.items() if red.lo <= o < red.hi]
         assert names and all(n.startswith(("proposal_generator.", "roi_heads.")) for n in names)
-        # mid-backward phase: conv weights + biases of stages vgg2..vgg4, adjacent to (not overlapping) the heads
         mid = [n for n, (o, k, _) in tr.optimizer.flat.offsets.items() if red.mlo <= o < red.mhi]
-        assert mid and all(n.startswith(("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4.")) for n in mid)
-        assert "backbone.vgg2.0.weight" in mid and "backbone.vgg4.6.bias" in mid and red.mhi <= red.lo
-        assert (red.mhi - red.mlo) > 0.9 * sum(p_.numel() for n, p_ in tr.model.backbone.named_parameters() if p_.dim() == 4)
+        if resnet:
+            # mid-backward phase: the convolution weights of res4 (buffer order: weights, then norm parameters, then frozen)
+            assert mid and all(n.startswith("backbone.res4.") for n in mid) and red.mhi <= red.lo
+            assert "backbone.res4.0.shortcut.weight" in mid and "backbone.res4.22.conv3.weight" in mid
+            live = sum(p_.numel() for n, p_ in tr.model.backbone.named_parameters() if p_.requires_grad)
+            assert (red.mhi - red.mlo) > 0.94 * live
+        else:
+            # mid-backward phase: conv weights + biases of stages vgg2..vgg4, adjacent to (not overlapping) the heads
+            assert mid and all(n.startswith(("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4.")) for n in mid)
+            assert "backbone.vgg2.0.weight" in mid and "backbone.vgg4.6.bias" in mid and red.mhi <= red.lo
+            assert (red.mhi - red.mlo) > 0.9 * sum(p_.numel() for n, p_ in tr.model.backbone.named_parameters() if p_.dim() == 4)
+        # what is left for the blocking phase after the backward (frozen and domain-classifier slots carry zeros)
+        rest_elems = tr.optimizer.flat.n_norm_end - (red.hi - red.lo) - (red.mhi - red.mlo)
+        assert 0 < 4 * rest_elems < 10e6, f"blocking final slice {4e-6 * rest_elems:.1f} MB"
         # Ordering of the three phases: a phase may only be launched once every gradient of its slice is FINAL.  A copy
         # of the slice enqueued right behind each launch (same stream order the collective is ordered against) must
         # equal the slice of the finished backward -- a kernel that still wrote into it afterwards would show.  The
