@@ -313,6 +313,50 @@ def main():
         rl_segment = (f"{rl_steps} single-stream steps after the timed region ({1000.0 * rl_elapsed / rl_steps:.2f} ms/step): "
                       "the timed steps run the teacher on a second stream, where a kernel's event duration includes "
                       "time shared with concurrent kernels")
+    # ---- is the GPU waiting for the host?  Un-profiled, on single-stream steps: (a) how long the host needs to ENQUEUE a
+    # step (no synchronisation inside) against how long the GPU needs to run it, (b) HIP events around EVERY call into the
+    # library: the share of the step's wall time its own launches cover -- the rest is torch's small kernels
+    # (tools/profile_torch_ops.py lists them) plus idle gaps.  N = 1 only.
+    gpu_fill = None
+    if world == 1 and not args.no_kernel_timer:
+        n_id = max(1, min(5, args.steps))
+        trainer.overlap_teacher = False
+        bbs = [m.backbone for m in (trainer.model, getattr(trainer, "model_teacher", None)) if m is not None]
+        ws_saved = [getattr(b, "wgrad_stream", None) for b in bbs]
+        for b in bbs:
+            if hasattr(b, "wgrad_stream"):
+                b.wgrad_stream = False
+        run_steps(trainer, args.warmup + args.steps + 20, 1)
+        sync()
+        th0 = time.perf_counter()
+        run_steps(trainer, args.warmup + args.steps + 21, n_id)
+        host_ms = (time.perf_counter() - th0) * 1000.0 / n_id          # enqueue only: the queue is drained afterwards
+        sync()
+        allk = sfod.native.KernelTimer(watch=None)
+        sfod.native.set_timer(allk)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        sync()
+        e0.record()
+        run_steps(trainer, args.warmup + args.steps + 30, n_id)
+        e1.record()
+        sync()
+        sfod.native.set_timer(None)
+        span_ms = e0.elapsed_time(e1) / n_id
+        summ_all = allk.summary()
+        native_ms = sum(v["ms"] for v in summ_all.values()) / n_id
+        gpu_fill = {"steps": n_id, "gpu_ms_per_step_single_stream": round(span_ms, 3),
+                    "host_enqueue_ms_per_step": round(host_ms, 3),
+                    "native_kernel_ms_per_step": round(native_ms, 3),
+                    "native_launches_per_step": sum(v["launches"] for v in summ_all.values()) // n_id,
+                    "not_in_native_kernels_frac": round(max(0.0, 1.0 - native_ms / span_ms), 4),
+                    "note": "HIP events around every call into libsfod_hip.so on single-stream steps (with the events the "
+                            "step itself runs a few % slower); what the library's launches do not cover = torch's small "
+                            "kernels + idle gaps.  host_enqueue < gpu time: the host runs ahead, the GPU is never waiting "
+                            "for a launch"}
+        trainer.overlap_teacher = None
+        for b, w_ in zip(bbs, ws_saved):
+            if w_ is not None:
+                b.wgrad_stream = w_
     if world > 1:
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -377,7 +421,7 @@ def main():
                                           "trunk_slice_async": round(max(0.0, early_mid_ms - early_ms), 3),
                                           "final_slice_blocking": round(max(0.0, step_ms - early_mid_ms), 3),
                                           "slices_MB": [round(4e-6 * (red.hi - red.lo), 1), round(4e-6 * (red.mhi - red.mlo), 1),
-                                                        round(4e-6 * (flat.grad.numel() - (red.hi - red.lo) - (red.mhi - red.mlo)), 2)]}
+                                                        round(4e-6 * red.final_elements(), 2)]}
                                          if red is not None else None),
                 "overlap_fraction": round(min(1.0, max(0.0, 1.0 - max(0.0, step_ms - nocomm_ms) / max(ar_ms, 1e-9))), 3)}
 
@@ -443,7 +487,7 @@ def main():
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "dtype_note": {
             "bf16x3": ("split precision: operands as (hi, lo) bf16 pairs (~16 significand bits each), hi*hi + hi*lo + lo*hi on "
-                       "v_mfma_f32_32x32x16_bf16 with fp32 accumulation; fp32 activations / statistics / losses.  Gated at "
+                       "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 with fp32 accumulation; fp32 activations / statistics / losses.  Gated at "
                        "600x1200 by tests/test_gpu_fullsize.py: " +
                        ("losses and decoded boxes within 1e-4 of the CPU oracle, intermediates (RPN logits / deltas, box "
                         "scores / deltas) within 2e-4 (measured 6e-5 .. 1e-4), every discrete decision bit-exact"
@@ -474,6 +518,8 @@ def main():
         "step_tflops_per_gpu": round(sflops * value / world / 1e12, 2),
         "losses": {k: round(v, 5) for k, v in rec.items() if k.startswith("loss") or k.startswith("roi_head")},
     }
+    if gpu_fill is not None:
+        out["gpu_fill"] = gpu_fill
     if comm is not None:
         out["exchange"] = comm
     if secondary is not None:
@@ -497,7 +543,8 @@ def main():
         key = max(cands, key=lambda k_: summ[k_]["ms"]) if cands else "sfod_conv_fwd:gemm"
         k = summ.get(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
         ach = k["flops"] / (k["ms"] * 1e-3) / 1e12 if k["ms"] > 0 else 0.0
-        kname = ("k_conv3x3_patch (halo-patch MFMA conv3x3 fwd + dgrad)" if key.endswith("patch3x3")
+        kname = ("k_conv3x3_patch / k_conv3x3_m16 (halo-patch MFMA conv3x3 fwd + dgrad; operand pairs: the 256 x 128 shape on "
+                 "v_mfma_f32_16x16x32, the 64-channel shape on 32x32x16)" if key.endswith("patch3x3")
                  else "k_conv_fwd (MFMA implicit GEMM)")
         out["roofline"] = {
             "kernel": kname,
@@ -508,8 +555,10 @@ def main():
             "frac_of_bf16_peak_algorithmic": round(ach / PEAK["bf16"], 4),
             # HBM bytes per launch from the committed PMC passes of THIS mode's kernel (tools/pmc_hbm_run.sh); null otherwise
             # only when THIS run is the configuration the counters were captured on (else null)
-            "traffic": ((pmc_traffic(args.model, "k_conv3x3_patch<", {"bf16x3": ("float, true", "float, 1,"), "f16x3": ("float, 2,",),
-                                                                      "bf16": ("__bf16, false", "__bf16, 0,")}.get(args.dtype, "-"))
+            "traffic": ((pmc_traffic(args.model, ("k_conv3x3_patch<", "k_conv3x3_m16<"),
+                                     {"bf16x3": ("float, true", "float, 1,", "m16<8, 4, 1,", "m16<4, 8, 1,"),
+                                      "f16x3": ("float, 2,", "m16<8, 4, 2,", "m16<4, 8, 2,"),
+                                      "bf16": ("__bf16, false", "__bf16, 0,")}.get(args.dtype, "-"))
                          if key.endswith("patch3x3") else
                          pmc_traffic(args.model, "k_conv_fwd<", {"bf16x3": (", 1, 64>", ", 1, 128>"), "f16x3": (", 2, 64>", ", 2, 128>")}.get(args.dtype, "-")))
                         if pmc_matches(args) else None),

@@ -1219,7 +1219,7 @@ static bool p3_best_tile(int H, int W, int BM, int cap, int& TH, int& TW, int& t
   return best >= 0.0;
 }
 
-P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout) {
+P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout, int pairs) {
   P3Plan p;
   p.ok = 0;
   p.m16 = 0;

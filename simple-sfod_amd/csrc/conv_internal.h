@@ -13,9 +13,10 @@ struct P3Plan {
   int TH, TW;            // output pixels per tile (TH*TW <= 512 | 256, (TH+2)*(TW+2) <= 640 | 384)
   int tiles_y, tiles_x, tiles_n;
   int nblk;              // BatchNorm statistics blocks = B * tiles_y * tiles_x
-  int m16;               // G = 1, FM = 2 only: operand-pair launches with Cin % 64 == 0 run k_conv3x3_m16 (same tiles)
+  int m16;               // G = 1, FM = 2: operand-pair launches with Cin % 64 == 0 run k_conv3x3_m16 (1: 8 waves, 2: 4 waves; same tiles)
 };
-P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout);
+// pairs: the operands are (hi, lo) pairs (SFOD_BF16X3 / SFOD_F16X3; Cin in physical 16-bit channels)
+P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout, int pairs = 0);
 // BatchNorm-backward reduction folded into a data-gradient launch (fp32 output [B,H,W,Cout] dense): see P3Args
 struct P3BnRed {
   const float* y;        // saved pre-BatchNorm output of the layer whose output gradient is being produced

@@ -507,14 +507,14 @@ static bool use_wide_gemm(int M, int Cout, int ks);
 
 extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16)) return 3;
-  const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
+  const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout, sfod_is_pairs(dt)) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return 2;
   return (sfod_is_pairs(dt) && use_wide_gemm(B * H * W, Cout, ksize)) ? 4 : 1;     // (fp32 output assumed: bf16x3 has no other)
 }
 
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16)) return sfod_f1_nblk(B, H, W);
-  const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout) : P3Plan{};
+  const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout, sfod_is_pairs(dt)) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;
   return (B * H * W + 127) / 128;
 }
@@ -656,7 +656,7 @@ extern "C" int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_
   const int split = split_code(dt);
   Cin = phys_ch(dt, Cin);           // from here on: bf16 channels as stored
   if (ksize == 3 && is_bf16_storage(dt)) {
-    const P3Plan p = sfod_p3_plan(B, H, W, Cin, Cout);
+    const P3Plan p = sfod_p3_plan(B, H, W, Cin, Cout, split != 0);
     if (use_patch_kernel(p, B, H, W, ksize, dt))
       return sfod_p3_launch(p, x, w, bias, y, stats, B, H, W, Cin, Cout, ldy, act, out_dt == SFOD_F32, s, split, nullptr,
                             w_absmax);
@@ -689,7 +689,7 @@ extern "C" int sfod_conv_dgrad_bnred_blocks(int B, int H, int W, int Cin, int Co
   if (dt != SFOD_BF16X3 && dt != SFOD_BF16) return 0;
   if (dt == SFOD_BF16) return 0;        // bf16 mode writes bf16 gradients: no fp32 tile to reduce
   if (Cout % 4 != 0) return 0;
-  const P3Plan p = sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout);
+  const P3Plan p = sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout, sfod_is_pairs(dt));
   return use_patch_kernel(p, B, H, W, 3, dt) ? p.nblk : 0;
 }
 
@@ -700,7 +700,7 @@ extern "C" int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int
                "conv_dgrad_bnred: shape not served (sfod_conv_dgrad_bnred_blocks)");
   SFOD_REQUIRE(y && mean && invstd && gamma && beta && red_ws, "conv_dgrad_bnred: null argument");
   const int pc = phys_ch(dt, Cin);
-  const P3Plan p = sfod_p3_plan(B, H, W, pc, Cout);
+  const P3Plan p = sfod_p3_plan(B, H, W, pc, Cout, sfod_is_pairs(dt));
   const P3BnRed red{y, mean, invstd, gamma, beta, red_ws};
   return sfod_p3_launch(p, x, w, nullptr, dz, nullptr, B, H, W, pc, Cout, Cout, 0, 1, (hipStream_t)stream,
                         dt == SFOD_BF16X3, &red);

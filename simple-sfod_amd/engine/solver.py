@@ -175,17 +175,24 @@ class FusedSGD:
         self._steps = sd["steps"]
         self.set_lr(sd["lr"])
 
-    def torch_param_order(self):
+    def torch_param_order(self, rule="norm"):
         """Names of the reference stack's optimiser parameters in ``torch.optim.SGD`` index order: Detectron2's
         ``get_default_optimizer_params`` walks the modules' own parameters (= ``named_parameters()`` order), skips
-        ``requires_grad == False``, gives norm-layer parameters ``WEIGHT_DECAY_NORM`` and everything else
-        ``WEIGHT_DECAY`` (bias factor / bias decay equal the defaults in the named yamls), ``reduce_param_groups``
-        merges the per-parameter groups by hyper-parameters in first-seen order, and torch numbers the parameters
-        group by group.  -> [[names of group 0], [names of group 1], ...]."""
+        ``requires_grad == False``, assigns per-parameter hyper-parameters, ``reduce_param_groups`` merges the
+        per-parameter groups by hyper-parameters in first-seen order, and torch numbers the parameters group by group.
+        Which parameters share hyper-parameters depends on the Detectron2 version that wrote the checkpoint -- ``rule``:
+          "norm"         norm-layer weights AND biases take WEIGHT_DECAY_NORM, everything else WEIGHT_DECAY (current d2;
+                         WEIGHT_DECAY_BIAS None / equal, BIAS_LR_FACTOR 1 as in the named yamls)
+          "norm_weight"  a parameter called ``bias`` takes WEIGHT_DECAY_BIAS (= WEIGHT_DECAY by default) before the norm
+                         test: only the norm WEIGHTS form the no-decay group (sizes [N + #norms, #norms])
+          "single"       WEIGHT_DECAY_NORM == WEIGHT_DECAY: one group
+        -> [[names of group 0], [names of group 1], ...]."""
         f = self.flat
         norm = {n for n, (o, _, _) in f.offsets.items() if f.n_decay <= o < f.n_norm_end}
-        if self.weight_decay_norm == self.weight_decay:
+        if rule == "single" or (rule == "norm" and self.weight_decay_norm == self.weight_decay):
             norm = set()
+        elif rule == "norm_weight":
+            norm = {n for n in norm if not n.endswith("bias")}
         groups, index = [], {}
         for n in f.named_order:
             if not f.params[n].requires_grad:
@@ -201,19 +208,36 @@ class FusedSGD:
     def _load_torch_sgd_state(self, sd):
         """Momentum buffers + learning rate from a ``torch.optim.SGD.state_dict()`` (fvcore ``Checkpointer.save``
         stores it under "optimizer", daod/engine/trainers/source_free_adaptive_teacher.py:84-89).  Accepts the merged
-        groups of current Detectron2 and the one-group-per-parameter layout of older versions.  Parameters this
+        groups of current Detectron2, the merged groups of versions that put the norm biases with the decayed
+        parameters (``torch_param_order``'s rules, chosen by group sizes and buffer shapes) and the one-group-per-parameter
+        layout of older versions.  Parameters this
         optimiser does not update (zero-gradient domain-classifier heads with DOMAIN_CLASSIFIER off) are skipped."""
         f = self.flat
-        ours = self.torch_param_order()
         theirs = [list(g["params"]) for g in sd["param_groups"]]
-        if [len(g) for g in theirs] == [len(g) for g in ours]:
-            names = {i: n for g_t, g_o in zip(theirs, ours) for i, n in zip(g_t, g_o)}
-        elif all(len(g) == 1 for g in theirs) and len(theirs) == sum(len(g) for g in ours):
+
+        def shapes_fit(names):
+            for i, st in sd["state"].items():
+                buf, n = st.get("momentum_buffer"), names.get(int(i))
+                if buf is not None and n is not None and tuple(buf.shape) != tuple(f.offsets[n][2]):
+                    return False
+            return True
+
+        # the grouping is read off the checkpoint: the rule whose group sizes AND momentum-buffer shapes fit it
+        names, tried = None, []
+        for rule in ("norm", "norm_weight", "single"):
+            ours = self.torch_param_order(rule)
+            tried.append([len(g) for g in ours])
+            if [len(g) for g in theirs] == tried[-1]:
+                cand = {i: n for g_t, g_o in zip(theirs, ours) for i, n in zip(g_t, g_o)}
+                if shapes_fit(cand):
+                    names = cand
+                    break
+        if names is None and all(len(g) == 1 for g in theirs) and len(theirs) == sum(tried[0]):
             order = [n for n in f.named_order if f.params[n].requires_grad]   # one group per parameter, in walk order
             names = {g[0]: n for g, n in zip(theirs, order)}
-        else:
+        if names is None:
             raise ValueError("optimizer state does not fit this model: checkpoint groups {} vs {} here".format(
-                [len(g) for g in theirs], [len(g) for g in ours]))
+                [len(g) for g in theirs], tried))
         self.mom.zero_()
         loaded = 0
         for i, st in sd["state"].items():

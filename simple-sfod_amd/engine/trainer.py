@@ -131,13 +131,43 @@ class GradientReducer:
     point-to-point, so few large messages (not 25 MB DDP buckets) keep every link busy."""
 
     def __init__(self, flat, prefixes=("proposal_generator.", "roi_heads."),
-                 mid_prefixes=("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4.")):
+                 mid_prefixes=("backbone.vgg2.", "backbone.vgg3.", "backbone.vgg4."), skip_prefixes=()):
+        """``skip_prefixes``: parameters whose gradient is identically zero on every rank in this run (a zero-weighted,
+        elided domain classifier: 3.1 M parameters of the hot yaml) -- never exchanged."""
         self.flat = flat
         self.work, self.work_mid = None, None
         self.lo, self.hi = self._pure_run(prefixes)
         self.mlo, self.mhi = self._pure_run(mid_prefixes) if mid_prefixes else (0, 0)
         if self.mhi > self.mlo and self.hi > self.lo and not (self.mhi <= self.lo or self.hi <= self.mlo):
             self.mlo = self.mhi = 0          # overlapping slices: keep the heads phase only
+        self.skip = self._runs(tuple(skip_prefixes)) if skip_prefixes else []
+
+    def _runs(self, prefixes):
+        """every maximal run of consecutive parameters (buffer order) matching ``prefixes`` -> [(lo, hi)] in elements"""
+        items = sorted(((o, n) for n, (o, k, _) in self.flat.offsets.items()), key=lambda t: t[0])
+        out, cur = [], None
+        for i, (o, n) in enumerate(items):
+            nxt = items[i + 1][0] if i + 1 < len(items) else self.flat.grad.numel()
+            if n.startswith(prefixes):
+                cur = (cur[0], nxt) if cur is not None else (o, nxt)
+            elif cur is not None:
+                out.append(cur)
+                cur = None
+        if cur is not None:
+            out.append(cur)
+        return out
+
+    def final_elements(self):
+        """elements the blocking phase exchanges after the backward (diagnostics / tests)"""
+        end = int(getattr(self.flat, "n_norm_end", self.flat.grad.numel()))
+        covered = sorted([(self.lo, self.hi), (self.mlo, self.mhi)] + list(self.skip))
+        pos = tot = 0
+        for lo, hi in covered + [(end, end)]:
+            lo, hi = min(lo, end), min(hi, end)
+            if lo > pos:
+                tot += lo - pos
+            pos = max(pos, hi)
+        return tot
 
     def _pure_run(self, prefixes):
         """Longest run of consecutive parameters (in buffer order) that all match ``prefixes`` -> [lo, hi) in
@@ -178,10 +208,7 @@ class GradientReducer:
             self.work = self.work_mid = None
             return
         done = sorted([(lo, hi) for lo, hi, w in ((self.lo, self.hi, self.work), (self.mlo, self.mhi, self.work_mid))
-                       if w is not None])
-        if not done:
-            dist.all_reduce(g)
-            return
+                       if w is not None] + [(min(lo, g.numel()), min(hi, g.numel())) for lo, hi in self.skip])
         pos = 0
         for lo, hi in done + [(g.numel(), g.numel())]:
             if lo > pos:
@@ -249,7 +276,8 @@ class BaseTrainer:
             short = min(cfg.INPUT.MIN_SIZE_TRAIN) if len(cfg.INPUT.MIN_SIZE_TRAIN) else 600
             bb = self.model.backbone
             mids = tuple(bb.reduce_schedule(b_local * short * short * 2)) if hasattr(bb, "reduce_schedule") else ()
-            self._reducer = GradientReducer(self.optimizer.flat, mid_prefixes=mids)
+            # (this branch runs only when the domain classifier contributes no gradient: its slots stay zero everywhere)
+            self._reducer = GradientReducer(self.optimizer.flat, mid_prefixes=mids, skip_prefixes=("DC_img.", "DC_ins."))
             bb._pre_backward = self._reducer.launch_early
             bb._mid_backward = self._reducer.launch_mid if mids else None
 

@@ -215,13 +215,20 @@ def operands_for(t, dtype, need_grad):
     return as_operand(t, dtype), as_operand(t, gdt)
 
 
+class _Everything:
+    def __contains__(self, item):
+        return True
+
+
 class KernelTimer:
     """Optional per-entry-point timing with HIP events recorded on the launch stream (used by
     bench.py for the roofline figure of the dominant kernels).  ``flops`` is the algorithmic work
     of the launch (2 x MACs of the GEMM the entry point computes)."""
 
     def __init__(self, watch=("sfod_conv_fwd", "sfod_conv_wgrad", "sfod_conv_wgrad_oihw")):
-        self.watch = set(watch)   # entry points; records are keyed "<entry>[:<kernel tag>]"
+        # entry points; records are keyed "<entry>[:<kernel tag>]".  watch=None: EVERY entry point (bench.py's
+        # `native_kernel_time` figure: how much of a step's wall time the library's own launches cover)
+        self.watch = _Everything() if watch is None else set(watch)
         self.records = []      # (name, flops, start_event, end_event)
 
     def summary(self):

@@ -105,7 +105,7 @@ def _worker(rank, world, port, q):
     redr = sfod.engine.trainer.GradientReducer(rflat, mid_prefixes=mids)
     live = sum(p_.numel() for p_ in r101.backbone.parameters() if p_.requires_grad)
     # (buffer order: weights, norm parameters, then everything that is not optimised -- the disabled domain classifier here)
-    rest = rflat.n_norm_end - (redr.hi - redr.lo) - (redr.mhi - redr.mlo)
+    rest = redr.final_elements()
     ok_r101 = (tuple(mids) == ("backbone.res4.",) and (redr.mhi - redr.mlo) > 0.94 * live and redr.mhi <= redr.lo
                and (redr.hi - redr.lo) > 100_000_000 and 0 < 4 * rest < 10_000_000 and rflat.n_norm_end < rflat.grad.numel())
     rflat.grad[rflat.n_norm_end:].zero_()            # no gradient is ever written there

@@ -402,10 +402,8 @@ def test_values_beyond_half_range_are_reported(native):
     fp = native.cast(feat, native.SPLITH_DTYPE)
     with pytest.raises(FloatingPointError):    # the conversion itself saturates 1e5
         native.check_f16x3_range(dev)
-    native.roi_align_fwd(fp, rois, 7, 1.0 / 32)                 # pooled values 1e5 again: reported by THAT kernel's flag
-    with pytest.raises(FloatingPointError):
-        native.check_f16x3_range(dev)
-    native.check_f16x3_range(dev)
+    native.roi_align_fwd(fp, rois, 7, 1.0 / 32)                 # pooled values are convex combinations of saturated (in-range)
+    native.check_f16x3_range(dev)                               # inputs: nothing left to clamp in that kernel, silent
 
 
 @pytest.mark.parametrize("fmt", ["f16", "bf16"])

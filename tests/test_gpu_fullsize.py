@@ -93,9 +93,14 @@ def _report(tag, errs, gates, info=None):
     assert not bad, f"{tag}: outside the gate: {bad}"
 
 
-def _teacher_student_parity(sfod, yaml, ocfg, dtype, B, plant, tag, seed=7, tracking_only=False):
+def _teacher_student_parity(sfod, yaml, ocfg, dtype, B, plant, tag, seed=7, tracking_only=False, last_gamma=None):
     """Teacher pass (captured intermediates) and student pass of ``yaml`` at 600x1200 against the oracle ``ocfg``.
-    ``tracking_only``: the looser GATE_TRACKING set (a mode that is not the config's parity mode)."""
+    ``tracking_only``: the looser GATE_TRACKING set (a mode that is not the config's parity mode).
+    ``last_gamma`` (ResNet): the BatchNorm weight of every bottleneck's LAST norm is set to this value (the default
+    initialisation is 1; torchvision / Detectron2 checkpoints of trained networks sit well below, ``zero_init_residual``
+    starts at 0): the block's branch then re-injects that fraction of the accumulated rounding error into the residual
+    stream instead of all of it, the reference arithmetic's own fp32-vs-fp64 floor drops below 1e-5, and the FIXED gates
+    (1e-4 on every box coordinate, 2e-5 on the intermediates) apply without any floor scaling."""
     NS = GATE_TRACKING["north_star"] if tracking_only else GATE_NORTH_STAR
     PX = GATE_TRACKING["px"] if tracking_only else GATE_NORTH_STAR
     S = sfod.structures
@@ -106,6 +111,13 @@ def _teacher_student_parity(sfod, yaml, ocfg, dtype, B, plant, tag, seed=7, trac
     with torch.no_grad():       # planted labels: some detections clear the 0.8 pseudo-label threshold
         model.roi_heads.box_predictor.cls_score.weight.mul_(plant[0])
         model.roi_heads.box_predictor.bbox_pred.weight.mul_(plant[1])
+        if last_gamma is not None:
+            n_set = 0
+            for name, p_ in model.named_parameters():
+                if name.startswith("backbone.res") and name.endswith("conv3.norm.weight") and p_.requires_grad:
+                    p_.fill_(last_gamma)
+                    n_set += 1
+            assert n_set >= 20, n_set
     sd = om.clone_state({k: v.detach().float().cpu() if v.dtype != torch.int64 else v.detach().cpu()
                          for k, v in model.state_dict().items()})
     sd0 = om.clone_state(sd)        # before the train-mode passes move the running statistics
@@ -156,7 +168,9 @@ def _teacher_student_parity(sfod, yaml, ocfg, dtype, B, plant, tag, seed=7, trac
             l64, d64 = om.rpn_head(sd64, om.backbone_forward(sd64, x.double(), ocfg, training=True))
         floor = max(rel_err(logits_ref, l64), rel_err(deltas_ref, d64))
         del sd64, l64, d64
-        if not tracking_only:
+        if last_gamma is not None:
+            assert floor < 1e-5, f"the well-conditioned weight set should have a floor below 1e-5, got {floor:.2e}"
+        elif not tracking_only:
             TI = max(TI, 3.0 * floor)
             # the worst of 2.7e5 coordinates sits ~5 sigma out: the reference arithmetic's own worst coordinate on this
             # network is ~5 x its relative L2 (the relative-L2 box gates keep the fixed 1e-4)
@@ -299,6 +313,17 @@ def test_r101_yaml_teacher_and_student_at_600x1200(sfod, native, dtype):
     this config's parity modes: losses / boxes at 1e-4.  ``bf16x3`` is held to the labelled tracking gates only (header)."""
     _teacher_student_parity(sfod, R101_YAML, om.Cfg.r101_c4(), dtype, 2, plant=(3.0, 4.0), tag="R101-C4 yaml",
                             tracking_only=(dtype == "bf16x3"))
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "f16x3"])
+def test_r101_yaml_on_a_well_conditioned_weight_set_at_600x1200(sfod, native, dtype):
+    """BASELINE config #5 once more, on weights whose conditioning is that of a trained residual network rather than of the
+    default random initialisation: gamma of every bottleneck's last BatchNorm = 0.1.  The reference arithmetic's own error on
+    this network (fp32 oracle vs fp64 oracle) is then < 1e-5 -- asserted -- so nothing is scaled by it: every box coordinate
+    within 1e-4 of max(frame width, box extent), intermediates within 2e-5 relative L2, losses and boxes within 1e-4, discrete
+    steps bit-exact -- the gates the VGG16 yaml is held to, in both of this config's parity modes."""
+    _teacher_student_parity(sfod, R101_YAML, om.Cfg.r101_c4(), dtype, 2, plant=(12.0, 4.0), tag="R101-C4 yaml, last gamma 0.1",
+                            last_gamma=0.1)
 
 
 def _check_discrete_steps_on_captured_tensors(model, inputs, B, H, W, with_gt, native, ocfg=None):

@@ -297,6 +297,23 @@ def test_reads_checkpoints_in_the_reference_stacks_formats(sfod, tmp_path):
     for n, m in moms.items():
         o, k, shp = opt.flat.offsets[n]
         assert torch.equal(opt.mom[o:o + k].view(shp), m), n
+    # Detectron2 versions whose WEIGHT_DECAY_BIAS default (= WEIGHT_DECAY) catches the norm layers' biases before the norm
+    # test: merged groups [N + 13, 13] -- only the 13 BatchNorm weights form the no-decay group.  The grouping is read off
+    # the checkpoint (group sizes + momentum-buffer shapes), not assumed
+    g_old = opt.torch_param_order("norm_weight")
+    assert [len(g) for g in g_old] == [len(moms) - 13, 13] and all(n.endswith(".weight") for n in g_old[1])
+    idx, sd_b = 0, {"state": {}, "param_groups": []}
+    for grp in g_old:
+        sd_b["param_groups"].append({"lr": 0.0025, "weight_decay": 1e-4 if grp is g_old[0] else 0.0,
+                                     "params": list(range(idx, idx + len(grp)))})
+        for n in grp:
+            sd_b["state"][idx] = {"momentum_buffer": moms[n].clone()}
+            idx += 1
+    opt.mom.zero_()
+    assert opt.load_state_dict(sd_b) == len(moms)
+    for n, m in moms.items():
+        o, k, shp = opt.flat.offsets[n]
+        assert torch.equal(opt.mom[o:o + k].view(shp), m), n
     with pytest.raises(ValueError, match="does not fit this model"):
         opt.load_state_dict({"state": {}, "param_groups": [{"lr": 0.1, "params": [0, 1, 2]}]})
 
