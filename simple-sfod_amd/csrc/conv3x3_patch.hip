@@ -1177,18 +1177,19 @@ static std::atomic<int> g_p3_variant{-1};
 // 16x16x32 form of the 256 x 128 shape for operand pairs (k_conv3x3_m16): -1 not initialised (SFOD_P3_M16, default on)
 static std::atomic<int> g_p3_m16{-1};
 extern "C" int sfod_set_conv3x3_m16(int on) {
-  g_p3_m16.store(on ? 1 : 0, std::memory_order_relaxed);
+  g_p3_m16.store((on >= 0 && on <= 2) ? on : 1, std::memory_order_relaxed);
   return 0;
 }
-static bool p3_m16_enabled() {
+static int p3_m16_enabled() {       // 0 off, 1 the 8-wave form (default), 2 the 4-wave form (SFOD_P3_M16=2: co-residency experiments)
   int v = g_p3_m16.load(std::memory_order_relaxed);
   if (v < 0) {
     const char* ev = getenv("SFOD_P3_M16");
-    int want = ev ? (atoi(ev) != 0) : 1, expect = -1;
+    int want = ev ? atoi(ev) : 1, expect = -1;
+    if (want < 0 || want > 2) want = 1;
     g_p3_m16.compare_exchange_strong(expect, want, std::memory_order_relaxed);
     v = g_p3_m16.load(std::memory_order_relaxed);
   }
-  return v != 0;
+  return v;
 }
 
 extern "C" int sfod_set_conv3x3_variant(int variant) {
@@ -1232,7 +1233,7 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout, int pairs) {
     g_p3_variant.compare_exchange_strong(expect, variant, std::memory_order_relaxed);   // a concurrent setter wins
     variant = g_p3_variant.load(std::memory_order_relaxed);
   }
-  p.m16 = (variant == 5) ? 1 : (variant == 6 ? 2 : ((variant < 1 || variant > 6) ? (p3_m16_enabled() ? 1 : 0) : 0));
+  p.m16 = (variant == 5) ? 1 : (variant == 6 ? 2 : ((variant < 1 || variant > 6) ? p3_m16_enabled() : 0));
   if (variant == 5 || variant == 6) variant = 2;
   if (variant < 1 || variant > 4) {
     const int64_t mt = ((int64_t)B * H * W + 255) / 256;          // 256-pixel tiles (lower bound)

@@ -300,7 +300,7 @@ def set_deterministic(on):
 
 def set_conv3x3_m16(on):
     """Automatic shape choice: run the 256 x 128 shape on 16x16x32 MFMAs (default on; include/sfod_hip.h)."""
-    load().sfod_set_conv3x3_m16(int(bool(on)))
+    load().sfod_set_conv3x3_m16(int(on))       # 0 off, 1 the 8-wave form, 2 the 4-wave form
 
 
 # =================================================================================================
