@@ -107,6 +107,17 @@ int sfod_conv_dgrad_bnred_blocks(int B, int H, int W, int Cin, int Cout, int dt)
 int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, int W, int Cin, int Cout, int dt,
                           const float* y, const float* mean, const float* invstd, const float* gamma,
                           const float* beta, float* red_ws, void* stream);
+/* K2 with the PRODUCER's BatchNorm + ReLU folded into the operand path (vgg.py:18-20: conv -> BatchNorm2d -> ReLU -> conv, the
+ * activated tensor consumed by nobody else: forward-only passes such as the teacher's, source_free_adaptive_teacher.py:385-390).
+ * x_pre: the producer's pre-BatchNorm output, fp32 [B,H,W,Cin]; in_mean / in_invstd / in_gamma / in_beta [Cin]: its batch
+ * statistics and affine parameters.  The kernel computes relu((x - mean) * (invstd * gamma) + beta) and the (hi, lo) split of
+ * SFOD_BF16X3 -- the arithmetic of sfod_bn_relu_pool_fwd, bit for bit -- on each patch slice in LDS; w / bias / y / stats / act
+ * as in sfod_conv_fwd (3x3, y fp32).  _supported: 1 when the shape is served (dt SFOD_BF16X3, Cin % 32 == 0, the halo-patch
+ * kernel's 256 x 128 shape); otherwise run sfod_bn_relu_pool_fwd + sfod_conv_fwd. */
+int sfod_conv_fwd_bnin_supported(int B, int H, int W, int Cin, int Cout, int dt);
+int sfod_conv_fwd_bnin(const float* x_pre, const float* in_mean, const float* in_invstd, const float* in_gamma,
+                       const float* in_beta, const void* w, const float* bias, float* y, int B, int H, int W, int Cin,
+                       int Cout, int ldy, int act, float* stats, int dt, void* stream);
 /* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
  * 4 = 512 x 64 (applied where the channel counts allow it), 5 = 256 x 128 on v_mfma_f32_16x16x32 (operand pairs with
  * Cin % 32 == 0; otherwise as 2: 8 waves x (64 px x 64 ch), four waves per SIMD), 6 = the same with 4 waves x (128 px x

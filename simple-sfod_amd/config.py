@@ -402,6 +402,10 @@ def add_native_config(cfg):
     # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass
     # that stores the activated output directly; sfod_conv_first_fused)
     _C.SFOD.FUSE_FIRST_LAYER = True
+    # forward-only passes (the teacher), bf16x3: a convolution whose input is a non-pooled BatchNorm + ReLU reads the
+    # producer's pre-BatchNorm output and applies BatchNorm + ReLU + the operand split in its LDS patch
+    # (sfod_conv_fwd_bnin): the elementwise apply pass of conv2_1, conv3_1/2, conv4_1/2 disappears
+    _C.SFOD.FUSE_BN_INPUT = True
     # d2's EvalHook inside Trainer.train(): Trainer.test every TEST.EVAL_PERIOD iterations and after the last one
     _C.SFOD.EVAL_HOOK = True
     # json file {"<dataset name>": {"json_file": ..., "image_root": ...}}: COCO-format datasets for the names in

@@ -87,6 +87,12 @@ struct P3Args {
   const float* red_beta;
   float* red_ws;
   const unsigned* wamax;    // SFOD_F16X3: bits of max|w| of the scaled packed weights (common.h), or nullptr
+  // k_conv3x3_m16<.., XF>: x is the PRODUCER's pre-BatchNorm fp32 output [B,H,W,Cin/2] (the same bytes per pixel as operand
+  // pairs); the kernel applies relu((x - mean) * (invstd * gamma) + beta) and the (hi, lo) split to each patch slice in LDS
+  const float* xf_mean;
+  const float* xf_invstd;
+  const float* xf_gamma;
+  const float* xf_beta;
 };
 
 // 16 bytes per lane, global -> LDS (wave-uniform LDS base + lane * 16), through a raw buffer
@@ -724,9 +730,12 @@ template <int NW, int NIP> struct M16Lay {
 __device__ unsigned long long g_m16_stamps[8];
 #endif
 
-template <int NW, int NIP, int FMT, bool RED>
+typedef float __attribute__((address_space(4))) cfloat_k;      // a float in the constant address space
+
+template <int NW, int NIP, int FMT, bool RED, bool XF = false>
 __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::LDS)) / 4) k_conv3x3_m16(P3Args a) {
   using L = M16Lay<NW, NIP>;
+  static_assert(!XF || (NW == 4 && NIP == 8 && FMT == 1 && !RED), "the in-LDS BatchNorm transform lives in the 4-wave bf16-pair forward kernel");
 #ifdef M16_STAMP
   const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -805,6 +814,91 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
   for (int k = 0; k < NPW; ++k) issue_patch(k, 0, 0);
   issue_w(0, 0, 0);
 
+  // ---- XF: fp32 y -> relu(bn(y)) -> (hi, lo) pairs, in place in a patch buffer -----------------------------------------
+  // A patch row is 64 bytes = 16 fp32 channels of one patch pixel = the 16 logical channels of the slice; its operand image is
+  // hi 0-7 | lo 0-7 | hi 8-15 | lo 8-15 (16-byte chunks at the row's swizzled positions).  The unit of work is a HALF row
+  // (8 channels: read two chunks, write the same two): 384 rows x 2 halves = 3 units per thread, all lanes busy, nobody else
+  // touches a unit's 32 bytes.  Unit k of thread t: k = 0 -> (row t, half 0); k = 1 -> (row t + 256, half 0) in waves 0-1,
+  // (row t - 128, half 1) in waves 2-3; k = 2 -> (row t + 128, half 1): the half is wave-uniform, so the BatchNorm
+  // coefficients are scalar loads.  Rows outside the image (the DMA wrote zeros: padding, tile overhang) must stay zero --
+  // relu(beta - mean * scale) is not -- so each lane keeps a validity bit per unit.  The arithmetic is k_bn_relu_pool_fwd's,
+  // operation for operation (the fused and the unfused path agree bit for bit).
+  unsigned xf_valid = 0;
+  int xf_row[3] = {0, 0, 0};
+  const int xf_g1 = __builtin_amdgcn_readfirstlane(wave >= 2 ? 1 : 0);
+  if constexpr (XF) {
+    const int tid = (int)threadIdx.x;
+    xf_row[0] = tid;
+    xf_row[1] = (wave >= 2) ? tid - 128 : tid + 256;
+    xf_row[2] = tid + 128;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const int row = xf_row[k];
+      const int py = (int)fdiv((unsigned)row, (unsigned)PW, a.m_pw), px = row - py * PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      const bool ok = (py < a.TH + 2) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      xf_valid |= ok ? (1u << k) : 0u;
+    }
+  }
+  auto transform = [&](int buf, int slice) {
+    if constexpr (XF) {
+      const int pbuf = buf * PATCH_BYTES;
+      const int c0 = __builtin_amdgcn_readfirstlane(slice * 16);
+      float4 v[3][2];
+      int pa[3][2];                          // byte offsets in the LDS image (32-bit: pointers would double the registers)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {          // all six reads first: one LDS latency, not three
+        const int g = (k == 0) ? 0 : (k == 2 ? 1 : xf_g1);
+        const int row = xf_row[k], sw = (row >> 2) & 3;
+        pa[k][0] = pbuf + row * 64 + (((2 * g) ^ sw) << 4);
+        pa[k][1] = pbuf + row * 64 + (((2 * g + 1) ^ sw) << 4);
+        v[k][0] = *reinterpret_cast<const float4*>(smem + pa[k][0]);       // channels 8 g .. 8 g + 3
+        v[k][1] = *reinterpret_cast<const float4*>(smem + pa[k][1]);       // channels 8 g + 4 .. 8 g + 7
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int g = (k == 0) ? 0 : (k == 2 ? 1 : xf_g1);
+        const int cb = c0 + 8 * g;                                  // wave-uniform: scalar loads
+        const float yv[8] = {v[k][0].x, v[k][0].y, v[k][0].z, v[k][0].w, v[k][1].x, v[k][1].y, v[k][1].z, v[k][1].w};
+        // relu and the validity select in one op: med3(t, 0, +inf) = max(t, 0), med3(t, 0, 0) = 0
+        const float top = ((xf_valid >> k) & 1u) ? __builtin_inff() : 0.f;
+        union { unsigned u[4]; uint4 q; } hi, lo;
+        // constant address space: a wave-uniform load from it is a scalar load (s_load_dwordx8).  As plain global loads
+        // these were VECTOR loads -- the kernel stores to global memory, so the compiler will not call the arrays invariant
+        // -- and their vmcnt(0) waits drained the LDS-DMA pipeline in every transform.
+        const cfloat_k* k_mean = (const cfloat_k*)(uintptr_t)a.xf_mean + cb;
+        const cfloat_k* k_invstd = (const cfloat_k*)(uintptr_t)a.xf_invstd + cb;
+        const cfloat_k* k_gamma = (const cfloat_k*)(uintptr_t)a.xf_gamma + cb;
+        const cfloat_k* k_beta = (const cfloat_k*)(uintptr_t)a.xf_beta + cb;
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          float z[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const float sc = k_invstd[e + i] * k_gamma[e + i];
+            const float t = fmaf(yv[e + i] - k_mean[e + i], sc, k_beta[e + i]);
+            z[i] = __builtin_amdgcn_fmed3f(t, 0.f, top);
+          }
+          // two channels per conversion (v_cvt_pk_bf16_f32); the high parts back as floats are a shift and a mask
+          typedef float f32x2_t __attribute__((ext_vector_type(2)));
+          typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+          const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{z[0], z[1]}, bf16x2_t));
+          const float h0 = __builtin_bit_cast(float, h << 16), h1 = __builtin_bit_cast(float, h & 0xffff0000u);
+          hi.u[e >> 1] = h;
+          lo.u[e >> 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{z[0] - h0, z[1] - h1}, bf16x2_t));
+        }
+        *reinterpret_cast<uint4*>(smem + pa[k][0]) = hi.q;
+        *reinterpret_cast<uint4*>(smem + pa[k][1]) = lo.q;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  if constexpr (XF) {
+    wait_vm<WPW>();                 // the first patch has landed (this wave's pieces); the first weights may still be in flight
+    __builtin_amdgcn_s_barrier();
+    transform(0, 0);
+  }
+
   // ---- fragment addressing -----------------------------------------------------------------------------------------
   int rowA[NIP];
 #pragma unroll
@@ -851,7 +945,8 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
 #ifndef M16_KO_BAR
     if (nprev == 0) wait_vm<0>();
     else if (nprev == 1) wait_vm<1>();
-    else wait_vm<2>();
+    else if (nprev == 2) wait_vm<2>();
+    else wait_vm<3>();
 #ifdef M16_STAMP
     const unsigned long long st_a2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -861,6 +956,11 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
 #ifdef M16_STAMP
     const unsigned long long st_b = __builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (XF) {             // the slice that landed during the last two stages: convert it in place, one stage before its first use
+      if (j == 3) transform(1, 2 * sb + 1);
+      else if (j == 8 && sb + 1 < nsb) transform(0, 2 * sb + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 
     const unsigned char* wsl = smem + WR_OFF + par * WSLOT;
     bf16x8 wh[4], wl[4];
@@ -884,9 +984,12 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
     else if (!last) issue_w(sb + 1, 0, par ^ 1);
 #endif
     // patch pieces of this stage (<= PPS): slice 1 of this super-body -> buffer 1 in stages 0-2, slice 0 of the next -> buffer 0 in 5-7
+    // (XF: all pieces in TWO stages, 0-1 / 5-6, so that the slice has landed one stage before its first use and is
+    // converted in place during that stage: 3 / 8)
+    constexpr int PPS = XF ? (NPW + 1) / 2 : L::PPS;
     int np = 0, pslice = 0, pbuf = 0, pk = 0;
-    if (j < 3) { pk = L::PPS * j; np = min(L::PPS, NPW - pk); pslice = 2 * sb + 1; pbuf = 1; }
-    else if (j >= 5 && j < 8 && !last) { pk = L::PPS * (j - 5); np = min(L::PPS, NPW - pk); pslice = 2 * sb + 2; pbuf = 0; }
+    if (j < (XF ? 2 : 3)) { pk = PPS * j; np = min(PPS, NPW - pk); pslice = 2 * sb + 1; pbuf = 1; }
+    else if (j >= 5 && j < (XF ? 7 : 8) && !last) { pk = PPS * (j - 5); np = min(PPS, NPW - pk); pslice = 2 * sb + 2; pbuf = 0; }
     __builtin_amdgcn_sched_barrier(0);
 #ifdef M16_STAMP
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -914,7 +1017,7 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
       for (int ic = 0; ic < 4; ++ic) acc[ic][ip] = mfma16<FMT>(wh[ic], ch, acc[ic][ip]);
 #endif
 #ifndef M16_KO_PDMA
-      if (ip < L::PPS) { if (ip < np) issue_patch(pk + ip, pslice, pbuf); }
+      if (ip < PPS) { if (ip < np) issue_patch(pk + ip, pslice, pbuf); }
 #endif
 #if defined(M16_V_LATEW) && !defined(M16_KO_WDMA)
       if (ip == 2) {
@@ -1275,9 +1378,9 @@ extern "C" int sfod_debug_m16_stamps(unsigned long long* out8, int reset) {
 }
 #endif
 
-template <int NW, int NIP, int FMT, bool RED>
+template <int NW, int NIP, int FMT, bool RED, bool XF = false>
 static int p3_launch_m16(P3Args a, hipStream_t s) {
-  auto kern = k_conv3x3_m16<NW, NIP, FMT, RED>;
+  auto kern = k_conv3x3_m16<NW, NIP, FMT, RED, XF>;
   constexpr int LDS = M16Lay<NW, NIP>::LDS;
   static const hipError_t attr_rc =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1299,12 +1402,24 @@ static int p3_launch_one(const P3Args& a, hipStream_t s) {
   return sfod_check_launch("conv3x3_patch");
 }
 
+bool sfod_p3_bnin_ok(const P3Plan& p, int Cin_phys, int split) {
+  return p.ok && p.m16 != 0 && p.G == 1 && p.FM == 2 && Cin_phys % 64 == 0 && split == 1;
+}
+
 // split 1 / 2: SFOD_BF16X3 / SFOD_F16X3 operands; Cin is then the PHYSICAL 16-bit channel count (2 x logical), the output is fp32
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
                    int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split,
-                   const P3BnRed* red, const unsigned* wamax) {
+                   const P3BnRed* red, const unsigned* wamax, const P3BnIn* bnin) {
   P3Args a;
   a.wamax = wamax;
+  a.xf_mean = a.xf_invstd = a.xf_gamma = a.xf_beta = nullptr;
+  if (bnin != nullptr) {
+    if (!sfod_p3_bnin_ok(p, Cin, split) || red != nullptr || !out_f32) {
+      sfod_set_error("conv3x3_patch: the BatchNorm-input form needs bf16x3 operands, the 256 x 128 shape, Cin % 32 == 0");
+      return SFOD_EBADARG;
+    }
+    a.xf_mean = bnin->mean; a.xf_invstd = bnin->invstd; a.xf_gamma = bnin->gamma; a.xf_beta = bnin->beta;
+  }
   a.red_y = nullptr; a.red_mean = a.red_invstd = a.red_gamma = a.red_beta = nullptr; a.red_ws = nullptr;
   if (red != nullptr) {
     if (!out_f32 || ldy != Cout || Cout % 4 != 0) { sfod_set_error("conv3x3_patch: BatchNorm-backward epilogue needs a dense fp32 output"); return SFOD_EBADARG; }
@@ -1324,6 +1439,7 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
   if (split) {
     if (!out_f32) { sfod_set_error("conv3x3_patch: operand pairs write fp32"); return SFOD_EBADARG; }
     // the 256 x 128 shape on 16x16x32 MFMAs: same tile plan (statistics blocks, reduction rows), two slices per super-body
+    if (bnin != nullptr) return p3_launch_m16<4, 8, 1, false, true>(a, s);
     if (p.m16 && p.G == 1 && p.FM == 2 && Cin % 64 == 0 && (red == nullptr || split == 1)) {
       if (p.m16 == 2) {                 // shape 6: 4 waves x (128 px x 64 ch), 2 x 208 of a SIMD lane's 512 registers
         if (red != nullptr) return p3_launch_m16<4, 8, 1, true>(a, s);

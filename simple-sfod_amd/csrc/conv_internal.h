@@ -26,9 +26,18 @@ struct P3BnRed {
   const float* beta;
   float* ws;             // [plan.nblk][2][Cout] partial (dbeta, dgamma) sums
 };
+// BatchNorm + ReLU of the PRODUCER folded into this launch's operand path (k_conv3x3_m16<4, 8, 1, false, true>): x is the
+// producer's pre-BatchNorm fp32 output, the kernel converts each patch slice to operand pairs in LDS.  Forward-only passes.
+struct P3BnIn {
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;
+};
+bool sfod_p3_bnin_ok(const P3Plan& p, int Cin_phys, int split);
 int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* bias, void* y, float* stats,
                    int B, int H, int W, int Cin, int Cout, int ldy, int act, int out_f32, hipStream_t s, int split = 0,
-                   const P3BnRed* red = nullptr, const unsigned* wamax = nullptr);
+                   const P3BnRed* red = nullptr, const unsigned* wamax = nullptr, const P3BnIn* bnin = nullptr);
 
 // BatchNorm statistics buffer layout shared by every conv kernel:
 //   stats[blk][0][c] = sum over the block's valid rows, stats[blk][1][c] = sum of squared deviations

@@ -681,6 +681,29 @@ extern "C" int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_
   return launch_conv_fwd<bf16_t, bf16_t>(x, w, bias, y, stats, a, s);
 }
 
+// 3x3 convolution whose INPUT is the previous layer's pre-BatchNorm output: relu(bn(x)) and the operand-pair split happen in
+// the kernel's LDS patch instead of in a separate elementwise pass (forward-only passes: nobody else needs the activated
+// tensor).  _supported: 1 when the shape is served (SFOD_BF16X3 operands, the 256 x 128 halo-patch shape, Cin % 32 == 0).
+extern "C" int sfod_conv_fwd_bnin_supported(int B, int H, int W, int Cin, int Cout, int dt) {
+  if (dt != SFOD_BF16X3 || (int64_t)B * H * W == 0 || g_conv_algo == 1) return 0;
+  const int pc = phys_ch(dt, Cin);
+  const P3Plan p = sfod_p3_plan(B, H, W, pc, Cout, 1);
+  return (use_patch_kernel(p, B, H, W, 3, dt) && sfod_p3_bnin_ok(p, pc, 1)) ? 1 : 0;
+}
+
+extern "C" int sfod_conv_fwd_bnin(const float* x_pre, const float* in_mean, const float* in_invstd, const float* in_gamma,
+                                  const float* in_beta, const void* w, const float* bias, float* y, int B, int H, int W,
+                                  int Cin, int Cout, int ldy, int act, float* stats, int dt, void* stream) {
+  SFOD_REQUIRE(sfod_conv_fwd_bnin_supported(B, H, W, Cin, Cout, dt), "conv_fwd_bnin: shape not served (sfod_conv_fwd_bnin_supported)");
+  SFOD_REQUIRE(x_pre && in_mean && in_invstd && in_gamma && in_beta && w && y, "conv_fwd_bnin: null argument");
+  SFOD_REQUIRE(ldy >= Cout, "conv_fwd_bnin: ldy < Cout");
+  const int pc = phys_ch(dt, Cin);
+  const P3Plan p = sfod_p3_plan(B, H, W, pc, Cout, 1);
+  const P3BnIn bnin{in_mean, in_invstd, in_gamma, in_beta};
+  return sfod_p3_launch(p, x_pre, w, bias, y, stats, B, H, W, pc, Cout, ldy, act, 1, (hipStream_t)stream, 1, nullptr, nullptr,
+                        &bnin);
+}
+
 // Data gradient of a 3x3 convolution (x = dy of the layer above as operand, w = its rotated weights) whose epilogue also
 // makes the BatchNorm-backward partial sums of the layer BELOW, i.e. of the tensor this launch writes (dz): halo-patch
 // kernel with fp32 output only.  sfod_conv_dgrad_bnred_blocks: number of partial rows it writes (0: shape / dtype not

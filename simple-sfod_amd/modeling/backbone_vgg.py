@@ -111,6 +111,8 @@ class vgg_backbone(nn.Module):
         # exactly: r <- r (1-m)^3 + s (1 - (1-m)^3), num_batches_tracked += 3.
         self.bn_updates_per_forward = 1
         self.fuse_first = bool(cfg.SFOD.FUSE_FIRST_LAYER) if "SFOD" in cfg and "FUSE_FIRST_LAYER" in cfg.SFOD else True
+        self.fuse_bn_input = bool(cfg.SFOD.FUSE_BN_INPUT) if "SFOD" in cfg and "FUSE_BN_INPUT" in cfg.SFOD else True
+        self.fuse_bn_input_min_bytes = int(os.environ.get("SFOD_BNIN_MIN_BYTES", str(256 << 20)))
         self.fuse_bn_reduce = os.environ.get("SFOD_NO_FUSE_BN_REDUCE", "0") != "1"   # A/B hook
         # execution plan: (conv, bn, pool_after, stage_end)
         self._plan = []
@@ -219,6 +221,23 @@ class vgg_backbone(nn.Module):
         n = len(self._plan)
         return views[:n], ([None] + list(views[n:]) if with_dgrad else None)
 
+    def _defer_bn(self, li, y, fwd_w, save, training):
+        """May layer ``li``'s BatchNorm + ReLU be left to the next convolution's operand path (sfod_conv_fwd_bnin)?  Only in a
+        train-mode forward-only pass (the teacher: nobody needs the activated tensor -- no backward, no pooling, not a stage
+        output) and where the consumer's shape is served."""
+        if save or not training or not self.fuse_bn_input or li + 1 >= len(self._plan):
+            return False
+        _, _, pool, stage_end = self._plan[li]
+        if pool or stage_end:
+            return False
+        # the in-LDS transform costs the convolution 12-15 % (it is not hidden behind the MFMAs); the apply pass it removes
+        # costs its HBM bytes, and a tensor that fits the 256 MB Infinity Cache is cheap to re-read: the fold pays for
+        # conv2_2 / conv3_2 / conv3_3 of a teacher batch at 600 x 1200 and loses on conv4_x (profiles/r4_bnin_layers.txt)
+        if y.numel() * 4 < self.fuse_bn_input_min_bytes:
+            return False
+        nxt = self._plan[li + 1][0]
+        return native.conv_fwd_bnin_supported(y, fwd_w[li + 1], nxt.out_channels)
+
     def _forward_impl(self, x, save=True):
         dt = native.dt_of(x)
         training = self.training
@@ -226,9 +245,27 @@ class vgg_backbone(nn.Module):
         fwd_w, rot_w = self._packed_weights(dt, x.shape[-1], save)
         self._rot_w = rot_w
         x_g = native.as_operand(x, self.grad_dtype) if save else None      # conv1_1's weight-gradient operand (8 channels)
+        pending = None      # (y, mean, invstd, bn) of the layer below when its BatchNorm + ReLU is left to this layer's conv
         for li, (conv, bn, pool, stage_end) in enumerate(self._plan):
             cout = conv.out_channels
             wp = fwd_w[li]
+            if pending is not None:
+                # forward-only pass: the layer below left its BatchNorm + ReLU to this convolution's operand path
+                yb, mb, ib, bnb = pending
+                pending = None
+                B, H, W, _ = yb.shape
+                y, stats = native.conv_fwd_bnin(yb, mb, ib, bnb.weight.detach(), bnb.bias.detach(), wp, conv.bias.detach(),
+                                                cout, want_stats=True)
+                mean, invstd = native.bn_finalize(stats, B * H * W, cout, bn.running_mean, bn.running_var,
+                                                  self.bn_momentum, self.bn_eps, self.bn_updates_per_forward,
+                                                  num_batches_tracked=bn.num_batches_tracked)
+                if self._defer_bn(li, y, fwd_w, save, training):
+                    pending = (y, mean, invstd, bn)
+                    continue
+                x = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool, out_dtype=x.dtype)
+                if stage_end:
+                    outs.append(x)
+                continue
             B, H, W, _ = x.shape
             if (li == 0 and training and not save and not pool and not stage_end and self.fuse_first
                     and native.conv_first_supported(x, cout)):
@@ -252,6 +289,9 @@ class vgg_backbone(nn.Module):
                 y = native.conv_fwd(x, wp, conv.bias.detach(), cout, 3)
                 mean = bn.running_mean
                 invstd = torch.rsqrt(bn.running_var + self.bn_eps)
+            if self._defer_bn(li, y, fwd_w, save, training):
+                pending = (y, mean, invstd, bn)
+                continue
             # bf16x3 / f16x3: y is fp32, z is written as (hi, lo) pairs; a pass that will be differentiated also gets
             # the operand of the next layer's weight gradient from the same launch (f16x3: bf16 pairs; else z itself)
             zz = native.bn_relu_pool_fwd(y, mean, invstd, bn.weight.detach(), bn.bias.detach(), pool,

@@ -637,6 +637,36 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     return (y, stats) if want_stats else y
 
 
+def conv_fwd_bnin_supported(y_pre, w_packed, cout):
+    """Can the 3x3 convolution that consumes relu(bn(y_pre)) take y_pre itself (BatchNorm + ReLU + pair split in the kernel's
+    LDS patch, include/sfod_hip.h: sfod_conv_fwd_bnin)?"""
+    if y_pre.dim() != 4 or y_pre.dtype != torch.float32 or w_packed.dtype != SPLIT_DTYPE:
+        return False
+    B, H, W, cin = y_pre.shape
+    return bool(query("sfod_conv_fwd_bnin_supported", B, H, W, cin, cout, BF16X3))
+
+
+def conv_fwd_bnin(y_pre, mean, invstd, gamma, beta, w_packed, bias, cout, act=0, want_stats=False):
+    """conv3x3(relu(bn(y_pre))) without materialising the activated tensor (forward-only passes).  -> y fp32 [B,H,W,cout]
+    (+ BatchNorm partial statistics), bit-identical to bn_relu_pool_fwd(pairs) followed by conv_fwd."""
+    B, H, W, cin = y_pre.shape
+    y = torch.empty((B, H, W, cout), dtype=torch.float32, device=y_pre.device)
+    stats = None
+    if want_stats:
+        nb = query("sfod_conv_stats_blocks", B, H, W, cin, cout, 3, BF16X3)
+        stats = torch.empty(nb * (2 * cout + 1), dtype=torch.float32, device=y_pre.device)
+        stats.nblk = nb
+    global _pending_flops, _pending_tag
+    _pending_flops = 2.0 * B * H * W * cout * 9 * cin
+    _pending_tag = ":patch3x3"
+    try:
+        call("sfod_conv_fwd_bnin", y_pre, mean, invstd, gamma, beta, w_packed, bias, y, B, H, W, cin, cout, cout, act, stats,
+             BF16X3, timer_name="sfod_conv_fwd")
+    finally:
+        _pending_tag = ""
+    return (y, stats) if want_stats else y
+
+
 def conv_first_supported(x, cout):
     if x.dim() != 4 or x.dtype not in (torch.bfloat16,) + PAIR_DTYPES:
         return False

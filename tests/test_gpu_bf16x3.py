@@ -514,3 +514,79 @@ def test_conv3x3_patch_wgrad_pipelined_loop_under_load(native):
     finally:
         native.set_conv_algo(0)
         native.set_wgrad3x3_pipe(2)
+
+
+@pytest.mark.parametrize("shape,forced", [
+    ((4, 150, 300, 256, 256), False),     # conv3_2 / conv3_3 of four 600 x 1200 frames: the planner's own choice
+    ((4, 75, 150, 512, 512), False),      # conv4_x
+    ((1, 300, 600, 128, 128), False),     # conv2_2, one frame
+    ((6, 77, 149, 128, 256), False),      # ragged right / bottom tiles (tile overhang and the zero padding share patch rows)
+    ((1, 150, 300, 256, 256), True),      # batch 1: the planner prefers another shape; the fold's own shape forced for both sides
+    ((3, 41, 67, 64, 128), True),         # one 64-channel super-body: the prologue transform is the only slice-0 one
+    ((2, 9, 13, 192, 64), True),          # three super-bodies, 64 output channels (half a channel tile), a map smaller than a tile
+])
+def test_conv3x3_with_batchnorm_folded_into_its_input(native, shape, forced):
+    """sfod_conv_fwd_bnin: the convolution DMAs the producer's pre-BatchNorm fp32 tensor and turns it into relu(bn(.)) operand
+    pairs inside its LDS patch.  Output and BatchNorm partial statistics must be bit-identical to the two-launch form
+    (sfod_bn_relu_pool_fwd writing pairs, then sfod_conv_fwd on the same kernel shape): same arithmetic, operation for
+    operation, and padding / tile-overhang rows stay zero (relu(beta - mean * scale) is not zero)."""
+    B, H, W, Cin, Cout = shape
+    g = torch.Generator(device=DEV).manual_seed(B + H + Cin)
+    y_pre = torch.randn(B, H, W, Cin, device=DEV, generator=g) * 1.7 + 0.4
+    gamma = torch.rand(Cin, device=DEV, generator=g) + 0.5
+    beta = torch.rand(Cin, device=DEV, generator=g) + 0.2       # positive: a non-zero padding row would show
+    mean = y_pre.mean(dim=(0, 1, 2))
+    invstd = torch.rsqrt(y_pre.var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+    w = to_split(native, torch.randn(Cout, 9, Cin, device=DEV, generator=g) / (3 * Cin ** 0.5))
+    bias = torch.randn(Cout, device=DEV, generator=g)
+    if forced:
+        assert not native.conv_fwd_bnin_supported(y_pre, w, Cout)        # (which is why it is forced)
+        with pytest.raises(RuntimeError, match="not served"):
+            native.conv_fwd_bnin(y_pre, mean, invstd, gamma, beta, w, bias, Cout)
+    z = native.bn_relu_pool_fwd(y_pre, mean, invstd, gamma, beta, False, out_dtype=native.SPLIT_DTYPE)
+    try:
+        if forced:
+            native.set_conv_algo(2)
+            native.set_conv3x3_variant(6)
+        assert native.conv_fwd_bnin_supported(y_pre, w, Cout), "a headline layer shape is not served"
+        native.set_conv3x3_m16(2)           # the fold lives in the 4-wave shape: compare on the same accumulation order
+        ref, ref_stats = native.conv_fwd(z, w, bias, Cout, 3, want_stats=True)
+        outs = [native.conv_fwd_bnin(y_pre, mean, invstd, gamma, beta, w, bias, Cout, want_stats=True) for _ in range(3)]
+        y1 = native.conv_fwd_bnin(y_pre, mean, invstd, gamma, beta, w, bias, Cout, act=1)
+        native.set_conv3x3_m16(1)
+        ref8, _ = native.conv_fwd(z, w, bias, Cout, 3, want_stats=True)
+        torch.cuda.synchronize()
+    finally:
+        native.set_conv3x3_m16(1)
+        native.set_conv3x3_variant(0)
+        native.set_conv_algo(0)
+    for y, st in outs:
+        assert torch.equal(y, ref), "folded BatchNorm input differs from the two-launch form: max |d| = {}".format(
+            (y - ref).abs().max().item())
+        assert torch.equal(st, ref_stats)
+    assert torch.equal(y1, torch.relu(ref))
+    assert rel_err(outs[0][0], ref8) < 2e-6
+
+
+def test_conv3x3_batchnorm_input_under_load_is_deterministic(native):
+    """Full-chip launch of the fold (the in-LDS transform runs between the pipeline's barriers: a transform racing a DMA or a
+    fragment read only shows under load)."""
+    B, H, W, Cin, Cout = 8, 150, 300, 256, 256
+    g = torch.Generator(device=DEV).manual_seed(5)
+    y_pre = torch.randn(B, H, W, Cin, device=DEV, generator=g)
+    gamma = torch.rand(Cin, device=DEV, generator=g) + 0.5
+    beta = torch.rand(Cin, device=DEV, generator=g)
+    mean = y_pre.mean(dim=(0, 1, 2))
+    invstd = torch.rsqrt(y_pre.var(dim=(0, 1, 2), unbiased=False) + 1e-5)
+    w = to_split(native, torch.randn(Cout, 9, Cin, device=DEV, generator=g) / (3 * Cin ** 0.5))
+    bias = torch.randn(Cout, device=DEV, generator=g)
+    z = native.bn_relu_pool_fwd(y_pre, mean, invstd, gamma, beta, False, out_dtype=native.SPLIT_DTYPE)
+    try:
+        native.set_conv3x3_m16(2)
+        ref, ref_stats = native.conv_fwd(z, w, bias, Cout, 3, want_stats=True)
+    finally:
+        native.set_conv3x3_m16(1)
+    outs = [native.conv_fwd_bnin(y_pre, mean, invstd, gamma, beta, w, bias, Cout, want_stats=True) for _ in range(6)]
+    torch.cuda.synchronize()
+    for y, st in outs:
+        assert torch.equal(y, ref) and torch.equal(st, ref_stats)

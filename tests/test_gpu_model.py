@@ -87,6 +87,38 @@ def test_backbone_matches_reference_golden(sfod, native, dtype):
                                        atol=1e-6 if dtype in ("fp32", "f16x3") else 2e-5)
 
 
+def test_teacher_backbone_with_batchnorm_folded_into_the_next_conv(sfod, native, monkeypatch):
+    """SFOD.FUSE_BN_INPUT: in a forward-only train-mode pass (the teacher) the non-pooled layers leave BatchNorm + ReLU to the
+    next convolution's operand path.  Same features and running statistics as the layer-by-layer form, bit for bit when
+    both run the fold's tile shape, and the fold is actually taken at frame size."""
+    feats, stats, calls = {}, {}, {}
+    x = torch.randn(4, 3, 600, 1200, generator=torch.Generator().manual_seed(3)).to(DEV)    # the teacher's batch per GPU
+    native.set_conv3x3_m16(2)       # every pair conv on the fold's own tile shape: the two forms must then agree bit for bit
+    for on in (False, True):
+        cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "bf16x3", "SFOD.FUSE_BN_INPUT", on])
+        torch.manual_seed(5)
+        bb = sfod.modeling.backbone_vgg.build_vgg_backbone(cfg, None).to(DEV).train()
+        bb.fuse_bn_input_min_bytes = 0          # every served layer, also those where the fold does not pay
+        n = [0]
+        orig = native.conv_fwd_bnin
+
+        def counted(*a, _orig=orig, _n=n, **k):
+            _n[0] += 1
+            return _orig(*a, **k)
+        monkeypatch.setattr(native, "conv_fwd_bnin", counted)
+        with torch.no_grad():
+            feats[on] = {k: v.clone() for k, v in bb(x).items()}
+        monkeypatch.setattr(native, "conv_fwd_bnin", orig)
+        stats[on] = {k: v.clone() for k, v in bb.state_dict().items() if "running" in k or "num_batches" in k}
+        calls[on] = n[0]
+    native.set_conv3x3_m16(1)
+    assert calls[False] == 0 and calls[True] >= 5, calls      # conv2_2, conv3_2, conv3_3, conv4_2, conv4_3
+    for k in feats[False]:
+        assert torch.equal(feats[True][k], feats[False][k]), k
+    for k in stats[False]:
+        assert torch.equal(stats[True][k], stats[False][k]), k
+
+
 def test_dann_modules_match_reference_golden(sfod, native):
     fx = np.load(os.path.join(GOLDEN, "dann_ref.npz"), allow_pickle=False)
     dann = sfod.modeling.dann
