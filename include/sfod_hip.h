@@ -87,6 +87,16 @@ int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int 
 int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B, int H,
                      int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
                      void* stream);
+/* the same with device scratch the library may use (sfod_conv_fwd_scratch_bytes for the shape; 0 = none wanted, and the
+ * call is then sfod_conv_fwd_ws).  Today: linear layers (ksize 1, fp32 output, no statistics) with so few rows that their
+ * grid fills less than half the chip -- the ROI head's fc1 at one frame per GPU, 512 x 25088 -> 1024 -- run split along K;
+ * the scratch holds the S partial outputs (S x rows x Cout floats), summed in index order with bias and activation by a
+ * second launch (run-to-run identical; differs from the unsplit kernel by fp32 summation order).  scratch == NULL or too
+ * small: the unsplit kernel.  SFOD_GEMM_SPLITK=0 in the environment switches the split form off (A/B runs). */
+int64_t sfod_conv_fwd_scratch_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int dt, int out_dt, int with_stats);
+int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B, int H,
+                          int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
+                          void* scratch, int64_t scratch_bytes, void* stream);
 /* number of statistics blocks nblk sfod_conv_fwd writes for this layer shape; `stats` holds
  * nblk * (2*Cout + 1) floats */
 int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt);

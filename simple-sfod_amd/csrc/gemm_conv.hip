@@ -39,6 +39,9 @@ struct ConvArgs {
   int ldy;        // row stride of y
   int act;        // 0 none, 1 relu, 2 leaky relu 0.2
   const unsigned* wamax;   // SFOD_F16X3 weights packed with a per-tensor power-of-two scale (common.h): max|w| bits, or nullptr
+  int kt_per;     // split-K (blockIdx.y = split): K tiles per split, 0 = the whole K range in one workgroup
+  int nsplit;     // split-K: grid.y (host side)
+  int64_t slab;   // split-K: elements between the splits' output slabs
 };
 
 template <typename T> struct Chunk { static constexpr int E = 16 / sizeof(T); };
@@ -126,7 +129,12 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   int b_row[BI];
   for (int i = 0; i < BI; ++i) b_row[i] = (wave * BI + i) * RPI + lane / CPR;
   const int pc = lane % CPR;
-  const int KT = (a.kchunks + CPR - 1) / CPR;
+  // split-K: this workgroup walks K tiles kt0 .. kt0 + KT - 1 of the KT_all and writes its partial products into slab
+  // blockIdx.y (no bias, no activation: the launcher's slab sum applies them); kt_per == 0: everything, as before
+  const int KT_all = (a.kchunks + CPR - 1) / CPR;
+  const int kt0 = a.kt_per ? (int)blockIdx.y * a.kt_per : 0;
+  const int KT = a.kt_per ? min(a.kt_per, KT_all - kt0) : KT_all;
+  if (a.kt_per) y += (int64_t)blockIdx.y * a.slab;
   const int64_t wrow_elems = (int64_t)a.kchunks * E;
 
   // hoisted per-row state of the uniform-tap path
@@ -164,6 +172,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
   auto stage_load = [&](int kt, int buf) {
     unsigned char* sA = smem + buf * STAGE;
     unsigned char* sB = sA + BM * BKB;
+    kt += kt0;
     if (UT) {
       // scalar (wave-uniform) tap decode for the whole K tile
       const int gq0 = kt * CPR;
@@ -536,9 +545,63 @@ static int launch_one(const void* x, const void* w, const float* bias, void* y, 
   if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute: %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
   const int tiles_m = (a.M + BM - 1) / BM, tiles_n = (a.Cout + BN - 1) / BN;
   const int nt = tiles_m * tiles_n;
-  hipLaunchKernelGGL(kern, dim3(nt), dim3(WR * 128), LDS, s, (const T*)x, (const T*)w, bias, (OutT*)y, stats, a,
-                     tiles_n, nt);
+  hipLaunchKernelGGL(kern, dim3(nt, a.kt_per ? a.nsplit : 1), dim3(WR * 128), LDS, s, (const T*)x, (const T*)w, bias, (OutT*)y,
+                     stats, a, tiles_n, nt);
   return sfod_check_launch("conv_fwd");
+}
+
+// ---- split-K for linear layers with few rows ----------------------------------------------------------------------------
+// One frame per GPU (the yaml's literal batch): fc1 of the student is 512 x 25088 -> 1024 = 32 workgroups of 256 x 64 on 256
+// CUs, each walking 784 K tiles (0.6 ms for 26 GFLOP).  With the K range cut in S pieces the grid is S x 32, every piece
+// writes its fp32 partial tile into slab s of the caller's scratch, and k_splitk_sum adds the slabs in index order (fixed:
+// run-to-run identical) together with bias and activation.  Chosen only when the plain grid leaves half the chip idle and
+// every piece still has >= 16 K tiles; the scratch is S x M x Cout floats.
+static int splitk_plan(int M, int kchunks, int Cout, int ks, bool fp32_out, bool stats) {
+  static const int on = []() { const char* e = getenv("SFOD_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
+  if (!on || ks != 1 || !fp32_out || stats || M < 1) return 0;
+  const int64_t wgs = (int64_t)((M + 255) / 256) * ((Cout + 63) / 64);
+  const int KT_all = (kchunks + 7) / 8;
+  if (wgs > 128) return 0;
+  int S = (int)(256 / wgs);
+  if (S > 8) S = 8;
+  if (S > KT_all / 16) S = KT_all / 16;
+  return S >= 2 ? S : 0;
+}
+
+__global__ void __launch_bounds__(256) k_splitk_sum(const float* __restrict__ ws, int S, int64_t slab, int M, int Cout,
+                                                    const float* __restrict__ bias, int act, float* __restrict__ y, int ldy) {
+  const int cv = Cout / 4;
+  const int64_t total = (int64_t)M * cv;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int m = (int)(t / cv), n = (int)(t % cv) * 4;
+    float4 v = *reinterpret_cast<const float4*>(ws + (int64_t)m * Cout + n);
+    for (int sidx = 1; sidx < S; ++sidx) {
+      const float4 u = *reinterpret_cast<const float4*>(ws + sidx * slab + (int64_t)m * Cout + n);
+      v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+    }
+    if (bias != nullptr) { v.x += bias[n]; v.y += bias[n + 1]; v.z += bias[n + 2]; v.w += bias[n + 3]; }
+    v.x = apply_act(v.x, act); v.y = apply_act(v.y, act); v.z = apply_act(v.z, act); v.w = apply_act(v.w, act);
+    float* dst = y + (int64_t)m * ldy + n;
+    if (ldy % 4 == 0) *reinterpret_cast<float4*>(dst) = v;
+    else { dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w; }
+  }
+}
+
+template <typename T, int SPLIT>
+static int launch_splitk(const void* x, const void* w, const float* bias, float* y, ConvArgs a, int S, float* ws,
+                         hipStream_t s) {
+  const int KT_all = (a.kchunks + 7) / 8;
+  a.kt_per = (KT_all + S - 1) / S;
+  a.nsplit = (KT_all + a.kt_per - 1) / a.kt_per;       // no empty split
+  a.slab = (int64_t)a.M * a.Cout;
+  const int act = a.act, ldy = a.ldy;
+  a.act = 0; a.ldy = a.Cout;
+  const int rc = launch_one<T, float, 1, true, 4, 3, SPLIT>(x, w, nullptr, ws, nullptr, a, s);
+  if (rc != 0) return rc;
+  const int64_t total = (int64_t)a.M * (a.Cout / 4);
+  const int grid = (int)std::min<int64_t>((total + 255) / 256, 2048);
+  hipLaunchKernelGGL(k_splitk_sum, dim3(grid), dim3(256), 0, s, ws, a.nsplit, a.slab, a.M, a.Cout, bias, act, y, ldy);
+  return sfod_check_launch("splitk_sum");
 }
 
 // bf16x3, ksize 1, fp32 out: does the 256 x 256 tile serve this shape?  (SFOD_GEMM_WIDE = 0 never / 2 always: A/B runs)
@@ -633,6 +696,10 @@ extern "C" int sfod_conv_first_fused_ws(const void* x, const void* w, const uint
   return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, (hipStream_t)stream, scale, shift, split_code(dt), w_absmax);
 }
 
+extern "C" int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y,
+                                     int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats,
+                                     int dt, int out_dt, void* scratch, int64_t scratch_bytes, void* stream);
+
 extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
                              int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
                              int out_dt, void* stream) {
@@ -642,6 +709,24 @@ extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, vo
 extern "C" int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B,
                                 int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
                                 int out_dt, void* stream) {
+  return sfod_conv_fwd_scratch(x, w, w_absmax, bias, y, B, H, W, Cin, Cout, ksize, ldy, act, stats, dt, out_dt, nullptr, 0,
+                               stream);
+}
+
+// Scratch the caller may offer to sfod_conv_fwd_scratch for this shape (0: none wanted): today the slabs of the split-K form
+// of linear layers with few rows (splitk_plan above).
+extern "C" int64_t sfod_conv_fwd_scratch_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int dt, int out_dt,
+                                               int with_stats) {
+  if (dt != SFOD_F32 && dt != SFOD_BF16 && !sfod_is_pairs(dt)) return 0;
+  const int E = (dt == SFOD_F32) ? 4 : 8;
+  if (ksize != 1 || Cout % 4 != 0 || Cin % E != 0 || (int64_t)B * H * W == 0 || (int64_t)B * H * W > (1 << 24)) return 0;
+  const int S = splitk_plan(B * H * W, phys_ch(dt, Cin) / E, Cout, ksize, out_dt == SFOD_F32, with_stats != 0);
+  return (int64_t)S * B * H * W * Cout * 4;
+}
+
+extern "C" int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y,
+                                     int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats,
+                                     int dt, int out_dt, void* scratch, int64_t scratch_bytes, void* stream) {
   SFOD_REQUIRE(w_absmax == nullptr || dt == SFOD_F16X3, "conv: scaled weights are an SFOD_F16X3 format");
   SFOD_REQUIRE(ksize == 1 || ksize == 3, "conv: ksize must be 1 or 3");
   SFOD_REQUIRE(ldy >= Cout, "conv: ldy < Cout");
@@ -671,6 +756,17 @@ extern "C" int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_
     SFOD_REQUIRE(a.cpt_shift >= 0, "conv3x3: Cin/chunk must be a power of two");
   }
   a.kchunks = ksize * ksize * cpt;
+  a.kt_per = 0; a.nsplit = 1; a.slab = 0;
+  if (scratch != nullptr && Cout % 4 == 0 && (int64_t)a.M <= (1 << 24)) {
+    const int S = splitk_plan(a.M, a.kchunks, Cout, ksize, out_dt == SFOD_F32, stats != nullptr);
+    if (S >= 2 && scratch_bytes >= (int64_t)S * a.M * Cout * 4) {
+      float* ws = (float*)scratch;
+      if (dt == SFOD_F32) return launch_splitk<float, 0>(x, w, bias, (float*)y, a, S, ws, s);
+      if (split == 2) return launch_splitk<bf16_t, 2>(x, w, bias, (float*)y, a, S, ws, s);
+      if (split) return launch_splitk<bf16_t, 1>(x, w, bias, (float*)y, a, S, ws, s);
+      return launch_splitk<bf16_t, 0>(x, w, bias, (float*)y, a, S, ws, s);
+    }
+  }
   if (dt == SFOD_F32) {
     SFOD_REQUIRE(out_dt == SFOD_F32, "conv: fp32 compute writes fp32");
     return launch_conv_fwd<float, float>(x, w, bias, y, stats, a, s);

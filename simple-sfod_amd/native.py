@@ -631,8 +631,16 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
     if _timer is not None:
         _pending_tag = ":patch3x3" if query("sfod_conv_fwd_algo", B, H, W, cin, cout, ksize, dt) == 2 else ":gemm"
-    call("sfod_conv_fwd_ws", x, w_packed, wscale_of(w_packed), bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
-         dt_of_dtype(out_dtype), timer_name="sfod_conv_fwd")
+    odt = dt_of_dtype(out_dtype)
+    # linear layers with few rows (one frame per GPU): the library asks for slab scratch and splits along K
+    nscratch = load().sfod_conv_fwd_scratch_bytes(B, H, W, cin, cout, ksize, dt, odt, int(want_stats)) if ksize == 1 else 0
+    if nscratch > 0:
+        scratch = torch.empty(nscratch, dtype=torch.uint8, device=x.device)
+        call("sfod_conv_fwd_scratch", x, w_packed, wscale_of(w_packed), bias, y, B, H, W, cin, cout, ksize, ldy, act, stats,
+             dt, odt, scratch, nscratch, timer_name="sfod_conv_fwd")
+    else:
+        call("sfod_conv_fwd_ws", x, w_packed, wscale_of(w_packed), bias, y, B, H, W, cin, cout, ksize, ldy, act, stats, dt,
+             odt, timer_name="sfod_conv_fwd")
     _pending_tag = ""
     return (y, stats) if want_stats else y
 

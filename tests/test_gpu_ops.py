@@ -996,3 +996,39 @@ def test_bn_add_relu_fwd_equals_the_two_pass_form(native, dtype):
         ref16 = torch.relu((yd.float().cpu() - mean) * (invstd * gamma) + beta + rd.float().cpu())
         torch.testing.assert_close(got.float().cpu(), ref16, rtol=1e-2, atol=1e-2)
         assert (got.float().cpu() - ref16).abs().max() <= (ref16.abs().max() / 128)
+
+
+@pytest.mark.parametrize("dtype", ["bf16x3", "f16x3", "fp32"])
+@pytest.mark.parametrize("shape", [(512, 25088, 1024), (1000, 25088, 1024), (300, 4096, 260), (64, 1024, 1024)])
+def test_linear_split_k_for_few_rows(native, dtype, shape):
+    """sfod_conv_fwd_scratch: a linear layer whose grid would fill less than half the chip (the ROI head's fc1 at one frame
+    per GPU) runs split along K into slabs + a fixed-order slab sum with bias and activation.  Same values as the unsplit
+    kernel up to fp32 summation order, run-to-run identical, and shapes that fill the chip ask for no scratch."""
+    M, K, N = shape
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K, device=DEV, generator=g)
+    w = torch.randn(N, K, device=DEV, generator=g) / K ** 0.5
+    bias = torch.randn(N, device=DEV, generator=g)
+    if dtype == "bf16x3":
+        xo, wo, dt = native.cast(x, native.SPLIT_DTYPE), native.cast(w, native.SPLIT_DTYPE), native.BF16X3
+    elif dtype == "f16x3":
+        xo, wo, dt = native.cast(x, native.SPLITH_DTYPE), native.pack_fc_weight(w, native.F16X3), native.F16X3
+    else:
+        xo, wo, dt = x, w, native.F32
+    nbytes = native.load().sfod_conv_fwd_scratch_bytes(M, 1, 1, K, N, 1, dt, native.F32, 0)
+    assert native.load().sfod_conv_fwd_scratch_bytes(16000, 1, 1, K, N, 1, dt, native.F32, 0) == 0
+    assert native.load().sfod_conv_fwd_scratch_bytes(M, 1, 1, K, N, 1, dt, native.F32, 1) == 0     # statistics: unsplit
+    assert nbytes > 0 and nbytes % (M * N * 4) == 0
+    ref = torch.empty(M, N, device=DEV)
+    native.call("sfod_conv_fwd_ws", xo, wo, native.wscale_of(wo), bias, ref, M, 1, 1, K, N, 1, N, 1, None, dt, native.F32)
+    outs = [native.conv_fwd(xo, wo, bias, N, 1, act=1) for _ in range(3)]
+    wide = native.conv_fwd(xo, wo, bias, N, 1, act=1, ldy=N + 8)
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(wide[:, :N], outs[0]) and float(wide[:, N:].abs().max()) == 0.0
+    exact = torch.relu(x.double() @ w.double().t() + bias.double())
+    err_ref = ((ref.double() - exact).norm() / exact.norm()).item()
+    err_split = ((outs[0].double() - exact).norm() / exact.norm()).item()
+    assert err_split <= max(1.5 * err_ref, 2e-6), (err_split, err_ref)
+    # (true-fp32 products over K = 25088 carry ~3e-6 of summation-order noise themselves)
+    assert ((outs[0] - ref).double().norm() / ref.double().norm()).item() < max(2e-6, 3 * err_ref)
