@@ -555,16 +555,18 @@ static int launch_one(const void* x, const void* w, const float* bias, void* y, 
 // CUs, each walking 784 K tiles (0.6 ms for 26 GFLOP).  With the K range cut in S pieces the grid is S x 32, every piece
 // writes its fp32 partial tile into slab s of the caller's scratch, and k_splitk_sum adds the slabs in index order (fixed:
 // run-to-run identical) together with bias and activation.  Chosen only when the plain grid leaves half the chip idle and
-// every piece still has >= 16 K tiles; the scratch is S x M x Cout floats.
+// every piece still has >= 32 of at least 256 K tiles; the scratch is S x M x Cout floats.
 static int splitk_plan(int M, int kchunks, int Cout, int ks, bool fp32_out, bool stats) {
   static const int on = []() { const char* e = getenv("SFOD_GEMM_SPLITK"); return e ? atoi(e) : 1; }();
   if (!on || ks != 1 || !fp32_out || stats || M < 1) return 0;
   const int64_t wgs = (int64_t)((M + 255) / 256) * ((Cout + 63) / 64);
   const int KT_all = (kchunks + 7) / 8;
-  if (wgs > 128) return 0;
+  // long K only (fc1-class layers: >= 256 K tiles = 8192 logical channels in the pair modes): a short-K layer with few rows
+  // is a 10 us launch either way, and every split is one more fp32 summation order in the model
+  if (wgs > 128 || KT_all < 256) return 0;
   int S = (int)(256 / wgs);
   if (S > 8) S = 8;
-  if (S > KT_all / 16) S = KT_all / 16;
+  if (S > KT_all / 32) S = KT_all / 32;
   return S >= 2 ? S : 0;
 }
 

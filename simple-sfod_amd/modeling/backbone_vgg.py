@@ -113,6 +113,7 @@ class vgg_backbone(nn.Module):
         self.fuse_first = bool(cfg.SFOD.FUSE_FIRST_LAYER) if "SFOD" in cfg and "FUSE_FIRST_LAYER" in cfg.SFOD else True
         self.fuse_bn_input = bool(cfg.SFOD.FUSE_BN_INPUT) if "SFOD" in cfg and "FUSE_BN_INPUT" in cfg.SFOD else True
         self.fuse_bn_input_min_bytes = int(os.environ.get("SFOD_BNIN_MIN_BYTES", str(256 << 20)))
+        self.wgrad_stream = os.environ.get("SFOD_VGG_WGRAD_STREAM", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("SFOD_NO_FUSE_BN_REDUCE", "0") != "1"   # A/B hook
         # execution plan: (conv, bn, pool_after, stage_end)
         self._plan = []
@@ -318,6 +319,14 @@ class vgg_backbone(nn.Module):
             if stage_end:
                 s += 1
         dz = dz_red = None
+        # weight gradients on a second HIP stream beside the data-gradient chain (the two MFMA kernels of a layer's backward
+        # are independent): fills the chip where one kernel's grid does not -- one frame per GPU, the ragged last round of
+        # the deep layers (SFOD_VGG_WGRAD_STREAM=0: everything on one stream)
+        side, side_keep = None, []
+        if self.wgrad_stream and dz_dev_is_cuda(out_grads):
+            side = self.__dict__.get("_side_stream")
+            if side is None:
+                side = self.__dict__["_side_stream"] = torch.cuda.Stream()
         mid_hook = getattr(self, "_mid_backward", None)
         mid_layer = self._first_layer_of_stage(getattr(self, "_mid_stage", 2)) if mid_hook is not None else -1
         for li in range(len(self._plan) - 1, -1, -1):
@@ -342,7 +351,18 @@ class vgg_backbone(nn.Module):
             if direct_bn:
                 dgamma = dbeta = None
             cout, cin = conv.out_channels, conv.in_channels
-            dw = native.conv_weight_grad(x, dy, conv.weight)
+            if side is not None:
+                # dy is complete on the main stream; the weight gradient reads (x, dy) on the side stream while the main one
+                # goes on with the data gradient.  Both stay referenced until the join (their memory belongs to the main
+                # stream's pool and must not be handed out again before the side kernel has run)
+                ev = torch.cuda.Event()
+                ev.record()
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    dw = native.conv_weight_grad(x, dy, conv.weight)
+                side_keep.append((x, dy, dw))
+            else:
+                dw = native.conv_weight_grad(x, dy, conv.weight)
             # a conv bias followed by train-mode BN has an analytically zero gradient
             # (sum_rows dy == 0); the reference's autograd produces rounding noise around 0.
             db = None if native.grad_sink(conv.bias) is not None else torch.zeros_like(conv.bias)
@@ -363,8 +383,20 @@ class vgg_backbone(nn.Module):
                     dz = native.conv_fwd(dy, self._rot_w[li], None, cin, 3)
             del saved[li]
             if li == mid_layer and mid_hook is not None:
+                if side is not None:     # the collective is ordered behind the main stream: the side stream's gradients first
+                    torch.cuda.current_stream().wait_stream(side)
                 mid_hook()   # gradients of vgg2..vgg4 are in the flat buffer: GradientReducer.launch_mid
+        if side is not None:             # every weight gradient is in its buffer before anyone (all-reduce, SGD, autograd) reads it
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            for _, _, dw in side_keep:
+                if dw is not None:
+                    dw.record_stream(main)
         return pgrads
+
+
+def dz_dev_is_cuda(grads):
+    return any(g is not None and g.is_cuda for g in grads)
 
 
 @BACKBONE_REGISTRY.register()

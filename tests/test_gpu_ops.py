@@ -999,7 +999,7 @@ def test_bn_add_relu_fwd_equals_the_two_pass_form(native, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["bf16x3", "f16x3", "fp32"])
-@pytest.mark.parametrize("shape", [(512, 25088, 1024), (1000, 25088, 1024), (300, 4096, 260), (64, 1024, 1024)])
+@pytest.mark.parametrize("shape", [(512, 25088, 1024), (1000, 25088, 1024), (300, 16384, 260), (64, 50176, 2048)])
 def test_linear_split_k_for_few_rows(native, dtype, shape):
     """sfod_conv_fwd_scratch: a linear layer whose grid would fill less than half the chip (the ROI head's fc1 at one frame
     per GPU) runs split along K into slabs + a fixed-order slab sum with bias and activation.  Same values as the unsplit
@@ -1018,6 +1018,7 @@ def test_linear_split_k_for_few_rows(native, dtype, shape):
     nbytes = native.load().sfod_conv_fwd_scratch_bytes(M, 1, 1, K, N, 1, dt, native.F32, 0)
     assert native.load().sfod_conv_fwd_scratch_bytes(16000, 1, 1, K, N, 1, dt, native.F32, 0) == 0
     assert native.load().sfod_conv_fwd_scratch_bytes(M, 1, 1, K, N, 1, dt, native.F32, 1) == 0     # statistics: unsplit
+    assert native.load().sfod_conv_fwd_scratch_bytes(M, 1, 1, 1024, N, 1, dt, native.F32, 0) == 0  # short K: unsplit
     assert nbytes > 0 and nbytes % (M * N * 4) == 0
     ref = torch.empty(M, N, device=DEV)
     native.call("sfod_conv_fwd_ws", xo, wo, native.wscale_of(wo), bias, ref, M, 1, 1, K, N, 1, N, 1, None, dt, native.F32)
