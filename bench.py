@@ -190,7 +190,8 @@ def build_trainer(sfod, args, dtype, world, rank, local_rank):
         opts += ["SOLVER.IMS_PER_BATCH_TARGET", str(args.batch * world)]
     if args.no_overlap:
         opts += ["SFOD.OVERLAP_TEACHER", "False"]
-        os.environ["SFOD_RESNET_WGRAD_STREAM"] = "0"      # ... and the ResNet backward's weight gradients too: ONE stream
+        os.environ["SFOD_RESNET_WGRAD_STREAM"] = "0"      # ... and the backward's weight gradients too: ONE stream
+        os.environ["SFOD_VGG_WGRAD_STREAM"] = "0"
     if args.res == "full":
         opts += ["INPUT.MIN_SIZE_TRAIN", "(1024,)", "INPUT.MAX_SIZE_TRAIN", "2048"]
     yaml = YAML["vgg_base"] if args.trainer == "base" else YAML[args.model]
