@@ -34,3 +34,28 @@ def test_missing_library_fails_loudly(sfod, tmp_path):
             sfod.native.load(str(tmp_path / "nope.so"))
     finally:
         sfod.native._lib = saved
+
+
+def test_launch_planners_answer_without_a_gpu(sfod):
+    """The shape queries of the library are host logic: which layers the BatchNorm-input form serves and where the split-K
+    form of a linear layer asks for scratch (include/sfod_hip.h: sfod_conv_fwd_bnin_supported, sfod_conv_fwd_scratch_bytes)."""
+    n = sfod.native
+    lib = n.load()
+    # BatchNorm-input convolution: bf16x3 only, only where the planner runs the 256 x 128 shape (enough tiles to fill the chip)
+    assert lib.sfod_conv_fwd_bnin_supported(8, 150, 300, 256, 256, n.BF16X3) == 1       # conv3_2 of a teacher batch
+    assert lib.sfod_conv_fwd_bnin_supported(8, 300, 600, 128, 128, n.BF16X3) == 1       # conv2_2
+    assert lib.sfod_conv_fwd_bnin_supported(1, 150, 300, 256, 256, n.BF16X3) == 0       # one frame: the 64-channel shape runs
+    assert lib.sfod_conv_fwd_bnin_supported(8, 150, 300, 256, 256, n.F16X3) == 0
+    assert lib.sfod_conv_fwd_bnin_supported(8, 150, 300, 256, 256, n.F32) == 0
+    assert lib.sfod_conv_fwd_bnin_supported(8, 600, 1200, 8, 64, n.BF16X3) == 0         # first layer: its own kernel
+    assert lib.sfod_conv_fwd_bnin_supported(0, 150, 300, 256, 256, n.BF16X3) == 0
+    # split-K: linear layers (ksize 1, fp32 out, no statistics) with few rows and a long K
+    for dt in (n.BF16X3, n.F16X3, n.F32):
+        b = lib.sfod_conv_fwd_scratch_bytes(512, 1, 1, 25088, 1024, 1, dt, n.F32, 0)    # fc1 of the ROI head, one frame per GPU
+        assert b > 0 and b % (512 * 1024 * 4) == 0 and 2 <= b // (512 * 1024 * 4) <= 8
+        assert lib.sfod_conv_fwd_scratch_bytes(4096, 1, 1, 25088, 1024, 1, dt, n.F32, 0) == 0      # eight frames: fills the chip
+        assert lib.sfod_conv_fwd_scratch_bytes(512, 1, 1, 1024, 1024, 1, dt, n.F32, 0) == 0        # short K
+        assert lib.sfod_conv_fwd_scratch_bytes(512, 1, 1, 25088, 1024, 1, dt, n.F32, 1) == 0       # statistics wanted
+        assert lib.sfod_conv_fwd_scratch_bytes(1, 37, 75, 512, 512, 3, dt, n.F32, 0) == 0          # 3x3: never
+    assert lib.sfod_conv_fwd_scratch_bytes(512, 1, 1, 25088, 1024, 1, n.BF16, n.BF16, 0) == 0      # 2-byte output: unsplit
+    assert lib.sfod_last_error() == b""

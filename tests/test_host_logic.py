@@ -380,3 +380,44 @@ def test_split_precision_definitions_and_their_own_error():
     e_h_unscaled = err(xh @ wh.t() + xh @ wl.t() + xl @ wh.t())
     assert 2e-6 < e_bf < 8e-6 and e_h < 2e-7 and e_h < e_bf / 20, (e_bf, e_h)
     assert e_h_unscaled > 2.5 * e_h, (e_h_unscaled, e_h)
+
+
+def test_teacher_pass_defers_batchnorm_only_where_it_pays(sfod, monkeypatch):
+    """backbone_vgg._defer_bn (SFOD.FUSE_BN_INPUT): a layer's BatchNorm + ReLU is left to the next convolution only in a
+    forward-only train-mode pass, only for layers nobody else reads (no pooling, not a stage output), only where the library
+    serves the consumer's shape and only where the pre-BatchNorm tensor is larger than the Infinity Cache."""
+    yaml = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "configs",
+                        "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml")
+    cfg = sfod.config.setup_cfg(yaml, ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", "bf16x3"])
+    bb = sfod.modeling.backbone_vgg.build_vgg_backbone(cfg, None).train()
+    assert bb.fuse_bn_input and bb.fuse_bn_input_min_bytes == 256 << 20
+    asked = []
+    monkeypatch.setattr(sfod.native, "conv_fwd_bnin_supported", lambda y, w, cout: asked.append((tuple(y.shape), cout)) or True)
+    names = ["conv1_1", "conv1_2", "conv2_1", "conv2_2", "conv3_1", "conv3_2", "conv3_3", "conv4_1", "conv4_2", "conv4_3",
+             "conv5_1", "conv5_2", "conv5_3"]
+    assert len(bb._plan) == len(names)
+    fwd_w = [None] * len(names)
+
+    def deferred(batch, save=False, training=True):
+        out = []
+        h, w = 600, 1200
+        for li, (conv, _, pool, _) in enumerate(bb._plan):
+            y = torch.empty(batch, h, w, conv.out_channels, device="meta")
+            if bb._defer_bn(li, y, fwd_w, save, training):
+                out.append(names[li])
+            if pool:
+                h, w = h // 2, w // 2
+        return out
+
+    # a teacher batch of 8 frames: conv2_1 (737 MB), conv3_1 / conv3_2 (368 MB); conv1_1 is 2.9 GB but the first layer has its
+    # own fused form upstream of this decision; conv4_x (184 MB) fits the cache
+    assert deferred(8) == ["conv1_1", "conv2_1", "conv3_1", "conv3_2"]
+    assert deferred(1) == []                                # one frame: every tensor fits the cache (conv1_1: 184 MB)
+    assert deferred(8, save=True) == [] and deferred(8, training=False) == []
+    bb.fuse_bn_input_min_bytes = 0                          # every non-pooled, non-stage-end layer the library serves
+    assert deferred(8) == ["conv1_1", "conv2_1", "conv3_1", "conv3_2", "conv4_1", "conv4_2", "conv5_1", "conv5_2"]
+    bb.fuse_bn_input = False
+    assert deferred(8) == []
+    monkeypatch.setattr(sfod.native, "conv_fwd_bnin_supported", lambda y, w, cout: False)
+    bb.fuse_bn_input = True
+    assert deferred(8) == []
