@@ -471,12 +471,15 @@ int sfod_aug_erase(uint8_t* img, int C, int H, int W, int i, int j, int h, int w
  * d2 build_optimizer + torch SGD (Appendix A.15) and _update_teacher_model
  * (source_free_adaptive_teacher.py:583-603).  lr is a device scalar (no host sync on schedule).
  * first_step: momentum buffer is initialised to the gradient (torch SGD semantics).
- * teacher may be NULL (no EMA). */
+ * teacher may be NULL (no EMA).
+ * ema_one_minus_keep: the caller's (1 - k) computed in double and rounded once (the reference multiplies by the python
+ * float 1 - keep_rate); the kernels use two rounded products and a rounded sum like torch's op chain, so the teacher
+ * is bit-identical to _update_teacher_model's (tests/golden/glue_ref.npz). */
 int sfod_sgd_ema(float* param, const float* grad, float* mom, float* teacher, int64_t n,
                  const float* lr, float momentum, float weight_decay, float grad_scale,
-                 float ema_keep, int first_step, void* stream);
+                 float ema_keep, float ema_one_minus_keep, int first_step, void* stream);
 /* t = s*(1-k) + t*k  on fp32 buffers (BN running stats) */
-int sfod_ema(float* teacher, const float* student, int64_t n, float keep, void* stream);
+int sfod_ema(float* teacher, const float* student, int64_t n, float keep, float one_minus_keep, void* stream);
 /* the same update on the int64 buffers (num_batches_tracked): fp32 arithmetic, truncated on the way back like the
  * reference's load_state_dict copy (source_free_adaptive_teacher.py:583-603, SURVEY A.17 iv).  Both factors are passed
  * as the caller rounded them (torch rounds the Python doubles k and 1 - k to fp32 separately). */

@@ -58,7 +58,18 @@ def gen_vgg():
     x.requires_grad_(True)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
     feats = model(x)
-    feats["vgg4"].sum().backward()
+    feats["vgg4"].sum().backward(retain_graph=True)
+    input_grad = x.grad.clone()
+    # parameter gradients of the reference's backward (conv weights, BatchNorm weight / bias; the conv biases in front of a
+    # train-mode BatchNorm have an analytically zero gradient) for a non-degenerate loss: sum over stages of <vgg_i, r_i>
+    model.zero_grad()
+    x.grad = None
+    gr = torch.Generator().manual_seed(4321)
+    rs = {i: torch.randn(feats[f"vgg{i}"].shape, generator=gr) for i in (2, 3, 4)}
+    sum((feats[f"vgg{i}"] * rs[i]).sum() for i in rs).backward()
+    pgrads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    input_grad2 = x.grad.clone()
+    x.grad = input_grad
     out = {
         "seed": np.int64(seed),
         "input": x.detach().numpy(),
@@ -79,6 +90,17 @@ def gen_vgg():
             out["wsum/" + k] = checksum(v)
         if "running" in k or "num_batches" in k:
             out["after/" + k] = sd1[k].numpy()
+    # the backward's fixture: per parameter the norm, a checksum and <= 4096 strided samples of the gradient
+    out["bwd_seed"] = np.int64(4321)
+    out["bwd_stages"] = np.array([2, 3, 4])
+    out["bwd_input_grad"] = input_grad2.numpy()
+    for k, gk in pgrads.items():
+        flat = gk.flatten()
+        stride = max(1, flat.numel() // 4096)
+        out["gnorm/" + k] = np.float64(flat.double().norm().item())
+        out["gsum/" + k] = checksum(gk)
+        out["gstride/" + k] = np.int64(stride)
+        out["g/" + k] = flat[::stride].numpy().copy()
     np.savez_compressed(os.path.join(OUT, "vgg_ref.npz"), **out)
     print("vgg_ref.npz:", {k: feats[k].shape for k in feats})
 
@@ -224,6 +246,275 @@ def gen_bpc():
     print("bpc_ref.npz:", cases)
 
 
+def _ref_modules():
+    """the reference's glue files, loaded by file path behind ``oracle/ref_stub/hook.py``"""
+    sys.path.insert(0, os.path.join(HERE, "ref_stub"))
+    import hook
+    hook.install()
+    mods = types.SimpleNamespace(hook=hook)
+    mods.trainer = _load_by_path("ref_sfat", os.path.join(REF, "daod/engine/trainers/source_free_adaptive_teacher.py"))
+    mods.frcnn = _load_by_path("ref_frcnn", os.path.join(REF, "daod/modeling/roi_heads/source_free_fast_rcnn.py"))
+    mods.common = _load_by_path("ref_common", os.path.join(REF, "daod/data/common.py"))
+    mods.rpn = _load_by_path("ref_rpn", os.path.join(REF, "daod/modeling/proposal_generator/rpn.py"))
+    mods.base = _load_by_path("ref_base", os.path.join(REF, "daod/engine/trainers/base.py"))
+    mods.config = _load_by_path("ref_config", os.path.join(REF, "daod/config.py"))
+    return mods
+
+
+def gen_glue():
+    """Reference-OWNED glue of the hot path, run here (not restated) and recorded -> ``tests/golden/glue_ref.npz`` +
+    ``config_ref.json``.  Every function is the reference's own code object, loaded from its file under
+    /root/reference behind the import hook and called unbound on a stub ``self``:
+
+      a6  ``SourceFreeFastRCNNOutputLayers.fast_rcnn_inference_new`` / ``..._single_image_new``
+          (daod/modeling/roi_heads/source_free_fast_rcnn.py:38-147): finite mask, background column dropped, clip,
+          ``scores > 0``, row index; class-specific and class-agnostic boxes
+      a7  ``threshold_bbox`` (roih + rpn) and ``process_pseudo_label`` (source_free_adaptive_teacher.py:150-183,256-280)
+          with scores exactly at float32(0.8) and one ulp either side
+      a9  ``_update_teacher_model`` (:583-603) on a conv + BatchNorm model: parameters, float buffers and the int64
+          ``num_batches_tracked`` (int64 * float -> float32 -> truncating copy), single process and under the DDP
+          ``module.`` prefix, the missing-key exception
+      a13 ``AspectRatioGroupedSemiSupDatasetTwoCropSourceFree.__iter__`` (daod/data/common.py:199-228): batch order
+      a4  ``PseudoLabRPN.forward`` (daod/modeling/proposal_generator/rpn.py:16-58): the (N,A,H,W)->(N,HWA) and
+          (N,4A,H,W)->(N,HWA,4) layout and the second multiplication by ``loss_weight``
+      a11 ``reset_bn_stats`` / ``recursive_traversal`` (daod/engine/trainers/base.py:318-328)
+      b   ``add_config`` (daod/config.py:8-142): every key and default it assigns
+    """
+    import json
+    m = _ref_modules()
+    from detectron2.structures import Boxes, Instances
+    g = torch.Generator().manual_seed(2024)
+    out = {"torch_version": np.array(torch.__version__)}
+
+    # ---- a6 ------------------------------------------------------------------------------------------------------
+    K = 8
+    layers = object.__new__(m.frcnn.SourceFreeFastRCNNOutputLayers)
+    sizes = [(60, 100), (75, 50)]
+    boxes_l, scores_l = [], []
+    for i, (h, w) in enumerate(sizes):
+        R = 37 + 5 * i
+        xy = torch.rand(R, K, 2, generator=g) * torch.tensor([w * 1.3, h * 1.3]) - torch.tensor([w * 0.15, h * 0.15])
+        wh = torch.rand(R, K, 2, generator=g) * 40
+        bx = torch.cat([xy, xy + wh], dim=2).reshape(R, 4 * K)
+        logits = torch.randn(R, K + 1, generator=g) * 4
+        logits[3, 2] = -200.0          # softmax underflows to exactly 0: dropped by ``scores > 0``
+        logits[5, :K] = -300.0         # a row whose foreground probabilities are all exactly 0
+        sc = torch.softmax(logits, dim=-1)
+        bx[7, 5] = float("nan")        # non-finite rows are removed BEFORE indexing: the row index skips them
+        bx[11, 0] = float("inf")
+        sc[20, 1] = float("nan")
+        boxes_l.append(bx)
+        scores_l.append(sc)
+    props = [Instances(s) for s in sizes]
+    res, kept = layers.fast_rcnn_inference_new([b.clone() for b in boxes_l], [s.clone() for s in scores_l], sizes,
+                                               0.05, 0.5, 100, props)
+    for i in range(2):
+        out[f"frcnn_boxes_in_{i}"], out[f"frcnn_scores_in_{i}"] = boxes_l[i].numpy(), scores_l[i].numpy()
+        out[f"frcnn_size_{i}"] = np.array(sizes[i])
+        out[f"frcnn_pred_boxes_{i}"] = res[i].pred_boxes.tensor.numpy()
+        out[f"frcnn_scores_{i}"] = res[i].scores.numpy()
+        out[f"frcnn_pred_classes_{i}"] = res[i].pred_classes.numpy()
+        out[f"frcnn_row_{i}"] = kept[i].numpy()
+    # class-agnostic regression (boxes R x 4): every class of a row shares the row's box
+    bx1 = boxes_l[0][:, :4].clone()
+    r1, k1 = layers.fast_rcnn_inference_single_image_new(bx1.clone(), scores_l[0].clone(), sizes[0], 0.05, 0.5, 100, props[0])
+    out["frcnn_agn_boxes_in"] = bx1.numpy()
+    out["frcnn_agn_pred_boxes"], out["frcnn_agn_scores"] = r1.pred_boxes.tensor.numpy(), r1.scores.numpy()
+    out["frcnn_agn_pred_classes"], out["frcnn_agn_row"] = r1.pred_classes.numpy(), k1.numpy()
+
+    # ---- a7 ------------------------------------------------------------------------------------------------------
+    tr = object.__new__(m.trainer.SourceFreeAdaptiveTeacherTrainer)
+    thr = 0.8
+    t32 = np.float32(thr)
+    insts = []
+    for i, n in enumerate((100, 0, 17)):
+        sc = torch.rand(n, generator=g)
+        if n >= 6:
+            sc[:6] = torch.tensor([t32, np.nextafter(t32, np.float32(1)), np.nextafter(t32, np.float32(0)), 1.0, 0.0, 0.9])
+        sc = sc.sort(descending=True).values      # what the teacher's fast_rcnn_inference hands over: NMS order = by score
+        p = Instances((600, 1200))
+        p.pred_boxes = Boxes(torch.rand(n, 4, generator=g) * 500)
+        p.scores = sc
+        p.pred_classes = torch.randint(0, K, (n,), generator=g)
+        insts.append(p)
+    lst, mean_n = m.trainer.SourceFreeAdaptiveTeacherTrainer.process_pseudo_label(tr, insts, thr, "roih", "thresholding")
+    out["thr"] = np.float64(thr)
+    out["pl_mean_count"] = np.float64(mean_n)
+    for i, (p, q) in enumerate(zip(insts, lst)):
+        out[f"pl_in_boxes_{i}"], out[f"pl_in_scores_{i}"] = p.pred_boxes.tensor.numpy(), p.scores.numpy()
+        out[f"pl_in_classes_{i}"] = p.pred_classes.numpy()
+        out[f"pl_gt_boxes_{i}"], out[f"pl_gt_classes_{i}"] = q.gt_boxes.tensor.numpy(), q.gt_classes.numpy()
+        out[f"pl_scores_{i}"] = q.scores.numpy()
+        out[f"pl_fields_{i}"] = np.array(sorted(q.get_fields().keys()))
+    rp = Instances((600, 1200))
+    rp.proposal_boxes = Boxes(torch.rand(50, 4, generator=g) * 500)
+    lg = torch.randn(50, generator=g) * 3
+    lg[:3] = torch.tensor([t32, np.nextafter(t32, np.float32(1)), np.nextafter(t32, np.float32(0))])
+    rp.objectness_logits = lg
+    q = m.trainer.SourceFreeAdaptiveTeacherTrainer.threshold_bbox(tr, rp, thres=thr, proposal_type="rpn")
+    out["rpn_in_boxes"], out["rpn_in_logits"] = rp.proposal_boxes.tensor.numpy(), lg.numpy()
+    out["rpn_gt_boxes"], out["rpn_logits"] = q.gt_boxes.tensor.numpy(), q.objectness_logits.numpy()
+    out["rpn_fields"] = np.array(sorted(q.get_fields().keys()))
+    try:
+        m.trainer.SourceFreeAdaptiveTeacherTrainer.process_pseudo_label(tr, insts, thr, "roih", "no_such_method")
+        out["pl_error"] = np.array("")
+    except ValueError as e:
+        out["pl_error"] = np.array(str(e))
+
+    # ---- a9 ------------------------------------------------------------------------------------------------------
+    def small_model(seed):
+        torch.manual_seed(seed)
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 6, 3), torch.nn.BatchNorm2d(6), torch.nn.Conv2d(6, 4, 1),
+                                  torch.nn.BatchNorm2d(4), torch.nn.Linear(5, 3))
+        with torch.no_grad():
+            for mod in net:
+                if isinstance(mod, torch.nn.BatchNorm2d):
+                    mod.running_mean.normal_()
+                    mod.running_var.uniform_(0.5, 2.0)
+        return net
+    student, teacher = small_model(1), small_model(2)
+    counters = [(3, 7), (1000, 4), (12, 12), (0, 1), (5, 123456789)]      # (student, teacher) num_batches_tracked
+    out["ema_keys"] = np.array(list(teacher.state_dict().keys()))
+    for k, v in student.state_dict().items():
+        out["ema_s/" + k] = v.numpy().copy()
+    for k, v in teacher.state_dict().items():
+        out["ema_t0/" + k] = v.numpy().copy()
+    stub = types.SimpleNamespace(model=student, model_teacher=teacher)
+    out["ema_counters"] = np.array(counters)
+    out["ema_keep"] = np.array([0.9996, 0.9996, 0.9, 0.5, 0.9996])
+    for step, ((cs, ct), keep) in enumerate(zip(counters, out["ema_keep"].tolist())):
+        student[1].num_batches_tracked.fill_(cs)
+        teacher[1].num_batches_tracked.fill_(ct)
+        student[3].num_batches_tracked.fill_(cs + 1)
+        teacher[3].num_batches_tracked.fill_(ct + 2)
+        m.trainer.SourceFreeAdaptiveTeacherTrainer._update_teacher_model(stub, keep_rate=keep)
+        for k, v in teacher.state_dict().items():
+            out[f"ema_t{step + 1}/" + k] = v.numpy().copy()
+    # DDP: the student's keys carry ``module.`` (key[7:] strips it)
+    m.hook.set_world_size(2)
+    teacher2 = small_model(2)
+    wrapped = types.SimpleNamespace(state_dict=lambda: {"module." + k: v for k, v in student.state_dict().items()})
+    stub2 = types.SimpleNamespace(model=wrapped, model_teacher=teacher2)
+    teacher2[1].num_batches_tracked.fill_(7)
+    student[1].num_batches_tracked.fill_(3)
+    t2_before = {k: v.clone() for k, v in teacher2.state_dict().items()}
+    m.trainer.SourceFreeAdaptiveTeacherTrainer._update_teacher_model(stub2, keep_rate=0.9996)
+    for k, v in teacher2.state_dict().items():
+        out["ema_ddp_t0/" + k] = t2_before[k].numpy()
+        out["ema_ddp_t1/" + k] = v.numpy().copy()
+    for k, v in student.state_dict().items():
+        out["ema_ddp_s/" + k] = v.numpy().copy()
+    m.hook.set_world_size(1)
+    short = types.SimpleNamespace(state_dict=lambda: {k: v for k, v in student.state_dict().items() if not k.startswith("4.")})
+    try:
+        m.trainer.SourceFreeAdaptiveTeacherTrainer._update_teacher_model(
+            types.SimpleNamespace(model=short, model_teacher=teacher), keep_rate=0.9996)
+        out["ema_error"] = np.array("")
+    except Exception as e:
+        out["ema_error"] = np.array(str(e))
+
+    # ---- a13 -----------------------------------------------------------------------------------------------------
+    wh = [(1200, 600), (600, 1200), (800, 800), (1333, 750), (500, 900)]
+    choice = torch.randint(0, len(wh), (60,), generator=g).tolist()
+    stream = [({"width": wh[c][0], "height": wh[c][1], "image_id": 2 * i}, {"width": wh[c][0], "height": wh[c][1],
+               "image_id": 2 * i + 1}) for i, c in enumerate(choice)]
+    out["bucket_wh"] = np.array([wh[c] for c in choice])
+    for bs in (1, 2, 3, 4):
+        ds = m.common.AspectRatioGroupedSemiSupDatasetTwoCropSourceFree(iter(stream), bs)
+        batches = list(iter(ds))
+        out[f"bucket_strong_ids_b{bs}"] = np.array([[d["image_id"] for d in s] for s, w in batches]).reshape(-1, bs)
+        out[f"bucket_weak_ids_b{bs}"] = np.array([[d["image_id"] for d in w] for s, w in batches]).reshape(-1, bs)
+
+    # ---- a4 ------------------------------------------------------------------------------------------------------
+    N, A, Hf, Wf = 2, 15, 4, 5
+    logits = torch.randn(N, A, Hf, Wf, generator=g)
+    deltas = torch.randn(N, 4 * A, Hf, Wf, generator=g)
+    cap = {}
+    rpn = object.__new__(m.rpn.PseudoLabRPN)
+    rpn.in_features = ["vgg4"]
+    rpn.training = True
+    rpn.anchor_generator = lambda feats: ["anchors"]
+    rpn.anchor_generator.box_dim = 4
+    rpn.rpn_head = lambda feats: ([logits], [deltas])
+    rpn.label_and_sample_anchors = lambda anchors, gt: ("labels", "boxes")
+    rpn.loss_weight = {"loss_rpn_cls": 1.5, "loss_rpn_loc": 0.5}
+
+    def losses(anchors, lg_, labels, dl_, boxes):
+        cap["loss_args"] = (lg_, dl_)
+        return {"loss_rpn_cls": torch.tensor(2.0), "loss_rpn_loc": torch.tensor(3.0), "other": torch.tensor(7.0)}
+
+    def predict(anchors, lg_, dl_, image_sizes):
+        cap["pred_args"] = (lg_, dl_, image_sizes)
+        return "proposals"
+    rpn.losses, rpn.predict_proposals = losses, predict
+    images = types.SimpleNamespace(image_sizes=[(64, 80), (60, 80)])
+    p_, l_ = m.rpn.PseudoLabRPN.forward(rpn, images, {"vgg4": torch.zeros(N, 1, Hf, Wf)}, gt_instances=["gt"])
+    out["rpn_glue_logits_in"], out["rpn_glue_deltas_in"] = logits.numpy(), deltas.numpy()
+    out["rpn_glue_logits_flat"] = cap["pred_args"][0][0].numpy()
+    out["rpn_glue_deltas_flat"] = cap["pred_args"][1][0].numpy()
+    out["rpn_glue_loss_keys"] = np.array(sorted(l_.keys()))
+    out["rpn_glue_loss_vals"] = np.array([float(l_[k]) for k in sorted(l_.keys())])
+    rpn.training = False            # eval and not compute_val_loss: no losses, proposals still produced
+    p2, l2 = m.rpn.PseudoLabRPN.forward(rpn, images, {"vgg4": torch.zeros(N, 1, Hf, Wf)})
+    _, l3 = m.rpn.PseudoLabRPN.forward(rpn, images, {"vgg4": torch.zeros(N, 1, Hf, Wf)}, compute_val_loss=True)
+    rpn.training = True
+    _, l4 = m.rpn.PseudoLabRPN.forward(rpn, images, {"vgg4": torch.zeros(N, 1, Hf, Wf)}, compute_loss=False)
+    out["rpn_glue_branches"] = np.array([len(l_), len(l2), len(l3), len(l4)])
+
+    # ---- a11 -----------------------------------------------------------------------------------------------------
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4),
+                              torch.nn.Sequential(torch.nn.Conv2d(4, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.ReLU()))
+    with torch.no_grad():
+        for mod in net.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.running_mean.normal_()
+                mod.running_var.uniform_(0.5, 2.0)
+                mod.num_batches_tracked.fill_(41)
+                mod.weight.normal_()
+    keys_before = list(net.state_dict().keys())
+    w_before = net[1].weight.detach().clone()
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        m.base.recursive_traversal(net)
+        m.base.recursive_traversal(net)        # the reference calls it twice (base.py:331-332)
+    sd = net.state_dict()
+    out["adabn_keys_before"], out["adabn_keys_after"] = np.array(keys_before), np.array(list(sd.keys()))
+    for k, v in sd.items():
+        if "running" in k or "num_batches" in k:
+            out["adabn_after/" + k] = v.numpy().copy()
+    out["adabn_weight_untouched"] = np.array(bool(torch.equal(net[1].weight.detach(), w_before)))
+    out["adabn_param_names"] = np.array([n for n, _ in net.named_parameters()])
+    out["adabn_requires_grad"] = np.array([bool(p.requires_grad) for _, p in net.named_parameters()])
+    # a train-mode forward still refreshes the (now Parameter) statistics with momentum 0.1
+    net.train()
+    x = torch.randn(2, 3, 12, 12, generator=g)
+    with torch.no_grad():
+        net(x)
+    out["adabn_x"] = x.numpy()
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            out["adabn_fwd/" + k] = v.numpy().copy()
+    for k, v in net.state_dict().items():
+        if k.endswith("weight") or k.endswith("bias"):
+            out["adabn_w/" + k] = v.numpy().copy()
+
+    np.savez_compressed(os.path.join(OUT, "glue_ref.npz"), **out)
+
+    # ---- b: add_config -------------------------------------------------------------------------------------------
+    node = m.hook.RecordingNode()
+    m.config.add_config(node)
+
+    def plain(n):
+        return {k: (plain(v) if isinstance(v, dict) else (list(v) if isinstance(v, tuple) else v)) for k, v in n.items()}
+    with open(os.path.join(OUT, "config_ref.json"), "w") as f:
+        json.dump({"source": "daod/config.py::add_config run on a recording node", "assigned": plain(node)}, f, indent=1,
+                  sort_keys=True)
+    m.hook.uninstall()
+    print("glue_ref.npz: frcnn rows", [len(k) for k in kept], "pseudo mean", mean_n, "ema err:", str(out["ema_error"]),
+          "buckets b2:", out["bucket_weak_ids_b2"].shape, "cfg keys:", sorted(node.keys()))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "--upstream":
@@ -244,7 +535,14 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "bpc":
         gen_bpc()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "glue":
+        gen_glue()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vgg":
+        gen_vgg()
+        sys.exit(0)
     gen_vgg()
     gen_dann()
     gen_adaptive()
     gen_bpc()
+    gen_glue()

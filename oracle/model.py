@@ -238,6 +238,11 @@ def rpn_head(sd, feat):
     t = F.relu(F.conv2d(feat, sd[r + "conv.weight"], sd[r + "conv.bias"], padding=1))
     obj = F.conv2d(t, sd[r + "objectness_logits.weight"], sd[r + "objectness_logits.bias"])
     dlt = F.conv2d(t, sd[r + "anchor_deltas.weight"], sd[r + "anchor_deltas.bias"])
+    return rpn_flatten(obj, dlt)
+
+
+def rpn_flatten(obj, dlt):
+    """(N,A,H,W) -> (N,H*W*A) and (N,4A,H,W) -> (N,H*W*A,4) (rpn.py:28-41; pinned by tests/golden/glue_ref.npz)."""
     n, a, h, w = obj.shape
     logits = obj.permute(0, 2, 3, 1).flatten(1)
     deltas = dlt.view(n, a, 4, h, w).permute(0, 3, 4, 1, 2).flatten(1, -2)
@@ -411,16 +416,24 @@ def convert_bbox_scores(scores, deltas, boxes_per_image, image_sizes, cfg):
             sc = F.softmax(scores[off:off + n], dim=-1)
             bx = B.apply_deltas(deltas[off:off + n], pb, cfg.roi_bbox_weights)
             off += n
-            valid = torch.isfinite(bx).all(dim=1) & torch.isfinite(sc).all(dim=1)
-            if not valid.all():
-                bx, sc = bx[valid], sc[valid]
-            sc = sc[:, :-1]
-            bx = B.clip_boxes(bx.reshape(-1, 4), size).view(-1, K, 4)
-            mask = sc > 0
-            inds = mask.nonzero()
-            # roi_idx: ``filter_inds[:, 0]`` (:147) -- an index into the rows that survived the finite filter
-            out.append({"boxes": bx[mask], "scores": sc[mask], "classes": inds[:, 1], "roi_idx": inds[:, 0]})
+            out.append(frcnn_inference_new_single(bx, sc, size))
     return out
+
+
+def frcnn_inference_new_single(bx, sc, size):
+    """``fast_rcnn_inference_single_image_new`` (source_free_fast_rcnn.py:82-147; pinned by tests/golden/glue_ref.npz):
+    per-class boxes [R, 4K] (or class-agnostic [R, 4]) and probabilities [R, K+1] -> every (row, class) with score > 0."""
+    valid = torch.isfinite(bx).all(dim=1) & torch.isfinite(sc).all(dim=1)
+    if not valid.all():
+        bx, sc = bx[valid], sc[valid]
+    sc = sc[:, :-1]
+    nreg = bx.shape[1] // 4
+    bx = B.clip_boxes(bx.reshape(-1, 4), size).view(-1, nreg, 4)
+    mask = sc > 0
+    inds = mask.nonzero()
+    # roi_idx: ``filter_inds[:, 0]`` (:147) -- an index into the rows that survived the finite filter
+    boxes = bx[inds[:, 0], 0] if nreg == 1 else bx[mask]
+    return {"boxes": boxes, "scores": sc[mask], "classes": inds[:, 1], "roi_idx": inds[:, 0]}
 
 
 def bpc_loss(class_number, gts, dets, iou_thresh=0.5):

@@ -1788,10 +1788,12 @@ k_sgd_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict_
     reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
     if (t) {
       float4 tv = reinterpret_cast<float4*>(t)[i];
-      tv.x = pp[0] * one_minus_keep + tv.x * keep;
-      tv.y = pp[1] * one_minus_keep + tv.y * keep;
-      tv.z = pp[2] * one_minus_keep + tv.z * keep;
-      tv.w = pp[3] * one_minus_keep + tv.w * keep;
+      // the reference's operation order (student * (1 - k) + teacher * k in torch ops): two rounded products, a rounded
+      // sum, no contraction -- bit-identical to _update_teacher_model (tests/golden/glue_ref.npz)
+      tv.x = __fadd_rn(__fmul_rn(pp[0], one_minus_keep), __fmul_rn(tv.x, keep));
+      tv.y = __fadd_rn(__fmul_rn(pp[1], one_minus_keep), __fmul_rn(tv.y, keep));
+      tv.z = __fadd_rn(__fmul_rn(pp[2], one_minus_keep), __fmul_rn(tv.z, keep));
+      tv.w = __fadd_rn(__fmul_rn(pp[3], one_minus_keep), __fmul_rn(tv.w, keep));
       reinterpret_cast<float4*>(t)[i] = tv;
     }
   }
@@ -1804,15 +1806,17 @@ k_sgd_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict_
     const float pp = p[i] - lr * mm;
     p[i] = pp;
     m[i] = mm;
-    if (t) t[i] = pp * one_minus_keep + t[i] * keep;
+    if (t) t[i] = __fadd_rn(__fmul_rn(pp, one_minus_keep), __fmul_rn(t[i], keep));
   }
 }
 
 extern "C" int sfod_sgd_ema(float* param, const float* grad, float* mom, float* teacher, int64_t n,
                             const float* lr, float momentum, float weight_decay, float grad_scale,
-                            float ema_keep, int first_step, void* stream) {
+                            float ema_keep, float ema_one_minus_keep, int first_step, void* stream) {
   if (n == 0) return 0;
-  const float omk = (float)(1.0 - (double)ema_keep);
+  // 1 - k is the HOST's double subtraction rounded once (the reference: python float (1 - keep_rate) -> float32 scalar);
+  // recomputing it from the float32 k would be off by 1.7e-5 relative for k = 0.9996
+  const float omk = ema_one_minus_keep;
   hipLaunchKernelGGL(k_sgd_ema, dim3(ew_grid(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, param, grad, mom,
                      teacher, n, lr, momentum, weight_decay, grad_scale, ema_keep, omk, first_step);
   return sfod_check_launch("sgd_ema");
@@ -1820,13 +1824,14 @@ extern "C" int sfod_sgd_ema(float* param, const float* grad, float* mom, float* 
 
 __global__ void k_ema(float* __restrict__ t, const float* __restrict__ s, int64_t n, float keep, float omk) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    t[i] = s[i] * omk + t[i] * keep;
+    t[i] = __fadd_rn(__fmul_rn(s[i], omk), __fmul_rn(t[i], keep));
 }
 
-extern "C" int sfod_ema(float* teacher, const float* student, int64_t n, float keep, void* stream) {
+extern "C" int sfod_ema(float* teacher, const float* student, int64_t n, float keep, float one_minus_keep,
+                        void* stream) {
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_ema, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, teacher, student, n, keep,
-                     (float)(1.0 - (double)keep));
+                     one_minus_keep);
   return sfod_check_launch("ema");
 }
 

@@ -140,25 +140,38 @@ class SourceFreeFastRCNNOutputLayers(FastRCNNOutputLayers):
     def convert_bbox_scores(self, predictions, proposals):
         boxes = self.predict_boxes(predictions, proposals)
         scores = self.predict_probs(predictions, proposals)
-        results, kept = [], []
-        for bx, sc, prop in zip(boxes, scores, proposals):
-            valid = torch.isfinite(bx).all(dim=1) & torch.isfinite(sc).all(dim=1)
-            if not valid.all():
-                bx, sc = bx[valid], sc[valid]
-            sc = sc[:, :-1]
-            K = bx.shape[1] // 4
-            b = Boxes(bx.reshape(-1, 4))
-            b.clip(prop.image_size)
-            bx = b.tensor.view(-1, K, 4)
-            mask = sc > 0                     # "We do not filter out anything here"; NMS is commented out (:132-138)
-            inds = mask.nonzero()
-            res = Instances(prop.image_size)
-            res.pred_boxes = Boxes(bx[mask])
-            res.scores = sc[mask]
-            res.pred_classes = inds[:, 1]
-            results.append(res)
-            kept.append(inds[:, 0])
-        return results, kept
+        image_shapes = [x.image_size for x in proposals]
+        return self.fast_rcnn_inference_new(boxes, scores, image_shapes, self.test_score_thresh, self.test_nms_thresh,
+                                            self.test_topk_per_image, proposals)
+
+    def fast_rcnn_inference_new(self, boxes, scores, image_shapes, score_thresh, nms_thresh, topk_per_image, proposals):
+        """:38-80 -- per image ``fast_rcnn_inference_single_image_new``; -> (list[Instances], list[row index])."""
+        per_image = [self.fast_rcnn_inference_single_image_new(b, s, shape, score_thresh, nms_thresh, topk_per_image, p)
+                     for s, b, shape, p in zip(scores, boxes, image_shapes, proposals)]
+        return [x[0] for x in per_image], [x[1] for x in per_image]
+
+    def fast_rcnn_inference_single_image_new(self, boxes, scores, image_shape, score_thresh=0.0, nms_thresh=0.0,
+                                             topk_per_image=-1, proposal=None):
+        """:82-147 -- rows with a non-finite box or score are dropped first (the returned row index counts the
+        survivors), the background column goes, boxes are clipped, every (row, class) with ``score > 0`` is kept in
+        row-major order; the thresholds are accepted and unused like the reference's (its NMS is commented out, :132-138).
+        ``boxes`` [R, 4K] per-class or [R, 4] class-agnostic; ``scores`` [R, K+1] probabilities.
+        Pinned by the reference-run fixture tests/golden/glue_ref.npz."""
+        valid = torch.isfinite(boxes).all(dim=1) & torch.isfinite(scores).all(dim=1)
+        if not valid.all():
+            boxes, scores = boxes[valid], scores[valid]
+        scores = scores[:, :-1]
+        nreg = boxes.shape[1] // 4
+        b = Boxes(boxes.reshape(-1, 4))
+        b.clip(image_shape)
+        boxes = b.tensor.view(-1, nreg, 4)
+        mask = scores > 0                     # "We do not filter out anything here"
+        inds = mask.nonzero()
+        res = Instances(image_shape)
+        res.pred_boxes = Boxes(boxes[inds[:, 0], 0] if nreg == 1 else boxes[mask])
+        res.scores = scores[mask]
+        res.pred_classes = inds[:, 1]
+        return res, inds[:, 0]
 
 
 class InstanceProposals:

@@ -1200,11 +1200,11 @@ def adaptive_pseudo_labels_(d, thr, reserve, row, class_acc, select):
 
 def sgd_ema_(param, grad, mom, teacher, lr, momentum, weight_decay, grad_scale, ema_keep, first_step):
     call("sfod_sgd_ema", param, grad, mom, teacher, param.numel(), lr, float(momentum), float(weight_decay),
-         float(grad_scale), float(ema_keep), int(first_step))
+         float(grad_scale), float(ema_keep), float(1.0 - float(ema_keep)), int(first_step))
 
 
 def ema_(teacher, student, keep):
-    call("sfod_ema", teacher, student, teacher.numel(), float(keep))
+    call("sfod_ema", teacher, student, teacher.numel(), float(keep), float(1.0 - float(keep)))
 
 
 def ema_i64_(teacher, student, keep):

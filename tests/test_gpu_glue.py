@@ -1,0 +1,197 @@
+"""The HIP path against vectors the REFERENCE'S OWN functions produced (oracle/gen_golden.py::gen_glue, gen_vgg):
+no oracle in between.  CPU twins of these checks: tests/test_oracle_glue.py (same fixtures, the restatements).
+
+  a7  sfod_frcnn_finalize's pseudo-label threshold  <-  threshold_bbox / process_pseudo_label, scores at float32(0.8) +- 1 ulp
+      sfod_teacher_metrics' RPN count                <-  threshold_bbox(proposal_type="rpn")
+  a9  sfod_ema / sfod_ema_i64 / sfod_sgd_ema         <-  _update_teacher_model, floats bit for bit, int64 counters ==
+  a6  convert_bbox_scores' row indices on the device <-  fast_rcnn_inference_single_image_new
+  a4  sfod_rpn_decode's anchor order                 <-  PseudoLabRPN.forward's permute / flatten
+  a1  VGG16 weight / BatchNorm gradients             <-  autograd through the reference's vgg_backbone
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import box_ops as OB
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HOT_YAML = os.path.join(os.path.dirname(GOLDEN), "..", "configs",
+                        "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(GOLDEN, "glue_ref.npz"), allow_pickle=False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def test_pseudo_label_threshold_kernel_equals_the_reference_threshold_bbox(fx, native):
+    thr = float(fx["thr"])
+    counts = [len(fx[f"pl_in_scores_{i}"]) for i in range(3)]
+    B, n, max_det = 3, max(counts), 100
+    sb = torch.zeros(B, n, 4)
+    ss = torch.zeros(B, n)
+    sc = torch.zeros(B, n, dtype=torch.int32)
+    for i, c in enumerate(counts):
+        sb[i, :c], ss[i, :c], sc[i, :c] = T(fx[f"pl_in_boxes_{i}"]), T(fx[f"pl_in_scores_{i}"]), T(fx[f"pl_in_classes_{i}"]).int()
+        assert (ss[i, :c - 1] >= ss[i, 1:c]).all() if c > 1 else True      # what NMS hands over: descending scores
+    keep_idx = torch.arange(max_det, dtype=torch.int32).repeat(B, 1).to(DEV)
+    keep_cnt = torch.tensor(counts, dtype=torch.int32, device=DEV)
+    out = {k: torch.empty(B, max_det, *s, dtype=d, device=DEV) for k, s, d in (
+        ("det_boxes", (4,), torch.float32), ("det_scores", (), torch.float32), ("det_classes", (), torch.int32),
+        ("gt_boxes", (4,), torch.float32), ("gt_classes", (), torch.int32))}
+    dcount = torch.empty(B, dtype=torch.int32, device=DEV)
+    gcount = torch.empty(B, dtype=torch.int32, device=DEV)
+    native.call("sfod_frcnn_finalize", sb.to(DEV), ss.to(DEV), sc.to(DEV), keep_idx, keep_cnt, B, n, max_det, thr,
+                out["det_boxes"], out["det_scores"], out["det_classes"], dcount, out["gt_boxes"], out["gt_classes"], gcount)
+    assert dcount.tolist() == counts
+    got_mean = 0.0
+    for i in range(3):
+        g = int(gcount[i])
+        ref_b, ref_c = T(fx[f"pl_gt_boxes_{i}"]), T(fx[f"pl_gt_classes_{i}"])
+        assert g == len(ref_c), (i, g, len(ref_c))
+        assert torch.equal(out["gt_boxes"][i, :g].cpu(), ref_b) and torch.equal(out["gt_classes"][i, :g].cpu().long(), ref_c)
+        assert torch.equal(out["det_scores"][i, :g].cpu(), T(fx[f"pl_scores_{i}"]))
+        got_mean += g
+    assert got_mean / 3 == float(fx["pl_mean_count"])
+    # the score exactly at float32(0.8) is the first one NOT taken, its upper neighbour the last one taken
+    t32 = np.float32(thr)
+    g0 = int(gcount[0])
+    assert out["det_scores"][0, g0 - 1].item() == np.nextafter(t32, np.float32(1)) and out["det_scores"][0, g0].item() == t32
+    # the logged scalars: mean pseudo-label count and the RPN flavour's count (objectness_logits > thr)
+    lg = T(fx["rpn_in_logits"]).sort(descending=True).values.view(1, -1).repeat(B, 1).contiguous().to(DEV)
+    m = native.teacher_metrics(out["det_scores"], dcount, lg, torch.full((B,), lg.shape[1], dtype=torch.int32, device=DEV),
+                               gcount, thr)
+    assert m[1].item() == len(fx["rpn_logits"]) and abs(m[2].item() - float(fx["pl_mean_count"])) < 1e-6
+
+
+def test_ema_kernels_equal_the_reference_update_bit_for_bit(fx, native):
+    keys = [str(k) for k in fx["ema_keys"]]
+    fkeys = [k for k in keys if fx["ema_s/" + k].dtype == np.float32]
+    ikeys = [k for k in keys if fx["ema_s/" + k].dtype == np.int64]
+    flat = lambda prefix: torch.cat([T(fx[prefix + k]).flatten() for k in fkeys])
+    s = flat("ema_s/").to(DEV)
+    t = flat("ema_t0/").to(DEV)
+    t_fused = t.clone()
+    p_fused, mom = s.clone(), torch.zeros_like(s)
+    lr0 = torch.zeros(1, device=DEV)
+    for step, ((cs, ct), keep) in enumerate(zip(fx["ema_counters"].tolist(), fx["ema_keep"].tolist())):
+        native.ema_(t, s, keep)
+        ref = flat(f"ema_t{step + 1}/")
+        assert torch.equal(t.cpu(), ref), (step, (t.cpu() - ref).abs().max())
+        # the fused optimiser kernel's EMA half (lr = 0, zero gradient, no decay: the student does not move)
+        native.sgd_ema_(p_fused, torch.zeros_like(s), mom, t_fused, lr0, 0.9, 0.0, 1.0, keep, step == 0)
+        assert torch.equal(p_fused, s) and torch.equal(t_fused.cpu(), ref), step
+        si = torch.tensor([cs, cs + 1], dtype=torch.int64, device=DEV)
+        ti = torch.tensor([ct, ct + 2], dtype=torch.int64, device=DEV)
+        native.ema_i64_(ti, si, keep)
+        assert ti.tolist() == [int(fx[f"ema_t{step + 1}/{k}"]) for k in ikeys], (step, ti.tolist())
+    assert int(fx["ema_t1/" + ikeys[0]]) == 6      # the reference's teacher counter goes DOWN: 3 * 0.0004 + 7 * 0.9996 -> 6
+
+
+def test_ema_through_the_optimizer_equals_the_reference_update(fx, sfod, native):
+    """FusedSGD.step(ema=True) on a conv + BatchNorm model with the fixture's values: every key of the teacher's
+    state dict (parameters, running statistics, num_batches_tracked) equals ``_update_teacher_model``'s result."""
+    def build(prefix):
+        net = torch.nn.Sequential(torch.nn.Conv2d(3, 6, 3), torch.nn.BatchNorm2d(6), torch.nn.Conv2d(6, 4, 1),
+                                  torch.nn.BatchNorm2d(4), torch.nn.Linear(5, 3))
+        net.load_state_dict({str(k): T(fx[prefix + str(k)]) for k in fx["ema_keys"]})
+        return net.to(DEV)
+    student, teacher = build("ema_s/"), build("ema_t0/")
+    cs, ct = fx["ema_counters"][0].tolist()
+    with torch.no_grad():
+        student[1].num_batches_tracked.fill_(cs), teacher[1].num_batches_tracked.fill_(ct)
+        student[3].num_batches_tracked.fill_(cs + 1), teacher[3].num_batches_tracked.fill_(ct + 2)
+    cfg = sfod.config.setup_cfg(HOT_YAML, ["SOLVER.BASE_LR", "0.0", "SOLVER.WEIGHT_DECAY", "0.0", "SOLVER.WARMUP_ITERS", "0"])
+    opt = sfod.engine.build_optimizer(cfg, student)
+    tflat = sfod.engine.FlatModelState(teacher, with_grad=False)
+    opt.attach_teacher(tflat, float(fx["ema_keep"][0]))
+    opt.zero_grad()
+    opt.step(ema=True)
+    for k, v in teacher.state_dict().items():
+        assert torch.equal(v.cpu(), T(fx["ema_t1/" + k])), k
+    for k, v in student.state_dict().items():      # lr 0: the student is where it was
+        if v.dtype != torch.int64:
+            assert torch.equal(v.cpu(), T(fx["ema_s/" + k])), k
+
+
+def test_convert_bbox_scores_rows_on_the_device_equal_the_reference(fx, sfod, native):
+    layers = object.__new__(sfod.modeling.roi_heads.SourceFreeFastRCNNOutputLayers)
+    for i in range(2):
+        size = tuple(int(v) for v in fx[f"frcnn_size_{i}"])
+        inst, row = layers.fast_rcnn_inference_single_image_new(T(fx[f"frcnn_boxes_in_{i}"]).to(DEV),
+                                                                T(fx[f"frcnn_scores_in_{i}"]).to(DEV), size)
+        assert inst.pred_boxes.tensor.is_cuda
+        assert torch.equal(row.cpu(), T(fx[f"frcnn_row_{i}"])) and torch.equal(inst.pred_classes.cpu(), T(fx[f"frcnn_pred_classes_{i}"]))
+        assert torch.equal(inst.pred_boxes.tensor.cpu(), T(fx[f"frcnn_pred_boxes_{i}"]))
+        assert torch.equal(inst.scores.cpu(), T(fx[f"frcnn_scores_{i}"]))
+
+
+def test_rpn_decode_reads_the_head_output_in_the_reference_anchor_order(fx, sfod, native):
+    """``PseudoLabRPN.forward`` flattens (N,A,H,W) logits to (N, H*W*A) and (N,4A,H,W) deltas to (N, H*W*A, 4)
+    (rpn.py:28-41).  The product's fused head writes one row of 5A values per pixel (A logits, then 4A deltas in the
+    1x1 convolutions' channel order); ``sfod_rpn_decode`` must hand scores and boxes over in the reference's order:
+    scores == the recorded flattened logits, boxes == the recorded flattened deltas applied to the (y, x, a) anchors."""
+    lg, dl = T(fx["rpn_glue_logits_in"]), T(fx["rpn_glue_deltas_in"])
+    N, A, Hf, Wf = lg.shape
+    cfg = sfod.config.setup_cfg(HOT_YAML, [])
+    ag = sfod.modeling.rpn.DefaultAnchorGenerator(cfg, [sfod.structures.ShapeSpec(channels=512, stride=32)])
+    cell = ag.cell_anchors._buffers["0"].to(DEV)
+    assert cell.shape[0] == A
+    ld = (5 * A + 7) // 8 * 8
+    rpn_out = torch.zeros(N * Hf * Wf, ld)
+    rpn_out[:, :A] = lg.permute(0, 2, 3, 1).reshape(-1, A)              # channel a of the objectness conv
+    rpn_out[:, A:5 * A] = dl.permute(0, 2, 3, 1).reshape(-1, 4 * A)     # channel 4a + c of the delta conv
+    sizes = torch.tensor([[10 ** 6, 10 ** 6]] * N, dtype=torch.int32, device=DEV)
+    flags = torch.zeros(1, dtype=torch.int32, device=DEV)
+    props, scores = native.rpn_decode(rpn_out.to(DEV), cell, N, Hf, Wf, 32, sizes, flags)
+    assert torch.equal(scores.cpu(), T(fx["rpn_glue_logits_flat"]))
+    anchors = ag([torch.zeros(N, 1, Hf, Wf)])[0]
+    for n in range(N):
+        ref = OB.apply_deltas(T(fx["rpn_glue_deltas_flat"])[n], anchors.cpu(), (1.0, 1.0, 1.0, 1.0))
+        torch.testing.assert_close(props[n].cpu(), ref, rtol=1e-6, atol=1e-4)
+    assert flags.item() == 0
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16x3", "f16x3"])
+def test_vgg_parameter_gradients_match_the_reference_backward(sfod, native, dtype):
+    """HIP backward of the VGG16-BN trunk (data gradients, 3x3 weight gradients, fused BatchNorm backward) against
+    autograd through the reference's own ``vgg_backbone`` (tests/golden/vgg_ref.npz, ``g/*``: <= 4096 strided samples +
+    the norm of every parameter gradient) for the loss sum_i <vgg_i, r_i>, i = 2, 3, 4."""
+    fx = np.load(os.path.join(GOLDEN, "vgg_ref.npz"), allow_pickle=False)
+    cfg = sfod.config.setup_cfg(HOT_YAML, ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", dtype])
+    torch.manual_seed(int(fx["seed"]))
+    bb = sfod.modeling.backbone_vgg.build_vgg_backbone(cfg, None).to(DEV).train()
+    feats = bb(T(fx["input"]).to(DEV))
+    gr = torch.Generator().manual_seed(int(fx["bwd_seed"]))
+    loss = 0
+    for i in fx["bwd_stages"].tolist():
+        loss = loss + (feats[f"vgg{i}"] * torch.randn(feats[f"vgg{i}"].shape, generator=gr).to(DEV)).sum()
+    loss.backward()
+    torch.cuda.synchronize()
+    worst = {}
+    for name, p in bb.named_parameters():
+        ref, stride = T(fx["g/" + name]), int(fx["gstride/" + name])
+        parts = name.split(".")
+        if parts[-1] == "bias" and parts[1] in ("0", "3", "6"):
+            # conv bias in front of train-mode BatchNorm: analytically zero; the reference's autograd leaves 1e-5 .. 6e-3 of
+            # rounding noise (``gnorm/*`` in the fixture), the product writes exact zeros (DESIGN.md deviation 4)
+            assert float(fx["gnorm/" + name]) < 1e-2 and (p.grad is None or p.grad.abs().max().item() == 0.0)
+            continue
+        g = p.grad.detach().flatten().cpu()
+        err = ((g[::stride] - ref).double().norm() / ref.double().norm()).item()
+        nerr = abs(g.double().norm().item() / float(fx["gnorm/" + name]) - 1.0)
+        worst[name] = max(err, nerr)
+        # 64 pixels per channel in the deepest layers, 13 layers of train-mode BatchNorm: the gradient's own condition
+        # (ReLU / arg-max ties are not in play at 1e-5 forward agreement, see tests/test_gpu_flipfree.py)
+        tol = 2e-4 if dtype == "fp32" else 2e-3
+        assert err < tol and nerr < tol, (name, err, nerr)
+    print(f"\n[vgg backward vs reference, {dtype}] worst parameter-gradient error {max(worst.values()):.2e} "
+          f"({max(worst, key=worst.get)})")

@@ -1,0 +1,301 @@
+"""Reference-OWNED glue of the hot path, pinned by fixtures the reference's own functions produced.
+
+``tests/golden/glue_ref.npz`` / ``config_ref.json`` were recorded by ``oracle/gen_golden.py::gen_glue``, which loads the
+reference's files by path behind ``oracle/ref_stub/hook.py`` and RUNS (not restates)
+
+  a6   SourceFreeFastRCNNOutputLayers.fast_rcnn_inference_new        daod/modeling/roi_heads/source_free_fast_rcnn.py:38-147
+  a7   threshold_bbox / process_pseudo_label                         daod/engine/trainers/source_free_adaptive_teacher.py:150-183,256-280
+  a9   _update_teacher_model                                         ... :583-603
+  a13  AspectRatioGroupedSemiSupDatasetTwoCropSourceFree.__iter__    daod/data/common.py:199-228
+  a4   PseudoLabRPN.forward (layout + second loss weight)            daod/modeling/proposal_generator/rpn.py:16-58
+  a11  reset_bn_stats / recursive_traversal                          daod/engine/trainers/base.py:318-328
+  b    add_config                                                    daod/config.py:8-142
+  a1   vgg_backbone backward: parameter gradients                    daod/modeling/meta_arch/vgg.py (vgg_ref.npz ``g/*``)
+
+Here (no GPU): the oracle's restatements and the product's host-side twins (pure torch / Python) against those vectors.
+The HIP kernels meet the same vectors in tests/test_gpu_glue.py.  ``Boxes.clip`` inside a6 is d2's (restated in the
+stub): the fixture pins the reference's use of it, not d2's arithmetic.
+"""
+import json
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+from util_weights import reference_vgg_state
+
+from oracle import box_ops as B
+from oracle import model as om
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(GOLDEN, "glue_ref.npz"), allow_pickle=False)
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ---- a6 ----------------------------------------------------------------------------------------------------------------
+def test_fast_rcnn_inference_new_restatement_and_product_twin_equal_the_reference(fx, sfod):
+    layers = object.__new__(sfod.modeling.roi_heads.SourceFreeFastRCNNOutputLayers)
+    for i in range(2):
+        bx, sc, size = T(fx[f"frcnn_boxes_in_{i}"]), T(fx[f"frcnn_scores_in_{i}"]), tuple(int(v) for v in fx[f"frcnn_size_{i}"])
+        assert not torch.isfinite(bx).all() and not torch.isfinite(sc).all()      # the case has non-finite rows
+        assert (sc[:, :-1] == 0).any()                                           # ... and exact zeros
+        ref = {k: T(fx[f"frcnn_{k}_{i}"]) for k in ("pred_boxes", "scores", "pred_classes", "row")}
+        o = om.frcnn_inference_new_single(bx.clone(), sc.clone(), size)
+        assert torch.equal(o["boxes"], ref["pred_boxes"]) and torch.equal(o["scores"], ref["scores"])
+        assert torch.equal(o["classes"], ref["pred_classes"]) and torch.equal(o["roi_idx"], ref["row"])
+        inst, row = layers.fast_rcnn_inference_single_image_new(bx.clone(), sc.clone(), size, 0.05, 0.5, 100, None)
+        assert torch.equal(inst.pred_boxes.tensor, ref["pred_boxes"]) and torch.equal(inst.scores, ref["scores"])
+        assert torch.equal(inst.pred_classes, ref["pred_classes"]) and torch.equal(row, ref["row"])
+        assert inst.image_size == size
+        # what the fixture says about the function: rows index the finite survivors, so they stay below their number
+        n_finite = int((torch.isfinite(bx).all(1) & torch.isfinite(sc).all(1)).sum())
+        assert int(ref["row"].max()) == n_finite - 1 < len(bx) - 1
+        assert (ref["pred_boxes"][:, 0::2] <= size[1]).all() and (ref["pred_boxes"][:, 1::2] <= size[0]).all()
+        assert (ref["pred_boxes"] >= 0).all() and (ref["scores"] > 0).all()
+    # class-agnostic regression: one box per row, shared by its classes
+    bx, sc, size = T(fx["frcnn_agn_boxes_in"]), T(fx["frcnn_scores_in_0"]), tuple(int(v) for v in fx["frcnn_size_0"])
+    o = om.frcnn_inference_new_single(bx.clone(), sc.clone(), size)
+    inst, row = layers.fast_rcnn_inference_single_image_new(bx.clone(), sc.clone(), size)
+    for got_b, got_s, got_c, got_r in ((o["boxes"], o["scores"], o["classes"], o["roi_idx"]),
+                                       (inst.pred_boxes.tensor, inst.scores, inst.pred_classes, row)):
+        assert torch.equal(got_b, T(fx["frcnn_agn_pred_boxes"])) and torch.equal(got_s, T(fx["frcnn_agn_scores"]))
+        assert torch.equal(got_c, T(fx["frcnn_agn_pred_classes"])) and torch.equal(got_r, T(fx["frcnn_agn_row"]))
+    # the list-level entry point, with the reference's argument order (boxes, scores, image_shapes, ...)
+    res, kept = layers.fast_rcnn_inference_new([T(fx[f"frcnn_boxes_in_{i}"]) for i in range(2)],
+                                               [T(fx[f"frcnn_scores_in_{i}"]) for i in range(2)],
+                                               [tuple(int(v) for v in fx[f"frcnn_size_{i}"]) for i in range(2)],
+                                               0.05, 0.5, 100, [None, None])
+    assert [len(r) for r in res] == [len(fx["frcnn_row_0"]), len(fx["frcnn_row_1"])]
+    assert torch.equal(kept[1], T(fx["frcnn_row_1"]))
+
+
+# ---- a7 ----------------------------------------------------------------------------------------------------------------
+def test_threshold_bbox_and_process_pseudo_label_equal_the_reference(fx, sfod):
+    thr = float(fx["thr"])
+    tr_mod = sfod.engine.trainer
+    S = sfod.structures
+    stub = object.__new__(tr_mod.SourceFreeAdaptiveTeacherTrainer)
+    insts = []
+    for i in range(3):
+        p = S.Instances((600, 1200))
+        p.pred_boxes = S.Boxes(T(fx[f"pl_in_boxes_{i}"]))
+        p.scores = T(fx[f"pl_in_scores_{i}"])
+        p.pred_classes = T(fx[f"pl_in_classes_{i}"])
+        insts.append(p)
+        # oracle
+        o = om.threshold_bbox({"boxes": p.pred_boxes.tensor, "scores": p.scores, "classes": p.pred_classes}, thr)
+        assert torch.equal(o["gt_boxes"], T(fx[f"pl_gt_boxes_{i}"])) and torch.equal(o["gt_classes"], T(fx[f"pl_gt_classes_{i}"]))
+        assert torch.equal(o["scores"], T(fx[f"pl_scores_{i}"]))
+    out, mean_n = tr_mod.SourceFreeAdaptiveTeacherTrainer.process_pseudo_label(stub, insts, thr, "roih", "thresholding")
+    assert mean_n == float(fx["pl_mean_count"])
+    for i, q in enumerate(out):
+        assert sorted(q.get_fields().keys()) == list(fx[f"pl_fields_{i}"])
+        assert torch.equal(q.gt_boxes.tensor, T(fx[f"pl_gt_boxes_{i}"])) and torch.equal(q.gt_classes, T(fx[f"pl_gt_classes_{i}"]))
+        assert torch.equal(q.scores, T(fx[f"pl_scores_{i}"]))
+    # strict '>' in float32: a score of exactly float32(0.8) is NOT a pseudo label, one ulp above is
+    t32 = np.float32(thr)
+    s0, kept0 = fx["pl_in_scores_0"], fx["pl_scores_0"]
+    assert t32 in s0 and t32 not in kept0 and np.nextafter(t32, np.float32(1)) in kept0
+    assert np.nextafter(t32, np.float32(0)) in s0 and kept0.min() > t32
+    assert len(fx["pl_scores_1"]) == 0 and len(fx["pl_in_scores_1"]) == 0        # an image without detections
+    # RPN flavour
+    rp = S.Instances((600, 1200))
+    rp.proposal_boxes = S.Boxes(T(fx["rpn_in_boxes"]))
+    rp.objectness_logits = T(fx["rpn_in_logits"])
+    q = tr_mod.threshold_bbox(rp, thres=thr, proposal_type="rpn")
+    assert sorted(q.get_fields().keys()) == list(fx["rpn_fields"])
+    assert torch.equal(q.gt_boxes.tensor, T(fx["rpn_gt_boxes"])) and torch.equal(q.objectness_logits, T(fx["rpn_logits"]))
+    with pytest.raises(ValueError) as e:
+        tr_mod.SourceFreeAdaptiveTeacherTrainer.process_pseudo_label(stub, insts, thr, "roih", "no_such_method")
+    assert str(e.value) == str(fx["pl_error"])
+
+
+# ---- a9 ----------------------------------------------------------------------------------------------------------------
+def _ema_states(fx, prefix):
+    return {str(k): T(fx[prefix + str(k)]).clone() for k in fx["ema_keys"]}
+
+
+def test_ema_update_restatement_equals_the_reference_including_the_int64_counters(fx):
+    student, teacher = _ema_states(fx, "ema_s/"), _ema_states(fx, "ema_t0/")
+    int_keys = [k for k, v in teacher.items() if v.dtype == torch.int64]
+    assert int_keys == ["1.num_batches_tracked", "3.num_batches_tracked"]
+    for step, ((cs, ct), keep) in enumerate(zip(fx["ema_counters"].tolist(), fx["ema_keep"].tolist())):
+        student["1.num_batches_tracked"].fill_(cs)
+        teacher["1.num_batches_tracked"].fill_(ct)
+        student["3.num_batches_tracked"].fill_(cs + 1)
+        teacher["3.num_batches_tracked"].fill_(ct + 2)
+        om.ema_update(teacher, student, keep)
+        for k, v in teacher.items():
+            assert torch.equal(v, T(fx[f"ema_t{step + 1}/{k}"])), (step, k)
+    # what the reference's arithmetic does to the counter: int64 * python float -> float32, truncated by the copy back
+    assert int(fx["ema_t1/1.num_batches_tracked"]) == 6            # 3 * 0.0004 + 7 * 0.9996 = 6.9984 -> 6
+    assert int(fx["ema_t5/1.num_batches_tracked"]) == int(np.float32(np.float32(5) * np.float32(1 - 0.9996))
+                                                          + np.float32(np.float32(123456789) * np.float32(0.9996)))
+    # DDP: the student's keys carry "module."; same numbers
+    s2 = {k[len("ema_ddp_s/"):]: T(fx[k]).clone() for k in fx.files if k.startswith("ema_ddp_s/")}
+    t2 = {k[len("ema_ddp_t0/"):]: T(fx[k]).clone() for k in fx.files if k.startswith("ema_ddp_t0/")}
+    om.ema_update(t2, s2, 0.9996)
+    for k, v in t2.items():
+        assert torch.equal(v, T(fx["ema_ddp_t1/" + k])), k
+    with pytest.raises(Exception) as e:
+        om.ema_update(dict(teacher), {k: v for k, v in student.items() if not k.startswith("4.")}, 0.9996)
+    assert str(e.value) == str(fx["ema_error"]) == "4.weight is not found in student model"
+
+
+# ---- a13 ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("bs", [1, 2, 3, 4])
+def test_two_crop_loader_batches_in_the_reference_bucket_order(fx, sfod, bs):
+    """The product's loader on the recorded (width, height) stream: the same images in the same batches in the same
+    order as ``AspectRatioGroupedSemiSupDatasetTwoCropSourceFree`` yielded them (strong ids even, weak ids odd)."""
+    wh = fx["bucket_wh"]
+    cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs", "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml"),
+                                ["SOLVER.IMS_PER_BATCH_TARGET", str(bs), "INPUT.RANDOM_FLIP", "none", "MODEL.DEVICE", "cpu"])
+    items = [{"image": torch.zeros(3, 4, 4, dtype=torch.uint8), "boxes": torch.zeros(0, 4), "classes": torch.zeros(0, dtype=torch.int64),
+              "height": int(h), "width": int(w), "image_id": i, "file_name": str(i), "size": (4, 4)} for i, (w, h) in enumerate(wh)]
+    ds = types.SimpleNamespace(items=items, size=(4, 4), __len__=lambda: len(items))
+
+    class DS(list):
+        items, size = ds.items, ds.size
+    loader = sfod.data.TwoCropLoader(cfg, torch.device("cpu"), dataset=DS(items))
+    loader.sampler = iter(range(len(items)))
+    ref_w = fx[f"bucket_weak_ids_b{bs}"]
+    assert np.array_equal(fx[f"bucket_strong_ids_b{bs}"] + 1, ref_w)      # the two crops of one image travel together
+    got = []
+    for _ in range(len(ref_w)):
+        strong, weak = next(loader)
+        assert [d["image_id"] for d in strong] == [d["image_id"] for d in weak]
+        got.append([2 * d["image_id"] + 1 for d in weak])
+    assert np.array_equal(np.array(got).reshape(-1, bs), ref_w)
+    # one aspect class per batch (w > h | otherwise)
+    for row in ref_w:
+        cls = {bool(wh[(i - 1) // 2][0] > wh[(i - 1) // 2][1]) for i in row}
+        assert len(cls) == 1
+
+
+# ---- a4 ----------------------------------------------------------------------------------------------------------------
+def test_rpn_flatten_layout_and_second_loss_weight_equal_the_reference(fx):
+    lg, dl = om.rpn_flatten(T(fx["rpn_glue_logits_in"]), T(fx["rpn_glue_deltas_in"]))
+    assert torch.equal(lg, T(fx["rpn_glue_logits_flat"])) and torch.equal(dl, T(fx["rpn_glue_deltas_flat"]))
+    # element (n, a, y, x) lands at (n, (y * W + x) * A + a); delta channel 4a + c at [.., c]
+    N, A, H, W = fx["rpn_glue_logits_in"].shape
+    n, a, y, x, c = 1, 7, 2, 3, 2
+    assert fx["rpn_glue_logits_flat"][n, (y * W + x) * A + a] == fx["rpn_glue_logits_in"][n, a, y, x]
+    assert fx["rpn_glue_deltas_flat"][n, (y * W + x) * A + a, c] == fx["rpn_glue_deltas_in"][n, 4 * a + c, y, x]
+    # PseudoLabRPN.forward multiplies what RPN.losses() returned by loss_weight AGAIN (rpn.py:49), unknown keys by 1:
+    # the stub losses() returned cls 2, loc 3, other 7 with loss_weight {cls 1.5, loc 0.5}
+    assert list(fx["rpn_glue_loss_keys"]) == ["loss_rpn_cls", "loss_rpn_loc", "other"]
+    assert fx["rpn_glue_loss_vals"].tolist() == [3.0, 1.5, 7.0]
+    # losses: (training and compute_loss) or compute_val_loss -- [train, eval, eval+val_loss, train+compute_loss False]
+    assert fx["rpn_glue_branches"].tolist() == [3, 0, 3, 0]
+
+
+# ---- a11 ---------------------------------------------------------------------------------------------------------------
+def test_adabn_reset_equals_the_reference(fx, sfod):
+    keys = [str(k) for k in fx["adabn_keys_after"]]
+    assert keys == [str(k) for k in fx["adabn_keys_before"]]          # the state-dict surface survives buffer -> Parameter
+    assert bool(fx["adabn_weight_untouched"])
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4),
+                              torch.nn.Sequential(torch.nn.Conv2d(4, 4, 3), torch.nn.BatchNorm2d(4), torch.nn.ReLU()))
+    sd = {k[len("adabn_w/"):]: T(fx[k]) for k in fx.files if k.startswith("adabn_w/")}
+    net.load_state_dict(sd, strict=False)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.5, 2.0)
+                m.num_batches_tracked.fill_(41)
+    sfod.engine.trainer.reset_bn_stats(net)
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(v, T(fx["adabn_after/" + k])), k      # mean 0, var 1, the counter is NOT reset (41)
+    net.train()
+    with torch.no_grad():
+        net(T(fx["adabn_x"]))
+    for k, v in net.state_dict().items():
+        if "running" in k or "num_batches" in k:
+            torch.testing.assert_close(v, T(fx["adabn_fwd/" + k]), rtol=1e-6, atol=1e-7)
+    assert int(net[1].num_batches_tracked) == 42
+
+
+# ---- b -----------------------------------------------------------------------------------------------------------------
+def test_config_defaults_equal_what_add_config_assigns(sfod):
+    with open(os.path.join(GOLDEN, "config_ref.json")) as f:
+        ref = json.load(f)["assigned"]
+    cfg = sfod.config.get_cfg()          # d2's defaults ...
+    sfod.config.add_config(cfg)          # ... + the product's twin of the reference's function
+    n = [0]
+
+    def walk(node, r, path):
+        for k, v in r.items():
+            assert k in node, "missing config key " + ".".join(path + [k])
+            if isinstance(v, dict):
+                walk(node[k], v, path + [k])
+            else:
+                got = node[k]
+                got = list(got) if isinstance(got, (tuple, list)) else got
+                assert got == v, (".".join(path + [k]), got, v)
+                n[0] += 1
+    walk(cfg, ref, [])
+    assert n[0] == 43
+
+
+# ---- a1 backward -------------------------------------------------------------------------------------------------------
+def test_oracle_vgg_parameter_gradients_equal_the_reference_backward():
+    fx = np.load(os.path.join(GOLDEN, "vgg_ref.npz"), allow_pickle=False)
+    sd = om.clone_state(reference_vgg_state(int(fx["seed"])), requires_grad=True)
+    x = T(fx["input"]).clone().requires_grad_(True)
+    feats = om.vgg_forward(sd, x, om.Cfg(), training=True, return_all=True)
+    gr = torch.Generator().manual_seed(int(fx["bwd_seed"]))
+    loss = 0
+    for i in fx["bwd_stages"].tolist():
+        loss = loss + (feats[f"vgg{i}"] * torch.randn(feats[f"vgg{i}"].shape, generator=gr)).sum()
+    loss.backward()
+    torch.testing.assert_close(x.grad, T(fx["bwd_input_grad"]), rtol=1e-3, atol=1e-5)
+    n = 0
+    for k in fx.files:
+        if not k.startswith("g/"):
+            continue
+        name = k[2:]
+        g = sd["backbone." + name].grad.flatten()
+        ref, stride = T(fx[k]), int(fx["gstride/" + name])
+        if name.endswith("bias") and name.split(".")[1] in ("0", "3", "6"):
+            # a conv bias in front of train-mode BatchNorm: analytically zero, the reference's autograd leaves rounding noise
+            assert float(fx["gnorm/" + name]) < 1e-2 and g.norm() < 1e-2
+            continue
+        err = ((g[::stride] - ref).double().norm() / ref.double().norm()).item()
+        assert err < 2e-4, (name, err)
+        np.testing.assert_allclose(g.double().norm().item(), float(fx["gnorm/" + name]), rtol=1e-4)
+        n += 1
+    assert n == 39
+
+
+# ---- third-party cross-check of the unpinned half ----------------------------------------------------------------------
+def test_pairwise_iou_against_the_independent_box_iou_in_transformers():
+    """detectron2 / torchvision are absent, so ``oracle.box_ops.pairwise_iou`` cannot be pinned to them here;
+    ``transformers`` (installed) carries its own port of torchvision's ``box_iou`` -- an implementation written by
+    somebody else.  d2's differs from it only in the ``where(inter > 0)`` guard (0 instead of 0/0 for two empty boxes)."""
+    loss_mod = pytest.importorskip("transformers.loss.loss_for_object_detection")
+    g = torch.Generator().manual_seed(3)
+    xy = torch.rand(300, 2, generator=g) * 900
+    wh = torch.rand(300, 2, generator=g) * 200 + 1
+    a = torch.cat([xy, xy + wh], 1)
+    xy = torch.rand(120, 2, generator=g) * 900
+    wh = torch.rand(120, 2, generator=g) * 300 + 1
+    b = torch.cat([xy, xy + wh], 1)
+    b[:10] = a[:10]                       # IoU exactly 1
+    b[10:20, :2] = a[10:20, 2:]           # touching corners: intersection 0
+    b[10:20, 2:] = a[10:20, 2:] + 50
+    ref, _ = loss_mod.box_iou(a, b)
+    got = B.pairwise_iou(a, b)
+    assert torch.equal(got, ref)
+    assert (got[torch.arange(10), torch.arange(10)] == 1).all() and (got[torch.arange(10, 20), torch.arange(10, 20)] == 0).all()
+    # box_area agrees too
+    assert torch.equal(B.box_area(a), loss_mod.box_area(a))
