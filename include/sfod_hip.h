@@ -123,7 +123,13 @@ int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, 
  * statistics and affine parameters.  The kernel computes relu((x - mean) * (invstd * gamma) + beta) and the (hi, lo) split of
  * SFOD_BF16X3 -- the arithmetic of sfod_bn_relu_pool_fwd, bit for bit -- on each patch slice in LDS; w / bias / y / stats / act
  * as in sfod_conv_fwd (3x3, y fp32).  _supported: 1 when the shape is served (dt SFOD_BF16X3, Cin % 32 == 0, the halo-patch
- * kernel's 256 x 128 shape); otherwise run sfod_bn_relu_pool_fwd + sfod_conv_fwd. */
+ * kernel's 256 x 128 shape); otherwise run sfod_bn_relu_pool_fwd + sfod_conv_fwd.  It also answers 0 -- process-wide
+ * settings, not properties of the shape -- when the generic implicit-GEMM path is forced (sfod_set_conv_algo(1)), when the
+ * 16x16x32 form is switched off (sfod_set_conv3x3_m16(0) / SFOD_P3_M16=0: the fold exists on that form only) and when a
+ * workgroup-shape variant other than auto / 2 / 5 / 6 is forced (sfod_set_conv3x3_variant).  The caller decides WHETHER to
+ * use it (the in-LDS transform costs the convolution 12-15 %; backbone_vgg.py takes it in forward-only train-mode passes
+ * for producers whose fp32 output is >= 256 MB: conv2_1 from 3 frames per GPU at 600 x 1200, conv3_1 / conv3_2 from 6;
+ * conv4_x never, see profiles/r4_bnin_layers.txt). */
 int sfod_conv_fwd_bnin_supported(int B, int H, int W, int Cin, int Cout, int dt);
 int sfod_conv_fwd_bnin(const float* x_pre, const float* in_mean, const float* in_invstd, const float* in_gamma,
                        const float* in_beta, const void* w, const float* bias, float* y, int B, int H, int W, int Cin,

@@ -404,7 +404,11 @@ def add_native_config(cfg):
     _C.SFOD.FUSE_FIRST_LAYER = True
     # forward-only passes (the teacher), bf16x3: a convolution whose input is a non-pooled BatchNorm + ReLU reads the
     # producer's pre-BatchNorm output and applies BatchNorm + ReLU + the operand split in its LDS patch
-    # (sfod_conv_fwd_bnin): the elementwise apply pass of conv2_1, conv3_1/2, conv4_1/2 disappears
+    # (sfod_conv_fwd_bnin).  Taken only where it pays (backbone_vgg.py::_defer_bn): the producer's fp32 output must be
+    # >= 256 MB (SFOD_BNIN_MIN_BYTES) -- conv2_1 (92 MB per 600x1200 frame) from 3 frames per GPU, conv3_1 / conv3_2
+    # (46 MB per frame) from 6, conv4_x never (the fold loses there); so the yaml's one frame per GPU never takes it and
+    # bench.py's batch 8 removes three apply passes.  Also needs the 16x16x32 kernel form (SFOD_P3_M16 != 0) and an
+    # auto / 2 / 5 / 6 tile variant (sfod_conv_fwd_bnin_supported)
     _C.SFOD.FUSE_BN_INPUT = True
     # d2's EvalHook inside Trainer.train(): Trainer.test every TEST.EVAL_PERIOD iterations and after the last one
     _C.SFOD.EVAL_HOOK = True

@@ -66,9 +66,10 @@ class EventStorage:
         self._pending[name] = value
         (self._rank_mean.add if rank_mean else self._rank_mean.discard)(name)
 
-    def put_scalars(self, rank_mean=False, **kw):
+    def put_scalars(self, _rank_mean=False, **kw):
+        """``_rank_mean`` is positional / underscored so that a metric may itself be called ``rank_mean``."""
         for k, v in kw.items():
-            self.put_scalar(k, v, rank_mean=rank_mean)
+            self.put_scalar(k, v, rank_mean=_rank_mean)
 
     def flush(self, reduce_over_ranks=False):
         """-> the record of this writer period.  ``reduce_over_ranks``: the ``rank_mean`` keys of the period are stacked
@@ -80,8 +81,16 @@ class EventStorage:
             return {}
         names = list(self._pending)
         vals = [v.detach().float().reshape(()) if isinstance(v, torch.Tensor) else None for v in self._pending.values()]
-        dev_idx = [i for i, v in enumerate(vals) if v is not None]
         world = get_world_size() if reduce_over_ranks else 1
+        if world > 1:
+            # host floats among the rank-mean keys are averaged like the device scalars (the reference's _write_metrics
+            # averages every key of the gathered dicts); data_time keeps its own MAX reduction below
+            dev0 = next((v.device for v in vals if v is not None), torch.device("cuda", torch.cuda.current_device())
+                        if torch.cuda.is_available() else torch.device("cpu"))
+            for i, n_ in enumerate(names):
+                if vals[i] is None and n_ in self._rank_mean and n_ != "data_time":
+                    vals[i] = torch.tensor(float(self._pending[n_]), dtype=torch.float32, device=dev0)
+        dev_idx = [i for i, v in enumerate(vals) if v is not None]
         shared = [i for i in dev_idx if names[i] in self._rank_mean] if world > 1 else []
         has_dt = world > 1 and "data_time" in self._rank_mean and "data_time" in self._pending
         if world > 1:
@@ -223,7 +232,11 @@ class GradientReducer:
 def _apply_process_knobs(cfg):
     """Config keys that are process-wide library settings: applied when a trainer is constructed."""
     if "DETERMINISTIC" in cfg.SFOD and torch.device(cfg.MODEL.DEVICE).type == "cuda":
-        native.set_deterministic(bool(cfg.SFOD.DETERMINISTIC))
+        # the mode is on when EITHER the config key or the SFOD_DETERMINISTIC=1 environment setting asks for it
+        # (include/sfod_hip.h documents both): a trainer built from a default config no longer switches a user's
+        # environment setting off.  Process-wide: the last trainer constructed decides.
+        want = bool(cfg.SFOD.DETERMINISTIC) or os.environ.get("SFOD_DETERMINISTIC", "0") == "1"
+        native.set_deterministic(want)
 
 
 class BaseTrainer:
@@ -362,6 +375,13 @@ class BaseTrainer:
         if w > 1:
             red = getattr(self, "_reducer", None)
             if red is not None:
+                if red.skip and not self.__dict__.get("_skip_checked"):
+                    # the skipped slots (a zero-weighted, elided domain classifier) are exchanged by nobody: that is only
+                    # right while their gradients are exactly zero on this rank -- checked once, on the first step
+                    self._skip_checked = True
+                    g = self.optimizer.flat.grad
+                    nz = sum(float(g[lo:min(hi, g.numel())].abs().max()) for lo, hi in red.skip if hi > lo)
+                    assert nz == 0.0, "GradientReducer skips parameters with non-zero gradients (DC_img / DC_ins)"
                 red.finish()
             else:
                 dist.all_reduce(self.optimizer.flat.grad)
@@ -372,8 +392,8 @@ class BaseTrainer:
         if loss_keys:
             self.storage.put_scalar("total_loss", total if total is not None
                                     else sum(metrics_dict[k].detach() for k in loss_keys), rank_mean=True)
-        self.storage.put_scalars(rank_mean=True, **{k: (v.detach() if isinstance(v, torch.Tensor) else v)
-                                                    for k, v in metrics_dict.items()})
+        self.storage.put_scalars(True, **{k: (v.detach() if isinstance(v, torch.Tensor) else v)
+                                          for k, v in metrics_dict.items()})
 
     def after_step(self):
         """d2 hook order (source_free_adaptive_teacher.py:622-679 ``build_hooks``): LRScheduler, PeriodicCheckpointer,

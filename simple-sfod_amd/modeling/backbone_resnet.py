@@ -431,13 +431,17 @@ class ResNet(nn.Module):
         side = self.__dict__.get("_side")
         if side is not None:
             # dy is complete on the main stream; the weight gradient reads (x_in, dy) on the side stream while the main
-            # stream goes on with the data gradient.  Both tensors stay referenced until the join at the end of the backward.
+            # stream goes on with the data gradient.  record_stream keeps the allocator from handing their memory out again
+            # before the side kernel has run, so they need not stay referenced until the join at the end of the backward.
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(side):
                 side.wait_event(ev)
                 dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.grad_dtype)
-            self._side_keep.append((x_in, dy, dw))
+            for t_ in (x_in, dy):
+                if t_ is not None:
+                    t_.record_stream(side)
+            self._side_keep.append(dw)
         else:
             dw = native.conv_weight_grad(x_in, dy, conv.weight, operand=self.grad_dtype)
         dx = None
@@ -522,7 +526,7 @@ class ResNet(nn.Module):
         if self._side is not None:      # every weight gradient is in its buffer before anyone (all-reduce, SGD, autograd) reads it
             main = torch.cuda.current_stream()
             main.wait_stream(self._side)
-            for _, _, dw in self._side_keep:      # a gradient tensor made on the side stream is consumed on the main one
+            for dw in self._side_keep:      # a gradient tensor made on the side stream is consumed on the main one
                 if dw is not None:
                     dw.record_stream(main)
             self._side, self._side_keep = None, []

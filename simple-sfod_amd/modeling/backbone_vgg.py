@@ -353,14 +353,18 @@ class vgg_backbone(nn.Module):
             cout, cin = conv.out_channels, conv.in_channels
             if side is not None:
                 # dy is complete on the main stream; the weight gradient reads (x, dy) on the side stream while the main one
-                # goes on with the data gradient.  Both stay referenced until the join (their memory belongs to the main
-                # stream's pool and must not be handed out again before the side kernel has run)
+                # goes on with the data gradient.  Their memory belongs to the main stream's pool: record_stream tells the
+                # allocator not to hand it out again before the side kernel has run, so the references can be dropped
+                # layer by layer (holding all 13 (x, dy) pairs until the join cost ~180 MB per image and layer at conv1_x)
                 ev = torch.cuda.Event()
                 ev.record()
                 with torch.cuda.stream(side):
                     side.wait_event(ev)
                     dw = native.conv_weight_grad(x, dy, conv.weight)
-                side_keep.append((x, dy, dw))
+                for t_ in (x, dy):
+                    if t_ is not None:
+                        t_.record_stream(side)
+                side_keep.append(dw)
             else:
                 dw = native.conv_weight_grad(x, dy, conv.weight)
             # a conv bias followed by train-mode BN has an analytically zero gradient
@@ -389,7 +393,7 @@ class vgg_backbone(nn.Module):
         if side is not None:             # every weight gradient is in its buffer before anyone (all-reduce, SGD, autograd) reads it
             main = torch.cuda.current_stream()
             main.wait_stream(side)
-            for _, _, dw in side_keep:
+            for dw in side_keep:
                 if dw is not None:
                     dw.record_stream(main)
         return pgrads

@@ -120,24 +120,24 @@ def _worker(rank, world, port, q):
     # logged metrics: mean over ranks of the period's device scalars with one small all-reduce, data_time = max over
     # ranks (reference base.py:198-209: comm.gather + np.mean / np.max)
     st = sfod.engine.trainer.EventStorage(0)
-    st.put_scalars(rank_mean=True, loss_cls=torch.tensor(float(rank + 1)), total_loss=torch.tensor(10.0 * (rank + 1)),
-                   data_time=0.25 * (rank + 1), **{"lr_note": 3.0})
+    st.put_scalars(True, loss_cls=torch.tensor(float(rank + 1)), total_loss=torch.tensor(10.0 * (rank + 1)),
+                   data_time=0.25 * (rank + 1), **{"lr_note": 3.0 * (rank + 1), "rank_mean": torch.tensor(2.0 * (rank + 1))})
     # what a hook or the teacher pass puts beside the step's metrics_dict stays rank-local (the reference logs the main
     # process's storage: val_loss.py:64-66, source_free_adaptive_teacher.py:411-423)
     st.put_scalar("roi_head/mean_confidence", torch.tensor(0.5 + rank))
     st.put_scalar("total_loss_val", torch.tensor(7.0 * (rank + 1)))
     rec = st.flush(reduce_over_ranks=True)
     ok_sum = ok_sum and rec["loss_cls"] == 1.5 and rec["total_loss"] == 15.0 and rec["data_time"] == 0.5 \
-        and rec["lr_note"] == 3.0 and rec["roi_head/mean_confidence"] == 0.5 + rank \
+        and rec["lr_note"] == 4.5 and rec["rank_mean"] == 3.0 and rec["roi_head/mean_confidence"] == 0.5 + rank \
         and rec["total_loss_val"] == 7.0 * (rank + 1) and st.flush(reduce_over_ranks=True) == {}
     # rank-local keys may differ in number between ranks (an empty share of a tiny evaluation set): they are never part
     # of a collective, the rank-mean keys are still averaged
-    st.put_scalars(rank_mean=True, a=torch.tensor(float(rank)))
+    st.put_scalars(True, a=torch.tensor(float(rank)))
     st.put_scalars(**({"b": torch.tensor(5.0)} if rank == 0 else {}))
     rec = st.flush(reduce_over_ranks=True)
     ok_sum = ok_sum and rec["a"] == 0.5 and (("b" in rec) == (rank == 0))
     # ranks that disagree on the number of rank-mean keys: no mismatched collective, every rank keeps its own values
-    st.put_scalars(rank_mean=True, a=torch.tensor(float(rank)), **({"c": torch.tensor(5.0)} if rank == 0 else {}))
+    st.put_scalars(True, a=torch.tensor(float(rank)), **({"c": torch.tensor(5.0)} if rank == 0 else {}))
     rec = st.flush(reduce_over_ranks=True)
     ok_sum = ok_sum and rec["a"] == float(rank) and (("c" in rec) == (rank == 0))
     # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream

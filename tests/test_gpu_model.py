@@ -119,6 +119,30 @@ def test_teacher_backbone_with_batchnorm_folded_into_the_next_conv(sfod, native,
         assert torch.equal(stats[True][k], stats[False][k]), k
 
 
+@pytest.mark.parametrize("batch,expected", [(1, 0), (8, 3)])
+def test_batchnorm_fold_gate_at_the_default_config(sfod, native, monkeypatch, batch, expected):
+    """SFOD.FUSE_BN_INPUT defaults to True but is taken only for producers with >= 256 MB of fp32 output: never at the
+    yaml's one 600x1200 frame per GPU, three layers (conv2_2, conv3_2, conv3_3 read their producer's pre-BatchNorm
+    output) at the bench's eight (config.py / include/sfod_hip.h state exactly this)."""
+    cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", "bf16x3"])
+    assert cfg.SFOD.FUSE_BN_INPUT is True
+    torch.manual_seed(5)
+    bb = sfod.modeling.backbone_vgg.build_vgg_backbone(cfg, None).to(DEV).train()
+    assert bb.fuse_bn_input_min_bytes == 256 << 20
+    n = [0]
+    orig = native.conv_fwd_bnin
+
+    def counted(*a, **k):
+        n[0] += 1
+        return orig(*a, **k)
+    monkeypatch.setattr(native, "conv_fwd_bnin", counted)
+    x = torch.randn(batch, 3, 600, 1200, generator=torch.Generator().manual_seed(3)).to(DEV)
+    with torch.no_grad():
+        bb(x)
+    torch.cuda.synchronize()
+    assert n[0] == expected, n[0]
+
+
 def test_dann_modules_match_reference_golden(sfod, native):
     fx = np.load(os.path.join(GOLDEN, "dann_ref.npz"), allow_pickle=False)
     dann = sfod.modeling.dann

@@ -1,0 +1,220 @@
+"""BASELINE config #4's code path with world_size 2 on the HIP kernels (reference
+daod/engine/trainers/source_free_adaptive_teacher.py:70-73 DDP(broadcast_buffers=False), daod/data/build.py:337-343
+per-rank batch, daod/engine/trainers/base.py:186-220 rank-mean metrics).
+
+Two fresh interpreters (tests/helpers/two_rank_worker.py) share ``cuda:0`` and talk over gloo -- RCCL refuses two ranks
+on one device, and the trainer only sees ``torch.distributed``, so the code that runs is the code an 8-GPU job runs.
+Each rank does ONE ``run_step`` at one frame per rank.  Checked here, in the parent:
+
+  * the constructor's broadcast: different RNG draws per rank, identical students (rank 0's) afterwards;
+  * disjoint loader shards (rank r takes elements r, r + 2, ... of one shared-seed stream);
+  * all three phases of ``GradientReducer`` were launched from inside the backward, the early and mid ones still in
+    flight when the next one started, the zero-gradient domain-classifier slots never exchanged;
+  * after the step: students bit-identical across ranks (parameters and momentum), teachers identical in their
+    parameters and DIFFERENT in their BatchNorm statistics (per-rank EMA, no buffer broadcast);
+  * the logged losses are the mean over ranks;
+  * the update equals the oracle's: per rank ``om.teacher_forward`` + ``om.student_losses`` on that rank's frame from
+    that rank's buffers -> backward -> MEAN of the two gradients -> ``om.sgd_step`` -> ``om.ema_update``, at the
+    trajectory test's tolerances; every per-rank running statistic and counter against the oracle's per-rank pass.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import model as om
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "helpers", "two_rank_worker.py")
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run_two_ranks(tmp_path, model, dtype):
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("MASTER_ADDR", None)
+        log = open(os.path.join(tmp_path, f"rank{r}.log"), "w")
+        procs.append((subprocess.Popen([sys.executable, WORKER, "--model", model, "--dtype", dtype, "--out", str(tmp_path),
+                                        "--port", str(port)], env=env, stdout=log, stderr=subprocess.STDOUT), log))
+    codes = []
+    try:
+        for p, log in procs:
+            codes.append(p.wait(timeout=600))
+    finally:
+        for p, log in procs:
+            if p.poll() is None:
+                p.kill()          # exactly the children started above
+            log.close()
+    if any(codes):
+        tails = "\n".join(open(os.path.join(tmp_path, f"rank{r}.log")).read()[-3000:] for r in range(2))
+        pytest.fail(f"worker exit codes {codes}\n{tails}")
+    return [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+
+
+@pytest.mark.parametrize("model,dtype", [("vgg", "fp32"), ("vgg", "bf16x3"), ("r101", "f16x3")])
+def test_two_ranks_on_one_gpu_take_the_oracles_mean_gradient_step(tmp_path, model, dtype):
+    resnet = model == "r101"
+    R = _run_two_ranks(str(tmp_path), model, dtype)
+    r0, r1 = R
+    KEEP, LR = 0.9, 2.5e-5
+    print(f"\n[two ranks {model} {dtype}] gloo on device tensors: {r0['gloo_device_tensors']}"
+          + ("" if r0["gloo_device_tensors"] else f" ({r0.get('gloo_error')})"))
+    # ---- construction --------------------------------------------------------------------------------------------------
+    assert r0["world"] == r1["world"] == 2 and r0["batch_per_rank"] == r1["batch_per_rank"] == 1
+    assert not torch.equal(r0["rng_probe"], r1["rng_probe"])
+    for k, v in r0["init_student"].items():
+        assert torch.equal(v, r1["init_student"][k]), f"after the constructor's broadcast rank 1 differs in {k}"
+    # ---- shards --------------------------------------------------------------------------------------------------------
+    ids = [r["image_ids"] + r["next_image_ids"] for r in R]
+    stream = iter(__import__("importlib").import_module("simple-sfod_amd").data.TrainingSampler(8, seed=3, rank=0, world=1))
+    full = [next(stream) for _ in range(4)]
+    assert ids[0] == full[0::2] and ids[1] == full[1::2], (ids, full)
+    assert not set(r0["image_ids"]) & set(r1["image_ids"])
+    assert not torch.equal(r0["images"][0], r1["images"][0])
+    # ---- the exchange ---------------------------------------------------------------------------------------------------
+    for r in R:
+        red, names = r["reducer"], [x[0] for x in r["launched"]]
+        assert red is not None and names == ["launch_early", "launch_mid", "finish"], names
+        assert red["early"][1] > red["early"][0] and red["mid"][1] > red["mid"][0]
+        # early still pending when mid starts, both pending when finish starts, nothing pending afterwards
+        assert r["launched"][1][1] == (True, False) and r["launched"][2][1] == (True, True) and r["launched"][2][2] == (False, False)
+        assert r["grad_scale"] == 0.5 and r["grad_sum"] > 0
+        if r["dc_on"]:
+            assert red["skip"] and r["dc_grad_abs"] == 0.0      # zero on every rank: never exchanged, still zero
+        assert red["final_elements"] * 4 < 10_000_000
+    # ---- after the step -------------------------------------------------------------------------------------------------
+    names, frozen = r0["names"], r0["frozen"]
+    assert bool(frozen) == resnet
+    for k, v in r0["after_student"].items():
+        if om.is_param(k):
+            assert torch.equal(v, r1["after_student"][k]), f"students differ in {k}"
+            assert torch.equal(r0["after_teacher"][k], r1["after_teacher"][k]), f"teachers differ in {k}"
+    for n in names:
+        assert torch.equal(r0["momentum"][n], r1["momentum"][n]), n
+    live_stats = [k for k, v in r0["after_teacher"].items() if "running" in k and
+                  not torch.equal(r0["before_teacher"][k], v)]
+    assert live_stats, "no BatchNorm statistic moved"
+    n_diff_t = sum(not torch.equal(r0["after_teacher"][k], r1["after_teacher"][k]) for k in live_stats)
+    n_diff_s = sum(not torch.equal(r0["after_student"][k], r1["after_student"][k]) for k in live_stats)
+    assert n_diff_t == len(live_stats) and n_diff_s == len(live_stats), (n_diff_t, n_diff_s, len(live_stats))
+    # ---- metrics: mean over ranks ---------------------------------------------------------------------------------------
+    keys = ("loss_rpn_cls_pseudo", "loss_rpn_loc_pseudo", "loss_cls_pseudo", "loss_box_reg_pseudo", "total_loss")
+    for k in keys:
+        assert r0["record"][k] == r1["record"][k]
+        np.testing.assert_allclose(r0["record"][k], 0.5 * (r0["local_metrics"][k] + r1["local_metrics"][k]), rtol=1e-6)
+    assert r0["local_metrics"]["loss_cls_pseudo"] != r1["local_metrics"]["loss_cls_pseudo"]
+    # rank-local scalars stay rank-local (the reference writes the main process's storage)
+    assert r0["record"]["roi_head/num_pseudo_proposals"] == r0["local_metrics"]["roi_head/num_pseudo_proposals"]
+    # ---- the oracle's step: mean of the per-rank gradients --------------------------------------------------------------
+    ocfg = om.Cfg.r101_c4() if resnet else om.Cfg()
+    passes = 3 if r0["dc_on"] else 1
+    assert r0["elided_bn_updates"] == passes
+    grads_per_rank, losses_per_rank, sd_rank = [], [], []
+    for r in R:
+        sd_s = om.clone_state({k: v.float() if v.dtype != torch.int64 else v.clone() for k, v in r["before_student"].items()})
+        sd_t = om.clone_state({k: v.float() if v.dtype != torch.int64 else v.clone() for k, v in r["before_teacher"].items()})
+        for k, v in sd_s.items():
+            if om.is_param(k):
+                v.requires_grad_(True)
+        om.teacher_forward(sd_t, r["images"], ocfg)
+        assert len(r["pseudo_boxes"][0]) > 0, "a rank without pseudo labels exercises nothing"
+        losses = om.student_losses(sd_s, r["images"], r["pseudo_boxes"], r["pseudo_classes"], list(r["rpn_keys"]),
+                                   list(r["roi_keys"]), ocfg, proposals=r["props"])
+        with torch.no_grad():
+            x, _ = om.preprocess(r["images"])
+            for _ in range(passes - 1):
+                om.backbone_forward(sd_s, x, ocfg, training=True)
+        sum(v for k, v in losses.items() if k != "loss_bpc").backward()
+        grads_per_rank.append({n: sd_s[n].grad for n in names})
+        losses_per_rank.append({k: v.item() for k, v in losses.items()})
+        sd_rank.append((sd_s, sd_t))
+    for k in ("loss_rpn_cls", "loss_rpn_loc", "loss_cls", "loss_box_reg"):
+        for i, r in enumerate(R):
+            np.testing.assert_allclose(r["local_metrics"][k + "_pseudo"], losses_per_rank[i][k], rtol=1e-4, atol=1e-7)
+        np.testing.assert_allclose(r0["record"][k + "_pseudo"], 0.5 * (losses_per_rank[0][k] + losses_per_rank[1][k]),
+                                   rtol=1e-4, atol=1e-7)
+    dc_on = r0["dc_on"]
+    mean_grads = {}
+    for n in names:
+        g0, g1 = grads_per_rank[0][n], grads_per_rank[1][n]
+        if g0 is None and g1 is None:
+            mean_grads[n] = torch.zeros_like(sd_rank[0][0][n]) if (dc_on or not n.startswith("DC_")) else None
+        else:
+            z = torch.zeros_like(sd_rank[0][0][n])
+            mean_grads[n] = 0.5 * ((g0 if g0 is not None else z) + (g1 if g1 is not None else z))
+    sd_new = om.clone_state({k: v.detach().clone() for k, v in sd_rank[0][0].items()})
+    bufs = {}
+    om.sgd_step(sd_new, mean_grads, bufs, lr=om.lr_at(0, LR, warmup_iters=0))
+
+    def tol(name):      # tests/test_gpu_trajectory.py::tol (flip sensitivity of the oracle itself)
+        x3 = dtype in ("bf16x3", "f16x3")
+        if name.startswith("backbone"):
+            return 8e-2 if resnet else (6e-2 if x3 else 4e-2)
+        if name.startswith("roi_heads"):
+            return 8e-3 if resnet else (4e-3 if x3 else 2e-3)
+        if ".rpn_head." in name:
+            return 3e-2
+        return 2e-3 if (x3 or resnet) else 2e-4
+    worst = {}
+    for n in names:
+        parts = n.split(".")
+        if n.startswith("DC_"):
+            torch.testing.assert_close(r0["after_student"][n], sd_new[n].detach(), rtol=1e-6, atol=1e-9)
+            continue
+        if parts[0] == "backbone" and parts[1].startswith("vgg") and parts[-1] == "bias" and parts[2] in ("0", "3", "6"):
+            continue        # conv bias in front of train-mode BatchNorm: analytically zero gradient
+        d_dev = r0["after_student"][n] - r0["before_student"][n]
+        d_ref = sd_new[n].detach() - sd_rank[0][0][n].detach()
+        e = rel_err(d_dev, d_ref)
+        ulp = 2 * 6e-8 * sd_new[n].detach().double().norm().item() / (d_ref.double().norm().item() + 1e-30)
+        worst[n] = e
+        assert e < tol(n) + ulp, (n, e, ulp)
+        assert rel_err(r0["momentum"][n], bufs[n]) < tol(n), (n, "momentum")
+    for n in frozen:
+        assert torch.equal(r0["after_student"][n], r0["before_student"][n]), n
+    # per-rank EMA: teacher parameters from the (shared) new student, buffers from this rank's own passes
+    for i, r in enumerate(R):
+        sd_s, sd_t = sd_rank[i]
+        with torch.no_grad():
+            for n in names:
+                sd_s[n].copy_(sd_new[n])
+        om.ema_update(sd_t, {k: v.detach() for k, v in sd_s.items()}, KEEP)
+        for k, v in r["after_teacher"].items():
+            if v.dtype == torch.int64:
+                assert int(v) == int(sd_t[k]), (i, k, int(v), int(sd_t[k]))
+                assert int(r["after_student"][k]) == int(sd_s[k]) == passes, (i, k)
+            elif "running" in k:
+                a = 1e-6 if (dtype == "fp32" and not resnet) else 2e-5
+                torch.testing.assert_close(v, sd_t[k].detach(), rtol=2e-4, atol=a, msg=lambda m: f"rank {i} teacher {k}: {m}")
+                torch.testing.assert_close(r["after_student"][k], sd_s[k].detach(), rtol=2e-4, atol=a,
+                                           msg=lambda m: f"rank {i} student {k}: {m}")
+            elif k in names and not k.startswith("DC_"):
+                parts = k.split(".")
+                if parts[0] == "backbone" and parts[1].startswith("vgg") and parts[-1] == "bias" and parts[2] in ("0", "3", "6"):
+                    continue
+                d_t = sd_t[k].detach() - r["before_teacher"][k]
+                e_t = rel_err(v - r["before_teacher"][k], d_t)
+                ulp = 2 * 6e-8 * sd_t[k].detach().double().norm().item() / (d_t.double().norm().item() + 1e-30)
+                assert e_t < tol(k) + 1e-3 + ulp, (i, k, "teacher update", e_t)
+    print(f"[two ranks {model} {dtype}] pseudo labels per rank {[len(r['pseudo_boxes'][0]) for r in R]}; worst update error per "
+          "group: " + ", ".join(f"{g} {max(v for n, v in worst.items() if n.startswith(g)):.2e}"
+                                for g in ("backbone", "proposal_generator", "roi_heads")))
