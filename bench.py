@@ -52,8 +52,14 @@ PARITY_DTYPE = {"vgg": "bf16x3", "r101": "f16x3"}
 # further modes that pass the same fullsize gates on the config (reported beside `value`, measured by child processes)
 # (fp32 = the reference's own arithmetic: every default line carries one number in it)
 OTHER_PARITY = {"vgg": {"bf16x3": ["f16x3", "fp32"], "f16x3": ["fp32"]}, "r101": {"f16x3": ["fp32"]}}
-# "planted-label" scale on cls_score: 10-30 teacher detections per image clear the 0.8 threshold
-PLANT = {"vgg": 60.0, "r101": 3.0}
+# "planted-label" mode (BASELINE.md section 3 / SURVEY 8d: "teacher box-predictor bias is set so ~10-30 boxes/image pass"):
+# seeded random weights give no detection above 0.8, so the class logits are spread by a moderate scale on cls_score's
+# weights (PLANT) and the BACKGROUND bias is calibrated at start-up, by bisection over untimed teacher passes on the bench's
+# own frames, until the mean number of pseudo labels per image is PLANT_TARGET (plant_labels below).  The realised count
+# and the student's loss_cls_pseudo over warm-up + timed steps are asserted and reported in `config`.
+PLANT = {"vgg": 8.0, "r101": 2.0}
+PLANT_TARGET = 20.0
+PLANT_RANGE = (10.0, 30.0)
 # the committed PMC captures (profiles/pmc_hbm_traffic_latest.json: VGG16 bf16x3; pmc_hbm_traffic_r101_latest.json: R101 f16x3)
 # were taken on exactly these run configurations
 PMC_CAPTURE = {"trainer": "source_free", "res": "r600", "batch": 8,
@@ -104,8 +110,9 @@ def cpu_baseline(res, planted, model="vgg"):
     torch.set_num_threads(cores)
     cfg = om.Cfg.r101_c4() if model == "r101" else om.Cfg()
     sd_t = om.init_state(cfg, seed=0)
-    if planted:
-        sd_t["roi_heads.box_predictor.cls_score.weight"] *= PLANT[model]
+    if planted:      # the GPU run's planted head: same weight scale, the background bias it calibrated
+        sd_t["roi_heads.box_predictor.cls_score.weight"] *= planted["cls_score_weight_scale"]
+        sd_t["roi_heads.box_predictor.cls_score.bias"][-1] = planted["background_bias"]
     sd_s = om.clone_state(sd_t, requires_grad=True)
     h, w = (600, 1200) if res == "r600" else (1024, 2048)
     g = torch.Generator().manual_seed(42)
@@ -153,6 +160,11 @@ def pmc_traffic(model, *kernel_substrs):
     if not os.path.exists(path):
         return None
     try:
+        # the capture is only valid for the kernels it was taken on: tools/pmc_summary.py stamps it with the fingerprint of
+        # simple-sfod_amd/csrc + include/ (csrc/build.py::source_fingerprint); a different source tree -> no traffic figure
+        meta = json.load(open(path + ".meta")) if os.path.exists(path + ".meta") else {}
+        if meta.get("csrc_fingerprint") != csrc_fingerprint():
+            return None
         # an entry of kernel_substrs may be a tuple of alternatives (template arguments print differently across builds)
         rows = [r for r in json.load(open(path))
                 if all(any(a in r["kernel"] for a in ((k,) if isinstance(k, str) else k)) for k in kernel_substrs)]
@@ -164,6 +176,13 @@ def pmc_traffic(model, *kernel_substrs):
                 "kernels": len(rows), "launches_counted": n, "source": "profiles/" + fname}
     except Exception:
         return None
+
+
+def csrc_fingerprint():
+    spec = importlib.util.spec_from_file_location("sfod_csrc_build", os.path.join(ROOT, "simple-sfod_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.source_fingerprint()
 
 
 def pmc_matches(args):
@@ -201,17 +220,77 @@ def build_trainer(sfod, args, dtype, world, rank, local_rank):
         trainer = sfod.engine.BaseTrainer(cfg)
     else:
         trainer = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
-        if not args.no_planted:
-            with torch.no_grad():  # "planted-label" mode: confident teacher scores
-                trainer.model.roi_heads.box_predictor.cls_score.weight.mul_(PLANT[args.model])
-                trainer._copy_main_model()
     return cfg, trainer
+
+
+def plant_labels(trainer, scale, target=PLANT_TARGET, note=lambda m: None):
+    """Planted-label mode: cls_score.weight *= scale (spreads the class logits of the random-weight head), then the
+    background bias is bisected over untimed teacher passes on the loader's frames until the mean pseudo-label count per
+    image is ``target``; student and teacher get the same values (teacher <- student copy, as at construction).
+    -> dict(scale, background_bias, pseudo labels per image on the calibration frames: mean / min / max)."""
+    import torch
+    bp = trainer.model.roi_heads.box_predictor
+    K = bp.cls_score.bias.numel() - 1
+    batches = [next(trainer._data_loader_iter)[1] for _ in range(2)]      # weak views of 2 batches
+
+    def counts(delta):
+        with torch.no_grad():
+            bp.cls_score.bias[K] = delta
+            trainer._copy_main_model()
+            c = [trainer._teacher_pass([dict(d) for d in b]).count.float() for b in batches]
+        trainer.storage._pending.clear()
+        return torch.cat(c)
+
+    with torch.no_grad():
+        bp.cls_score.weight.mul_(scale)
+    lo, hi = -40.0, 40.0          # more background bias -> fewer foreground detections: the count is monotone in it
+    for _ in range(24):
+        mid = 0.5 * (lo + hi)
+        if counts(mid).mean().item() > target:
+            lo = mid
+        else:
+            hi = mid
+    c = counts(0.5 * (lo + hi))
+    out = {"cls_score_weight_scale": scale, "background_bias": round(0.5 * (lo + hi), 4),
+           "calibration_pseudo_labels_per_image": {"mean": round(c.mean().item(), 2), "min": int(c.min().item()),
+                                                   "max": int(c.max().item()), "images": int(c.numel())}}
+    note(f"planted labels: {out}")
+    return out
+
+
+class StepLog:
+    """per-step device scalars of the run (no host sync until ``summary``): pseudo labels per image, loss_cls_pseudo"""
+
+    def __init__(self):
+        self.n_pseudo, self.loss_cls = [], []
+
+    def after_step(self, trainer):
+        p = trainer.storage._pending
+        if "roi_head/num_pseudo_proposals" in p:
+            self.n_pseudo.append(p["roi_head/num_pseudo_proposals"])
+        if "loss_cls_pseudo" in p:
+            self.loss_cls.append(p["loss_cls_pseudo"])
+
+    def summary(self):
+        import torch
+        out = {}
+        for k, v in (("pseudo_labels_per_image", self.n_pseudo), ("loss_cls_pseudo", self.loss_cls)):
+            if v:
+                t = torch.stack([x.detach().float().reshape(()) for x in v]).cpu()
+                out[k] = {"mean": round(t.mean().item(), 3), "min": round(t.min().item(), 3), "max": round(t.max().item(), 3),
+                          "steps": int(t.numel())}
+        return out
+
+
+STEP_LOG = None
 
 
 def run_steps(trainer, first_iter, n):
     for i in range(n):
         trainer.iter = first_iter + i
         trainer.run_step()
+        if STEP_LOG is not None:
+            STEP_LOG.after_step(trainer)
         trainer.scheduler.step()
 
 
@@ -233,6 +312,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reduced-precision (bf16) secondary block")
     ap.add_argument("--no-planted", action="store_true")
+    ap.add_argument("--plant-scale", type=float, default=0.0, help="planted-label mode: scale on cls_score.weight (default: PLANT)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--opts", nargs="*", default=[], help="extra KEY VALUE config overrides (A/B runs)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -273,6 +353,16 @@ def main():
         torch.cuda.synchronize()
 
     note("trainer built")
+    planted = None
+    global STEP_LOG
+    if args.trainer != "base" and not args.no_planted:
+        planted = plant_labels(trainer, args.plant_scale if args.plant_scale else PLANT[args.model], note=note)
+        if world > 1:       # every rank calibrated on its own shard: take rank 0's bias everywhere (one broadcast, untimed)
+            bp = trainer.model.roi_heads.box_predictor
+            with torch.no_grad():
+                dist.broadcast(bp.cls_score.bias, 0)
+                trainer._copy_main_model()
+    STEP_LOG = StepLog()
     run_steps(trainer, 0, args.warmup)
     # Per-kernel HIP-event timing is only meaningful when kernels do not share the GPU: with
     # SFOD.OVERLAP_TEACHER the teacher pass runs on a second stream beside the student's forward, so the
@@ -289,6 +379,7 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     sfod.native.set_timer(None)
+    step_log, STEP_LOG = STEP_LOG, None        # warm-up + timed steps; the measurement segments below are not logged
     rl_steps, rl_elapsed, rl_segment = args.steps, elapsed, "the timed region"
     if not args.no_kernel_timer and overlapped:
         rl_steps = max(1, min(5, args.steps))
@@ -454,6 +545,7 @@ def main():
                    "--batch", str(args.batch), "--res", args.res, "--model", args.model, "--trainer", args.trainer,
                    "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"]
             cmd += (["--no-planted"] if args.no_planted else []) + (["--no-overlap"] if args.no_overlap else [])
+            cmd += ["--plant-scale", str(args.plant_scale)] if args.plant_scale else []
             cmd += (["--opts"] + list(args.opts)) if args.opts else []
             try:
                 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
@@ -513,12 +605,19 @@ def main():
                                "RandomFlip on the device every step, prefetched one batch ahead on a loader stream"
                                if bool(cfg.SFOD.SYNTHETIC.DEVICE_RESIZE) else
                                "frames resized once at start-up (Pillow), RandomFlip on the device every step"), "elide_zero_weight_branches": bool(cfg.SFOD.ELIDE_DEAD_BRANCHES),
-            "planted_labels": not args.no_planted and args.trainer != "base",
+            "planted_labels": planted if planted is not None else False,
+            **(step_log.summary() if step_log is not None and args.trainer != "base" else {}),
             "algorithmic_tflop_per_image": round(sflops / 1e12, 3),
         },
         "step_tflops_per_gpu": round(sflops * value / world / 1e12, 2),
         "losses": {k: round(v, 5) for k, v in rec.items() if k.startswith("loss") or k.startswith("roi_head")},
     }
+    if planted is not None:
+        # the student is trained on 10-30 pseudo labels per image with an O(1) classification loss over
+        # warm-up + timed steps -- a bench line whose workload is not that is not printed
+        pl, lc = out["config"].get("pseudo_labels_per_image"), out["config"].get("loss_cls_pseudo")
+        assert pl is not None and PLANT_RANGE[0] <= pl["mean"] <= PLANT_RANGE[1], f"pseudo labels per image {pl}"
+        assert lc is not None and 0.0 < lc["max"] < 5.0, f"loss_cls_pseudo {lc}"
     if gpu_fill is not None:
         out["gpu_fill"] = gpu_fill
     if comm is not None:
@@ -591,7 +690,7 @@ def main():
                                      "share_of_step_time": round(wk["ms"] / (1000.0 * rl_elapsed), 4)}
     if world == 1 and not args.no_cpu_baseline and args.trainer != "base":
         note("cpu baseline ...")
-        out["cpu_baseline"] = cpu_baseline(args.res, not args.no_planted, args.model)
+        out["cpu_baseline"] = cpu_baseline(args.res, planted, args.model)
     note("done")
     print(json.dumps(out), flush=True)
     if world > 1:

@@ -399,6 +399,9 @@ def add_native_config(cfg):
     _C.SFOD.ELIDE_DEAD_BRANCHES = True
     _C.SFOD.OVERLAP_TEACHER = True
     _C.SFOD.DETERMINISTIC = False
+    # roctx ranges around the stages of a step (teacher / student_forward / student_backward / exchange / update) for
+    # rocprofv3 --marker-trace; also SFOD_ROCTX=1 (engine/trainer.py::stage)
+    _C.SFOD.PROFILE_RANGES = False
     # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass
     # that stores the activated output directly; sfod_conv_first_fused)
     _C.SFOD.FUSE_FIRST_LAYER = True

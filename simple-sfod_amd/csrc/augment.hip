@@ -165,7 +165,10 @@ float gaussian_box_radius(float radius, int passes) {
 
 extern "C" int sfod_aug_color(const uint8_t* in, uint8_t* out, int H, int W, int n_ops, const int32_t* codes,
                               const float* factors, void* ws, void* stream) {
+  SFOD_REQUIRE_EXTENTS("aug_color", H, W, n_ops);
   SFOD_REQUIRE(n_ops >= 0 && n_ops <= AUG_MAX_OPS, "aug_color: at most 8 ops");
+  SFOD_REQUIRE(n_ops == 0 || (codes != nullptr && factors != nullptr), "aug_color: codes / factors are host arrays of n_ops entries");
+  SFOD_REQUIRE(sfod_prod_fits({H, W}, 1LL << 40), "aug_color: oversized image");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n = (int64_t)H * W;
   if (n == 0) return 0;
@@ -198,10 +201,13 @@ extern "C" int sfod_aug_color(const uint8_t* in, uint8_t* out, int H, int W, int
 
 extern "C" int sfod_aug_gaussian_blur(const uint8_t* in, uint8_t* out, uint8_t* tmp, int C, int H, int W,
                                       float sigma, void* stream) {
+  SFOD_REQUIRE_EXTENTS("aug_gaussian_blur", C, H, W);
+  SFOD_REQUIRE(sfod_prod_fits({C, H, W}, 1LL << 40), "aug_gaussian_blur: oversized image");
   hipStream_t s = (hipStream_t)stream;
   const int64_t n = (int64_t)C * H * W;
   if (n == 0) return 0;
   SFOD_REQUIRE(in != out && in != tmp && out != tmp, "aug_gaussian_blur: in / out / tmp must be distinct");
+  SFOD_REQUIRE(sigma > 0.f && sigma <= 1024.f, "aug_gaussian_blur: sigma outside (0, 1024]");      // (NaN fails both)
   const float fr = gaussian_box_radius(sigma, 3);
   const int radius = (int)fr;
   const unsigned ww = (unsigned)((1 << 24) / (fr * 2 + 1));
@@ -222,7 +228,10 @@ extern "C" int sfod_aug_gaussian_blur(const uint8_t* in, uint8_t* out, uint8_t* 
 
 extern "C" int sfod_aug_erase(uint8_t* img, int C, int H, int W, int i, int j, int h, int w, const float* noise,
                               void* stream) {
-  SFOD_REQUIRE(i >= 0 && j >= 0 && h >= 0 && w >= 0 && i + h <= H && j + w <= W, "aug_erase: rectangle outside the image");
+  SFOD_REQUIRE_EXTENTS("aug_erase", C, H, W, i, j, h, w);
+  SFOD_REQUIRE(i >= 0 && j >= 0 && h >= 0 && w >= 0 && (int64_t)i + h <= H && (int64_t)j + w <= W,
+               "aug_erase: rectangle outside the image");
+  SFOD_REQUIRE(sfod_prod_fits({C, H, W}, 1LL << 40), "aug_erase: oversized image");
   const int64_t n = (int64_t)C * h * w;
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_aug_erase, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, img, C, H, W, i, j, h, w,

@@ -27,6 +27,35 @@ static inline int sfod_check_launch(const char* what) {
     }                                                \
   } while (0)
 
+// Entry-point hygiene (tests/test_abi.py fuzzes the host side under ASan / UBSan): every extent of a call is
+// non-negative and small enough that the +255 / +63 roundings of the launch arithmetic cannot wrap an int (int64
+// element / byte counts: below 2^40); products of extents that the host code forms are checked where they are formed
+// (sfod_prod_fits) -- otherwise SFOD_EBADARG before anything is computed or launched.
+#include <initializer_list>
+static inline bool sfod_ints_ok(std::initializer_list<long long> dims) {
+  for (long long d : dims)
+    if (d < 0 || d > 2147483647LL - 65536) return false;
+  return true;
+}
+static inline bool sfod_i64s_ok(std::initializer_list<long long> dims) {
+  for (long long d : dims)
+    if (d < 0 || d > (1LL << 40)) return false;
+  return true;
+}
+// does the product of (already non-negative) extents stay <= limit?  saturating, no overflow on the way
+static inline bool sfod_prod_fits(std::initializer_list<long long> dims, long long limit = 2147483647LL - 65536) {
+  unsigned long long p = 1;
+  bool over = false;
+  for (long long d : dims) {
+    if (d < 0) return false;
+    if (d == 0) return true;                          // an empty tensor, whatever the other extents say
+    if (over || p > (unsigned long long)limit / (unsigned long long)d) over = true;
+    else p *= (unsigned long long)d;
+  }
+  return !over;
+}
+#define SFOD_REQUIRE_EXTENTS(what, ...) SFOD_REQUIRE(sfod_ints_ok({__VA_ARGS__}), what ": negative or oversized extent")
+
 typedef __bf16 bf16_t;
 
 __device__ __forceinline__ float to_f32(float v) { return v; }

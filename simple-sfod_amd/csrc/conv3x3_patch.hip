@@ -1371,6 +1371,7 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout, int pairs) {
 
 #ifdef M16_STAMP
 extern "C" int sfod_debug_m16_stamps(unsigned long long* out8, int reset) {
+  SFOD_REQUIRE_EXTENTS("debug_m16_stamps", reset);
   hipDeviceSynchronize();
   hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_m16_stamps), 64);
   if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_m16_stamps), z, 64); }

@@ -109,6 +109,10 @@ __global__ void k_rpn_decode(const float* __restrict__ rpn_out, int ld, const fl
 extern "C" int sfod_rpn_decode(const float* rpn_out, int ld, const float* cell_anchors, int A, int B,
                                int Hf, int Wf, int stride, const int32_t* image_sizes, float* props,
                                float* scores, int32_t* flags, void* stream) {
+  SFOD_REQUIRE_EXTENTS("rpn_decode", ld, A, B, Hf, Wf, stride);
+  SFOD_REQUIRE(sfod_prod_fits({Hf, Wf, A}) && sfod_prod_fits({5, A}) && sfod_prod_fits({B, Hf, Wf, ld}, 1LL << 40),
+               "rpn_decode: oversized anchor grid");
+  SFOD_REQUIRE(rpn_out && cell_anchors && image_sizes && props && scores && flags, "rpn_decode: null argument");
   SFOD_REQUIRE(ld >= 5 * A, "rpn_out leading dim < 5A");
   const int NA = Hf * Wf * A;
   dim3 grid(cdiv(NA, 256), B);
@@ -135,6 +139,7 @@ __global__ void k_rpn_gather_topk(const float* __restrict__ props, const float* 
 extern "C" int sfod_rpn_gather_topk(const float* props, const float* sorted_scores,
                                     const int32_t* sorted_idx, int B, int NA, int k, float* cand_boxes,
                                     float* cand_scores, uint8_t* cand_valid, void* stream) {
+  SFOD_REQUIRE_EXTENTS("rpn_gather_topk", B, NA, k);
   SFOD_REQUIRE(k <= NA, "k > NA");
   dim3 grid(cdiv(k, 256), B);
   hipLaunchKernelGGL(k_rpn_gather_topk, grid, dim3(256), 0, (hipStream_t)stream, props, sorted_scores,
@@ -446,6 +451,7 @@ k_nms_reduce_wide(const uint64_t* __restrict__ mask, const uint8_t* __restrict__
 }
 
 extern "C" int64_t sfod_nms_mask_bytes(int B, int n) {
+  if (!sfod_ints_ok({B, n}) || !sfod_prod_fits({B, n, n / 64 + 1, 8}, 1LL << 40)) return 0;      // hostile extents
   // bit mask + one "keep list final" flag per image (progressive phases)
   return (int64_t)B * n * ((n + 63) / 64) * 8 + (((int64_t)B * 4 + 255) / 256) * 256;
 }
@@ -461,6 +467,9 @@ extern "C" int sfod_nms(const float* boxes, const float* alt_boxes, const int32_
                         const int32_t* mode, const uint8_t* valid, const int32_t* n_per_image, int B,
                         int n, float thr, int max_keep, uint64_t* mask, int32_t* keep_idx,
                         int32_t* keep_count, void* stream) {
+  SFOD_REQUIRE_EXTENTS("nms", B, n, max_keep);
+  SFOD_REQUIRE(sfod_prod_fits({B, n, n / 64 + 1, 8}, 1LL << 40) && sfod_prod_fits({B, max_keep}), "nms: oversized problem");
+  SFOD_REQUIRE(boxes && mask && keep_idx && keep_count, "nms: null argument (boxes, mask, keep_idx, keep_count)");
   SFOD_REQUIRE(B >= 1 && n >= 0 && max_keep >= 1, "nms sizes");
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
@@ -530,6 +539,7 @@ __global__ void k_gather_kept(const float* __restrict__ cboxes, const float* __r
 extern "C" int sfod_gather_kept(const float* cand_boxes, const float* cand_scores, const int32_t* keep_idx,
                                 const int32_t* keep_count, int B, int n, int max_keep, float* out_boxes,
                                 float* out_scores, void* stream) {
+  SFOD_REQUIRE_EXTENTS("gather_kept", B, n, max_keep);
   dim3 grid(cdiv(max_keep, 256), B);
   hipLaunchKernelGGL(k_gather_kept, grid, dim3(256), 0, (hipStream_t)stream, cand_boxes, cand_scores,
                      keep_idx, keep_count, n, max_keep, out_boxes, out_scores);
@@ -601,6 +611,10 @@ k_anchor_match_b(const float* __restrict__ cell, int A, int Hf, int Wf, int stri
 extern "C" int sfod_anchor_match(const float* cell_anchors, int A, int B, int Hf, int Wf, int stride,
                                  const float* gt_boxes, const int32_t* gt_count, int Gcap, float lo,
                                  float hi, int32_t* matched, int8_t* labels, float* gtmax, void* stream) {
+  SFOD_REQUIRE_EXTENTS("anchor_match", A, B, Hf, Wf, stride, Gcap);
+  SFOD_REQUIRE(sfod_prod_fits({Hf, Wf, A}) && sfod_prod_fits({B, Hf, Wf, A}, 1LL << 40) && sfod_prod_fits({B, Gcap}),
+               "anchor_match: oversized anchor grid");
+  SFOD_REQUIRE(cell_anchors && gt_boxes && gt_count && matched && labels && gtmax, "anchor_match: null argument");
   SFOD_REQUIRE(Gcap <= GT_MAX, "Gcap > 256");
   hipStream_t s = (hipStream_t)stream;
   const int NA = Hf * Wf * A;
@@ -648,6 +662,7 @@ extern "C" int sfod_roi_match(const float* boxes, const int32_t* box_count, int 
                               const float* gt_boxes, const int32_t* gt_classes, const int32_t* gt_count,
                               int Gcap, float thr, int num_classes, int32_t* matched, int32_t* cls,
                               void* stream) {
+  SFOD_REQUIRE_EXTENTS("roi_match", B, P, Gcap, num_classes);
   SFOD_REQUIRE(Gcap <= GT_MAX, "Gcap > 256");
   dim3 grid(cdiv(P, 256), B);
   hipLaunchKernelGGL(k_roi_match, grid, dim3(256), 0, (hipStream_t)stream, boxes, box_count, P, gt_boxes,
@@ -846,6 +861,7 @@ k_subsample(void* lab, const uint32_t* __restrict__ keys, int n, int num, float 
 extern "C" int sfod_subsample(void* labels_or_cls, const uint32_t* keys, int B, int n, int num,
                               float pos_frac, int bg_label, int mode, int32_t* out_idx, int32_t* out_count,
                               void* stream) {
+  SFOD_REQUIRE_EXTENTS("subsample", B, n, num);
   SFOD_REQUIRE(n >= 1 && n < (1 << 24), "subsample n");
   if (mode == 0)
     hipLaunchKernelGGL(k_subsample<0>, dim3(B), dim3(SS_THREADS), 0, (hipStream_t)stream, labels_or_cls,
@@ -943,6 +959,10 @@ extern "C" int sfod_rpn_loss(const float* rpn_out, int ld, const float* cell_anc
                              const float* gt_boxes, const int32_t* gt_count, int Gcap, int batch_per_image,
                              float* loss, const float* grad_scale, float* d_rpn_out, float* ws,
                              void* stream) {
+  SFOD_REQUIRE_EXTENTS("rpn_loss", ld, A, B, Hf, Wf, stride, Gcap, batch_per_image);
+  SFOD_REQUIRE(sfod_prod_fits({Hf, Wf, A}) && sfod_prod_fits({B, Hf, Wf, ld}, 1LL << 40) && sfod_prod_fits({batch_per_image, B}),
+               "rpn_loss: oversized anchor grid");
+  SFOD_REQUIRE(rpn_out && cell_anchors && labels && matched && gt_boxes && gt_count && loss && ws, "rpn_loss: null argument");
   hipStream_t s = (hipStream_t)stream;
   const int NA = Hf * Wf * A;
   const float inv_norm = 1.f / (float)(batch_per_image * B);
@@ -981,6 +1001,8 @@ __global__ void k_append_gt(const float* __restrict__ props, const int32_t* __re
 extern "C" int sfod_append_gt(const float* props, const int32_t* prop_count, int B, int P,
                               const float* gt_boxes, const int32_t* gt_count, int Gcap, float* out_boxes,
                               int32_t* out_count, void* stream) {
+  SFOD_REQUIRE_EXTENTS("append_gt", B, P, Gcap);
+  SFOD_REQUIRE(sfod_prod_fits({B, (long long)P + Gcap}), "append_gt: oversized problem");
   dim3 grid(cdiv(P + Gcap, 256), B);
   hipLaunchKernelGGL(k_append_gt, grid, dim3(256), 0, (hipStream_t)stream, props, prop_count, P, gt_boxes,
                      gt_count, Gcap, out_boxes, out_count);
@@ -1020,6 +1042,7 @@ extern "C" int sfod_roi_build_samples(const float* boxes, const int32_t* cls, co
                                       int S, const float* gt_boxes, const int32_t* gt_count, int Gcap,
                                       float* rois, int32_t* gt_cls, float* gt_box, int32_t* n_valid,
                                       void* stream) {
+  SFOD_REQUIRE_EXTENTS("roi_build_samples", B, P, S, Gcap);
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(n_valid, 0, sizeof(int32_t), s);
   dim3 grid(cdiv(S, 256), B);
@@ -1046,6 +1069,7 @@ __global__ void k_make_rois(const float* __restrict__ props, const int32_t* __re
 
 extern "C" int sfod_make_rois(const float* props, const int32_t* prop_count, int B, int P, float* rois,
                               void* stream) {
+  SFOD_REQUIRE_EXTENTS("make_rois", B, P);
   dim3 grid(cdiv(P, 256), B);
   hipLaunchKernelGGL(k_make_rois, grid, dim3(256), 0, (hipStream_t)stream, props, prop_count, P, rois);
   return sfod_check_launch("make_rois");
@@ -1108,6 +1132,7 @@ extern "C" int sfod_frcnn_loss(const float* pred, int ld, int R, int K, const fl
                                const int32_t* gt_cls, const float* gt_box, const int32_t* n_valid,
                                float* loss, const float* grad_scale, float* d_pred, float* ws,
                                void* stream) {
+  SFOD_REQUIRE_EXTENTS("frcnn_loss", ld, R, K);
   SFOD_REQUIRE(K <= KMAX && ld >= 5 * K + 1, "frcnn_loss K / ld");
   hipStream_t s = (hipStream_t)stream;
   if (grad_scale) {
@@ -1171,6 +1196,7 @@ extern "C" int sfod_frcnn_candidates(const float* pred, int ld, int B, int P, in
                                      const int32_t* prop_count, const int32_t* image_sizes,
                                      float score_thresh, float* cand_boxes, float* cand_scores,
                                      int32_t* cand_count, void* stream) {
+  SFOD_REQUIRE_EXTENTS("frcnn_candidates", ld, B, P, K);
   SFOD_REQUIRE(K <= KMAX && ld >= 5 * K + 1, "frcnn_candidates K / ld");
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(cand_count, 0, sizeof(int32_t) * B, s);
@@ -1217,6 +1243,7 @@ extern "C" int sfod_frcnn_prepare_nms(const float* cand_boxes, const float* sort
                                       const int32_t* sorted_idx, const int32_t* cand_count, int B, int n,
                                       int K, int numel_limit, float* s_boxes, float* s_alt_boxes,
                                       int32_t* s_classes, int32_t* mode, float* maxcoord_ws, void* stream) {
+  SFOD_REQUIRE_EXTENTS("frcnn_prepare_nms", B, n, K, numel_limit);
   (void)sorted_scores;
   hipStream_t s = (hipStream_t)stream;
   (void)hipMemsetAsync(maxcoord_ws, 0, sizeof(float) * B, s);
@@ -1271,6 +1298,7 @@ extern "C" int sfod_frcnn_finalize(const float* s_boxes, const float* sorted_sco
                                    float* det_boxes, float* det_scores, int32_t* det_classes,
                                    int32_t* det_count, float* gt_boxes, int32_t* gt_classes,
                                    int32_t* gt_count, void* stream) {
+  SFOD_REQUIRE_EXTENTS("frcnn_finalize", B, n, max_det);
   hipLaunchKernelGGL(k_frcnn_finalize, dim3(B), dim3(128), 0, (hipStream_t)stream, s_boxes, sorted_scores,
                      s_classes, keep_idx, keep_count, n, max_det, pseudo_thr, det_boxes, det_scores,
                      det_classes, det_count, gt_boxes, gt_classes, gt_count);
@@ -1382,6 +1410,7 @@ extern "C" int sfod_bpc_loss(const float* pred, int ld, int R, int K, const floa
                              int B, const int32_t* image_sizes, const float* gt_boxes, const int32_t* gt_classes,
                              const int32_t* gt_count, int G, float iou_thresh, float* loss, void* ws,
                              void* stream) {
+  SFOD_REQUIRE_EXTENTS("bpc_loss", ld, R, K, B, G);
   SFOD_REQUIRE(K >= 1 && K <= KMAX && ld >= 5 * K + 1, "bpc_loss K / ld");
   hipStream_t s = (hipStream_t)stream;
   if (B > 0) (void)hipMemsetAsync(ws, 0, sizeof(double) * 4 * B, s);
@@ -1484,6 +1513,7 @@ extern "C" int sfod_adaptive_pseudo_labels(const float* det_boxes, const float* 
                                            int max_det, int K, float thr, float* reserve, int R, int row,
                                            float* class_acc, int select, float* gt_boxes, int32_t* gt_classes,
                                            float* gt_scores, int32_t* gt_count, void* stream) {
+  SFOD_REQUIRE_EXTENTS("adaptive_pseudo_labels", B, max_det, K, R, row);
   SFOD_REQUIRE(K >= 1 && K <= 64, "adaptive_pseudo_labels: 1 <= K <= 64");
   SFOD_REQUIRE(R >= 1 && row >= 0 && row < R, "adaptive_pseudo_labels: row outside the reserve ring");
   if (B == 0) return 0;

@@ -107,6 +107,7 @@ __global__ void k_preprocess(const uint8_t* const* __restrict__ imgs, const int3
 extern "C" int sfod_preprocess(const void* const* img_ptrs, const int32_t* sizes, int B, int Hp, int Wp,
                                int Cpad, const float* mean3, const float* std3, void* out, int dt,
                                void* stream) {
+  SFOD_REQUIRE_EXTENTS("preprocess", B, Hp, Wp, Cpad);
   SFOD_REQUIRE(Cpad >= 3, "Cpad < 3");
   dim3 grid(cdiv(Wp, 256), Hp, B);
   hipStream_t s = (hipStream_t)stream;
@@ -153,6 +154,8 @@ k_hflip_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int rows,
 }
 
 extern "C" int sfod_hflip_u8(const void* src, void* dst, int C, int H, int W, void* stream) {
+  SFOD_REQUIRE_EXTENTS("hflip_u8", C, H, W);
+  SFOD_REQUIRE(sfod_prod_fits({C, H}) && sfod_prod_fits({C, H, W}, 1LL << 40), "hflip_u8: oversized image");
   if ((int64_t)C * H * W == 0) return 0;
   const int64_t total = (int64_t)C * H * ((W + 15) / 16);
   hipLaunchKernelGGL(k_hflip_u8, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)src,
@@ -269,6 +272,9 @@ extern "C" int sfod_resize_bilinear_u8(const void* src, void* dst, int C, int H,
                                        const int32_t* hbounds, const int32_t* hcoef, int ksize_h,
                                        const int32_t* vbounds, const int32_t* vcoef, int ksize_v, int flip,
                                        void* stream) {
+  SFOD_REQUIRE_EXTENTS("resize_bilinear_u8", C, H, W, h, w, ksize_h, ksize_v);
+  SFOD_REQUIRE(sfod_prod_fits({C, H, W}, 1LL << 40) && sfod_prod_fits({C, h, w}, 1LL << 40) &&
+               sfod_prod_fits({C, H, w}, 1LL << 40), "resize: oversized image");
   if ((int64_t)C * h * w == 0) return 0;
   SFOD_REQUIRE(ksize_h >= 1 && ksize_v >= 1 && H >= 1 && W >= 1, "resize: bad sizes");
   if (ksize_h <= 8 && (int64_t)C * H * W >= 8)
@@ -363,12 +369,16 @@ k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __r
   }
 }
 
-extern "C" int sfod_bn_finalize_ws_floats(int C) { return BNF_SPLITS * 3 * C * 2; }
+extern "C" int sfod_bn_finalize_ws_floats(int C) {
+  if (!sfod_prod_fits({BNF_SPLITS * 6, C})) return 0;
+  return BNF_SPLITS * 3 * C * 2;
+}
 
 extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
                                 float* mean, float* invstd, float* running_mean, float* running_var,
                                 float momentum, float eps, int update_running, int64_t* num_batches_tracked,
                                 float* ws, void* stream) {
+  SFOD_REQUIRE_EXTENTS("bn_finalize", nblocks, M, C);
   SFOD_REQUIRE(ws != nullptr && ((uintptr_t)ws & 7) == 0, "bn_finalize: 8-byte aligned workspace required");
   hipStream_t s = (hipStream_t)stream;
   int nsplit = (nblocks + 63) / 64;   // >= 64 blocks (4 per wave) per slice
@@ -585,6 +595,7 @@ static inline int ew_grid(int64_t total) {
 extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const float* invstd, const float* gamma,
                                     const float* beta, const void* residual, void* z, void* z_pairs, void* z_pairs2,
                                     int64_t rows, int C, int dt, int pairs_dt, void* stream) {
+  SFOD_REQUIRE(sfod_ints_ok({C}) && sfod_i64s_ok({rows, C}), "bn_add_relu_fwd: negative or oversized extent");
   SFOD_REQUIRE(z_pairs2 == nullptr || (z_pairs != nullptr && pairs_dt == SFOD_F16X3),
                "bn_add_relu: the second (bf16-pair) copy accompanies SFOD_F16X3 pairs");
   const int V = (dt == SFOD_F32 && z_pairs == nullptr) ? 4 : 8;
@@ -612,6 +623,8 @@ extern "C" int sfod_bn_add_relu_fwd(const void* y, const float* mean, const floa
 extern "C" int sfod_bn_relu_pool_fwd2(const void* y, const float* mean, const float* invstd,
                                       const float* gamma, const float* beta, void* z, void* z2, int B, int H, int W,
                                       int C, int pool_flags, int dt, int out_dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("bn_relu_pool_fwd2", B, H, W, C, pool_flags);
+  SFOD_REQUIRE(sfod_prod_fits({B, H, W}) && sfod_prod_fits({B, H, W, C}, 1LL << 40), "bn_relu_pool_fwd2: oversized tensor");
   hipStream_t s = (hipStream_t)stream;
   const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
   SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && sfod_is_pairs(out_dt)),
@@ -939,6 +952,7 @@ k_bn_bwd_leftover(const T* __restrict__ y, const float* __restrict__ mean, const
 }
 
 extern "C" int sfod_bn_bwd_ws_floats(int M, int C) {
+  if (!sfod_ints_ok({M, C}) || !sfod_prod_fits({BNB_GRID_MAX * 2, C})) return 0;      // hostile extents: not served / nothing
   (void)M;
   return BNB_GRID_MAX * 2 * C;
 }
@@ -948,6 +962,8 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
                                      float* dbeta, float* dgamma_acc, float* dbeta_acc, float* ws, int B, int H,
                                      int W, int C, int pool_flags, int dt, int dy_dt, int reduced_blocks,
                                      void* stream) {
+  SFOD_REQUIRE_EXTENTS("bn_relu_pool_bwd", B, H, W, C, pool_flags, dy_dt, reduced_blocks);
+  SFOD_REQUIRE(sfod_prod_fits({B, H, W}) && sfod_prod_fits({B, H, W, C}, 1LL << 40), "bn_relu_pool_bwd: oversized tensor");
   hipStream_t s = (hipStream_t)stream;
   const int pool = pool_flags & 1, norelu = (pool_flags >> 1) & 1;
   SFOD_REQUIRE(reduced_blocks >= 0 && (reduced_blocks == 0 || (!pool && !norelu)),
@@ -956,7 +972,8 @@ extern "C" int sfod_bn_relu_pool_bwd(const void* dz, const void* y, const float*
                "bn_bwd: dz / y are fp32 or bf16; dy has the same type, or bf16x3 from fp32");
   const int V = (dt == SFOD_F32) ? 4 : 8;            // reduce pass (reads only)
   const int VO = (dy_dt == SFOD_F32) ? 4 : 8;        // apply pass
-  SFOD_REQUIRE(C % VO == 0 && C / V <= 256, "bn_bwd: unsupported channel count");
+  SFOD_REQUIRE(C >= 8 && C % VO == 0 && C / V <= 256, "bn_bwd: unsupported channel count");
+  SFOD_REQUIRE(dz && y && mean && invstd && gamma && beta && ws, "bn_bwd: null argument");
   const int Ho = pool ? H / 2 : H, Wo = pool ? W / 2 : W;
   const int cv = C / V, UL = 256 / cv;
   const int64_t units = (int64_t)B * Ho * Wo;
@@ -1029,6 +1046,7 @@ __global__ void k_act_bwd(T* __restrict__ dy, const T* __restrict__ y, int64_t n
 }
 
 extern "C" int sfod_act_bwd(void* dy, const void* y, int64_t n, int act, int dt, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "act_bwd: negative or oversized extent");
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(n % V == 0, "act_bwd: n not a multiple of the vector width");
   const int64_t nvec = n / V;
@@ -1056,6 +1074,7 @@ __global__ void k_add_inplace(T* __restrict__ a, const T* __restrict__ b, int64_
 }
 
 extern "C" int sfod_add_inplace(void* a, const void* b, int64_t n, int dt, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "add_inplace: negative or oversized extent");
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(n % V == 0, "add_inplace: n not a multiple of the vector width");
   const int64_t nvec = n / V;
@@ -1086,6 +1105,7 @@ __global__ void k_add_act_bwd(T* __restrict__ a, const T* __restrict__ b, const 
 }
 
 extern "C" int sfod_add_act_bwd(void* a, const void* b, const void* y, int64_t n, int dt, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "add_act_bwd: negative or oversized extent");
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(n % V == 0, "add_act_bwd: n not a multiple of the vector width");
   const int64_t nvec = n / V;
@@ -1114,6 +1134,7 @@ __global__ void k_mul_mask(T* __restrict__ a, const uint8_t* __restrict__ m, int
 }
 
 extern "C" int sfod_mul_mask(void* a, const uint8_t* mask, int64_t n, float scale, int dt, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "mul_mask: negative or oversized extent");
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(n % V == 0, "mul_mask: n not a multiple of the vector width");
   const int64_t nvec = n / V;
@@ -1150,6 +1171,7 @@ __global__ void k_add_act(const T* __restrict__ a, const T* __restrict__ b, T* _
 
 extern "C" int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, void* out_pairs2, int64_t n, int act,
                             int dt, int pairs_dt, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "add_act: negative or oversized extent");
   SFOD_REQUIRE(out_pairs2 == nullptr || (out_pairs != nullptr && pairs_dt == SFOD_F16X3),
                "add_act: the second (bf16-pair) copy accompanies SFOD_F16X3 pairs");
   const int V = (dt == SFOD_F32 && out_pairs == nullptr) ? 4 : 8;
@@ -1207,6 +1229,8 @@ __global__ void k_subsample2(const T* __restrict__ src, T* __restrict__ dst, int
 
 extern "C" int sfod_subsample2(const void* src, void* dst, int B, int H, int W, int C, int backward, int dt,
                                void* stream) {
+  SFOD_REQUIRE_EXTENTS("subsample2", B, H, W, C);
+  SFOD_REQUIRE(sfod_prod_fits({B, H, W}) && sfod_prod_fits({B, H, W, C}, 1LL << 40), "subsample2: oversized tensor");
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "subsample2: C not a multiple of the vector width");
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
@@ -1272,6 +1296,8 @@ __global__ void k_im2col_stem(const T* __restrict__ x, TO* __restrict__ out, int
 
 extern "C" int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, int out_dt,
                                 void* stream) {
+  SFOD_REQUIRE_EXTENTS("im2col_stem", B, H, W, Cp, Kpad);
+  SFOD_REQUIRE(sfod_prod_fits({B, H, W}) && sfod_prod_fits({B, H, W, Cp > Kpad ? Cp : Kpad}, 1LL << 40), "im2col_stem: oversized tensor");
   SFOD_REQUIRE(Kpad >= 152 && Kpad % 8 == 0 && Cp >= 3, "im2col_stem: Kpad must be a multiple of 8 >= 152");
   SFOD_REQUIRE(out_dt == dt || (dt == SFOD_F32 && sfod_is_pairs(out_dt)), "im2col_stem: output is the input type, or operand pairs from fp32");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -1325,6 +1351,9 @@ __global__ void k_maxpool3s2(const T* __restrict__ x, T* __restrict__ y, int B, 
 }
 
 extern "C" int sfod_maxpool3s2(const void* x, void* y, int B, int H, int W, int C, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("maxpool3s2", B, H, W, C);
+  SFOD_REQUIRE(sfod_prod_fits({B, H, W}) && sfod_prod_fits({B, H, W, C}, 1LL << 40), "maxpool3s2: oversized tensor");
+  if (B == 0 || H == 0 || W == 0 || C == 0) return 0;
   const int V = (dt == SFOD_F32) ? 4 : 8;
   SFOD_REQUIRE(C % V == 0, "maxpool3s2: C not a multiple of the vector width");
   const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
@@ -1406,6 +1435,9 @@ __global__ void k_pack_conv_weight(const float* __restrict__ w, T* __restrict__ 
 
 extern "C" int sfod_pack_conv_weight_ws(const float* w_oihw, void* w_packed, uint32_t* absmax, int Cout, int Cin,
                                         int ksize, int CinPad, int rot180, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("pack_conv_weight_ws", Cout, Cin, ksize, CinPad);
+  SFOD_REQUIRE(sfod_prod_fits({Cout > Cin ? Cout : Cin, Cin > CinPad ? Cin : CinPad, ksize, ksize}, 1LL << 40),
+               "pack_conv_weight: oversized tensor");
   const int rows = rot180 ? Cin : Cout;
   const int64_t total = (int64_t)rows * ksize * ksize * CinPad;
   hipStream_t s = (hipStream_t)stream;
@@ -1433,6 +1465,7 @@ extern "C" int sfod_pack_conv_weight_ws(const float* w_oihw, void* w_packed, uin
 
 extern "C" int sfod_pack_conv_weight(const float* w_oihw, void* w_packed, int Cout, int Cin, int ksize,
                                      int CinPad, int rot180, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("pack_conv_weight", Cout, Cin, ksize, CinPad);
   return sfod_pack_conv_weight_ws(w_oihw, w_packed, nullptr, Cout, Cin, ksize, CinPad, rot180, dt, stream);
 }
 
@@ -1492,6 +1525,8 @@ k_pack_conv_weights_multi(const long long* __restrict__ desc, int n, const unsig
 }
 
 extern "C" int sfod_pack_conv_weights_blocks(int Cout, int Cin, int ksize, int innerPad, int rot180) {
+  if (!sfod_ints_ok({Cout, Cin, ksize, innerPad})) return 0;      // hostile extents: not served / nothing
+  if (!sfod_prod_fits({(rot180 ? Cin : Cout) / PACK_T + 1, innerPad / PACK_T + 1})) return 0;
   (void)ksize;
   const int rowsN = rot180 ? Cin : Cout;
   return ((rowsN + PACK_T - 1) / PACK_T) * ((innerPad + PACK_T - 1) / PACK_T);
@@ -1499,6 +1534,7 @@ extern "C" int sfod_pack_conv_weights_blocks(int Cout, int Cin, int ksize, int i
 
 extern "C" int sfod_pack_conv_weights_multi_ws(const int64_t* desc, int n, int total_blocks, int dt, uint32_t* absmax,
                                                void* stream) {
+  SFOD_REQUIRE_EXTENTS("pack_conv_weights_multi_ws", n, total_blocks);
   SFOD_REQUIRE(n >= 1 && total_blocks >= 1, "pack_multi: empty table (kernel sizes 1 and 3 only)");
   SFOD_REQUIRE(absmax == nullptr || dt == SFOD_F16X3, "pack_multi: the per-tensor scales belong to SFOD_F16X3");
   hipStream_t s = (hipStream_t)stream;
@@ -1520,6 +1556,7 @@ extern "C" int sfod_pack_conv_weights_multi_ws(const int64_t* desc, int n, int t
 }
 
 extern "C" int sfod_pack_conv_weights_multi(const int64_t* desc, int n, int total_blocks, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("pack_conv_weights_multi", n, total_blocks);
   return sfod_pack_conv_weights_multi_ws(desc, n, total_blocks, dt, nullptr, stream);
 }
 
@@ -1539,6 +1576,8 @@ __global__ void k_unpack_conv_wgrad(const float* __restrict__ dwp, float* __rest
 
 extern "C" int sfod_unpack_conv_wgrad(const float* dw_packed, float* dw_oihw, int Cout, int Cin, int ksize,
                                       int CinPad, int accumulate, void* stream) {
+  SFOD_REQUIRE_EXTENTS("unpack_conv_wgrad", Cout, Cin, ksize, CinPad);
+  SFOD_REQUIRE(sfod_prod_fits({Cout, Cin > CinPad ? Cin : CinPad, ksize, ksize}, 1LL << 40), "unpack_conv_wgrad: oversized tensor");
   const int64_t total = (int64_t)Cout * Cin * ksize * ksize;
   hipLaunchKernelGGL(k_unpack_conv_wgrad, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, dw_packed,
                      dw_oihw, Cout, Cin, ksize, CinPad, accumulate);
@@ -1620,6 +1659,7 @@ k_pack_fc_chw_t(const float* __restrict__ w, T* __restrict__ out, int N, int C, 
 
 extern "C" int sfod_pack_fc_weight_ld_ws(const float* w, void* out, uint32_t* absmax, int N, int K, int chw_c,
                                          int transpose, int ld, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("pack_fc_weight_ld_ws", N, K, chw_c, ld);
   SFOD_REQUIRE(ld >= (transpose ? N : K), "pack_fc_weight: ld too small");
   SFOD_REQUIRE(!sfod_is_pairs(dt) || ld % 8 == 0, "pack_fc_weight: operand pairs need ld % 8 == 0");
   SFOD_REQUIRE(absmax == nullptr || dt == SFOD_F16X3, "pack_fc_weight: the per-tensor scale belongs to SFOD_F16X3");
@@ -1664,11 +1704,13 @@ extern "C" int sfod_pack_fc_weight_ld_ws(const float* w, void* out, uint32_t* ab
 
 extern "C" int sfod_pack_fc_weight_ld(const float* w, void* out, int N, int K, int chw_c, int transpose,
                                       int ld, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("pack_fc_weight_ld", N, K, chw_c, ld);
   return sfod_pack_fc_weight_ld_ws(w, out, nullptr, N, K, chw_c, transpose, ld, dt, stream);
 }
 
 extern "C" int sfod_pack_fc_weight(const float* w, void* out, int N, int K, int chw_c, int transpose,
                                    int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("pack_fc_weight", N, K, chw_c);
   return sfod_pack_fc_weight_ld(w, out, N, K, chw_c, transpose, transpose ? N : K, dt, stream);
 }
 
@@ -1705,6 +1747,7 @@ k_unpack_fc_chw(const float* __restrict__ dwp, float* __restrict__ dw, int C, in
 
 extern "C" int sfod_unpack_fc_wgrad_ld(const float* dw_packed, float* dw, int N, int K, int chw_c, int ld,
                                        int accumulate, void* stream) {
+  SFOD_REQUIRE_EXTENTS("unpack_fc_wgrad_ld", N, K, chw_c, ld);
   if (chw_c > 0 && K % chw_c == 0 && K / chw_c <= 64 && (int64_t)N * K >= (1 << 20)) {
     const int C = chw_c, PP = K / chw_c;
     hipLaunchKernelGGL(k_unpack_fc_chw, dim3(cdiv(C, 64), N), dim3(256), (size_t)64 * PP * 4, (hipStream_t)stream,
@@ -1719,6 +1762,7 @@ extern "C" int sfod_unpack_fc_wgrad_ld(const float* dw_packed, float* dw, int N,
 
 extern "C" int sfod_unpack_fc_wgrad(const float* dw_packed, float* dw, int N, int K, int chw_c,
                                     int accumulate, void* stream) {
+  SFOD_REQUIRE_EXTENTS("unpack_fc_wgrad", N, K, chw_c);
   return sfod_unpack_fc_wgrad_ld(dw_packed, dw, N, K, chw_c, K, accumulate, stream);
 }
 
@@ -1746,6 +1790,7 @@ k_bias_grad(const T* __restrict__ dy, float* __restrict__ db, int M, int N, int 
 
 extern "C" int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, int accumulate, int dt,
                               void* stream) {
+  SFOD_REQUIRE_EXTENTS("bias_grad", M, N, ld);
   hipStream_t s = (hipStream_t)stream;
   if (!accumulate) (void)hipMemsetAsync(db, 0, sizeof(float) * N, s);
   if (M == 0) return 0;
@@ -1813,6 +1858,8 @@ k_sgd_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict_
 extern "C" int sfod_sgd_ema(float* param, const float* grad, float* mom, float* teacher, int64_t n,
                             const float* lr, float momentum, float weight_decay, float grad_scale,
                             float ema_keep, float ema_one_minus_keep, int first_step, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "sgd_ema: negative or oversized extent");
+  SFOD_REQUIRE(param != nullptr && grad != nullptr && mom != nullptr && lr != nullptr, "sgd_ema: null argument (param, grad, mom, lr)");
   if (n == 0) return 0;
   // 1 - k is the HOST's double subtraction rounded once (the reference: python float (1 - keep_rate) -> float32 scalar);
   // recomputing it from the float32 k would be off by 1.7e-5 relative for k = 0.9996
@@ -1829,6 +1876,8 @@ __global__ void k_ema(float* __restrict__ t, const float* __restrict__ s, int64_
 
 extern "C" int sfod_ema(float* teacher, const float* student, int64_t n, float keep, float one_minus_keep,
                         void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "ema: negative or oversized extent");
+  SFOD_REQUIRE(n == 0 || (teacher != nullptr && student != nullptr), "ema: null argument");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_ema, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, teacher, student, n, keep,
                      one_minus_keep);
@@ -1850,6 +1899,7 @@ __global__ void k_ema_i64(long long* __restrict__ t, const long long* __restrict
 }
 extern "C" int sfod_ema_i64(int64_t* teacher, const int64_t* student, int n, float keep, float one_minus_keep,
                             void* stream) {
+  SFOD_REQUIRE_EXTENTS("ema_i64", n);
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_ema_i64, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, (long long*)teacher,
                      (const long long*)student, n, keep, one_minus_keep);
@@ -1886,7 +1936,9 @@ k_teacher_metrics(const float* __restrict__ det_scores, const int* __restrict__ 
 extern "C" int sfod_teacher_metrics(const float* det_scores, const int* det_count, int D, const float* rpn_logits,
                                     const int* rpn_count, int P, const int* gt_count, int B, float thr, float* out,
                                     void* stream) {
-  if (B <= 0) return SFOD_EBADARG;
+  SFOD_REQUIRE_EXTENTS("teacher_metrics", D, P, B);
+  SFOD_REQUIRE(B >= 1, "teacher_metrics: B < 1");
+  SFOD_REQUIRE(det_scores && det_count && rpn_logits && rpn_count && gt_count && out, "teacher_metrics: null argument");
   hipLaunchKernelGGL(k_teacher_metrics, dim3(1), dim3(256), 0, (hipStream_t)stream, det_scores, det_count, D, rpn_logits,
                      rpn_count, P, gt_count, B, thr, out);
   return sfod_check_launch("teacher_metrics");
@@ -1897,6 +1949,7 @@ __global__ void k_fill(float* p, int64_t n, float v) {
     p[i] = v;
 }
 extern "C" int sfod_fill_f32(float* p, int64_t n, float v, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "fill_f32: negative or oversized extent");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_fill, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, p, n, v);
   return sfod_check_launch("fill");
@@ -1926,6 +1979,7 @@ __global__ void k_cast8_both(const float* __restrict__ s, splith_t* __restrict__
   }
 }
 extern "C" int sfod_cast_pairs_both(const float* src, void* dst_f16x3, void* dst_bf16x3, int64_t n, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "cast_pairs_both: negative or oversized extent");
   SFOD_REQUIRE(n % 8 == 0, "cast_pairs_both: operand-pair tensors hold whole 8-element groups");
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_cast8_both, dim3(ew_grid(n / 8)), dim3(256), 0, (hipStream_t)stream, src, (splith_t*)dst_f16x3,
@@ -1934,6 +1988,7 @@ extern "C" int sfod_cast_pairs_both(const float* src, void* dst_f16x3, void* dst
 }
 
 extern "C" int sfod_cast(const void* src, void* dst, int64_t n, int src_dt, int dst_dt, void* stream) {
+  SFOD_REQUIRE(sfod_i64s_ok({n}), "cast: negative or oversized extent");
   if (n == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const dim3 g(ew_grid(n)), b(256);

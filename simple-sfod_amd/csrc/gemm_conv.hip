@@ -514,7 +514,15 @@ static bool use_first_kernel(int B, int H, int W, int Cin, int Cout, int ksize, 
 
 static bool use_wide_gemm(int M, int Cout, int ks);
 
+// host arithmetic of the conv family runs on int pixel counts (M = B * H * W) and int K (Cin * ksize^2): both must fit
+static inline bool conv_shape_fits(int B, int H, int W, int Cin, int Cout, int ksize) {
+  return sfod_ints_ok({B, H, W, Cin, Cout, ksize}) && ksize <= 7 && sfod_prod_fits({B, H, W}) &&
+         sfod_prod_fits({Cin, ksize, ksize}) && sfod_prod_fits({Cout, ksize, ksize}) &&
+         sfod_prod_fits({B, H, W, Cin > Cout ? Cin : Cout}, 1LL << 40);
+}
+
 extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
+  if (!conv_shape_fits(B, H, W, Cin, Cout, ksize)) return 0;      // hostile extents: not served / nothing
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16)) return 3;
   const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout, sfod_is_pairs(dt)) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return 2;
@@ -522,6 +530,7 @@ extern "C" int sfod_conv_fwd_algo(int B, int H, int W, int Cin, int Cout, int ks
 }
 
 extern "C" int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt) {
+  if (!conv_shape_fits(B, H, W, Cin, Cout, ksize)) return 0;      // hostile extents: not served / nothing
   if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, 64, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16)) return sfod_f1_nblk(B, H, W);
   const P3Plan p = (ksize == 3 && is_bf16_storage(dt)) ? sfod_p3_plan(B, H, W, phys_ch(dt, Cin), Cout, sfod_is_pairs(dt)) : P3Plan{};
   if (use_patch_kernel(p, B, H, W, ksize, dt)) return p.nblk;
@@ -678,18 +687,22 @@ static int launch_conv_fwd(const void* x, const void* w, const float* bias, void
 }
 
 extern "C" int sfod_conv_first_supported(int B, int H, int W, int Cin, int Cout, int dt, int ldy) {
+  if (!(conv_shape_fits(B, H, W, Cin, Cout, 3) && sfod_ints_ok({ldy}))) return 0;      // hostile extents: not served / nothing
   return use_first_kernel(B, H, W, Cin, Cout, 3, dt, ldy, sfod_is_pairs(dt) ? SFOD_F32 : SFOD_BF16) ? 1 : 0;
 }
 
 extern "C" int sfod_conv_first_fused(const void* x, const void* w, const float* bias, const float* scale,
                                      const float* shift, void* y, float* stats, int B, int H, int W, int ldy,
                                      int act, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("conv_first_fused", B, H, W, ldy);
   return sfod_conv_first_fused_ws(x, w, nullptr, bias, scale, shift, y, stats, B, H, W, ldy, act, dt, stream);
 }
 
 extern "C" int sfod_conv_first_fused_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias,
                                         const float* scale, const float* shift, void* y, float* stats, int B, int H,
                                         int W, int ldy, int act, int dt, void* stream) {
+  SFOD_REQUIRE(conv_shape_fits(B, H, W, 8, 64, 3) && sfod_ints_ok({ldy}), "conv_first_fused: negative or oversized extent");
+  SFOD_REQUIRE(x != nullptr && w != nullptr, "conv_first_fused: null operand");
   SFOD_REQUIRE(w_absmax == nullptr || dt == SFOD_F16X3, "conv_first: scaled weights are an SFOD_F16X3 format");
   SFOD_REQUIRE(sfod_conv_first_supported(B, H, W, 8, 64, dt, ldy),
                "conv_first_fused: shape not served by the first-layer kernel (sfod_conv_first_supported)");
@@ -705,12 +718,14 @@ extern "C" int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_
 extern "C" int sfod_conv_fwd(const void* x, const void* w, const float* bias, void* y, int B, int H, int W,
                              int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
                              int out_dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("conv_fwd", B, H, W, Cin, Cout, ksize, ldy);
   return sfod_conv_fwd_ws(x, w, nullptr, bias, y, B, H, W, Cin, Cout, ksize, ldy, act, stats, dt, out_dt, stream);
 }
 
 extern "C" int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B,
                                 int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt,
                                 int out_dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("conv_fwd_ws", B, H, W, Cin, Cout, ksize, ldy);
   return sfod_conv_fwd_scratch(x, w, w_absmax, bias, y, B, H, W, Cin, Cout, ksize, ldy, act, stats, dt, out_dt, nullptr, 0,
                                stream);
 }
@@ -719,6 +734,7 @@ extern "C" int sfod_conv_fwd_ws(const void* x, const void* w, const uint32_t* w_
 // of linear layers with few rows (splitk_plan above).
 extern "C" int64_t sfod_conv_fwd_scratch_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int dt, int out_dt,
                                                int with_stats) {
+  if (!conv_shape_fits(B, H, W, Cin, Cout, ksize)) return 0;      // hostile extents: not served / nothing
   if (dt != SFOD_F32 && dt != SFOD_BF16 && !sfod_is_pairs(dt)) return 0;
   const int E = (dt == SFOD_F32) ? 4 : 8;
   if (ksize != 1 || Cout % 4 != 0 || Cin % E != 0 || (int64_t)B * H * W == 0 || (int64_t)B * H * W > (1 << 24)) return 0;
@@ -729,6 +745,11 @@ extern "C" int64_t sfod_conv_fwd_scratch_bytes(int B, int H, int W, int Cin, int
 extern "C" int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y,
                                      int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats,
                                      int dt, int out_dt, void* scratch, int64_t scratch_bytes, void* stream) {
+  SFOD_REQUIRE(conv_shape_fits(B, H, W, Cin, Cout, ksize) && sfod_ints_ok({ldy}) && sfod_i64s_ok({scratch_bytes}),
+               "conv_fwd: negative or oversized extent");
+  SFOD_REQUIRE(x != nullptr && w != nullptr && y != nullptr, "conv_fwd: null operand (x, w, y)");
+  SFOD_REQUIRE(act >= 0 && act <= 2, "conv_fwd: unknown act");
+  SFOD_REQUIRE(out_dt == SFOD_F32 || out_dt == SFOD_BF16 || sfod_is_pairs(out_dt), "conv_fwd: unknown out_dt");
   SFOD_REQUIRE(w_absmax == nullptr || dt == SFOD_F16X3, "conv: scaled weights are an SFOD_F16X3 format");
   SFOD_REQUIRE(ksize == 1 || ksize == 3, "conv: ksize must be 1 or 3");
   SFOD_REQUIRE(ldy >= Cout, "conv: ldy < Cout");
@@ -783,6 +804,7 @@ extern "C" int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_
 // the kernel's LDS patch instead of in a separate elementwise pass (forward-only passes: nobody else needs the activated
 // tensor).  _supported: 1 when the shape is served (SFOD_BF16X3 operands, the 256 x 128 halo-patch shape, Cin % 32 == 0).
 extern "C" int sfod_conv_fwd_bnin_supported(int B, int H, int W, int Cin, int Cout, int dt) {
+  if (!conv_shape_fits(B, H, W, Cin, Cout, 3)) return 0;      // hostile extents: not served / nothing
   if (dt != SFOD_BF16X3 || (int64_t)B * H * W == 0 || g_conv_algo == 1) return 0;
   const int pc = phys_ch(dt, Cin);
   const P3Plan p = sfod_p3_plan(B, H, W, pc, Cout, 1);
@@ -792,6 +814,7 @@ extern "C" int sfod_conv_fwd_bnin_supported(int B, int H, int W, int Cin, int Co
 extern "C" int sfod_conv_fwd_bnin(const float* x_pre, const float* in_mean, const float* in_invstd, const float* in_gamma,
                                   const float* in_beta, const void* w, const float* bias, float* y, int B, int H, int W,
                                   int Cin, int Cout, int ldy, int act, float* stats, int dt, void* stream) {
+  SFOD_REQUIRE(conv_shape_fits(B, H, W, Cin, Cout, 3) && sfod_ints_ok({ldy}), "conv_fwd_bnin: negative or oversized extent");
   SFOD_REQUIRE(sfod_conv_fwd_bnin_supported(B, H, W, Cin, Cout, dt), "conv_fwd_bnin: shape not served (sfod_conv_fwd_bnin_supported)");
   SFOD_REQUIRE(x_pre && in_mean && in_invstd && in_gamma && in_beta && w && y, "conv_fwd_bnin: null argument");
   SFOD_REQUIRE(ldy >= Cout, "conv_fwd_bnin: ldy < Cout");
@@ -807,6 +830,7 @@ extern "C" int sfod_conv_fwd_bnin(const float* x_pre, const float* in_mean, cons
 // kernel with fp32 output only.  sfod_conv_dgrad_bnred_blocks: number of partial rows it writes (0: shape / dtype not
 // served -- run sfod_conv_fwd and the separate reduction instead).
 extern "C" int sfod_conv_dgrad_bnred_blocks(int B, int H, int W, int Cin, int Cout, int dt) {
+  if (!conv_shape_fits(B, H, W, Cin, Cout, 3)) return 0;      // hostile extents: not served / nothing
   if (dt != SFOD_BF16X3 && dt != SFOD_BF16) return 0;
   if (dt == SFOD_BF16) return 0;        // bf16 mode writes bf16 gradients: no fp32 tile to reduce
   if (Cout % 4 != 0) return 0;
@@ -817,6 +841,8 @@ extern "C" int sfod_conv_dgrad_bnred_blocks(int B, int H, int W, int Cin, int Co
 extern "C" int sfod_conv_dgrad_bnred(const void* x, const void* w, void* dz, int B, int H, int W, int Cin, int Cout,
                                      int dt, const float* y, const float* mean, const float* invstd,
                                      const float* gamma, const float* beta, float* red_ws, void* stream) {
+  SFOD_REQUIRE(conv_shape_fits(B, H, W, Cin, Cout, 3), "conv_dgrad_bnred: negative or oversized extent");
+  SFOD_REQUIRE(x != nullptr && w != nullptr && dz != nullptr, "conv_dgrad_bnred: null operand");
   SFOD_REQUIRE(sfod_conv_dgrad_bnred_blocks(B, H, W, Cin, Cout, dt) > 0,
                "conv_dgrad_bnred: shape not served (sfod_conv_dgrad_bnred_blocks)");
   SFOD_REQUIRE(y && mean && invstd && gamma && beta && red_ws, "conv_dgrad_bnred: null argument");
@@ -1410,6 +1436,7 @@ static GenWgradPlan gen_wgrad_plan(int M, int Cout, int Ntot, int dt) {
 }
 
 extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
+  if (!(conv_shape_fits(B, H, W, Cin, Cout, ksize) && sfod_ints_ok({lddy}))) return 0;      // hostile extents: not served / nothing
   int nb = 0;
   if (dt != SFOD_F32) {
     const W3Plan p = w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
@@ -1423,6 +1450,7 @@ extern "C" int64_t sfod_conv_wgrad_ws_bytes(int B, int H, int W, int Cin, int Co
 }
 
 extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int Cout, int ksize, int lddy, int dt) {
+  if (!(conv_shape_fits(B, H, W, Cin, Cout, ksize) && sfod_ints_ok({lddy}))) return 0;      // hostile extents: not served / nothing
   int nb;
   w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
   return nb > 0 ? 1 : 0;
@@ -1431,6 +1459,10 @@ extern "C" int sfod_conv_wgrad_oihw_supported(int B, int H, int W, int Cin, int 
 extern "C" int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oihw, int B, int H, int W, int Cin,
                                     int Cout, int ksize, int lddy, int dt, int accumulate, void* ws,
                                     int64_t ws_bytes, void* stream) {
+  SFOD_REQUIRE(conv_shape_fits(B, H, W, Cin, Cout, ksize) && sfod_ints_ok({lddy}) && sfod_i64s_ok({ws_bytes}),
+               "conv_wgrad_oihw: negative or oversized extent");
+  SFOD_REQUIRE(x != nullptr && dy != nullptr && dw_oihw != nullptr, "conv_wgrad_oihw: null operand");
+  SFOD_REQUIRE(lddy >= Cout, "conv_wgrad_oihw: lddy < Cout");
   int nb;
   w3_plan_chunked(B, H, W, Cin, Cout, ksize, lddy, dt, nb);
   SFOD_REQUIRE(nb > 0, "wgrad_oihw: shape not served by the halo-patch kernel (query sfod_conv_wgrad_oihw_supported)");
@@ -1441,6 +1473,10 @@ extern "C" int sfod_conv_wgrad_oihw(const void* x, const void* dy, float* dw_oih
 extern "C" int sfod_conv_wgrad(const void* x, const void* dy, float* dw, int B, int H, int W, int Cin,
                                int Cout, int ksize, int lddy, int dt, void* ws, int64_t ws_bytes,
                                void* stream) {
+  SFOD_REQUIRE(conv_shape_fits(B, H, W, Cin, Cout, ksize) && sfod_ints_ok({lddy}) && sfod_i64s_ok({ws_bytes}),
+               "conv_wgrad: negative or oversized extent");
+  SFOD_REQUIRE(x != nullptr && dy != nullptr && dw != nullptr, "conv_wgrad: null operand");
+  SFOD_REQUIRE(lddy >= Cout, "conv_wgrad: lddy < Cout");
   SFOD_REQUIRE(ksize == 1 || ksize == 3, "wgrad: ksize must be 1 or 3");
   SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || dt == SFOD_BF16X3, "wgrad: unknown dt");
   const int E = (dt == SFOD_F32) ? 4 : 8;

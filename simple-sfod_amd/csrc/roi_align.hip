@@ -556,8 +556,15 @@ static int dispatch_roi_bwd(const void* dout, int B, int H, int W, int C, const 
 
 extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, const float* rois, int R,
                                   int pooled, float scale, void* out, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("roi_align_fwd", B, H, W, C, R, pooled);
   (void)B;
   if (R == 0) return 0;
+  SFOD_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, "roi_align: empty feature map");
+  SFOD_REQUIRE(pooled >= 1 && pooled <= ROI_MAXP, "roi_align: pooled size must be in [1, 8]");
+  SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || sfod_is_pairs(dt), "roi_align: unknown dt");
+  SFOD_REQUIRE(feat != nullptr && rois != nullptr && out != nullptr, "roi_align: null argument (feat, rois, out)");
+  SFOD_REQUIRE(sfod_prod_fits({B, H, W, C}, 1LL << 40) && sfod_prod_fits({R, C, pooled, pooled}, 1LL << 40) &&
+               sfod_prod_fits({R, C / 256 + 1}), "roi_align: oversized problem");
   SFOD_REQUIRE(C % ((dt == SFOD_F32) ? 4 : 8) == 0, "roi_align: C must be a multiple of the 16-byte vector");
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)pooled * (H + W) * 4 + 4 * pooled * 4;
@@ -597,9 +604,13 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
 
 extern "C" int sfod_roi_align_bwd(const void* dout, int B, int H, int W, int C, const float* rois, int R,
                                   int pooled, float scale, float* dfeat, int dt, void* stream) {
+  SFOD_REQUIRE_EXTENTS("roi_align_bwd", B, H, W, C, R, pooled);
   if (R == 0 || B == 0) return 0;
   SFOD_REQUIRE(C % 8 == 0, "roi_align_bwd: C must be a multiple of 8");
   SFOD_REQUIRE(pooled >= 1 && pooled <= ROI_MAXP, "roi_align_bwd: pooled size must be <= 8");
+  SFOD_REQUIRE(dout != nullptr && rois != nullptr && dfeat != nullptr, "roi_align_bwd: null argument (dout, rois, dfeat)");
+  SFOD_REQUIRE(sfod_prod_fits({B, H, W, C}, 1LL << 40) && sfod_prod_fits({R, C, pooled, pooled}, 1LL << 40),
+               "roi_align_bwd: oversized problem");
   hipStream_t s = (hipStream_t)stream;
   SFOD_REQUIRE(!sfod_is_pairs(dt), "roi_align_bwd: the upstream gradient is fp32 in the operand-pair modes");
   if (dt == SFOD_F32) return dispatch_roi_bwd<float>(dout, B, H, W, C, rois, R, pooled, scale, dfeat, s);

@@ -131,6 +131,7 @@ k_sort_emit(const unsigned long long* __restrict__ sorted, const float* __restri
 }
 
 extern "C" int64_t sfod_sort_ws_bytes(int B, int n) {
+  if (!sfod_ints_ok({B, n}) || !sfod_prod_fits({B, n, 32}, 1LL << 40)) return 0;      // hostile extents: not served / nothing
   if (n <= SINGLE_MAX) return 256;
   const int ch = sort_chunk_of(n);
   const int64_t NP = (int64_t)((n + ch - 1) / ch) * ch;
@@ -145,7 +146,9 @@ static int sort_set_lds_attr(const void* kern) {
 
 extern "C" int sfod_segmented_sort_desc(const float* keys, int B, int n, float* out_keys, int32_t* out_idx,
                                         void* ws, int64_t ws_bytes, void* stream) {
+  SFOD_REQUIRE(sfod_ints_ok({B, n}) && sfod_i64s_ok({B, n, ws_bytes}), "segmented_sort_desc: negative or oversized extent");
   SFOD_REQUIRE(B >= 1 && n >= 1, "sort sizes");
+  SFOD_REQUIRE(keys != nullptr && out_keys != nullptr && out_idx != nullptr && ws != nullptr, "sort: null argument");
   SFOD_REQUIRE(ws_bytes >= sfod_sort_ws_bytes(B, n), "sort workspace too small");
   hipStream_t s = (hipStream_t)stream;
   // (idempotent attribute calls; repeating them from two threads is harmless)

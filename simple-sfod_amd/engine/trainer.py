@@ -39,6 +39,25 @@ from .solver import FlatModelState, WarmupMultiStepLR, build_optimizer
 WRITER_PERIOD = 20  # hooks.PeriodicWriter(period=20), source_free_adaptive_teacher.py:679
 
 
+# Stage markers for rocprofv3 --marker-trace (the reference has no profiler hooks; d2's would be
+# torch.profiler).  SFOD_ROCTX=1 (or SFOD.PROFILE_RANGES True): roctx ranges "sfod/teacher", "sfod/student_forward",
+# "sfod/student_backward", "sfod/exchange", "sfod/update" around the stages of run_step, so that a kernel trace can be cut
+# by stage (tools/stage_times.py).  Off: a no-op context manager, nothing is pushed.
+_ROCTX = [os.environ.get("SFOD_ROCTX", "0") == "1"]
+
+
+@contextlib.contextmanager
+def stage(name):
+    if not _ROCTX[0]:
+        yield
+        return
+    torch.cuda.nvtx.range_push("sfod/" + name)      # = roctxRangePush on ROCm builds of torch
+    try:
+        yield
+    finally:
+        torch.cuda.nvtx.range_pop()
+
+
 def get_world_size():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -237,6 +256,8 @@ def _apply_process_knobs(cfg):
         # environment setting off.  Process-wide: the last trainer constructed decides.
         want = bool(cfg.SFOD.DETERMINISTIC) or os.environ.get("SFOD_DETERMINISTIC", "0") == "1"
         native.set_deterministic(want)
+    if "PROFILE_RANGES" in cfg.SFOD and cfg.SFOD.PROFILE_RANGES:
+        _ROCTX[0] = True
 
 
 class BaseTrainer:
@@ -355,16 +376,20 @@ class BaseTrainer:
         start = time.perf_counter()
         data = next(self._data_loader_iter)
         data_time = time.perf_counter() - start
-        record_dict = self.model(data)
+        with stage("student_forward"):
+            record_dict = self.model(data)
         loss_dict = {k: v for k, v in record_dict.items() if k[:4] == "loss" and k[-3:] != "val"}
         losses = sum(loss_dict.values())
         metrics_dict = dict(record_dict)
         metrics_dict["data_time"] = data_time
         self._write_metrics(metrics_dict)
         self.optimizer.zero_grad()
-        losses.backward()
-        self._reduce_gradients()
-        self.optimizer.step()
+        with stage("student_backward"):
+            losses.backward()
+        with stage("exchange"):
+            self._reduce_gradients()
+        with stage("update"):
+            self.optimizer.step()
 
     def _reduce_gradients(self):
         """The one exchange step: sum the flat gradient buffer over ranks (RCCL); the 1/world averaging
@@ -756,18 +781,19 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             if side is None:
                 side = self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)
             side.wait_stream(main)       # EMA'd teacher weights, input frames, last step's readers of side buffers
-            with torch.cuda.stream(side):
+            with torch.cuda.stream(side), stage("teacher"):
                 pseudo = self._teacher_pass(unlabel_data_k)
-            with self._student_pass_bn_updates():
+            with self._student_pass_bn_updates(), stage("student_forward"):
                 self.model.prefetch_features(unlabel_data_q)
             main.wait_stream(side)
         else:
-            pseudo = self._teacher_pass(unlabel_data_k)
+            with stage("teacher"):
+                pseudo = self._teacher_pass(unlabel_data_k)
         # 3. attach the pseudo-labels
         unlabel_data_q = self.add_label(unlabel_data_q, pseudo)
         unlabel_data_k = self.add_label(unlabel_data_k, pseudo)
         # 5. student on the pseudo-labelled target data
-        with self._student_pass_bn_updates():
+        with self._student_pass_bn_updates(), stage("student_forward"):
             record_all_unlabel_data, _, _, _ = self.model(unlabel_data_q, branch="supervised_target", batched=True)
         for key, v in record_all_unlabel_data.items():
             record_dict[key + "_pseudo"] = v
@@ -807,9 +833,12 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         metrics_dict["data_time"] = data_time
         self._write_metrics(metrics_dict, total=losses.detach())
         self.optimizer.zero_grad()
-        losses.backward()
-        self._reduce_gradients()
-        self.optimizer.step(ema=self.ema_enabled)  # EMA fused: _update_teacher_model (:583-603)
+        with stage("student_backward"):
+            losses.backward()
+        with stage("exchange"):
+            self._reduce_gradients()
+        with stage("update"):
+            self.optimizer.step(ema=self.ema_enabled)  # EMA fused: _update_teacher_model (:583-603)
 
     def _flush_metrics(self):
         self.model_teacher.proposal_generator.check_finite()

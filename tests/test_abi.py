@@ -59,3 +59,35 @@ def test_launch_planners_answer_without_a_gpu(sfod):
         assert lib.sfod_conv_fwd_scratch_bytes(1, 37, 75, 512, 512, 3, dt, n.F32, 0) == 0          # 3x3: never
     assert lib.sfod_conv_fwd_scratch_bytes(512, 1, 1, 25088, 1024, 1, n.BF16, n.BF16, 0) == 0      # 2-byte output: unsplit
     assert lib.sfod_last_error() == b""
+
+
+def test_c_abi_host_side_survives_hostile_arguments_under_asan_and_ubsan(sfod, tmp_path):
+    """The library's HOST code (argument validation, launch planners, ``*_supported`` / ``*_bytes`` / ``*_blocks`` queries)
+    built with -fsanitize=address,undefined and no device code (csrc/build.py::build_host_sanitized), fuzzed by
+    tests/helpers/abi_fuzz.py in a child process under the ASan runtime: random hostile vectors into every entry point
+    (negative / huge / misaligned sizes, NULL pointers, NaN floats) produce no sanitizer report and no crash, every
+    SFOD_EBADARG comes with a message, no query answers with a negative number; and for the entry points the hot path
+    calls, each single broken argument of an otherwise valid call (size < 0, channels not a multiple of the 8-group,
+    ldy < Cout, NULL operand, unknown dtype) returns -1000 before any launch."""
+    import importlib.util
+    import json
+    import pytest
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("sfod_csrc_build", os.path.join(here, "..", "simple-sfod_amd", "csrc", "build.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    if not os.path.exists(b.HIPCC):
+        pytest.skip("no hipcc")
+    rt = b.asan_runtime()
+    if rt is None:
+        pytest.skip("no shared ASan runtime in this toolchain")
+    so = b.build_host_sanitized()
+    env = dict(os.environ, LD_PRELOAD=rt, ASAN_OPTIONS="halt_on_error=0:detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=0")
+    r = subprocess.run([sys.executable, os.path.join(here, "helpers", "abi_fuzz.py"), so, "200"], env=env, cwd=str(tmp_path),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    err = r.stderr.decode(errors="replace")
+    rep = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert "runtime error" not in err and "AddressSanitizer" not in err, err[-3000:]
+    assert r.returncode == 0, (rep, err[-2000:])
+    assert rep["entry_points"] >= 85 and rep["random_calls"] >= 15000 and rep["random_violations"] == 0
+    assert rep["contract_cases"] >= 70 and rep["contract_violations"] == []

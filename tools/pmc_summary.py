@@ -34,3 +34,10 @@ for us, k, n, rd, wr, avg in rows[:14]:
                 "hbm_write_MB_per_launch": round(wr / 1e6, 3), "GBps": round(gbs, 1)})
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], "w"), indent=1)
+    # stamp: the source tree these counters were taken on (bench.py drops roofline.traffic when it differs)
+    import importlib.util, os
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("sfod_csrc_build", os.path.join(here, "simple-sfod_amd", "csrc", "build.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    json.dump({"csrc_fingerprint": mod.source_fingerprint()}, open(sys.argv[3] + ".meta", "w"))
