@@ -23,13 +23,33 @@ in plain fp32 PyTorch-CPU + numpy (+ one small C file for ROIAlign).
 
 Parity pin status
 -----------------
-* PINNED against the reference itself (imported in the build container, outputs
-  committed under ``tests/golden/`` by ``oracle/gen_golden.py``): the VGG16-BN backbone
-  (``vgg.py``, loaded by file path behind ``oracle/ref_stub``) forward, train-mode BN
-  running stats and input gradient; ``dann.py`` discriminators + gradient reversal.
-* PARITY UNPINNED for everything that lives in Detectron2 / torchvision (anchors,
-  Box2BoxTransform, Matcher, NMS, ROIAlign, RPN / Fast R-CNN losses and inference):
-  the reference ships no tests or golden vectors and those libraries are absent, so
-  those functions are restated from their published algorithms and anchored on the
-  reference's call sites plus hand-computed known-answer cases (tests/test_oracle_*.py).
+* PINNED against the reference itself -- its own code objects, loaded from /root/reference in the build container and
+  RUN by ``oracle/gen_golden.py``; only the recorded inputs / outputs are committed (``tests/golden/``):
+
+    fixture            reference code that produced it                                          rows
+    vgg_ref.npz        daod/modeling/meta_arch/vgg.py: forward, train-mode BN statistics,       a1 (fwd + bwd)
+                       input gradient, PARAMETER gradients of the backward (round 5)
+    dann_ref.npz       daod/modeling/dann/dann.py: discriminators, gradient reversal            a12
+    adaptive_ref.npz   daod/modeling/adaptive_thresh/adaptive_confidence.py                     f4
+    bpc_ref.npz        daod/loss/bpc_loss.py                                                    f4
+    glue_ref.npz       (round 5, behind the import hook oracle/ref_stub/hook.py)
+                       daod/modeling/roi_heads/source_free_fast_rcnn.py:38-147                  a6
+                       daod/engine/trainers/source_free_adaptive_teacher.py:150-183,256-280     a7
+                       ... :583-603 (_update_teacher_model incl. int64 counters, DDP prefix)    a9
+                       daod/data/common.py:199-228 (aspect bucketing)                           a13
+                       daod/modeling/proposal_generator/rpn.py:16-58 (layout, 2nd loss weight)  a4 (glue only)
+                       daod/engine/trainers/base.py:318-328 (reset_bn_stats)                    a11
+    config_ref.json    daod/config.py:8-142 (add_config on a recording node)                    b
+
+  ``tests/test_oracle_golden.py`` / ``tests/test_oracle_glue.py`` hold the restatements in this directory to those vectors
+  (bit-exact for everything discrete and for the EMA; 1e-4 for the VGG trunk), ``tests/test_gpu_glue.py`` /
+  ``tests/test_gpu_model.py`` hold the HIP path to the same vectors directly.
+* PARITY UNPINNED for everything that lives in Detectron2 / torchvision (anchors, Box2BoxTransform, Matcher, NMS,
+  ROIAlign, RPN / Fast R-CNN losses and inference, ``Boxes.clip``, ResNet): the reference ships no tests or golden vectors
+  and those libraries are absent, so those functions are restated from their published algorithms and anchored on the
+  reference's call sites plus hand-computed known-answer cases (tests/test_oracle_*.py).  One third-party cross-check
+  exists: ``transformers`` (installed) carries an independent port of torchvision's ``box_iou``;
+  ``oracle.box_ops.pairwise_iou`` / ``box_area`` equal it bit for bit (tests/test_oracle_glue.py).  The generator for the
+  real pin is committed (``python -m oracle.gen_golden --upstream`` on a machine with detectron2 + torchvision ->
+  tests/golden/upstream_ref.npz, checked by tests/test_oracle_upstream.py, which skips until that file exists).
 """

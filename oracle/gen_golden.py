@@ -258,7 +258,161 @@ def _ref_modules():
     mods.rpn = _load_by_path("ref_rpn", os.path.join(REF, "daod/modeling/proposal_generator/rpn.py"))
     mods.base = _load_by_path("ref_base", os.path.join(REF, "daod/engine/trainers/base.py"))
     mods.config = _load_by_path("ref_config", os.path.join(REF, "daod/config.py"))
+    import importlib
+    importlib.import_module("daod.modeling.roi_heads")       # (made up by the hook) parent of the file's relative import
+    mods.roi_heads = _load_by_path("daod.modeling.roi_heads.ref_roi_heads", os.path.join(
+        REF, "daod/modeling/roi_heads/source_free_adaptive_teacher_roi_heads.py"))
     return mods
+
+
+def gen_roi_heads_glue(m, out, g):
+    """a5: ``SourceFreeAdaptiveTeacherStandardROIHeads.{label_and_sample_proposals, forward, _forward_box}``
+    (daod/modeling/roi_heads/source_free_adaptive_teacher_roi_heads.py:68-215), the reference's own code objects on a stub
+    ``self``.  The Detectron2 primitives they call (``add_ground_truth_to_proposals``, ``pairwise_iou``, the Matcher,
+    ``subsample_labels`` behind ``_sample_proposals``) are absent: the oracle's restatements stand in for them (with the
+    sampling keys as an input, oracle/box_ops.py A.9) -- so what these vectors pin is the reference-OWNED part: which
+    proposals receive which ground-truth fields, the zero boxes of an image without ground truth, the logged foreground /
+    background counts and their key names, the return arity of every flag combination, the order of the calls in the box
+    branch and the overwrite of the sampled proposals' boxes (:136-143)."""
+    import math
+    from detectron2.structures import Boxes, Instances
+    from oracle import box_ops as OB
+    mod = m.roi_heads
+    cls = mod.SourceFreeAdaptiveTeacherStandardROIHeads
+    K, BATCH, FRAC = 8, 64, 0.25
+
+    def add_gt(gt_boxes, proposals):
+        logit = math.log((1.0 - 1e-10) / (1 - (1.0 - 1e-10)))
+        res = []
+        for gb, p in zip(gt_boxes, proposals):
+            q = Instances(p.image_size)
+            q.proposal_boxes = Boxes(torch.cat([p.proposal_boxes.tensor, gb.tensor]))
+            q.objectness_logits = torch.cat([p.objectness_logits, logit * torch.ones(len(gb))])
+            res.append(q)
+        return res
+    mod.add_ground_truth_to_proposals = add_gt
+    mod.pairwise_iou = lambda a, b: OB.pairwise_iou(a.tensor, b.tensor)
+    scalars = {}
+    mod.get_event_storage = lambda: types.SimpleNamespace(put_scalar=lambda k, v: scalars.__setitem__(k, float(v)))
+
+    stub = object.__new__(cls)
+    stub.proposal_append_gt = True
+    stub.num_classes = K
+    stub.proposal_matcher = lambda M: OB.matcher(M, [0.5], [0, 1], False)
+    keys_iter = []
+
+    def sample(matched_idxs, matched_labels, gt_classes):
+        if gt_classes.numel() > 0:
+            gc = gt_classes[matched_idxs]
+            gc[matched_labels == 0] = K
+            gc[matched_labels == -1] = -1
+        else:
+            gc = torch.zeros_like(matched_idxs) + K
+        keys = keys_iter.pop(0)
+        fg, bg = OB.subsample_labels(gc, BATCH, FRAC, K, keys[: len(gc)])
+        idx = torch.cat([fg, bg], dim=0)
+        return idx, gc[idx]
+    stub._sample_proposals = sample
+    size = (300, 400)
+    props, targets, keys = [], [], []
+    for i, ng in enumerate((5, 0, 3)):
+        gb = torch.rand(ng, 2, generator=g) * torch.tensor([250.0, 180.0])
+        gb = torch.cat([gb, gb + torch.rand(ng, 2, generator=g) * 120 + 20], 1)
+        n = 150
+        pb = torch.rand(n, 2, generator=g) * torch.tensor([300.0, 220.0])
+        pb = torch.cat([pb, pb + torch.rand(n, 2, generator=g) * 150 + 8], 1)
+        if ng:
+            near = torch.randint(0, ng, (60,), generator=g)
+            pb[:60] = gb[near] + torch.randn(60, 4, generator=g) * 6
+        p = Instances(size)
+        p.proposal_boxes = Boxes(pb)
+        p.objectness_logits = torch.randn(n, generator=g)
+        t = Instances(size)
+        t.gt_boxes = Boxes(gb)
+        t.gt_classes = torch.randint(0, K, (ng,), generator=g)
+        t.scores = torch.rand(ng, generator=g)              # a non-"gt_" field: must NOT be copied to the proposals
+        props.append(p)
+        targets.append(t)
+        keys.append(torch.randint(0, 2 ** 31 - 1, (n + ng,), generator=g))
+    keys_iter.extend(k.clone() for k in keys)
+    res = cls.label_and_sample_proposals(stub, props, targets, branch="supervised_target")
+    out["roi_K"], out["roi_batch"], out["roi_frac"] = np.int64(K), np.int64(BATCH), np.float64(FRAC)
+    out["roi_size"] = np.array(size)
+    for i in range(3):
+        out[f"roi_in_boxes_{i}"], out[f"roi_in_logits_{i}"] = props[i].proposal_boxes.tensor.numpy(), props[i].objectness_logits.numpy()
+        out[f"roi_gt_boxes_{i}"], out[f"roi_gt_classes_{i}"] = targets[i].gt_boxes.tensor.numpy(), targets[i].gt_classes.numpy()
+        out[f"roi_keys_{i}"] = keys[i].numpy()
+        r = res[i]
+        out[f"roi_out_fields_{i}"] = np.array(sorted(r.get_fields().keys()))
+        out[f"roi_out_boxes_{i}"], out[f"roi_out_logits_{i}"] = r.proposal_boxes.tensor.numpy(), r.objectness_logits.numpy()
+        out[f"roi_out_gt_classes_{i}"], out[f"roi_out_gt_boxes_{i}"] = r.gt_classes.numpy(), r.gt_boxes.tensor.numpy()
+    out["roi_scalar_keys"] = np.array(sorted(scalars))
+    out["roi_scalar_vals"] = np.array([scalars[k] for k in sorted(scalars)])
+
+    # ---- forward / _forward_box: which path runs, what comes back ------------------------------------------------------
+    trace = []
+    stub.box_in_features = ["vgg4"]
+    stub.box_pooler = lambda feats, boxes: trace.append(("box_pooler", len(boxes))) or "pooled"
+    stub.box_head = lambda x: trace.append(("box_head", x)) or "box_features"
+
+    class Predictor:
+        def __call__(self, x):
+            trace.append(("box_predictor", x))
+            return "predictions"
+
+        def losses(self, predictions, proposals):
+            trace.append(("losses", [float(p.proposal_boxes.tensor.sum()) for p in proposals]))
+            return {"loss_cls": 1.0, "loss_box_reg": 2.0}
+
+        def predict_boxes_for_gt_classes(self, predictions, proposals):
+            trace.append(("predict_boxes_for_gt_classes",))
+            return [p.proposal_boxes.tensor + 1.0 for p in proposals]
+
+        def convert_bbox_scores(self, predictions, proposals):
+            trace.append(("convert_bbox_scores", [float(p.proposal_boxes.tensor.sum()) for p in proposals]))
+            return "instance_proposals", "rows"
+
+        def inference(self, predictions, proposals):
+            trace.append(("inference",))
+            return "pred_instances", "rows"
+    stub.box_predictor = Predictor()
+    feats = {"vgg4": "feature"}
+    combos = [(True, True, False), (True, False, False), (False, True, False), (False, False, True), (True, False, True)]
+    arity, paths, appended = [], [], []
+    for training, compute_loss, compute_val_loss in combos:
+        stub.training = training
+        del trace[:]
+        keys_iter.extend(k.clone() for k in keys)
+        seen = []
+        orig = stub._sample_proposals
+
+        def spy(mi, ml, gc, _o=orig):
+            seen.append(bool(stub.proposal_append_gt))
+            return _o(mi, ml, gc)
+        stub._sample_proposals = spy
+        fresh = []
+        for p in props:
+            q = Instances(size)
+            q.proposal_boxes = Boxes(p.proposal_boxes.tensor.clone())
+            q.objectness_logits = p.objectness_logits.clone()
+            fresh.append(q)
+        r = cls.forward(stub, None, feats, fresh, targets, compute_loss=compute_loss, branch="b",
+                        compute_val_loss=compute_val_loss)
+        stub._sample_proposals = orig
+        del keys_iter[:]
+        arity.append(len(r))
+        paths.append("|".join(t[0] for t in trace))
+        appended.append(int(seen[0]) if seen else -1)
+        if training and compute_loss:
+            # the sampled proposals' boxes were overwritten AFTER the losses and BEFORE convert_bbox_scores (:136-143)
+            l = [t for t in trace if t[0] == "losses"][0][1]
+            c = [t for t in trace if t[0] == "convert_bbox_scores"][0][1]
+            out["roi_fwd_box_sum_at_losses"], out["roi_fwd_box_sum_at_convert"] = np.array(l), np.array(c)
+            out["roi_fwd_box_sum_returned"] = np.array([float(p.proposal_boxes.tensor.sum()) for p in r[0]])
+            out["roi_fwd_rows"] = np.array([len(p) for p in r[0]])
+    out["roi_fwd_flags"] = np.array(combos)
+    out["roi_fwd_arity"], out["roi_fwd_paths"], out["roi_fwd_append_gt_seen"] = np.array(arity), np.array(paths), np.array(appended)
+    assert stub.proposal_append_gt is True
 
 
 def gen_glue():
@@ -499,6 +653,7 @@ def gen_glue():
         if k.endswith("weight") or k.endswith("bias"):
             out["adabn_w/" + k] = v.numpy().copy()
 
+    gen_roi_heads_glue(m, out, g)
     np.savez_compressed(os.path.join(OUT, "glue_ref.npz"), **out)
 
     # ---- b: add_config -------------------------------------------------------------------------------------------

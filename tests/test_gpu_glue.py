@@ -195,3 +195,55 @@ def test_vgg_parameter_gradients_match_the_reference_backward(sfod, native, dtyp
         assert err < tol and nerr < tol, (name, err, nerr)
     print(f"\n[vgg backward vs reference, {dtype}] worst parameter-gradient error {max(worst.values()):.2e} "
           f"({max(worst, key=worst.get)})")
+
+
+def test_label_and_sample_proposals_on_the_device_equals_the_reference_method(fx, sfod, native):
+    """The product's ``label_and_sample_proposals`` (sfod_append_gt -> sfod_roi_match -> sfod_subsample -> sfod_roi_build_samples)
+    on the recorded proposals / ground truth / sampling keys: the same sampled rows as the reference's method produced
+    (source_free_adaptive_teacher_roi_heads.py:165-215): proposal box, class (background = K), matched ground-truth box
+    (zeros for the image without ground truth).  Rows are compared as sets per image (the loss does not depend on their order)."""
+    K, batch, frac = int(fx["roi_K"]), int(fx["roi_batch"]), float(fx["roi_frac"])
+    cfg = sfod.config.setup_cfg(HOT_YAML, ["OUTPUT_DIR", "", "SFOD.COMPUTE_DTYPE", "fp32", "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", str(batch),
+                                           "MODEL.ROI_HEADS.POSITIVE_FRACTION", str(frac)])
+    torch.manual_seed(0)
+    heads = sfod.modeling.build_model(cfg).roi_heads
+    assert heads.num_classes == K and heads.proposal_append_gt
+    size = tuple(int(v) for v in fx["roi_size"])
+    S = sfod.structures
+    from importlib import import_module
+    batched = import_module("simple-sfod_amd.modeling.batched")
+    props, targets = [], []
+    for i in range(3):
+        p = S.Instances(size)
+        p.proposal_boxes = S.Boxes(T(fx[f"roi_in_boxes_{i}"]))
+        p.objectness_logits = T(fx[f"roi_in_logits_{i}"])
+        t = S.Instances(size)
+        t.gt_boxes = S.Boxes(T(fx[f"roi_gt_boxes_{i}"]).reshape(-1, 4))
+        t.gt_classes = T(fx[f"roi_gt_classes_{i}"])
+        props.append(p)
+        targets.append(t)
+    bp = sfod.modeling.roi_heads._proposals_from_instances(props, torch.device(DEV))
+    bt = batched.BatchedGT.from_instances(targets, torch.device(DEV))
+    P = bp.boxes.shape[1]
+    ncap = P + bt.boxes.shape[1]
+    keys = torch.zeros(3, ncap, dtype=torch.int32)
+    for i in range(3):
+        k = T(fx[f"roi_keys_{i}"]).to(torch.int32)
+        keys[i, : len(k)] = k
+    sm = heads.label_and_sample_proposals(bp, bt, branch="supervised_target", keys=keys.to(DEV))
+    rois, gt_cls, gt_box, cnt = sm["rois"].cpu(), sm["gt_cls"].cpu().long(), sm["gt_box"].cpu(), sm["count"].cpu().tolist()
+
+    def rows(boxes, cls, gtb):
+        m = torch.cat([boxes.double(), cls.double().view(-1, 1), gtb.double()], dim=1)
+        return m[np.lexsort(m.numpy().T[::-1])]
+    for i in range(3):
+        ref_b, ref_c, ref_g = T(fx[f"roi_out_boxes_{i}"]), T(fx[f"roi_out_gt_classes_{i}"]), T(fx[f"roi_out_gt_boxes_{i}"])
+        assert cnt[i] == len(ref_c), (i, cnt[i], len(ref_c))
+        sel = slice(i * batch, i * batch + cnt[i])
+        assert (rois[sel, 0] == i).all()
+        got = rows(rois[sel, 1:5], gt_cls[sel], gt_box[sel])
+        ref = rows(ref_b, ref_c, ref_g)
+        assert torch.equal(got, ref), i
+    assert (gt_box[batch:batch + cnt[1]] == 0).all() and (gt_cls[batch:batch + cnt[1]] == K).all()      # the image without ground truth
+    nbg = [int((gt_cls[i * batch:i * batch + cnt[i]] == K).sum()) for i in range(3)]
+    np.testing.assert_allclose(fx["roi_scalar_vals"], [np.mean(nbg), np.mean([c - b for c, b in zip(cnt, nbg)])])

@@ -299,3 +299,51 @@ def test_pairwise_iou_against_the_independent_box_iou_in_transformers():
     assert (got[torch.arange(10), torch.arange(10)] == 1).all() and (got[torch.arange(10, 20), torch.arange(10, 20)] == 0).all()
     # box_area agrees too
     assert torch.equal(B.box_area(a), loss_mod.box_area(a))
+
+
+# ---- a5 ----------------------------------------------------------------------------------------------------------------
+def test_roi_label_and_sample_equals_the_reference_method(fx):
+    """``label_and_sample_proposals`` (source_free_adaptive_teacher_roi_heads.py:165-215) run by the generator on the
+    oracle's Detectron2 primitives: the oracle's one-piece restatement returns the same rows in the same order -- proposals
+    (ground truth appended), their classes (background = K), the matched ground-truth boxes (zeros for the image without
+    ground truth); only ``gt_*`` fields travel to the proposals; the logged means and their key names."""
+    K, batch, frac = int(fx["roi_K"]), int(fx["roi_batch"]), float(fx["roi_frac"])
+    cfg = om.Cfg(roi_batch=batch, roi_pos_frac=frac, num_classes=K)
+    props = [(T(fx[f"roi_in_boxes_{i}"]), T(fx[f"roi_in_logits_{i}"])) for i in range(3)]
+    gtb = [T(fx[f"roi_gt_boxes_{i}"]).reshape(-1, 4) for i in range(3)]
+    gtc = [T(fx[f"roi_gt_classes_{i}"]) for i in range(3)]
+    keys = [T(fx[f"roi_keys_{i}"]) for i in range(3)]
+    res = om.roi_label_and_sample(props, gtb, gtc, keys, cfg)
+    nfg, nbg = [], []
+    for i, r in enumerate(res):
+        assert torch.equal(r["boxes"], T(fx[f"roi_out_boxes_{i}"])), i
+        assert torch.equal(r["gt_classes"], T(fx[f"roi_out_gt_classes_{i}"])), i
+        assert torch.equal(r["gt_boxes"], T(fx[f"roi_out_gt_boxes_{i}"])), i
+        assert list(fx[f"roi_out_fields_{i}"]) == ["gt_boxes", "gt_classes", "objectness_logits", "proposal_boxes"]
+        nbg.append(int((r["gt_classes"] == K).sum()))
+        nfg.append(len(r["gt_classes"]) - nbg[-1])
+    assert len(gtb[1]) == 0 and (fx["roi_out_gt_boxes_1"] == 0).all() and (fx["roi_out_gt_classes_1"] == K).all()
+    assert list(fx["roi_scalar_keys"]) == ["roi_head/num_target_bg_samples_supervised_target",
+                                           "roi_head/num_target_fg_samples_supervised_target"]
+    np.testing.assert_allclose(fx["roi_scalar_vals"], [np.mean(nbg), np.mean(nfg)])
+
+
+def test_roi_heads_forward_control_flow_of_the_reference(fx, sfod):
+    """``forward`` / ``_forward_box`` (:68-163) on a stub: return arity per (training, compute_loss, compute_val_loss),
+    the calls of the box branch in order, ``proposal_append_gt`` switched off for the val-loss pass only, and the sampled
+    proposals' boxes overwritten with the gt-class predictions AFTER the losses and BEFORE ``convert_bbox_scores``.  The
+    product's ROI heads implement exactly these rules (simple-sfod_amd/modeling/roi_heads.py::forward; the 4-tuple /
+    2-tuple shapes are asserted on the device in tests/test_gpu_model.py)."""
+    flags = [tuple(bool(v) for v in r) for r in fx["roi_fwd_flags"]]
+    train_path = "box_pooler|box_head|box_predictor|losses|predict_boxes_for_gt_classes|convert_bbox_scores"
+    infer_path = "box_pooler|box_head|box_predictor|inference"
+    for (training, cl, cvl), arity, path, seen in zip(flags, fx["roi_fwd_arity"], fx["roi_fwd_paths"], fx["roi_fwd_append_gt_seen"]):
+        losses = (training and cl) or cvl
+        assert int(arity) == (4 if losses else 2) and str(path) == (train_path if losses else infer_path)
+        # GT is appended only in the training-loss pass; the val-loss pass samples from the proposals alone
+        assert int(seen) == (1 if (training and cl) else (0 if cvl else -1))
+    np.testing.assert_allclose(fx["roi_fwd_box_sum_at_convert"] - fx["roi_fwd_box_sum_at_losses"], 4.0 * fx["roi_fwd_rows"])
+    assert np.array_equal(fx["roi_fwd_box_sum_returned"], fx["roi_fwd_box_sum_at_convert"])
+    import inspect
+    src = inspect.getsource(sfod.modeling.roi_heads.StandardROIHeads.forward)
+    assert "compute_val_loss and not (self.training and compute_loss)" in src      # the same append-gt rule
