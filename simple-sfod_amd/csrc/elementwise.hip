@@ -1809,6 +1809,16 @@ extern "C" int sfod_bias_grad(const void* dy, float* db, int M, int N, int ld, i
 // ---------------------------------------------------------------------------------------------
 // K20 + K21: fused SGD(momentum, weight decay) + EMA over flat fp32 arrays, 16 B per lane
 // ---------------------------------------------------------------------------------------------
+// student * (1 - k) + teacher * k with the reference's roundings: two rounded products, then a rounded sum.  The contract
+// flag is attached where an operator is WRITTEN, so plain * and + under the pragma (HIP's __fmul_rn / __fadd_rn are plain
+// operators compiled under the header's default, contraction allowed, and did fuse into v_fmac in one of the kernels).
+__device__ __forceinline__ float ema_mix(float student, float one_minus_keep, float teacher, float keep) {
+#pragma clang fp contract(off)
+  const float a = student * one_minus_keep;
+  const float b = teacher * keep;
+  return a + b;
+}
+
 __global__ void __launch_bounds__(256)
 k_sgd_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ t,
           int64_t n, const float* __restrict__ lr_ptr, float momentum, float wd, float gscale, float keep,
@@ -1835,10 +1845,10 @@ k_sgd_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict_
       float4 tv = reinterpret_cast<float4*>(t)[i];
       // the reference's operation order (student * (1 - k) + teacher * k in torch ops): two rounded products, a rounded
       // sum, no contraction -- bit-identical to _update_teacher_model (tests/golden/glue_ref.npz)
-      tv.x = __fadd_rn(__fmul_rn(pp[0], one_minus_keep), __fmul_rn(tv.x, keep));
-      tv.y = __fadd_rn(__fmul_rn(pp[1], one_minus_keep), __fmul_rn(tv.y, keep));
-      tv.z = __fadd_rn(__fmul_rn(pp[2], one_minus_keep), __fmul_rn(tv.z, keep));
-      tv.w = __fadd_rn(__fmul_rn(pp[3], one_minus_keep), __fmul_rn(tv.w, keep));
+      tv.x = ema_mix(pp[0], one_minus_keep, tv.x, keep);
+      tv.y = ema_mix(pp[1], one_minus_keep, tv.y, keep);
+      tv.z = ema_mix(pp[2], one_minus_keep, tv.z, keep);
+      tv.w = ema_mix(pp[3], one_minus_keep, tv.w, keep);
       reinterpret_cast<float4*>(t)[i] = tv;
     }
   }
@@ -1851,7 +1861,7 @@ k_sgd_ema(float* __restrict__ p, const float* __restrict__ g, float* __restrict_
     const float pp = p[i] - lr * mm;
     p[i] = pp;
     m[i] = mm;
-    if (t) t[i] = __fadd_rn(__fmul_rn(pp, one_minus_keep), __fmul_rn(t[i], keep));
+    if (t) t[i] = ema_mix(pp, one_minus_keep, t[i], keep);
   }
 }
 
@@ -1871,7 +1881,7 @@ extern "C" int sfod_sgd_ema(float* param, const float* grad, float* mom, float* 
 
 __global__ void k_ema(float* __restrict__ t, const float* __restrict__ s, int64_t n, float keep, float omk) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-    t[i] = __fadd_rn(__fmul_rn(s[i], omk), __fmul_rn(t[i], keep));
+    t[i] = ema_mix(s[i], omk, t[i], keep);
 }
 
 extern "C" int sfod_ema(float* teacher, const float* student, int64_t n, float keep, float one_minus_keep,
@@ -1892,9 +1902,7 @@ __global__ void k_ema_i64(long long* __restrict__ t, const long long* __restrict
   if (i < n) {
     // torch's operation order: two rounded fp32 products, then a rounded sum (no fused multiply-add: with equal
     // counters the result sits exactly on an integer and one contracted rounding decides the truncation)
-    const float a = __fmul_rn((float)s[i], omk);
-    const float b = __fmul_rn((float)t[i], keep);
-    t[i] = (long long)__fadd_rn(a, b);
+    t[i] = (long long)ema_mix((float)s[i], omk, (float)t[i], keep);
   }
 }
 extern "C" int sfod_ema_i64(int64_t* teacher, const int64_t* student, int n, float keep, float one_minus_keep,

@@ -36,6 +36,34 @@ def native(sfod):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# Which cases are sweeps (one table instead of marks scattered over the parametrisations).  What stays in the default GPU
+# selection: every parity gate at BASELINE sizes in the mode bench.py reports for that config, every golden-fixture test, the
+# two-rank run of config #4, and ONE case per kernel family and variant axis (the planner's own choice); the exhaustive
+# axes -- forced workgroup shapes, forced algorithms, the other arithmetic modes of the long oracle comparisons -- run
+# with -m "gpu and sweep".  Durations that decided the cut: gpurun_out / profiles/r5_gpu_suite_durations.txt.
+import re
+
+SWEEP_PATTERNS = [re.compile(p) for p in (
+    # forced workgroup shapes of the halo-patch convolution: keep auto (0) and the 16x16x32 default (5)
+    r"test_conv3x3_patch_kernel\[(1|2|3|4|6)-",
+    r"test_gpu_bf16x3\.py::test_dgrad_with_fused_batchnorm_backward_reduction\[(1|2|4|5|6)-",
+    r"test_gpu_bf16x3\.py::test_conv_dgrad_and_wgrad\[(1|4)-",                  # forced algorithms; 0 = the planner
+    r"test_gpu_bf16x3\.py::test_conv3x3_patch_wgrad\[(1|0)-",                   # the non-default loops of the weight gradient
+    r"test_gpu_bf16x3\.py::test_conv3x3_with_batchnorm_folded_into_its_input\[(2|6)",
+    # long oracle comparisons: the default keeps the mode bench.py reports for the config (+ one fp32 / non-elided case)
+    r"test_three_steps_match_the_oracle_trajectory\[(vgg-fp32-True|r101-fp32-True|vgg-f16x3-True|vgg-f16x3-False)\]",
+    r"test_two_ranks_on_one_gpu_take_the_oracles_mean_gradient_step\[vgg-bf16x3\]",
+    r"test_hot_yaml_teacher_and_student_at_600x1200\[(f16x3-2|bf16x3-2)\]",
+    r"test_r101_yaml_teacher_and_student_at_600x1200\[(fp32|bf16x3)\]",
+    r"test_r101_yaml_on_a_well_conditioned_weight_set_at_600x1200\[fp32\]",
+)]
+
+
+def pytest_itemcollected(item):
+    if any(p.search(item.nodeid) for p in SWEEP_PATTERNS):
+        item.add_marker(pytest.mark.sweep)
+
+
 def pytest_collection_modifyitems(config, items):
     """``sweep`` tests run only when the -m expression names them: ``-m gpu`` (the driver's selection: parity gates at
     BASELINE sizes, golden fixtures, one case per kernel family) stays well inside its time limit, ``-m "gpu and sweep"``
