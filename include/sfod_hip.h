@@ -97,6 +97,13 @@ int64_t sfod_conv_fwd_scratch_bytes(int B, int H, int W, int Cin, int Cout, int 
 int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B, int H,
                           int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
                           void* scratch, int64_t scratch_bytes, void* stream);
+/* y = act(conv(x) + bias + res): the residual join of a bottleneck whose norm is folded into its weights (FrozenBN stages of
+ * d2's ResNet: BottleneckBlock.forward, out = relu(conv3(out) + shortcut)) done in the convolution's epilogue instead of a
+ * separate pass over three tensors.  res: fp32 [B*H*W][ldres], ldres >= Cout; y fp32 [B*H*W][ldy].  (acc + bias) and
+ * (+ res) are two fp32 roundings in that order -- bit-identical to sfod_conv_fwd followed by sfod_add_act.  Always the
+ * generic implicit-GEMM kernel; no statistics, no split-K. */
+int sfod_conv_fwd_res(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, const float* res, int ldres,
+                      void* y, int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, int dt, void* stream);
 /* number of statistics blocks nblk sfod_conv_fwd writes for this layer shape; `stats` holds
  * nblk * (2*Cout + 1) floats */
 int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt);
@@ -290,6 +297,15 @@ int sfod_add_act(const void* a, const void* b, void* out, void* out_pairs, void*
  * stride-2 conv, STRIDE_IN_1X1); backward=1: the adjoint (dst [B,H,W,C] zero except even pixels) */
 int sfod_subsample2(const void* src, void* dst, int B, int H, int W, int C, int backward, int dt,
                     void* stream);
+/* ResNet BasicStem as one kernel on operand pairs (d2 build_resnet_backbone: conv 7x7 stride 2 pad 3, 3 -> 64, FrozenBN
+ * folded into w / bias, ReLU): replaces sfod_im2col_stem + sfod_conv_fwd for dt SFOD_BF16X3 / SFOD_F16X3 -- the [pixels][160]
+ * operand matrix is gathered from an LDS patch of the input in registers and never written (bit-identical output: same k
+ * order, same splits, same MFMA sequence).  x fp32 [B,H,W,Cp] (channels 0-2 used, Cp % 4 == 0); w_packed: sfod_pack_fc_weight
+ * of the [64][160] matrix (k = (ky*7+kx)*3+c, zero columns from 147), w_absmax its SFOD_F16X3 scale word or NULL;
+ * y fp32 [B,Ho,Wo,64], Ho = (H-1)/2+1.  act 0 / 1 (ReLU).  The max-pool that follows stays sfod_maxpool3s2. */
+int sfod_stem7x7_supported(int B, int H, int W, int Cp, int dt);
+int sfod_stem7x7(const float* x, const void* w_packed, const uint32_t* w_absmax, const float* bias, float* y, int B, int H,
+                 int W, int Cp, int act, int dt, void* stream);
 /* im2col of BasicStem's 7x7 stride-2 pad-3 conv: out [B,Ho,Wo,Kpad], column (ky*7+kx)*3+c; out_dt = dt, or
  * SFOD_BF16X3 from fp32 input (the stem GEMM's operand pairs, written directly) */
 int sfod_im2col_stem(const void* x, void* out, int B, int H, int W, int Cp, int Kpad, int dt, int out_dt,

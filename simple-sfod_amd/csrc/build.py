@@ -23,6 +23,7 @@ SOURCES = {
     "conv3x3_patch.hip": [],
     "wgrad3x3_patch.hip": [],
     "conv_first.hip": [],
+    "stem7x7.hip": [],
     "sort.hip": [],
     "augment.hip": ["-ffp-contract=off"],
     "runtime.cpp": [],

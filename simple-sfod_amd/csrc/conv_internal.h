@@ -65,6 +65,7 @@ bool sfod_deterministic();
 void sfod_f16_poll_elementwise(unsigned* out, hipStream_t s);
 void sfod_f16_poll_roi(unsigned* out, hipStream_t s);
 void sfod_f16_poll_first(unsigned* out, hipStream_t s);
+void sfod_f16_poll_stem(unsigned* out, hipStream_t s);
 
 // ---- first layer (Cin = one padded chunk of 8, Cout = 64), bf16 / bf16x3 ------------------------------------------
 int sfod_f1_nblk(int B, int H, int W);

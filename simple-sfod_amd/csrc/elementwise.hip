@@ -2036,5 +2036,6 @@ extern "C" int sfod_f16x3_poll(uint32_t* word, void* stream) {
   sfod_f16_poll_elementwise(word, s);
   sfod_f16_poll_roi(word, s);
   sfod_f16_poll_first(word, s);
+  sfod_f16_poll_stem(word, s);
   return sfod_check_launch("f16x3_poll");
 }
