@@ -97,13 +97,6 @@ int64_t sfod_conv_fwd_scratch_bytes(int B, int H, int W, int Cin, int Cout, int 
 int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y, int B, int H,
                           int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats, int dt, int out_dt,
                           void* scratch, int64_t scratch_bytes, void* stream);
-/* y = act(conv(x) + bias + res): the residual join of a bottleneck whose norm is folded into its weights (FrozenBN stages of
- * d2's ResNet: BottleneckBlock.forward, out = relu(conv3(out) + shortcut)) done in the convolution's epilogue instead of a
- * separate pass over three tensors.  res: fp32 [B*H*W][ldres], ldres >= Cout; y fp32 [B*H*W][ldy].  (acc + bias) and
- * (+ res) are two fp32 roundings in that order -- bit-identical to sfod_conv_fwd followed by sfod_add_act.  Always the
- * generic implicit-GEMM kernel; no statistics, no split-K. */
-int sfod_conv_fwd_res(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, const float* res, int ldres,
-                      void* y, int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, int dt, void* stream);
 /* number of statistics blocks nblk sfod_conv_fwd writes for this layer shape; `stats` holds
  * nblk * (2*Cout + 1) floats */
 int sfod_conv_stats_blocks(int B, int H, int W, int Cin, int Cout, int ksize, int dt);

@@ -42,8 +42,6 @@ struct ConvArgs {
   int kt_per;     // split-K (blockIdx.y = split): K tiles per split, 0 = the whole K range in one workgroup
   int nsplit;     // split-K: grid.y (host side)
   int64_t slab;   // split-K: elements between the splits' output slabs
-  const float* res;   // optional fp32 residual [M][ldres] added to (acc + bias) before the activation (fp32 output only)
-  int ldres;
 };
 
 template <typename T> struct Chunk { static constexpr int E = 16 / sizeof(T); };
@@ -395,12 +393,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
         if (STAGED) {
           *reinterpret_cast<OutT*>(smem + ml * CPITCH + nl * 2) = from_f32<OutT>(apply_act(v, a.act));
         } else {
-          if (m < a.M && n < a.Cout) {
-            // residual join of a frozen bottleneck (relu(conv3 + shortcut)): (acc + bias) rounded, + residual rounded -- the two
-            // roundings of the separate add pass it replaces, in the same order
-            const float vr = (a.res != nullptr) ? v + a.res[(int64_t)m * a.ldres + n] : v;
-            y[(int64_t)m * a.ldy + n] = from_f32<OutT>(apply_act(vr, a.act));
-          }
+          if (m < a.M && n < a.Cout) y[(int64_t)m * a.ldy + n] = from_f32<OutT>(apply_act(v, a.act));
         }
       }
     }
@@ -749,32 +742,9 @@ extern "C" int64_t sfod_conv_fwd_scratch_bytes(int B, int H, int W, int Cin, int
   return (int64_t)S * B * H * W * Cout * 4;
 }
 
-static int conv_fwd_impl(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y,
-                         int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats,
-                         int dt, int out_dt, void* scratch, int64_t scratch_bytes, const float* res, int ldres, void* stream);
-
 extern "C" int sfod_conv_fwd_scratch(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y,
                                      int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats,
                                      int dt, int out_dt, void* scratch, int64_t scratch_bytes, void* stream) {
-  return conv_fwd_impl(x, w, w_absmax, bias, y, B, H, W, Cin, Cout, ksize, ldy, act, stats, dt, out_dt, scratch, scratch_bytes,
-                       nullptr, 0, stream);
-}
-
-// y = act(conv(x) + bias + res): the residual join of a bottleneck whose norm is folded into the weights (FrozenBN stages:
-// d2 BottleneckBlock.forward, out = relu(conv3(out) + shortcut)) in the convolution's epilogue instead of a separate
-// elementwise pass over three tensors.  Generic implicit-GEMM kernel only (fp32 output, no statistics, no split-K).
-extern "C" int sfod_conv_fwd_res(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, const float* res,
-                                 int ldres, void* y, int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act,
-                                 int dt, void* stream) {
-  SFOD_REQUIRE(res != nullptr, "conv_fwd_res: null residual");
-  SFOD_REQUIRE(sfod_ints_ok({ldres}) && ldres >= Cout, "conv_fwd_res: ldres < Cout");
-  return conv_fwd_impl(x, w, w_absmax, bias, y, B, H, W, Cin, Cout, ksize, ldy, act, nullptr, dt, SFOD_F32, nullptr, 0, res,
-                       ldres, stream);
-}
-
-static int conv_fwd_impl(const void* x, const void* w, const uint32_t* w_absmax, const float* bias, void* y,
-                         int B, int H, int W, int Cin, int Cout, int ksize, int ldy, int act, float* stats,
-                         int dt, int out_dt, void* scratch, int64_t scratch_bytes, const float* res, int ldres, void* stream) {
   SFOD_REQUIRE(conv_shape_fits(B, H, W, Cin, Cout, ksize) && sfod_ints_ok({ldy}) && sfod_i64s_ok({scratch_bytes}),
                "conv_fwd: negative or oversized extent");
   SFOD_REQUIRE(x != nullptr && w != nullptr && y != nullptr, "conv_fwd: null operand (x, w, y)");
@@ -789,11 +759,11 @@ static int conv_fwd_impl(const void* x, const void* w, const uint32_t* w_absmax,
   SFOD_REQUIRE(!sfod_is_pairs(dt) || out_dt == SFOD_F32, "conv: operand pairs write fp32");
   if ((int64_t)B * H * W == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  if (res == nullptr && use_first_kernel(B, H, W, Cin, Cout, ksize, dt, ldy, out_dt))
+  if (use_first_kernel(B, H, W, Cin, Cout, ksize, dt, ldy, out_dt))
     return sfod_f1_launch(x, w, bias, y, stats, B, H, W, ldy, act, s, nullptr, nullptr, split_code(dt), w_absmax);
   const int split = split_code(dt);
   Cin = phys_ch(dt, Cin);           // from here on: bf16 channels as stored
-  if (res == nullptr && ksize == 3 && is_bf16_storage(dt)) {
+  if (ksize == 3 && is_bf16_storage(dt)) {
     const P3Plan p = sfod_p3_plan(B, H, W, Cin, Cout, split != 0);
     if (use_patch_kernel(p, B, H, W, ksize, dt))
       return sfod_p3_launch(p, x, w, bias, y, stats, B, H, W, Cin, Cout, ldy, act, out_dt == SFOD_F32, s, split, nullptr,
@@ -810,7 +780,6 @@ static int conv_fwd_impl(const void* x, const void* w, const uint32_t* w_absmax,
   }
   a.kchunks = ksize * ksize * cpt;
   a.kt_per = 0; a.nsplit = 1; a.slab = 0;
-  a.res = res; a.ldres = ldres;
   if (scratch != nullptr && Cout % 4 == 0 && (int64_t)a.M <= (1 << 24)) {
     const int S = splitk_plan(a.M, a.kchunks, Cout, ksize, out_dt == SFOD_F32, stats != nullptr);
     if (S >= 2 && scratch_bytes >= (int64_t)S * a.M * Cout * 4) {

@@ -179,7 +179,6 @@ class ResNet(nn.Module):
         self.fuse_residual = os.environ.get("SFOD_NO_FUSE_RESIDUAL", "0") != "1"   # A/B hook: bn3 + shortcut + ReLU in one pass
         self.dual_join = os.environ.get("SFOD_NO_DUAL_JOIN", "0") != "1"           # A/B hook: join kernels also emit the operand pairs
         self.fuse_stem = os.environ.get("SFOD_NO_FUSE_STEM", "0") != "1"                   # A/B hook: 7x7 stem without the im2col matrix
-        self.fuse_frozen_join = os.environ.get("SFOD_NO_FUSE_FROZEN_JOIN", "0") != "1"   # A/B hook: frozen blocks' relu(conv3 + shortcut) in conv3's epilogue
         # weight gradients of the live bottleneck convolutions on a second HIP stream beside the data-gradient chain: at this
         # config's sizes (res4: 22 800 rows) one 1x1 kernel fills 70 % of the CUs for 60 us, so the two independent
         # GEMMs of a layer's backward share the chip (SFOD_RESNET_WGRAD_STREAM=0: everything on one stream)
@@ -360,15 +359,6 @@ class ResNet(nn.Module):
             sc = x if blk.shortcut is None else self._frozen_conv(xs_op, blk.shortcut, 0, dt)
             o = self._frozen_conv(xs_op, blk.conv1, 1, dt)
             o = self._frozen_conv(o, blk.conv2, 1, dt)
-            if self.fuse_frozen_join and sc.dtype == torch.float32 and native.out_dtype_of(self.compute_dtype) == torch.float32:
-                # relu(conv3 + shortcut) in conv3's epilogue (sfod_conv_fwd_res): the join pass over three tensors of 368 MB each
-                # (res2, B = 8) goes; what the next block needs as MFMA operands is one conversion pass over the result
-                wp3, shift3 = self._frozen_packed(blk.conv3, o.shape[-1], dt)
-                out = native.conv_fwd_res(o, wp3, shift3, sc.contiguous(), blk.conv3.out_channels, 1, act=1)
-                if dual:
-                    out_op, out_g = native.operands_for(out, self.compute_dtype, need_grad=want_g)
-                    return out, ((out_op, out_g) if want_g else out_op), None
-                return out, None, None
             o = self._frozen_conv(o, blk.conv3, 0, dt)
             if dual and want_g:
                 out, out_op, out_g = native.add_act(o, sc, 1, with_operand=self.compute_dtype, with_grad_operand=True)

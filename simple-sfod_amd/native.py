@@ -645,29 +645,6 @@ def conv_fwd(x, w_packed, bias, cout, ksize, act=0, out_dtype=None, ldy=None, wa
     return (y, stats) if want_stats else y
 
 
-def conv_fwd_res(x, w_packed, bias, residual, cout, ksize, act=1):
-    """act(conv(x) + bias + residual) in one launch (frozen bottleneck tail): x operand [B,H,W,Cin] (or [R,K], ksize 1),
-    residual fp32 [B,H,W,cout] -> fp32 [B,H,W,cout]."""
-    x = as_operand(x, w_packed.dtype)
-    dt = dt_of(x)
-    assert residual.dtype == torch.float32 and residual.is_contiguous() and residual.shape[-1] == cout
-    if x.dim() == 2:
-        B, H, W, cin = x.shape[0], 1, 1, x.shape[1]
-        y = torch.empty(B, cout, dtype=torch.float32, device=x.device)
-    else:
-        B, H, W, cin = x.shape
-        y = torch.empty(B, H, W, cout, dtype=torch.float32, device=x.device)
-    assert residual.numel() == y.numel()
-    global _pending_flops, _pending_tag
-    _pending_flops = 2.0 * B * H * W * cout * ksize * ksize * cin
-    if _timer is not None:
-        _pending_tag = ":gemm"
-    call("sfod_conv_fwd_res", x, w_packed, wscale_of(w_packed), bias, residual, cout, y, B, H, W, cin, cout, ksize, cout,
-         int(act), dt, timer_name="sfod_conv_fwd")
-    _pending_tag = ""
-    return y
-
-
 def conv_fwd_bnin_supported(y_pre, w_packed, cout):
     """Can the 3x3 convolution that consumes relu(bn(y_pre)) take y_pre itself (BatchNorm + ReLU + pair split in the kernel's
     LDS patch, include/sfod_hip.h: sfod_conv_fwd_bnin)?"""

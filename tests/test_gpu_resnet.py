@@ -190,53 +190,6 @@ def test_r101_c4_teacher_student_trainer_steps(native, dtype):
     assert 0 < d_t.item() < 0.01 * d_s.item()
 
 
-@pytest.mark.parametrize("dtype", ["f16x3", "bf16x3", "fp32"])
-def test_frozen_bottleneck_join_in_the_conv_epilogue_is_bit_identical(native, dtype, monkeypatch):
-    """FrozenBN stages (stem + res2 of the r101 yaml): relu(conv3(x) + shortcut) with the join in conv3's epilogue
-    (sfod_conv_fwd_res) against the separate join pass it replaces (sfod_conv_fwd + sfod_add_act): the same two fp32
-    roundings in the same order -- kernel level and through the whole backbone (features, live running statistics)."""
-    import numpy as np
-    n = native
-    tdt = n.mode_dtype(dtype)
-    dt = n.dt_of_dtype(tdt)
-    g = torch.Generator().manual_seed(5)
-    for (B, H, W, cin, cout) in ((2, 19, 23, 64, 256), (1, 7, 300, 128, 512)):
-        x = torch.randn(B, H, W, cin, generator=g).cuda()
-        w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.05).cuda()
-        bias = torch.randn(cout, generator=g).cuda()
-        res = torch.randn(B, H, W, cout, generator=g).cuda()
-        xo = n.as_operand(x, tdt)
-        wp = n.pack_conv_weight(w, xo.shape[-1], dt)
-        ref = n.add_act(n.conv_fwd(xo, wp, bias, cout, 1, act=0), res, 1)
-        got = n.conv_fwd_res(xo, wp, bias, res, cout, 1, act=1)
-        assert got.dtype == torch.float32 and torch.equal(got, ref), (B, H, W, cin, cout)
-        assert (got == 0).any() and (got > 0).any()
-    sfod, cfg = _cfg(50, dtype)
-    rn = importlib.import_module("simple-sfod_amd.modeling.backbone_resnet")
-    x = torch.randn(2, 3, 96, 128, generator=g)
-    outs, stats, calls = {}, {}, {}
-    for on in (False, True):
-        torch.manual_seed(3)
-        net = rn.ResNet(cfg).cuda().train()
-        net.fuse_frozen_join = on
-        cnt = [0]
-        orig = n.conv_fwd_res
-
-        def counted(*a, _o=orig, _c=cnt, **k):
-            _c[0] += 1
-            return _o(*a, **k)
-        monkeypatch.setattr(n, "conv_fwd_res", counted)
-        with torch.no_grad():
-            outs[on] = net(x.cuda())["res4"].clone()
-        monkeypatch.setattr(n, "conv_fwd_res", orig)
-        stats[on] = {k: v.clone() for k, v in net.state_dict().items() if "running" in k}
-        calls[on] = cnt[0]
-    assert calls[False] == 0 and calls[True] == 3           # the three bottlenecks of res2
-    assert torch.equal(outs[True], outs[False])
-    for k in stats[False]:
-        assert torch.equal(stats[True][k], stats[False][k]), k
-
-
 @pytest.mark.parametrize("dtype", ["f16x3", "bf16x3"])
 def test_stem_without_the_im2col_matrix_is_bit_identical(native, dtype):
     """csrc/stem7x7.hip (the 7x7 stride-2 stem with its operand rows gathered from an LDS patch in registers) against the
