@@ -223,7 +223,7 @@ def build_trainer(sfod, args, dtype, world, rank, local_rank):
     return cfg, trainer
 
 
-def plant_labels(trainer, scale, target=PLANT_TARGET, note=lambda m: None):
+def plant_labels(trainer, scale, target=PLANT_TARGET, note=lambda m: None, bias=None):
     """Planted-label mode: cls_score.weight *= scale (spreads the class logits of the random-weight head), then the
     background bias is bisected over untimed teacher passes on the loader's frames until the mean pseudo-label count per
     image is ``target``; student and teacher get the same values (teacher <- student copy, as at construction).
@@ -244,7 +244,9 @@ def plant_labels(trainer, scale, target=PLANT_TARGET, note=lambda m: None):
     with torch.no_grad():
         bp.cls_score.weight.mul_(scale)
     lo, hi = -40.0, 40.0          # more background bias -> fewer foreground detections: the count is monotone in it
-    for _ in range(24):
+    if bias is not None:          # --plant-bias: a bias calibrated by an earlier run of the same configuration (profiling runs:
+        lo = hi = float(bias)     # the ~50 teacher passes of the bisection stay out of the kernel trace)
+    for _ in range(0 if bias is not None else 24):
         mid = 0.5 * (lo + hi)
         if counts(mid).mean().item() > target:
             lo = mid
@@ -313,6 +315,9 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the reduced-precision (bf16) secondary block")
     ap.add_argument("--no-planted", action="store_true")
     ap.add_argument("--plant-scale", type=float, default=0.0, help="planted-label mode: scale on cls_score.weight (default: PLANT)")
+    ap.add_argument("--plant-bias", type=float, default=None,
+                    help="planted-label mode: use this background bias instead of calibrating it (profiling runs; take it "
+                         "from config.planted_labels.background_bias of an unprofiled run of the same configuration)")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--opts", nargs="*", default=[], help="extra KEY VALUE config overrides (A/B runs)")
     ap.add_argument("--no-overlap", action="store_true",
@@ -356,7 +361,8 @@ def main():
     planted = None
     global STEP_LOG
     if args.trainer != "base" and not args.no_planted:
-        planted = plant_labels(trainer, args.plant_scale if args.plant_scale else PLANT[args.model], note=note)
+        planted = plant_labels(trainer, args.plant_scale if args.plant_scale else PLANT[args.model], note=note,
+                               bias=args.plant_bias)
         if world > 1:       # every rank calibrated on its own shard: take rank 0's bias everywhere (one broadcast, untimed)
             bp = trainer.model.roi_heads.box_predictor
             with torch.no_grad():
@@ -546,6 +552,7 @@ def main():
                    "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"]
             cmd += (["--no-planted"] if args.no_planted else []) + (["--no-overlap"] if args.no_overlap else [])
             cmd += ["--plant-scale", str(args.plant_scale)] if args.plant_scale else []
+            cmd += ["--plant-bias", str(args.plant_bias)] if args.plant_bias is not None else []
             cmd += (["--opts"] + list(args.opts)) if args.opts else []
             try:
                 r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)

@@ -24,7 +24,7 @@ constexpr int ST_TH = 4, ST_TW = 32;                 // output tile: 4 rows x 32
 constexpr int ST_PR = 2 * ST_TH + 5, ST_PC = 2 * ST_TW + 5;      // input patch: 13 x 69 pixels
 constexpr int ST_K = 147, ST_KPAD = 160, ST_N = 64;
 constexpr int ST_WROW = ST_KPAD * 4 + 16;            // bytes per weight row in LDS (+16: conflict-free b128 reads over 16 rows)
-constexpr int ST_PATCH = ST_PR * ST_PC * 3;          // floats; slot ST_PATCH holds 0.0f (padding columns of K)
+constexpr int ST_PATCH = ST_PR * ST_PC * 3;          // words; slot ST_PATCH holds 0 (padding columns of K)
 constexpr int ST_LDS = ST_N * ST_WROW + (ST_PATCH + 4) * 4 + ST_KPAD * 4;
 
 template <int FMT> struct PairOf;
@@ -52,7 +52,9 @@ k_stem7x7(const float* __restrict__ x, const unsigned char* __restrict__ wpk, co
           int tiles_x, int tiles_y, int act) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned char* sW = smem;                                            // [64][ST_WROW]
-  float* sP = reinterpret_cast<float*>(smem + ST_N * ST_WROW);        // patch + the zero slot
+  // patch + the zero slot.  Every input value is split into its (hi, lo) pair ONCE, when the patch is written, and stored as
+  // hi | lo << 16: a window element is used by ~12 output pixels, the gathers below only pick the halves apart.
+  unsigned* sP = reinterpret_cast<unsigned*>(smem + ST_N * ST_WROW);
   int* sLut = reinterpret_cast<int*>(smem + ST_N * ST_WROW + (ST_PATCH + 4) * 4);   // k -> patch offset of (ky, kx, c)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int h = lane >> 5, px = lane & 31;
@@ -71,7 +73,7 @@ k_stem7x7(const float* __restrict__ x, const unsigned char* __restrict__ wpk, co
     }
     sLut[k] = off;
   }
-  if (tid < 4) sP[ST_PATCH + tid] = 0.f;
+  if (tid < 4) sP[ST_PATCH + tid] = 0u;                               // split(0.0f) = (0, 0)
   const float inv = (FMT == 2 && wamax != nullptr) ? winv_from_absmax(*wamax) : 1.f;
   float bcol[2];
 #pragma unroll
@@ -91,9 +93,13 @@ k_stem7x7(const float* __restrict__ x, const unsigned char* __restrict__ wpk, co
       const int iy = iy0 + r, ix = ix0 + c;
       float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const float4*>(xb + ((int64_t)iy * W + ix) * Cp);
-      sP[p * 3 + 0] = v.x;
-      sP[p * 3 + 1] = v.y;
-      sP[p * 3 + 2] = v.z;
+      const float vv[3] = {v.x, v.y, v.z};
+#pragma unroll
+      for (int c3 = 0; c3 < 3; ++c3) {
+        unsigned short hh, ll;
+        PairOf<FMT>::split(vv[c3], hh, ll);
+        sP[p * 3 + c3] = (unsigned)hh | ((unsigned)ll << 16);
+      }
     }
     __syncthreads();
 
@@ -106,12 +112,14 @@ k_stem7x7(const float* __restrict__ x, const unsigned char* __restrict__ wpk, co
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 #pragma unroll 2
     for (int s = 0; s < ST_KPAD / 16; ++s) {
-      union { unsigned short u[8]; bf16x8 v; } ah, al;
+      union { unsigned u[4]; bf16x8 v; } ah, al;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int off = sLut[16 * s + 8 * h + e];
-        const float v = sP[off == ST_PATCH ? ST_PATCH : pbase + off];
-        PairOf<FMT>::split(v, ah.u[e], al.u[e]);
+      for (int e = 0; e < 8; e += 2) {
+        const int o0 = sLut[16 * s + 8 * h + e], o1 = sLut[16 * s + 8 * h + e + 1];
+        const unsigned w0 = sP[o0 == ST_PATCH ? ST_PATCH : pbase + o0];
+        const unsigned w1 = sP[o1 == ST_PATCH ? ST_PATCH : pbase + o1];
+        ah.u[e >> 1] = __builtin_amdgcn_perm(w1, w0, 0x05040100u);     // (lo16 of w0) | (lo16 of w1) << 16: the two hi parts
+        al.u[e >> 1] = __builtin_amdgcn_perm(w1, w0, 0x07060302u);     // the two lo parts
       }
       bf16x8 bh[2], bl[2];
 #pragma unroll

@@ -7,14 +7,19 @@
 export TMPDIR=/tmp
 TAG=${1:-rX}; WHAT=${2:-all}
 O=gpurun_out
+# the planted-label background bias is calibrated at start-up (~50 teacher passes): profiled runs take the calibrated value
+# of an unprofiled run of the same configuration instead, so that the kernel trace holds the steps only
+bias_of() { python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timer 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['config']['planted_labels']['background_bias'])"; }
+VB=$(bias_of); RB=$(bias_of --model r101)
+echo "planted background bias: vgg $VB r101 $RB"
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   rm -rf $O/prof_kt
-  rocprofv3 --kernel-trace --stats -d $O/prof_kt -o kt -- python3 bench.py --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --steps 20 --warmup 5 > /dev/null 2> $O/${TAG}_kt.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_kt -o kt -- python3 bench.py --plant-bias $VB --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --steps 20 --warmup 5 > /dev/null 2> $O/${TAG}_kt.err
   DB=$(find $O/prof_kt -name "*.db" | head -1)
   python3 tools/rocpd_stats.py $DB 25 > $O/${TAG}_bf16x3_B8_r600_single_stream_kernel_stats.csv
   rm -rf $O/prof_kt
-  bash tools/pmc_sq_run.sh $O/${TAG}_sq_counters.json > $O/${TAG}_sq.log 2>&1
-  bash tools/pmc_hbm_run.sh $O/${TAG}_pmc_hbm_traffic_bf16x3.json > $O/${TAG}_hbm.log 2>&1
+  bash tools/pmc_sq_run.sh $O/${TAG}_sq_counters.json --plant-bias $VB > $O/${TAG}_sq.log 2>&1
+  bash tools/pmc_hbm_run.sh $O/${TAG}_pmc_hbm_traffic_bf16x3.json --plant-bias $VB > $O/${TAG}_hbm.log 2>&1
   python3 tools/bench_conv.py --dtype bf16x3 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bf16x3_conv_layers.txt
   python3 tools/bench_conv.py --dtype bf16x3 --wgrad 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bf16x3_conv_layers_wgrad.txt
 fi
@@ -35,7 +40,7 @@ if [ "$WHAT" = r101 ] || [ "$WHAT" = all ]; then
   # config #5 in its parity mode (f16x3): kernel trace of single-stream steps, GPU busy fraction (union of kernel intervals
   # over the span of the timed steps, and the un-profiled step time of the bench line beside the profiled kernel-time sum)
   rm -rf $O/prof_r101
-  rocprofv3 --kernel-trace --stats -d $O/prof_r101 -o r101 -- python3 bench.py --model r101 --no-overlap --steps 12 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timer > $O/${TAG}_r101_f16x3_profiled_bench.json 2> $O/${TAG}_r101_prof.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_r101 -o r101 -- python3 bench.py --model r101 --plant-bias $RB --no-overlap --steps 12 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timer > $O/${TAG}_r101_f16x3_profiled_bench.json 2> $O/${TAG}_r101_prof.err
   DB=$(find $O/prof_r101 -name "*.db" | head -1)
   python3 tools/rocpd_stats.py $DB 15 > $O/${TAG}_r101_f16x3_kernel_stats.csv
   python3 tools/busy_fraction.py $DB 0.3 > $O/${TAG}_r101_f16x3_busy_fraction.txt
