@@ -268,6 +268,75 @@ k_resize_bilinear_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst,
   }
 }
 
+// Tiled form of the common shape (3 channels, <= 2.5x downscale): the two passes really are separate -- a workgroup owns a
+// 16 x 64 output tile, phase A writes the horizontally filtered, rounded and clipped rows the tile needs (Pillow's temporary
+// image, ~1.7 x 16 + 5 rows here) into LDS ONCE, phase B filters them vertically.  The per-pixel kernel above recomputes the
+// horizontal pass of every source row for every output row that touches it: 2.8x the loads and 2.5x the multiply-adds.
+// Same integer arithmetic per value, so the result stays bit-identical to Pillow.
+#define RS_TH 16
+#define RS_TW 64
+#define RS_ROWS 48
+__global__ void __launch_bounds__(256)
+k_resize_bilinear_u8_tiled(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, int H, int W, int h, int w,
+                           const int32_t* __restrict__ hb, const int32_t* __restrict__ hk, int ksh,
+                           const int32_t* __restrict__ vb, const int32_t* __restrict__ vk, int ksv, int flip,
+                           int tiles_x) {
+  __shared__ uint8_t tmp[3][RS_ROWS][RS_TW];
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int y0 = ty * RS_TH, x0 = tx * RS_TW;
+  const int y1 = min(y0 + RS_TH, h) - 1;
+  const int rmin = vb[2 * y0];
+  const int nrows = min(vb[2 * y1] + vb[2 * y1 + 1] - rmin, RS_ROWS);
+  const int64_t plane_bytes = (int64_t)H * W;
+  // ---- phase A: thread = (column of the tile, row group); the column's taps are loaded once --------------------------
+  {
+    const int xl = threadIdx.x & (RS_TW - 1), rg = threadIdx.x / RS_TW;      // 64 columns x 4 row groups
+    const int x = x0 + xl;
+    if (x < w) {
+      const int xmin = hb[2 * x], xn = hb[2 * x + 1];
+      int kh[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) kh[i] = (i < xn) ? hk[x * ksh + i] : 0;
+      for (int r = rg; r < nrows; r += 256 / RS_TW) {
+        const int64_t off = (int64_t)(rmin + r) * W + xmin;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          // the 8-byte window must stay inside the tensor: shift it left at the very end (taps beyond carry weight 0)
+          const int64_t lim = (int64_t)(3 - c) * plane_bytes - 8;
+          const int64_t o2 = off <= lim ? off : lim;
+          unsigned long long t8;
+          __builtin_memcpy(&t8, src + (int64_t)c * plane_bytes + o2, 8);
+          t8 >>= ((int)(off - o2) * 8);
+          int sh = 1 << (RS_PREC - 1);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sh += (int)((t8 >> (8 * i)) & 0xffull) * kh[i];
+          tmp[c][r][xl] = (uint8_t)rs_clip8(sh);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase B: thread = output pixels (xl, yl), yl = row group + 4 k ------------------------------------------------------
+  {
+    const int xl = threadIdx.x & (RS_TW - 1), rg = threadIdx.x / RS_TW;
+    const int x = x0 + xl;
+    if (x < w) {
+      const int xo = flip ? (w - 1 - x) : x;
+      for (int yl = rg; yl < RS_TH; yl += 256 / RS_TW) {
+        const int y = y0 + yl;
+        if (y >= h) break;
+        const int r0 = vb[2 * y] - rmin, yn = vb[2 * y + 1];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          int acc = 1 << (RS_PREC - 1);
+          for (int j = 0; j < yn; ++j) acc += (int)tmp[c][r0 + j][xl] * vk[y * ksv + j];
+          dst[((int64_t)c * h + y) * w + xo] = (uint8_t)rs_clip8(acc);
+        }
+      }
+    }
+  }
+}
+
 extern "C" int sfod_resize_bilinear_u8(const void* src, void* dst, int C, int H, int W, int h, int w,
                                        const int32_t* hbounds, const int32_t* hcoef, int ksize_h,
                                        const int32_t* vbounds, const int32_t* vcoef, int ksize_v, int flip,
@@ -277,7 +346,16 @@ extern "C" int sfod_resize_bilinear_u8(const void* src, void* dst, int C, int H,
                sfod_prod_fits({C, H, w}, 1LL << 40), "resize: oversized image");
   if ((int64_t)C * h * w == 0) return 0;
   SFOD_REQUIRE(ksize_h >= 1 && ksize_v >= 1 && H >= 1 && W >= 1, "resize: bad sizes");
-  if (ksize_h <= 8 && (int64_t)C * H * W >= 8)
+  // rows a 16-row output tile needs: (its first and last rows' supports) <= 16 * H / h + ksize_v + 1
+  static const int tiled_on = []() { const char* e = getenv("SFOD_RESIZE_TILED"); return e ? atoi(e) : 1; }();    // A/B hook
+  const int64_t rows_needed = ((int64_t)RS_TH * H + h - 1) / h + ksize_v + 2;
+  if (tiled_on && C == 3 && ksize_h <= 8 && ksize_v <= 8 && rows_needed <= RS_ROWS && (int64_t)C * H * W >= 8 &&
+      sfod_prod_fits({(h + RS_TH - 1) / RS_TH, (w + RS_TW - 1) / RS_TW})) {
+    const int tiles_x = (w + RS_TW - 1) / RS_TW, tiles_y = (h + RS_TH - 1) / RS_TH;
+    hipLaunchKernelGGL(k_resize_bilinear_u8_tiled, dim3(tiles_x * tiles_y), dim3(256), 0, (hipStream_t)stream,
+                       (const uint8_t*)src, (uint8_t*)dst, H, W, h, w, hbounds, hcoef, ksize_h, vbounds, vcoef, ksize_v, flip,
+                       tiles_x);
+  } else if (ksize_h <= 8 && (int64_t)C * H * W >= 8)
     hipLaunchKernelGGL(k_resize_bilinear_u8<true>, dim3(ew_grid((int64_t)h * w)), dim3(256), 0, (hipStream_t)stream,
                        (const uint8_t*)src, (uint8_t*)dst, C, H, W, h, w, hbounds, hcoef, ksize_h, vbounds, vcoef,
                        ksize_v, flip);

@@ -826,7 +826,8 @@ def test_sgd_ema_fused(native):
     torch.testing.assert_close(td.cpu(), tref["w"], rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("shape", [(64, 128, 38, 75), (100, 50, 37, 19), (33, 77, 66, 154), (512, 1024, 300, 600)])
+@pytest.mark.parametrize("shape", [(64, 128, 38, 75), (100, 50, 37, 19), (33, 77, 66, 154), (512, 1024, 300, 600),
+                                   (1024, 2048, 600, 1200), (97, 131, 41, 53), (75, 64, 30, 64)])
 @pytest.mark.parametrize("flip", [False, True])
 def test_resize_bilinear_u8_equals_pillow(native, shape, flip):
     """sfod_resize_bilinear_u8 (the mapper's ResizeShortestEdge [+ RandomFlip] on device) is bit-exact with
