@@ -24,7 +24,15 @@ if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   python3 tools/bench_conv.py --dtype bf16x3 --wgrad 2>&1 | grep -v amdgpu.ids > $O/${TAG}_bf16x3_conv_layers_wgrad.txt
 fi
 if [ "$WHAT" = all ] && [ -s $O/${TAG}_pmc_hbm_traffic_bf16x3.json ]; then
-  cp $O/${TAG}_pmc_hbm_traffic_bf16x3.json profiles/pmc_hbm_traffic_latest.json    # the bench lines below carry THIS capture
+  # the bench lines below carry THIS capture; the .meta beside it (tools/pmc_summary.py) is the fingerprint of the kernel
+  # sources the counters were taken on -- bench.py drops roofline.traffic when the sources have changed since
+  cp $O/${TAG}_pmc_hbm_traffic_bf16x3.json profiles/pmc_hbm_traffic_latest.json
+  cp $O/${TAG}_pmc_hbm_traffic_bf16x3.json.meta profiles/pmc_hbm_traffic_latest.json.meta
+  bash tools/pmc_hbm_run.sh $O/${TAG}_pmc_hbm_traffic_r101_f16x3.json --model r101 --plant-bias $RB > $O/${TAG}_hbm_r101.log 2>&1
+  if [ -s $O/${TAG}_pmc_hbm_traffic_r101_f16x3.json ]; then
+    cp $O/${TAG}_pmc_hbm_traffic_r101_f16x3.json profiles/pmc_hbm_traffic_r101_latest.json
+    cp $O/${TAG}_pmc_hbm_traffic_r101_f16x3.json.meta profiles/pmc_hbm_traffic_r101_latest.json.meta
+  fi
 fi
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   python3 bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
