@@ -39,6 +39,13 @@ Parity pin status
                        daod/data/common.py:199-228 (aspect bucketing)                           a13
                        daod/modeling/proposal_generator/rpn.py:16-58 (layout, 2nd loss weight)  a4 (glue only)
                        daod/engine/trainers/base.py:318-328 (reset_bn_stats)                    a11
+                       daod/modeling/roi_heads/source_free_adaptive_teacher_roi_heads.py:68-215 a5 (glue: label_and_sample_proposals on the
+                         oracle's d2 primitives, forward / _forward_box control flow)
+                       daod/engine/trainers/source_free_adaptive_teacher.py:335-581 (run_step   a8
+                         on recorder models: call order, label handling, logged scalars, the
+                         weight of every loss key = the gradient backward() leaves on its leaf)
+                       daod/modeling/meta_arch/source_free_adaptive_teacher_rcnn.py:106-339     a3
+                         (forward on recorder sub-modules: calls + flags, arity, loss keys per branch)
     config_ref.json    daod/config.py:8-142 (add_config on a recording node)                    b
 
   ``tests/test_oracle_golden.py`` / ``tests/test_oracle_glue.py`` hold the restatements in this directory to those vectors

@@ -415,6 +415,179 @@ def gen_roi_heads_glue(m, out, g):
     assert stub.proposal_append_gt is True
 
 
+def gen_run_step(m, out, g):
+    """a8: ``SourceFreeAdaptiveTeacherTrainer.run_step`` (source_free_adaptive_teacher.py:335-581), the reference's own code
+    object on a stub ``self`` whose teacher / student are recorders: the order of the calls and their ``branch`` arguments,
+    q = deep copy of k without WEAK_STRONG_AUGMENT, labels removed before the teacher sees the data, the thresholded
+    detections attached as ``instances`` to BOTH lists, the ``*_unlabeled`` keys of the domain pass, the scalars put into the
+    storage, which keys reach ``_write_metrics`` -- and the weight of every loss key, read off as the gradient that
+    ``losses.backward()`` leaves on each (leaf) loss tensor, for every combination of the domain-classifier switches."""
+    from detectron2.structures import Boxes, Instances
+    T = m.trainer.SourceFreeAdaptiveTeacherTrainer
+    K = 8
+
+    def cfgns(dc_enabled, dc_img, dc_ins, unsup_w, dis_w, wsa):
+        ns = types.SimpleNamespace
+        return ns(STYLE=ns(ENABLED=False), WEAK_STRONG_AUGMENT=wsa, ADAPTIVE_THRESHOLD=ns(ENABLED=False, WARM_UP=100, RESERVE=500),
+                  SEMISUPNET=ns(BBOX_THRESHOLD=0.8, UNSUP_LOSS_WEIGHT=unsup_w, DIS_LOSS_WEIGHT=dis_w),
+                  DOMAIN_CLASSIFIER=ns(ENABLED=dc_enabled, IMAGE=dc_img, INSTANCE=dc_ins), MODEL=ns(ROI_HEADS=ns(NUM_CLASSES=K)))
+
+    def detections(n):
+        p = Instances((600, 1200))
+        p.pred_boxes = Boxes(torch.rand(n, 4, generator=g) * 500)
+        p.scores = torch.rand(n, generator=g).sort(descending=True).values
+        p.pred_classes = torch.randint(0, K, (n,), generator=g)
+        return p
+
+    def rpn_props(n):
+        p = Instances((600, 1200))
+        p.proposal_boxes = Boxes(torch.rand(n, 4, generator=g) * 500)
+        p.objectness_logits = torch.randn(n, generator=g) * 2
+        return p
+    dets = [detections(40), detections(25)]
+    props = [rpn_props(60), rpn_props(60)]
+    loss_keys = ["loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "loss_bpc"]
+    dc_keys = ["loss_DC_img_s", "loss_DC_img_t", "loss_DC_ins_s", "loss_DC_ins_t"]
+    combos = [(True, False, False, 1.0, 0.1, False), (True, True, False, 1.0, 0.1, False), (True, False, True, 4.0, 0.25, False),
+              (True, True, True, 1.0, 0.1, True), (False, False, False, 1.0, 0.1, True)]
+    out["rs_combos"] = np.array([[float(v) for v in c] for c in combos])
+    out["rs_loss_keys"], out["rs_dc_keys"] = np.array(loss_keys), np.array(dc_keys)
+    for ci, (dc_on, dc_img, dc_ins, unsup_w, dis_w, wsa) in enumerate(combos):
+        calls, scalars, written = [], {}, {}
+        leaves = {}
+
+        def teacher(data, branch=""):
+            calls.append(("teacher", branch, [("instances" in d) for d in data], [id(d) for d in data]))
+            return {}, props, dets
+
+        class Student:
+            training = True
+
+            def __call__(self, data, branch=""):
+                if branch == "supervised_target":
+                    calls.append(("student", branch, [len(d["instances"]) for d in data],
+                                  [sorted(d["instances"].get_fields().keys()) for d in data], [d["tag"] for d in data]))
+                    rec = {}
+                    for k in loss_keys:
+                        leaves[k + "_pseudo"] = torch.tensor(float(len(leaves) + 1), requires_grad=True)
+                        rec[k] = leaves[k + "_pseudo"]
+                    return rec, "predictions", None, None
+                calls.append(("student", branch, sorted(k for k in data[0].keys()), [d.get("tag_unlabeled") for d in data]))
+                rec = {}
+                for k in dc_keys:
+                    leaves[k] = torch.tensor(float(len(leaves) + 1), requires_grad=True)
+                    rec[k] = leaves[k]
+                return rec, None, None
+        q = [{"image": torch.zeros(3, 4, 4), "instances": "gt_q0", "tag": "q0"}, {"image": torch.zeros(3, 4, 4), "instances": "gt_q1", "tag": "q1"}]
+        k_ = [{"image": torch.ones(3, 4, 4), "instances": "gt_k0", "tag": "k0"}, {"image": torch.ones(3, 4, 4), "instances": "gt_k1", "tag": "k1"}]
+        opt = types.SimpleNamespace(n_zero=0, n_step=0)
+        opt.zero_grad = lambda: setattr(opt, "n_zero", opt.n_zero + 1)
+        opt.step = lambda: setattr(opt, "n_step", opt.n_step + 1)
+        stub = object.__new__(T)
+        stub.__dict__.update(dict(
+            iter=7, cfg=cfgns(dc_on, dc_img, dc_ins, unsup_w, dis_w, wsa), model=Student(), model_teacher=teacher, optimizer=opt,
+            _trainer=types.SimpleNamespace(iter=None, _data_loader_iter=iter([(q, k_)])),
+            storage=types.SimpleNamespace(put_scalar=lambda n, v: scalars.__setitem__(n, float(v))),
+            _write_metrics=lambda d: written.update({kk: (float(v) if not isinstance(v, float) else v) for kk, v in d.items()})))
+        T.run_step(stub)
+        pre = f"rs{ci}_"
+        out[pre + "call_order"] = np.array([c[0] + ":" + c[1] for c in calls])
+        out[pre + "teacher_saw_instances"] = np.array(calls[0][2])
+        st = [c for c in calls if c[0] == "student" and c[1] == "supervised_target"][0]
+        out[pre + "student_label_counts"] = np.array(st[2])
+        out[pre + "student_label_fields"] = np.array(st[3][0])
+        out[pre + "student_tags"] = np.array(st[4])          # k-tags: q was replaced by a deep copy of k
+        dcall = [c for c in calls if c[1] == "domain_classifier"]
+        out[pre + "domain_keys"] = np.array(dcall[0][2] if dcall else [])
+        out[pre + "domain_unlabeled_tags"] = np.array([str(t) for t in dcall[0][3]] if dcall else [])
+        out[pre + "weight_keys"] = np.array(sorted(leaves))
+        out[pre + "weights"] = np.array([float(leaves[kk].grad) if leaves[kk].grad is not None else np.nan for kk in sorted(leaves)])
+        out[pre + "scalar_keys"] = np.array(sorted(scalars))
+        out[pre + "scalar_vals"] = np.array([scalars[kk] for kk in sorted(scalars)])
+        out[pre + "metrics_keys"] = np.array(sorted(written))
+        out[pre + "metrics_vals"] = np.array([written[kk] if kk != "data_time" else -1.0 for kk in sorted(written)])
+        out[pre + "opt_calls"] = np.array([opt.n_zero, opt.n_step])
+        out[pre + "trainer_iter"] = np.int64(stub._trainer.iter)
+    for i in range(2):
+        out[f"rs_det_scores_{i}"], out[f"rs_det_boxes_{i}"] = dets[i].scores.numpy(), dets[i].pred_boxes.tensor.numpy()
+        out[f"rs_det_classes_{i}"] = dets[i].pred_classes.numpy()
+        out[f"rs_rpn_logits_{i}"] = props[i].objectness_logits.numpy()
+
+
+def gen_meta_arch(m, out, g):
+    """a3: ``SourceFreeAdaptiveTeacherGeneralizedRCNN.forward`` (source_free_adaptive_teacher_rcnn.py:106-339) on a stub
+    ``self`` whose sub-modules are recorders: per branch the sequence of sub-module calls with their flags (ground truth
+    passed or not, ``compute_loss``, ``branch``), the arity of the returned tuple, the loss keys -- incl. the second, loss-free
+    ROI pass and the BPC call of ``supervised_target``, the two backbone passes and label constants of ``domain_classifier``
+    (source 0 / target 1 through the gradient-reversal layer: the recorded losses are BCE-with-logits of the recorded logits
+    against those constants) and the x 0.001 of ``supervised``."""
+    import importlib
+    importlib.import_module("daod.modeling.meta_arch")
+    mod = _load_by_path("daod.modeling.meta_arch.ref_rcnn", os.path.join(
+        REF, "daod/modeling/meta_arch/source_free_adaptive_teacher_rcnn.py"))
+    dann = _load_by_path("ref_dann_for_rcnn", os.path.join(REF, "daod/modeling/dann/dann.py"))
+    mod.gradient_scalar = dann.gradient_scalar
+    mod.assign_boxes_to_levels = lambda boxes, *a: "levels"
+    cls = mod.SourceFreeAdaptiveTeacherGeneralizedRCNN
+    trace = []
+    mod.bpc_loss = lambda K, gt, props: trace.append("bpc_loss(K=%d,gt=%d,props=%s)" % (K, gt is not None, props)) or torch.tensor(0.25)
+    feat = torch.randn(2, 4, 3, 5, generator=g)
+    logits_by_call = []
+
+    def dc_img(x):
+        y = (x * torch.linspace(-1, 1, x.numel()).view_as(x)).sum(1, keepdim=True)
+        logits_by_call.append(y.detach().clone())
+        return y
+
+    def rpn(images, features, gt=None, compute_loss=True, compute_val_loss=False):
+        trace.append("rpn(images=%s,gt=%d,compute_loss=%d)" % (images.tag, gt is not None, compute_loss))
+        return "proposals_rpn", {"loss_rpn_cls": torch.tensor(1.0), "loss_rpn_loc": torch.tensor(2.0)}
+
+    def roi(images, features, proposals, targets=None, compute_loss=True, branch="", compute_val_loss=False):
+        trace.append("roi(images=%s,targets=%d,compute_loss=%d,branch=%s)" % (images.tag, targets is not None, compute_loss, branch))
+        if compute_loss:
+            return [types.SimpleNamespace(proposal_boxes="b")], {"loss_cls": torch.tensor(3.0), "loss_box_reg": torch.tensor(4.0)}, "box_features", "instance_proposals"
+        return "pred_instances", "predictions"
+    roi.box_pooler = types.SimpleNamespace(min_level=4, max_level=4, canonical_box_size=224, canonical_level=4)
+
+    def make(ins_dc):
+        stub = object.__new__(cls)
+        stub.__dict__.update(dict(
+            training=True, device=torch.device("cpu"), vis_period=0, dis_type="vgg4", ins_dc=ins_dc,
+            cfg=types.SimpleNamespace(MODEL=types.SimpleNamespace(ROI_HEADS=types.SimpleNamespace(NUM_CLASSES=8))),
+            preprocess_image=lambda b: types.SimpleNamespace(tensor="x", tag="k"),
+            preprocess_image_train=lambda b: (types.SimpleNamespace(tensor="xs", tag="s"), types.SimpleNamespace(tensor="xt", tag="t")),
+            backbone=lambda t: trace.append("backbone(%s)" % t) or {"vgg4": feat},
+            proposal_generator=rpn, roi_heads=roi, DC_img=dc_img,
+            instance_dc_loss=lambda bf, lv, label: trace.append("instance_dc_loss(%s,%s,label=%d)" % (bf, lv, label)) or torch.tensor(0.5 + label)))
+        return stub
+    inst = types.SimpleNamespace(to=lambda dev: "gt")
+    with_gt = [{"image": 0, "instances": inst, "instances_unlabeled": inst, "image_unlabeled": 0}]
+    without = [{"image": 0, "image_unlabeled": 0}]
+    cases = [("supervised_target", with_gt, False), ("unsup_data_weak", without, False), ("supervised", with_gt, False),
+             ("domain_classifier", with_gt, True), ("domain_classifier", without, True), ("domain_classifier", with_gt, False)]
+    names = []
+    for ci, (branch, data, ins_dc) in enumerate(cases):
+        del trace[:]
+        del logits_by_call[:]
+        r = cls.forward(make(ins_dc), data, branch=branch)
+        pre = f"ma{ci}_"
+        names.append("%s|gt=%d|ins_dc=%d" % (branch, "instances" in data[0], ins_dc))
+        out[pre + "trace"] = np.array(list(trace))
+        out[pre + "arity"] = np.int64(len(r))
+        out[pre + "loss_keys"] = np.array(sorted(r[0].keys()))
+        out[pre + "loss_vals"] = np.array([float(r[0][k]) for k in sorted(r[0].keys())])
+        out[pre + "rest"] = np.array([repr(x) for x in r[1:]])
+        for j, lg in enumerate(logits_by_call):
+            out[pre + f"dc_logits_{j}"] = lg.numpy()
+    out["ma_cases"] = np.array(names)
+    # eval mode and not val_mode -> inference()
+    stub = make(False)
+    stub.training = False
+    stub.inference = lambda b: "inference-result"
+    out["ma_eval_returns"] = np.array(repr(cls.forward(stub, without)))
+
+
 def gen_glue():
     """Reference-OWNED glue of the hot path, run here (not restated) and recorded -> ``tests/golden/glue_ref.npz`` +
     ``config_ref.json``.  Every function is the reference's own code object, loaded from its file under
@@ -654,6 +827,8 @@ def gen_glue():
             out["adabn_w/" + k] = v.numpy().copy()
 
     gen_roi_heads_glue(m, out, g)
+    gen_run_step(m, out, g)
+    gen_meta_arch(m, out, g)
     np.savez_compressed(os.path.join(OUT, "glue_ref.npz"), **out)
 
     # ---- b: add_config -------------------------------------------------------------------------------------------

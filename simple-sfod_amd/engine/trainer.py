@@ -562,6 +562,24 @@ def weighted_loss_sum(w, losses):
     return _WeightedLossSum.apply(w, *losses)
 
 
+def loss_weight(key, cfg):
+    """The weight ``run_step`` gives a loss key (source_free_adaptive_teacher.py:540-564, the same branch order): box
+    regression and every other ``*_pseudo`` loss UNSUP_LOSS_WEIGHT, ``loss_bpc_pseudo`` 0, the domain-classifier losses
+    DIS_LOSS_WEIGHT when their switch is on, everything else 0.  Pinned by running the reference's ``run_step`` on stubs
+    (tests/golden/glue_ref.npz ``rs*_weights``: the gradients its ``losses.backward()`` leaves on the loss leaves)."""
+    if key == "loss_rpn_loc_pseudo" or key == "loss_box_reg_pseudo":
+        return float(cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT)
+    if key == "loss_bpc_pseudo":
+        return 0.0
+    if key[-6:] == "pseudo":
+        return float(cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT)
+    if key in ("loss_DC_img_s", "loss_DC_img_t") and cfg.DOMAIN_CLASSIFIER.IMAGE:
+        return float(cfg.SEMISUPNET.DIS_LOSS_WEIGHT)
+    if key in ("loss_DC_ins_s", "loss_DC_ins_t") and cfg.DOMAIN_CLASSIFIER.INSTANCE:
+        return float(cfg.SEMISUPNET.DIS_LOSS_WEIGHT)
+    return 0.0
+
+
 def threshold_bbox(proposal_bbox_inst, thres=0.7, proposal_type="roih"):
     """Instances-level API twin of source_free_adaptive_teacher.py:150-183 (strict '>')."""
     new = Instances(proposal_bbox_inst.image_size)
@@ -808,23 +826,8 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         # loss weighting (:540-564): the same weights key by key; the products and their sum are ONE autograd node over
         # the stacked scalars (3 small kernels forward, 1 backward) instead of a multiply and an add per key and
         # direction -- ~30 single-element launches per step otherwise
-        keys, weights = [], []
-        for key in record_dict.keys():
-            if key.startswith("loss") and key[-3:] != "val":
-                if key == "loss_rpn_loc_pseudo" or key == "loss_box_reg_pseudo":
-                    w = cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
-                elif key == "loss_bpc_pseudo":
-                    w = 0
-                elif key[-6:] == "pseudo":
-                    w = cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT
-                elif (key == "loss_DC_img_s" or key == "loss_DC_img_t") and cfg.DOMAIN_CLASSIFIER.IMAGE:
-                    w = cfg.SEMISUPNET.DIS_LOSS_WEIGHT
-                elif (key == "loss_DC_ins_s" or key == "loss_DC_ins_t") and cfg.DOMAIN_CLASSIFIER.INSTANCE:
-                    w = cfg.SEMISUPNET.DIS_LOSS_WEIGHT
-                else:
-                    w = 0
-                keys.append(key)
-                weights.append(float(w))
+        keys = [key for key in record_dict.keys() if key.startswith("loss") and key[-3:] != "val"]
+        weights = [loss_weight(key, cfg) for key in keys]
         wdev = native.dev_const(tuple(weights), torch.float32, self.device)
         weighted, losses = weighted_loss_sum(wdev, [record_dict[k] for k in keys])
         loss_dict = {k: weighted[i] for i, k in enumerate(keys)}

@@ -256,3 +256,28 @@ def test_label_and_sample_proposals_on_the_device_equals_the_reference_method(fx
     assert (gt_box[batch:batch + cnt[1]] == 0).all() and (gt_cls[batch:batch + cnt[1]] == K).all()      # the image without ground truth
     nbg = [int((gt_cls[i * batch:i * batch + cnt[i]] == K).sum()) for i in range(3)]
     np.testing.assert_allclose(fx["roi_scalar_vals"], [np.mean(nbg), np.mean([c - b for c, b in zip(cnt, nbg)])])
+
+
+def test_teacher_pass_scalars_equal_the_reference_run_step(fx, native):
+    """The three scalars the reference's ``run_step`` logged on the recorded detections / proposals (mean detection
+    confidence = mean over images of the mean score; RPN proposals with objectness > 0.8 per image; pseudo labels per
+    image) from ``sfod_frcnn_finalize`` + ``sfod_teacher_metrics`` on the same data."""
+    thr, B, max_det = 0.8, 2, 100
+    nd = [len(fx[f"rs_det_scores_{i}"]) for i in range(B)]
+    n = max(nd)
+    sb, ss, sc = torch.zeros(B, n, 4), torch.zeros(B, n), torch.zeros(B, n, dtype=torch.int32)
+    for i in range(B):
+        sb[i, :nd[i]], ss[i, :nd[i]], sc[i, :nd[i]] = T(fx[f"rs_det_boxes_{i}"]), T(fx[f"rs_det_scores_{i}"]), T(fx[f"rs_det_classes_{i}"]).int()
+    keep_idx = torch.arange(max_det, dtype=torch.int32).repeat(B, 1).to(DEV)
+    out = {k: torch.empty(B, max_det, *s, dtype=d, device=DEV) for k, s, d in (
+        ("det_boxes", (4,), torch.float32), ("det_scores", (), torch.float32), ("det_classes", (), torch.int32),
+        ("gt_boxes", (4,), torch.float32), ("gt_classes", (), torch.int32))}
+    dcount, gcount = torch.empty(B, dtype=torch.int32, device=DEV), torch.empty(B, dtype=torch.int32, device=DEV)
+    native.call("sfod_frcnn_finalize", sb.to(DEV), ss.to(DEV), sc.to(DEV), keep_idx, torch.tensor(nd, dtype=torch.int32, device=DEV),
+                B, n, max_det, thr, out["det_boxes"], out["det_scores"], out["det_classes"], dcount, out["gt_boxes"], out["gt_classes"], gcount)
+    lg = torch.stack([T(fx[f"rs_rpn_logits_{i}"]) for i in range(B)]).to(DEV)
+    m = native.teacher_metrics(out["det_scores"], dcount, lg, torch.full((B,), lg.shape[1], dtype=torch.int32, device=DEV), gcount, thr)
+    ref = dict(zip([str(k) for k in fx["rs0_scalar_keys"]], fx["rs0_scalar_vals"]))
+    np.testing.assert_allclose(m[0].item(), ref["roi_head/mean_confidence"], rtol=1e-6)
+    assert m[1].item() == ref["rpn/num_pseudo_proposals"] and m[2].item() == ref["roi_head/num_pseudo_proposals"]
+    assert gcount.tolist() == fx["rs0_student_label_counts"].tolist()

@@ -347,3 +347,172 @@ def test_roi_heads_forward_control_flow_of_the_reference(fx, sfod):
     import inspect
     src = inspect.getsource(sfod.modeling.roi_heads.StandardROIHeads.forward)
     assert "compute_val_loss and not (self.training and compute_loss)" in src      # the same append-gt rule
+
+
+# ---- a8 ----------------------------------------------------------------------------------------------------------------
+def test_run_step_orchestration_and_loss_weights_equal_the_reference(fx, sfod):
+    """``run_step`` (source_free_adaptive_teacher.py:335-581) was RUN on a stub ``self`` whose teacher / student are recorders
+    (oracle/gen_golden.py::gen_run_step), for five combinations of the domain-classifier switches and loss weights.  The
+    product's ``loss_weight`` gives every key the weight the reference's ``losses.backward()`` left on its loss leaf; the
+    recorded orchestration is what ``engine/trainer.py::run_step`` does: teacher first (on data without labels, branch
+    ``unsup_data_weak``), then the student on ``supervised_target`` with the thresholded detections attached, the domain pass
+    only when the classifier is enabled, one ``zero_grad`` / ``step``, the four logged scalars."""
+    from types import SimpleNamespace as NS
+    tr = sfod.engine.trainer
+    thr = 0.8
+    n_roih = [int((fx[f"rs_det_scores_{i}"] > np.float32(thr)).sum()) for i in range(2)]
+    n_rpn = [int((fx[f"rs_rpn_logits_{i}"] > np.float32(thr)).sum()) for i in range(2)]
+    mean_conf = np.mean([fx[f"rs_det_scores_{i}"].mean() for i in range(2)])
+    for ci, (dc_on, dc_img, dc_ins, unsup_w, dis_w, wsa) in enumerate(fx["rs_combos"].tolist()):
+        pre = f"rs{ci}_"
+        cfg = NS(SEMISUPNET=NS(UNSUP_LOSS_WEIGHT=unsup_w, DIS_LOSS_WEIGHT=dis_w),
+                 DOMAIN_CLASSIFIER=NS(ENABLED=bool(dc_on), IMAGE=bool(dc_img), INSTANCE=bool(dc_ins)))
+        for key, w in zip(fx[pre + "weight_keys"], fx[pre + "weights"]):
+            assert np.float32(tr.loss_weight(str(key), cfg)) == np.float32(w), (ci, key, w)
+        order = [str(c) for c in fx[pre + "call_order"]]
+        assert order == ["teacher:unsup_data_weak", "student:supervised_target"] + (["student:domain_classifier"] if dc_on else [])
+        assert not fx[pre + "teacher_saw_instances"].any()                       # labels removed before the teacher pass
+        assert fx[pre + "student_label_counts"].tolist() == n_roih              # score > 0.8, per image
+        assert list(fx[pre + "student_label_fields"]) == ["gt_boxes", "gt_classes", "scores"]
+        # without WEAK_STRONG_AUGMENT the student's list is a deep copy of the WEAK list (tags k*), else the strong one
+        assert list(fx[pre + "student_tags"]) == (["q0", "q1"] if wsa else ["k0", "k1"])
+        if dc_on:
+            assert "image_unlabeled" in fx[pre + "domain_keys"] and "instances_unlabeled" in fx[pre + "domain_keys"]
+        sc = dict(zip([str(k) for k in fx[pre + "scalar_keys"]], fx[pre + "scalar_vals"]))
+        assert sorted(sc) == ["calibration/bpc_loss", "roi_head/mean_confidence", "roi_head/num_pseudo_proposals", "rpn/num_pseudo_proposals"]
+        np.testing.assert_allclose(sc["roi_head/mean_confidence"], mean_conf, rtol=1e-6)
+        assert sc["roi_head/num_pseudo_proposals"] == np.mean(n_roih) and sc["rpn/num_pseudo_proposals"] == np.mean(n_rpn)
+        assert sc["calibration/bpc_loss"] == 0.0                                  # the weighted (x 0) value is what is logged
+        # what reaches _write_metrics: the WEIGHTED losses + data_time
+        mk = [str(k) for k in fx[pre + "metrics_keys"]]
+        assert mk == sorted(["data_time"] + [str(k) for k in fx[pre + "weight_keys"]])
+        assert fx[pre + "opt_calls"].tolist() == [1, 1] and int(fx[pre + "trainer_iter"]) == 7
+    # the product's run_step builds its key list and weights the same way (one source of truth)
+    import inspect
+    src = inspect.getsource(tr.SourceFreeAdaptiveTeacherTrainer.run_step)
+    assert "loss_weight(key, cfg)" in src and 'branch="supervised_target"' in src and 'branch="domain_classifier"' in src
+
+
+# ---- a3 ----------------------------------------------------------------------------------------------------------------
+def test_meta_arch_branches_call_their_submodules_like_the_reference(fx, sfod, monkeypatch):
+    """``SourceFreeAdaptiveTeacherGeneralizedRCNN.forward`` of the REFERENCE was run on a stub whose sub-modules record their
+    calls (oracle/gen_golden.py::gen_meta_arch); here the PRODUCT's forward runs the same way (unbound, on a stub, CPU) and
+    must produce the same call sequence with the same flags, the same tuple arity and the same loss keys per branch.  Known,
+    documented differences: the product computes BPC through the ROI heads' ``InstanceProposals.bpc_loss`` (one fused
+    launch) instead of a module-level function; ``supervised`` (the with-source trainer's branch, out of scope) does not add
+    ``loss_DC_img_s * 0.001``; with SFOD.ELIDE_DEAD_BRANCHES the second, loss-free ROI pass of ``supervised_target`` is skipped."""
+    import types
+    ma = sfod.modeling.meta_arch
+    cls = ma.SourceFreeAdaptiveTeacherGeneralizedRCNN
+    S = sfod.structures
+    trace = []
+
+    def rpn(images, features, gt=None, compute_loss=True, compute_val_loss=False, as_instances=True):
+        trace.append("rpn(images=%s,gt=%d,compute_loss=%d)" % (images.tag, gt is not None, compute_loss))
+        return types.SimpleNamespace(boxes=None, count=None), {"loss_rpn_cls": torch.tensor(1.0), "loss_rpn_loc": torch.tensor(2.0)}
+
+    class Roi:
+        in_features = ["vgg4"]
+
+        def __call__(self, images, features, proposals, targets=None, compute_loss=True, branch="", compute_val_loss=False, as_instances=True):
+            trace.append("roi(images=%s,targets=%d,compute_loss=%d,branch=%s)" % (images.tag, targets is not None, compute_loss, branch))
+            if compute_loss:
+                ip = types.SimpleNamespace(bpc_loss=lambda gt: trace.append("bpc_loss(K=8,gt=%d,props=instance_proposals)" % (gt is not None)) or torch.tensor(0.25))
+                return "samples", {"loss_cls": torch.tensor(3.0), "loss_box_reg": torch.tensor(4.0)}, None, ip
+            return "pred_instances", "predictions"
+
+        def label_and_sample_proposals(self, props, gt, branch=""):
+            trace.append("roi(images=%s,targets=1,compute_loss=1,branch=%s)" % (self._tag, branch))
+            return {"rois": "rois"}
+    roi = Roi()
+
+    def make(elide, ins_dc):
+        stub = types.SimpleNamespace(training=True, device=torch.device("cpu"), elide=elide, ins_dc=ins_dc, dis_type="vgg4",
+                                     proposal_generator=rpn, roi_heads=roi, DC_img="DC_img", DC_ins="DC_ins")
+        stub._images_and_features = lambda b: (trace.append("backbone(x)") or types.SimpleNamespace(tag="k"), {"vgg4": "feat"})
+        tags = iter(["s", "t"])
+
+        def pre(b, key="image"):
+            return types.SimpleNamespace(tag=next(tags), key=key)
+        stub.preprocess_image = pre
+        stub._features = lambda images: trace.append("backbone(x%s)" % images.tag) or {"vgg4": "feat" + images.tag}
+        stub._forward_domain_classifier = lambda b: cls._forward_domain_classifier(stub, b)
+        return stub
+
+    def dc_img_loss(dc, feat, label):
+        return torch.tensor(float(label))
+
+    def dc_ins_loss(rh, dc, feat, rois, label, training=True):
+        trace.append("instance_dc_loss(box_features,levels,label=%d)" % label)
+        return torch.tensor(0.5 + label)
+    monkeypatch.setattr(ma, "dc_img_loss", dc_img_loss)
+    monkeypatch.setattr(ma, "dc_ins_loss", dc_ins_loss)
+
+    def inst():
+        i = S.Instances((64, 64))
+        i.gt_boxes = S.Boxes(torch.tensor([[1.0, 2.0, 30.0, 40.0]]))
+        i.gt_classes = torch.tensor([3])
+        return i
+    with_gt = [{"image": 0, "instances": inst(), "instances_unlabeled": inst(), "image_unlabeled": 0}]
+    without = [{"image": 0, "image_unlabeled": 0}]
+    cases = {str(n): i for i, n in enumerate(fx["ma_cases"])}
+    # ---- supervised_target, every branch of the reference executed (ELIDE False) -------------------------------------------
+    ci = cases["supervised_target|gt=1|ins_dc=0"]
+    del trace[:]
+    r = cls.forward(make(False, False), with_gt, branch="supervised_target")
+    assert trace == [str(t) for t in fx[f"ma{ci}_trace"]]
+    assert len(r) == int(fx[f"ma{ci}_arity"]) == 4 and sorted(r[0]) == [str(k) for k in fx[f"ma{ci}_loss_keys"]]
+    assert [float(r[0][k]) for k in sorted(r[0])] == fx[f"ma{ci}_loss_vals"].tolist()
+    assert r[1] == "pred_instances" and r[2] == [] and r[3] == []
+    # ... and with the dead second ROI pass elided: the same trace minus that one call, proposals_roih empty
+    del trace[:]
+    r = cls.forward(make(True, False), with_gt, branch="supervised_target")
+    ref = [str(t) for t in fx[f"ma{ci}_trace"]]
+    assert trace == [t for t in ref if t != "roi(images=k,targets=0,compute_loss=0,branch=supervised_target)"] and r[1] == []
+    # ---- unsup_data_weak ------------------------------------------------------------------------------------------------------
+    ci = cases["unsup_data_weak|gt=0|ins_dc=0"]
+    del trace[:]
+    r = cls.forward(make(True, False), without, branch="unsup_data_weak", batched=True)
+    assert trace == [str(t) for t in fx[f"ma{ci}_trace"]] and len(r) == int(fx[f"ma{ci}_arity"]) == 3 and r[0] == {}
+    # ---- supervised: same calls; loss keys = the reference's minus loss_DC_img_s (documented) -----------------------------------
+    ci = cases["supervised|gt=1|ins_dc=0"]
+    del trace[:]
+    r = cls.forward(make(True, False), with_gt, branch="supervised")
+    assert trace == [str(t) for t in fx[f"ma{ci}_trace"]] and len(r) == 3
+    assert sorted(r[0]) == [str(k) for k in fx[f"ma{ci}_loss_keys"] if str(k) != "loss_DC_img_s"]
+    lg = T(fx[f"ma{ci}_dc_logits_0"])
+    ref_l = torch.nn.functional.binary_cross_entropy_with_logits(lg, torch.zeros_like(lg)) * 0.001      # source label 0, x 0.001 (rcnn.py:256)
+    np.testing.assert_allclose(dict(zip(fx[f"ma{ci}_loss_keys"], fx[f"ma{ci}_loss_vals"]))["loss_DC_img_s"], ref_l.item(), rtol=1e-6)
+    # ---- domain_classifier ----------------------------------------------------------------------------------------------------
+    for name, data, ins_dc in (("domain_classifier|gt=1|ins_dc=1", with_gt, True), ("domain_classifier|gt=1|ins_dc=0", with_gt, False)):
+        ci = cases[name]
+        del trace[:]
+        roi._tag = None
+        stub = make(True, ins_dc)
+        seq = iter(["s", "t"])
+        orig_lasp = roi.label_and_sample_proposals
+
+        def lasp(props, gt, branch="", _seq=seq):
+            roi._tag = next(_seq)
+            return orig_lasp(props, gt, branch=branch)
+        stub.roi_heads = types.SimpleNamespace(in_features=["vgg4"], label_and_sample_proposals=lasp)
+
+        def rpn2(images, features, gt=None, compute_loss=True, as_instances=True):
+            return rpn(images, features, gt, compute_loss)
+        stub.proposal_generator = rpn2
+        r = cls.forward(stub, data, branch="domain_classifier")
+        ref = [str(t) for t in fx[f"ma{ci}_trace"]]
+        # the reference computes both instance-level losses after both ROI passes; the product computes each right after its
+        # pass: the same calls with the same flags, compared as a sorted list, the backbone passes first in both
+        assert sorted(trace) == sorted(t.replace("backbone(xs)", "backbone(xs)").replace("backbone(xt)", "backbone(xt)") for t in ref)
+        assert trace[:2] == ref[:2] == ["backbone(xs)", "backbone(xt)"]
+        assert len(r) == int(fx[f"ma{ci}_arity"]) == 3 and sorted(r[0]) == [str(k) for k in fx[f"ma{ci}_loss_keys"]]
+        assert r[1] == [] and r[2] == []
+        # label constants: source 0, target 1 (the reference's BCE values on its recorded logits say the same)
+        assert float(r[0]["loss_DC_img_s"]) == 0.0 and float(r[0]["loss_DC_img_t"]) == 1.0
+        l0, l1 = T(fx[f"ma{ci}_dc_logits_0"]), T(fx[f"ma{ci}_dc_logits_1"])
+        bce = torch.nn.functional.binary_cross_entropy_with_logits
+        vals = dict(zip([str(k) for k in fx[f"ma{ci}_loss_keys"]], fx[f"ma{ci}_loss_vals"]))
+        np.testing.assert_allclose(vals["loss_DC_img_s"], bce(l0, torch.zeros_like(l0)).item(), rtol=1e-6)
+        np.testing.assert_allclose(vals["loss_DC_img_t"], bce(l1, torch.ones_like(l1)).item(), rtol=1e-6)
+    assert str(fx["ma_eval_returns"]) == "'inference-result'"      # eval mode and not val_mode: inference()
