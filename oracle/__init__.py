@@ -44,6 +44,8 @@ Parity pin status
                        daod/engine/trainers/source_free_adaptive_teacher.py:335-581 (run_step   a8
                          on recorder models: call order, label handling, logged scalars, the
                          weight of every loss key = the gradient backward() leaves on its leaf)
+                       daod/engine/trainers/base.py:93-123,186-220 (BaseTrainer.run_step,       a10, e (metrics)
+                         _write_metrics with two ranks' dicts: max / mean / total_loss rule)
                        daod/modeling/meta_arch/source_free_adaptive_teacher_rcnn.py:106-339     a3
                          (forward on recorder sub-modules: calls + flags, arity, loss keys per branch)
     config_ref.json    daod/config.py:8-142 (add_config on a recording node)                    b

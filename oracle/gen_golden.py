@@ -588,6 +588,46 @@ def gen_meta_arch(m, out, g):
     out["ma_eval_returns"] = np.array(repr(cls.forward(stub, without)))
 
 
+def gen_base_trainer(m, out, g):
+    """a10: ``BaseTrainer.run_step`` / ``_write_metrics`` (daod/engine/trainers/base.py:93-123,186-220) on a stub ``self``:
+    which keys of the model's record are summed into the loss (prefix ``loss``, not ending in ``val``: read off as the
+    gradients on the leaves), what reaches ``_write_metrics``, and -- with ``comm.gather`` returning two ranks' dicts --
+    what is logged: ``data_time`` = max over ranks, every other key = mean over ranks (float64), ``total_loss`` = sum of the
+    averaged ``loss*`` keys (here the ``*_val`` keys are part of that sum: the prefix test only)."""
+    B = m.base.BaseTrainer
+    leaves = {k: torch.tensor(float(i + 1), requires_grad=True) for i, k in enumerate(
+        ["loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "loss_cls_val", "bbox_num/gt_bboxes", "lossy_extra"])}
+    written = {}
+    opt = types.SimpleNamespace(n_zero=0, n_step=0)
+    opt.zero_grad = lambda: setattr(opt, "n_zero", opt.n_zero + 1)
+    opt.step = lambda: setattr(opt, "n_step", opt.n_step + 1)
+    model = lambda data: dict(leaves)
+    model.training = True
+    stub = object.__new__(B)
+    stub.__dict__.update(dict(iter=3, model=model, optimizer=opt, _trainer=types.SimpleNamespace(iter=None, _data_loader_iter=iter(["batch"])),
+                              _write_metrics=lambda d: written.update({k: float(v) for k, v in d.items()})))
+    B.run_step(stub)
+    out["bt_keys"] = np.array(list(leaves))
+    out["bt_grads"] = np.array([float(v.grad) if v.grad is not None else np.nan for v in leaves.values()])
+    out["bt_written_keys"] = np.array(sorted(written))
+    out["bt_opt_calls"] = np.array([opt.n_zero, opt.n_step])
+    # _write_metrics with two ranks
+    scal = {}
+    storage = types.SimpleNamespace(put_scalar=lambda k, v: scal.__setitem__(k, float(v)),
+                                    put_scalars=lambda **kw: scal.update({k: float(v) for k, v in kw.items()}))
+    r0 = {"loss_cls": torch.tensor(1.25), "loss_box_reg": 0.5, "loss_cls_val": torch.tensor(2.0), "bbox_num/gt_bboxes": 7.0, "data_time": 0.25}
+    r1 = {"loss_cls": 3.0, "loss_box_reg": 1.0, "loss_cls_val": 4.0, "bbox_num/gt_bboxes": 9.0, "data_time": 0.75}
+    m.base.comm.gather = lambda d: [dict(d), dict(r1)]
+    stub2 = object.__new__(B)
+    stub2.__dict__.update(dict(storage=storage))
+    B._write_metrics(stub2, dict(r0))
+    out["bt_rank0"] = np.array([float(v) for v in r0.values()])
+    out["bt_rank1"] = np.array([float(v) for v in r1.values()])
+    out["bt_metric_keys"] = np.array(list(r0))
+    out["bt_logged_keys"] = np.array(sorted(scal))
+    out["bt_logged_vals"] = np.array([scal[k] for k in sorted(scal)])
+
+
 def gen_glue():
     """Reference-OWNED glue of the hot path, run here (not restated) and recorded -> ``tests/golden/glue_ref.npz`` +
     ``config_ref.json``.  Every function is the reference's own code object, loaded from its file under
@@ -829,6 +869,7 @@ def gen_glue():
     gen_roi_heads_glue(m, out, g)
     gen_run_step(m, out, g)
     gen_meta_arch(m, out, g)
+    gen_base_trainer(m, out, g)
     np.savez_compressed(os.path.join(OUT, "glue_ref.npz"), **out)
 
     # ---- b: add_config -------------------------------------------------------------------------------------------

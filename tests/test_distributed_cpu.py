@@ -140,6 +140,17 @@ def _worker(rank, world, port, q):
     st.put_scalars(True, a=torch.tensor(float(rank)), **({"c": torch.tensor(5.0)} if rank == 0 else {}))
     rec = st.flush(reduce_over_ranks=True)
     ok_sum = ok_sum and rec["a"] == float(rank) and (("c" in rec) == (rank == 0))
+    # the numbers the REFERENCE's _write_metrics logged for two ranks (tests/golden/glue_ref.npz, bt_*: base.py:186-220 run with
+    # comm.gather returning both ranks' dicts): the product's storage reproduces them rank by rank
+    import numpy as np
+    fxg = np.load(os.path.join(ROOT, "tests", "golden", "glue_ref.npz"), allow_pickle=False)
+    mk = [str(k) for k in fxg["bt_metric_keys"]]
+    mine_vals = dict(zip(mk, (fxg["bt_rank0"] if rank == 0 else fxg["bt_rank1"]).tolist()))
+    holder = SimpleNamespace(storage=sfod.engine.trainer.EventStorage(0))
+    sfod.engine.trainer.BaseTrainer._write_metrics(holder, {k: (torch.tensor(v) if k != "data_time" else v) for k, v in mine_vals.items()})
+    rec = holder.storage.flush(reduce_over_ranks=True)
+    logged = dict(zip([str(k) for k in fxg["bt_logged_keys"]], fxg["bt_logged_vals"].tolist()))
+    ok_sum = ok_sum and sorted(k for k in rec if k != "iteration") == sorted(logged) and all(abs(rec[k] - v) < 1e-6 for k, v in logged.items())
     # sampler: rank r takes elements r, r+W, ... of ONE shared-seed stream
     s = iter(sfod.data.TrainingSampler(10, seed=7, rank=rank, world=world))
     mine = [next(s) for _ in range(10)]

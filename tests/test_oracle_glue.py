@@ -516,3 +516,46 @@ def test_meta_arch_branches_call_their_submodules_like_the_reference(fx, sfod, m
         np.testing.assert_allclose(vals["loss_DC_img_s"], bce(l0, torch.zeros_like(l0)).item(), rtol=1e-6)
         np.testing.assert_allclose(vals["loss_DC_img_t"], bce(l1, torch.ones_like(l1)).item(), rtol=1e-6)
     assert str(fx["ma_eval_returns"]) == "'inference-result'"      # eval mode and not val_mode: inference()
+
+
+# ---- a10 ---------------------------------------------------------------------------------------------------------------
+def test_base_trainer_run_step_and_metrics_equal_the_reference(fx, sfod):
+    """``BaseTrainer.run_step`` (base.py:93-123) run on a recorder model: keys with prefix ``loss`` that do not end in ``val``
+    are summed into the loss (gradient 1 on their leaves, none on the others), the whole record + ``data_time`` reaches
+    ``_write_metrics``, one zero_grad / step.  The product's ``BaseTrainer.run_step``, run the same way on a stub, does the same.
+    ``_write_metrics`` with two ranks (base.py:186-220): data_time = max, every other key = mean, total_loss = sum of the
+    averaged ``loss*`` keys -- the numbers the 2-rank gloo test (tests/test_distributed_cpu.py) reproduces with the product's
+    EventStorage."""
+    import types
+    tr = sfod.engine.trainer
+    keys = [str(k) for k in fx["bt_keys"]]
+    leaves = {k: torch.tensor(float(i + 1), requires_grad=True) for i, k in enumerate(keys)}
+    written = {}
+    opt = types.SimpleNamespace(n_zero=0, n_step=0, flat=None, grad_scale=1.0)
+    opt.zero_grad = lambda: setattr(opt, "n_zero", opt.n_zero + 1)
+    opt.step = lambda: setattr(opt, "n_step", opt.n_step + 1)
+    model = lambda data: dict(leaves)
+    model.training = True
+    stub = types.SimpleNamespace(model=model, optimizer=opt, _data_loader_iter=iter(["batch"]),
+                                 _write_metrics=lambda d, total=None: written.update(d), _reduce_gradients=lambda: None)
+    tr.BaseTrainer.run_step(stub)
+    got = [float(v.grad) if v.grad is not None else float("nan") for v in leaves.values()]
+    assert np.array_equal(np.array(got), fx["bt_grads"], equal_nan=True)
+    assert sorted(written) == [str(k) for k in fx["bt_written_keys"]]
+    assert [opt.n_zero, opt.n_step] == fx["bt_opt_calls"].tolist()
+    # the two-rank logging semantics recorded from the reference
+    mk = [str(k) for k in fx["bt_metric_keys"]]
+    r0, r1 = dict(zip(mk, fx["bt_rank0"])), dict(zip(mk, fx["bt_rank1"]))
+    logged = dict(zip([str(k) for k in fx["bt_logged_keys"]], fx["bt_logged_vals"]))
+    assert logged["data_time"] == max(r0["data_time"], r1["data_time"])
+    for k in mk:
+        if k != "data_time":
+            assert logged[k] == 0.5 * (r0[k] + r1[k])
+    assert logged["total_loss"] == sum(logged[k] for k in mk if k[:4] == "loss")       # '*_val' keys included: prefix test only
+    # one rank, the product's storage: the same keys, total_loss by the same prefix rule
+    st = tr.EventStorage(0)
+    holder = types.SimpleNamespace(storage=st)
+    tr.BaseTrainer._write_metrics(holder, {k: torch.tensor(float(v)) if k != "data_time" else float(v) for k, v in r0.items()})
+    rec = st.flush()
+    assert sorted(k for k in rec if k != "iteration") == sorted(logged)
+    assert rec["total_loss"] == sum(r0[k] for k in mk if k[:4] == "loss") and rec["data_time"] == r0["data_time"]
