@@ -48,6 +48,8 @@ Parity pin status
                          _write_metrics with two ranks' dicts: max / mean / total_loss rule)
                        daod/modeling/meta_arch/source_free_adaptive_teacher_rcnn.py:106-339     a3
                          (forward on recorder sub-modules: calls + flags, arity, loss keys per branch)
+                       daod/data/build.py:312-367 (per-rank batch for world 1/2/4, the           a13, e
+                         divisibility assertion's text, the ASPECT_RATIO_GROUPING error)
     config_ref.json    daod/config.py:8-142 (add_config on a recording node)                    b
 
   ``tests/test_oracle_golden.py`` / ``tests/test_oracle_glue.py`` hold the restatements in this directory to those vectors

@@ -258,6 +258,7 @@ def _ref_modules():
     mods.rpn = _load_by_path("ref_rpn", os.path.join(REF, "daod/modeling/proposal_generator/rpn.py"))
     mods.base = _load_by_path("ref_base", os.path.join(REF, "daod/engine/trainers/base.py"))
     mods.config = _load_by_path("ref_config", os.path.join(REF, "daod/config.py"))
+    mods.build = _load_by_path("ref_build", os.path.join(REF, "daod/data/build.py"))
     import importlib
     importlib.import_module("daod.modeling.roi_heads")       # (made up by the hook) parent of the file's relative import
     mods.roi_heads = _load_by_path("daod.modeling.roi_heads.ref_roi_heads", os.path.join(
@@ -628,6 +629,43 @@ def gen_base_trainer(m, out, g):
     out["bt_logged_vals"] = np.array([scal[k] for k in sorted(scal)])
 
 
+def gen_loader_builder(m, out, g):
+    """a13 / e: ``build_semisup_batch_data_loader_two_crop_source_free`` (daod/data/build.py:312-353) with ``get_world_size``
+    set to 1 / 2 / 4: the per-rank batch = IMS_PER_BATCH_TARGET // world through the reference's own DataLoader + bucketing
+    chain, the divisibility assertion's message, the NotImplementedError without aspect grouping."""
+    mod = m.build
+    mod.AspectRatioGroupedSemiSupDatasetTwoCropSourceFree = m.common.AspectRatioGroupedSemiSupDatasetTwoCropSourceFree
+    mod.worker_init_reset_seed = None
+    items = [({"width": 1200, "height": 600, "image_id": 2 * i}, {"width": 1200, "height": 600, "image_id": 2 * i + 1}) for i in range(16)]
+
+    class DS(torch.utils.data.Dataset):
+        def __len__(self):
+            return len(items)
+
+        def __getitem__(self, i):
+            return items[i]            # the two-crop mapper's (strong, weak) pair; collate_fn = itemgetter(0) unwraps the batch of one
+    rows = []
+    for world, total in ((1, 4), (2, 4), (4, 4), (2, 8)):
+        mod.get_world_size = lambda w=world: w
+        loader = mod.build_semisup_batch_data_loader_two_crop_source_free(DS(), list(range(16)), total, aspect_ratio_grouping=True,
+                                                                          num_workers=0)
+        strong, weak = next(iter(loader))
+        rows.append([world, total, len(strong), len(weak)])
+    out["lb_world_total_batch"] = np.array(rows)
+    mod.get_world_size = lambda: 3
+    try:
+        mod.build_semisup_batch_data_loader_two_crop_source_free(DS(), list(range(16)), 4, aspect_ratio_grouping=True)
+        out["lb_assert_msg"] = np.array("")
+    except AssertionError as e:
+        out["lb_assert_msg"] = np.array(str(e))
+    mod.get_world_size = lambda: 1
+    try:
+        mod.build_semisup_batch_data_loader_two_crop_source_free(DS(), list(range(16)), 4, aspect_ratio_grouping=False)
+        out["lb_nogroup_error"] = np.array("")
+    except NotImplementedError as e:
+        out["lb_nogroup_error"] = np.array(str(e))
+
+
 def gen_glue():
     """Reference-OWNED glue of the hot path, run here (not restated) and recorded -> ``tests/golden/glue_ref.npz`` +
     ``config_ref.json``.  Every function is the reference's own code object, loaded from its file under
@@ -870,6 +908,7 @@ def gen_glue():
     gen_run_step(m, out, g)
     gen_meta_arch(m, out, g)
     gen_base_trainer(m, out, g)
+    gen_loader_builder(m, out, g)
     np.savez_compressed(os.path.join(OUT, "glue_ref.npz"), **out)
 
     # ---- b: add_config -------------------------------------------------------------------------------------------

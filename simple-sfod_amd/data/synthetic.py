@@ -189,8 +189,12 @@ class TwoCropLoader:
 
     def __init__(self, cfg, device, rank=0, world=1, labeled=False, dataset=None):
         total = cfg.SOLVER.IMS_PER_BATCH if labeled else cfg.SOLVER.IMS_PER_BATCH_TARGET
+        # build.py:337-343 (the message is the reference's: tests/golden/glue_ref.npz ``lb_assert_msg``; d2's labelled loader
+        # says "Total batch size")
         assert total > 0 and total % world == 0, \
-            "Total target batch size ({}) must be divisible by the number of gpus ({}).".format(total, world)
+            "Total {}batch size ({}) must be divisible by the number of gpus ({}).".format("" if labeled else "unlabel ", total, world)
+        if "ASPECT_RATIO_GROUPING" in cfg.DATALOADER and not cfg.DATALOADER.ASPECT_RATIO_GROUPING and not labeled:
+            raise NotImplementedError("ASPECT_RATIO_GROUPING = False is not supported yet")        # build.py:367
         self.batch = total // world
         if dataset is None:
             from .coco import build_dataset

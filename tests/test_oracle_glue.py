@@ -559,3 +559,26 @@ def test_base_trainer_run_step_and_metrics_equal_the_reference(fx, sfod):
     rec = st.flush()
     assert sorted(k for k in rec if k != "iteration") == sorted(logged)
     assert rec["total_loss"] == sum(r0[k] for k in mk if k[:4] == "loss") and rec["data_time"] == r0["data_time"]
+
+
+def test_loader_builder_per_rank_batch_and_errors_equal_the_reference(fx, sfod):
+    """``build_semisup_batch_data_loader_two_crop_source_free`` (daod/data/build.py:312-367) run with ``get_world_size``
+    patched: per-rank batch = IMS_PER_BATCH_TARGET // world, the divisibility assertion's text, and the
+    ``ASPECT_RATIO_GROUPING = False`` error.  The product's ``TwoCropLoader`` does the same on the same (world, total) rows."""
+    cfg = sfod.config.get_cfg()
+    sfod.config.add_config(cfg)
+    ds = [dict(image=torch.zeros(3, 8, 8, dtype=torch.uint8), boxes=torch.zeros(0, 4), classes=torch.zeros(0, dtype=torch.long))]
+    ds = type("DS", (list,), {"size": (8, 8)})(ds * 8)
+    for world, total, per_rank, group in fx["lb_world_total_batch"].tolist():
+        cfg.SOLVER.IMS_PER_BATCH_TARGET = int(total)
+        for rank in range(world):
+            ld = sfod.data.synthetic.TwoCropLoader(cfg, "cpu", rank=rank, world=world, dataset=ds)
+            assert ld.batch == per_rank == group
+    cfg.SOLVER.IMS_PER_BATCH_TARGET = 4
+    with pytest.raises(AssertionError) as e:
+        sfod.data.synthetic.TwoCropLoader(cfg, "cpu", rank=0, world=3, dataset=ds)
+    assert str(e.value) == str(fx["lb_assert_msg"])
+    cfg.DATALOADER.ASPECT_RATIO_GROUPING = False
+    with pytest.raises(NotImplementedError) as e:
+        sfod.data.synthetic.TwoCropLoader(cfg, "cpu", rank=0, world=1, dataset=ds)
+    assert str(e.value) == str(fx["lb_nogroup_error"])
