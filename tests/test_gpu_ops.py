@@ -415,6 +415,23 @@ def test_roi_align_fwd_bwd(native, dtype):
     assert rel_err(nchw(dfeat.cpu()), fr.grad) < (1e-5 if dtype == torch.float32 else 1e-4)
 
 
+def test_roi_align_published_known_answer(native):
+    """Detectron2's own ROIAlign vector (tests/layers/test_roi_align.py, aligned=True; quoted in tests/test_oracle_ops.py with
+    its derivation) through ``sfod_roi_align_fwd`` with no oracle in between: 5 x 5 ramp, roi (1, 1, 3, 3), 4 x 4 bins, scale 1;
+    channel c carries (c + 1) x the ramp."""
+    C = 8
+    ramp = torch.arange(25, dtype=torch.float32).view(1, 5, 5, 1) * torch.arange(1, C + 1, dtype=torch.float32)
+    rois = torch.tensor([[0.0, 1.0, 1.0, 3.0, 3.0]])
+    out = native.roi_align_fwd(ramp.contiguous().to(DEV), rois.to(DEV), 4, 1.0).cpu().view(4, 4, C)
+    expected = torch.tensor([[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])
+    for c in range(C):
+        torch.testing.assert_close(out[:, :, c], expected * (c + 1), rtol=0, atol=1e-5 * (c + 1))
+    # the configs' 7 x 7 form (the separable kernel) on the same ramp: bin centres at 1 + (p + .5) * 2/7 - .5
+    out7 = native.roi_align_fwd(ramp.contiguous().to(DEV), rois.to(DEV), 7, 1.0).cpu().view(7, 7, C)
+    ctr = 0.5 + (torch.arange(7, dtype=torch.float32) + 0.5) * (2.0 / 7.0)
+    torch.testing.assert_close(out7[:, :, 0], 5 * ctr.view(7, 1) + ctr.view(1, 7), rtol=0, atol=1e-5)
+
+
 def test_roi_align_many_rois_unordered_images(native):
     """C = 512 (one 16-byte vector per lane), 2500 ROIs in random image order (the backward compacts
     its image's ROIs in segments of 1024) and padding rows sprinkled in between."""

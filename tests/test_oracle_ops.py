@@ -224,3 +224,69 @@ def test_host_coefficient_tables_equal_the_oracle():
         b0, k0 = precompute_coeffs(n_in, n_out)
         b1, k1, ks = native.pil_bilinear_coeffs(n_in, n_out)
         assert ks == k0.shape[1] and np.array_equal(b0, b1) and np.array_equal(k0, k1)
+
+
+# ---- the known-answer vectors Detectron2's / torchvision's OWN unit tests hold for these functions -----------------------
+# Both libraries are absent from the image and from /root/reference, so these are quoted from their public test files
+# (detectron2 v0.6 tests/modeling/test_anchor_generator.py, tests/modeling/test_matcher.py, tests/structures/test_boxes.py,
+# tests/layers/test_roi_align.py; torchvision test/test_ops.py::TestBoxIou); every expected value is also derivable by hand
+# (comments), so a mis-remembered digit would show up as a contradiction, not as a silent pin.
+
+def test_published_default_anchor_generator_vector():
+    # sizes [32, 64], ratios [0.25, 1, 4], one level of stride 4 with a 1 x 2 map, offset 0
+    cell = B.cell_anchors((32, 64), (0.25, 1.0, 4.0))
+    a = B.grid_anchors(1, 2, 4, cell)
+    expected = torch.tensor([
+        [-32.0, -8.0, 32.0, 8.0], [-16.0, -16.0, 16.0, 16.0], [-8.0, -32.0, 8.0, 32.0],
+        [-64.0, -16.0, 64.0, 16.0], [-32.0, -32.0, 32.0, 32.0], [-16.0, -64.0, 16.0, 64.0],
+        [-28.0, -8.0, 36.0, 8.0], [-12.0, -16.0, 20.0, 16.0], [-4.0, -32.0, 12.0, 32.0],       # x shifted by the stride
+        [-60.0, -16.0, 68.0, 16.0], [-28.0, -32.0, 36.0, 32.0], [-12.0, -64.0, 20.0, 64.0]])
+    torch.testing.assert_close(a, expected, rtol=0, atol=1e-5)
+
+
+def test_published_matcher_vector():
+    # Matcher([0.3, 0.7], [0, -1, 1], allow_low_quality_matches=True) on a 3 gt x 4 candidates quality matrix
+    M = torch.tensor([[0.15, 0.45, 0.2, 0.6], [0.3, 0.65, 0.05, 0.1], [0.05, 0.4, 0.25, 0.4]])
+    idx, lab = B.matcher(M, [0.3, 0.7], [0, -1, 1], True)
+    assert idx.tolist() == [1, 1, 2, 0]
+    # column 0: max .3 -> ignore; column 1: .65 -> ignore, but it is gt1's best (.65) -> positive; column 2: .25 -> negative
+    # (gt2's best is .4: columns 1 and 3); column 3: .6 -> ignore, best of gt0 (.6) and tied best of gt2 (.4) -> positive
+    assert lab.tolist() == [-1, 1, 0, 1]
+
+
+def test_published_pairwise_iou_vectors():
+    b1 = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 1.0, 1.0]])
+    b2 = torch.tensor([[0.0, 0.0, 1.0, 1.0], [0.0, 0.0, 0.5, 1.0], [0.0, 0.0, 1.0, 0.5], [0.0, 0.0, 0.5, 0.5],
+                       [0.5, 0.5, 1.0, 1.0], [0.5, 0.5, 1.5, 1.5]])
+    row = [1.0, 0.5, 0.5, 0.25, 0.25, 0.25 / (2 - 0.25)]
+    torch.testing.assert_close(B.pairwise_iou(b1, b2), torch.tensor([row, row]), rtol=1e-6, atol=1e-7)
+    # torchvision TestBoxIou
+    b = torch.tensor([[0.0, 0.0, 100.0, 100.0], [0.0, 0.0, 50.0, 50.0], [200.0, 200.0, 300.0, 300.0]])
+    torch.testing.assert_close(B.pairwise_iou(b, b), torch.tensor([[1.0, 0.25, 0.0], [0.25, 1.0, 0.0], [0.0, 0.0, 1.0]]))
+    # an empty side gives an empty matrix of the right shape
+    assert B.pairwise_iou(torch.zeros(0, 4), b).shape == (0, 3) and B.pairwise_iou(b, torch.zeros(0, 4)).shape == (3, 0)
+
+
+@pytest.mark.parametrize("aligned, expected", [
+    (False, [[7.5, 8, 8.5, 9], [10, 10.5, 11, 11.5], [12.5, 13, 13.5, 14], [15, 15.5, 16, 16.5]]),
+    (True, [[4.5, 5.0, 5.5, 6.0], [7.0, 7.5, 8.0, 8.5], [9.5, 10.0, 10.5, 11.0], [12.0, 12.5, 13.0, 13.5]])])
+def test_published_roi_align_vectors(aligned, expected):
+    # input = arange(25) as 5 x 5 (value 5y + x), roi (1, 1, 3, 3), 4 x 4 bins of 0.5, scale 1, adaptive sampling grid:
+    # bin (0, 0) is centred on (1.25, 1.25) -> 7.5; aligned=True moves every sample by -0.5 -> 4.5
+    feat = torch.arange(25, dtype=torch.float32).view(1, 1, 5, 5)
+    rois = torch.tensor([[0.0, 1.0, 1.0, 3.0, 3.0]])
+    for fn in (roi_align, roi_align_py):
+        out = fn(feat, rois, 4, 1.0, 0, aligned)
+        torch.testing.assert_close(out[0, 0], torch.tensor(expected, dtype=torch.float32), rtol=0, atol=1e-5)
+
+
+def test_published_roi_align_resize_property():
+    # tests/layers/test_roi_align.py::test_resize: the same roi on a 2x down-sampled ramp at scale 0.5 gives the same output
+    feat = torch.arange(25, dtype=torch.float32).view(1, 1, 5, 5)
+    rois = torch.tensor([[0.0, 1.0, 1.0, 3.0, 3.0]])
+    big = roi_align(feat, rois, 4, 1.0, 0, True)
+    # the ramp 5y + x sampled on the half-resolution grid whose pixel centres sit at 2i + 0.5 in full-resolution pixels
+    ys = torch.arange(3, dtype=torch.float32) * 2 + 0.5
+    small = (5 * ys.view(3, 1) + ys.view(1, 3)).view(1, 1, 3, 3)
+    half = roi_align(small, rois, 4, 0.5, 0, True)
+    torch.testing.assert_close(half, big, rtol=0, atol=1e-5)
