@@ -343,9 +343,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
+    # SFOD_BENCH_ONE_GPU=1 (tests/test_gpu_two_rank.py only): the N ranks share cuda:0 and exchange over gloo -- RCCL refuses
+    # two ranks on one device -- so that every N > 1 line of this file executes on a one-GPU box.  Such a line says so
+    # ("test_hook") and is never a measurement.
+    one_gpu = world > 1 and os.environ.get("SFOD_BENCH_ONE_GPU") == "1"
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     note("torch imported")
     sfod = importlib.import_module("simple-sfod_amd")
@@ -510,7 +519,8 @@ def main():
         step_ms = 1000.0 * elapsed / args.steps
         comm = {"collective": "sum all-reduce of the flat fp32 student gradient, 3 phases overlapping the backbone backward "
                               "(engine/trainer.py::GradientReducer)",
-                "backend": "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version()),
+                "backend": ("gloo (SFOD_BENCH_ONE_GPU test hook)" if one_gpu else
+                            "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())),
                 "payload_MB": round(nbytes / 1e6, 1), "allreduce_alone_ms": round(ar_ms, 3),
                 "allreduce_bus_GBps": round(2.0 * (world - 1) / world * nbytes / (ar_ms * 1e-3) / 1e9, 1),
                 "step_without_exchange_ms": round(nocomm_ms, 3),
@@ -629,6 +639,8 @@ def main():
         out["gpu_fill"] = gpu_fill
     if comm is not None:
         out["exchange"] = comm
+    if one_gpu:
+        out["test_hook"] = "SFOD_BENCH_ONE_GPU: all ranks on cuda:0 over gloo -- exercises the N > 1 code path, not a measurement"
     if secondary is not None:
         out["reduced_precision_mode"] = secondary
     if other_modes:

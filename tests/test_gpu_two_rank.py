@@ -218,3 +218,35 @@ def test_two_ranks_on_one_gpu_take_the_oracles_mean_gradient_step(tmp_path, mode
     print(f"[two ranks {model} {dtype}] pseudo labels per rank {[len(r['pseudo_boxes'][0]) for r in R]}; worst update error per "
           "group: " + ", ".join(f"{g} {max(v for n, v in worst.items() if n.startswith(g)):.2e}"
                                 for g in ("backbone", "proposal_generator", "roi_heads")))
+
+
+@pytest.mark.parametrize("model", ["vgg", "r101"])
+def test_bench_two_ranks_on_one_gpu(tmp_path, model):
+    """``bench.py --gpus 2`` exactly as the driver starts it (``python -m torch.distributed.run --nproc-per-node 2 ...``),
+    with SFOD_BENCH_ONE_GPU=1: both ranks on cuda:0 over gloo.  Every N > 1 line of bench.py runs -- the broadcast of the planted
+    bias, barrier + max-over-ranks timing, the exchange block (all-reduce alone, the step without exchange, per-phase
+    exposure) -- and rank 0 prints ONE JSON line with the whole-job images/s of both ranks.  Not a measurement."""
+    import json
+    env = dict(os.environ, SFOD_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "4",
+           "--model", model]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-4000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 4 and d["scaling"] == "weak"
+    assert d["config"]["global_batch"] == 16 and d["config"]["batch_per_gpu"] == 8 and d["config"]["parallelism"] == "dp2"
+    assert abs(d["value"] - 16 * 6 / d["timed_region_s"]) < 0.01 * d["value"]        # whole job: both ranks' images
+    assert "test_hook" in d and "cpu_baseline" not in d and "roofline" in d
+    ex = d["exchange"]
+    assert ex["backend"].startswith("gloo") and ex["payload_MB"] > 50
+    assert ex["allreduce_alone_ms"] > 0 and ex["step_without_exchange_ms"] > 0
+    assert len(ex["exposed_ms_per_phase"]["slices_MB"]) == 3
+    # the three slices cover the flat gradient except the slots nobody exchanges (the zero-weight domain classifiers')
+    assert 0.85 * ex["payload_MB"] < sum(ex["exposed_ms_per_phase"]["slices_MB"]) <= ex["payload_MB"] + 0.5
+    pl = d["config"]["pseudo_labels_per_image"]
+    assert 10 <= pl["mean"] <= 30
