@@ -397,7 +397,7 @@ int sfod_make_rois(const float* props, const int32_t* prop_count, int B, int P, 
                    void* stream);
 
 /* ---- K13: ROIAlign (tv roi_align aligned=True, adaptive sampling; Appendix A.11) on NHWC
- * features.  out: [R, PH*PW, C] (dt).  rois with batch index < 0 produce zeros. */
+ * features.  out: [R, PH*PW, C] (dt).  rois with batch index < 0 produce zeros.  pooled in [1, 16] (the backward: [1, 8]). */
 int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, const float* rois, int R,
                        int pooled, float scale, void* out, int dt, void* stream);
 /* dfeat fp32 [B,H,W,C] += adjoint of the forward (zero-init by the caller); one workgroup per ROI,

@@ -295,6 +295,7 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
 // its channels in registers, contracts them with Ax and Ay and issues ONE atomic add per footprint
 // pixel and channel (a wavefront adds 256 contiguous bytes): ~5x fewer atomics than the scatter.
 #define ROI_MAXP 8
+#define ROI_MAXP_FWD 16
 
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -560,7 +561,9 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
   (void)B;
   if (R == 0) return 0;
   SFOD_REQUIRE(B >= 1 && H >= 1 && W >= 1 && C >= 1, "roi_align: empty feature map");
-  SFOD_REQUIRE(pooled >= 1 && pooled <= ROI_MAXP, "roi_align: pooled size must be in [1, 8]");
+  // (the backward's register tiles bound it at 8; the forward's bin loop has no such limit: 14 is Detectron2's default
+  // POOLER_RESOLUTION, the size its own unit tests' golden losses are computed at -- tests/test_gpu_d2_golden.py)
+  SFOD_REQUIRE(pooled >= 1 && pooled <= ROI_MAXP_FWD, "roi_align: pooled size must be in [1, 16]");
   SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || sfod_is_pairs(dt), "roi_align: unknown dt");
   SFOD_REQUIRE(feat != nullptr && rois != nullptr && out != nullptr, "roi_align: null argument (feat, rois, out)");
   SFOD_REQUIRE(sfod_prod_fits({B, H, W, C}, 1LL << 40) && sfod_prod_fits({R, C, pooled, pooled}, 1LL << 40) &&
