@@ -137,3 +137,27 @@ def test_sampler_follows_torchvision_get_params(sfod):
         hh, ww = int(g.integers(5, 700)), int(g.integers(5, 1300))
         sc, ra = ((0.05, 0.2), (0.3, 3.3)) if g.random() < 0.5 else ((0.02, 0.2), (0.05, 8.0))
         assert D.augment.erasing_params(hh, ww, sc, ra, draws) == A.erasing_params(hh, ww, sc, ra, draws)
+
+
+def test_torchvisions_published_adjust_vectors():
+    """The literal vectors of torchvision's own test/test_transforms.py (test_adjust_brightness / _contrast / _saturation:
+    one 2 x 2 RGB image, factors 0.5 and 2).  Brightness and contrast hold as published.  Saturation holds with the luma
+    those vectors were recorded under -- Pillow < 7 truncated ``convert("L")``, Pillow >= 7 (installed here and in any
+    environment that runs the reference today) rounds: pixel (90, 255, 1) has luma 176.71, and the published 215 / 88
+    become 216 / 89.  The restatement follows the installed Pillow (test above: exact); with the truncating luma it
+    reproduces the published saturation vectors too."""
+    x = np.array([0, 5, 13, 54, 135, 226, 37, 8, 234, 90, 255, 1], dtype=np.uint8).reshape(2, 2, 3)
+    pub = {
+        "brightness": {0.5: [0, 2, 6, 27, 67, 113, 18, 4, 117, 45, 127, 0], 2: [0, 10, 26, 108, 255, 255, 74, 16, 255, 180, 255, 2]},
+        "contrast": {0.5: [43, 45, 49, 70, 110, 156, 61, 47, 160, 88, 170, 43], 2: [0, 0, 0, 22, 184, 255, 0, 0, 255, 94, 255, 0]},
+        "saturation": {0.5: [2, 4, 8, 87, 128, 173, 39, 25, 138, 133, 215, 88], 2: [0, 6, 22, 0, 149, 255, 32, 0, 255, 4, 255, 0]}}
+    for f, ans in pub["brightness"].items():
+        assert A.adjust_brightness(x, f).reshape(-1).tolist() == ans
+    for f, ans in pub["contrast"].items():
+        assert A.adjust_contrast(x, f).reshape(-1).tolist() == ans
+    xi = x.astype(np.int64)
+    luma_trunc = ((xi[..., 0] * 19595 + xi[..., 1] * 38470 + xi[..., 2] * 7471) >> 16).astype(np.uint8)
+    for f, ans in pub["saturation"].items():
+        assert A.blend(np.repeat(luma_trunc[..., None], 3, -1), x, f).reshape(-1).tolist() == ans
+        now = A.adjust_saturation(x, f).reshape(-1)
+        assert np.abs(now.astype(int) - np.array(ans)).max() == 1 and (now[:9] == np.array(ans)[:9]).all()
