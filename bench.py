@@ -625,6 +625,9 @@ def main():
             "planted_labels": planted if planted is not None else False,
             **(step_log.summary() if step_log is not None and args.trainer != "base" else {}),
             "algorithmic_tflop_per_image": round(sflops / 1e12, 3),
+            # torch's caching allocator on this rank (the library allocates nothing itself): what the step holds of the 288 GB
+            "peak_hbm_reserved_GB": round(torch.cuda.max_memory_reserved() / 1e9, 1),
+            "peak_hbm_allocated_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1),
         },
         "step_tflops_per_gpu": round(sflops * value / world / 1e12, 2),
         "losses": {k: round(v, 5) for k, v in rec.items() if k.startswith("loss") or k.startswith("roi_head")},

@@ -2,8 +2,13 @@
 
 ``tests/golden/upstream_ref.npz`` is written by ``python -m oracle.gen_golden --upstream`` on a machine where
 detectron2 and torchvision import (they are absent from the build image and from /root/reference, so until someone runs
-that command this half of the oracle is PARITY UNPINNED and the comparisons below are skipped -- the oracle is still
-run on every case here, so the cases themselves cannot rot).  Tolerances: indices / labels bit-exact, floats 1e-6.
+that command the comparisons below are skipped -- the oracle is still run on every case here, so the cases themselves
+cannot rot).  Tolerances: indices / labels bit-exact, floats 1e-6.
+
+Since round 5 a large part of that half IS pinned another way: Detectron2's own unit-test goldens for the RPN, the ROI
+heads' training path, the losses, anchors, Matcher, IoU, ROIAlign and the LR schedule (tests/test_oracle_d2_golden.py,
+tests/test_oracle_ops.py).  What only this file would pin: ``fast_rcnn_inference``, multi-class ``batched_nms`` in both
+strategies, ``roi_align``'s backward, random-input sweeps of everything.
 """
 import os
 

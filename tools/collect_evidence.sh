@@ -10,6 +10,17 @@ O=gpurun_out
 # the planted-label background bias is calibrated at start-up (~50 teacher passes): profiled runs take the calibrated value
 # of an unprofiled run of the same configuration instead, so that the kernel trace holds the steps only
 bias_of() { python3 bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timer 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['config']['planted_labels']['background_bias'])"; }
+# A process that held > 100 GB (the 1024x2048 configurations) is still giving its VRAM back for several seconds after it
+# exits; a bench started meanwhile finds little free memory and spends its steps in the allocator's free-and-retry path
+# (round 5: the --res full line came back at 15 images/s twice, 64 when run alone).  Wait until the device is empty.
+wait_vram() {
+  for i in $(seq 1 60); do
+    used=$(rocm-smi --showmeminfo vram --json 2>/dev/null | python3 -c "import json,sys; d=json.load(sys.stdin); c=next(iter(d.values())); print(int(next(v for k,v in c.items() if 'Used' in k)) >> 30)" 2>/dev/null || echo 0)
+    [ "${used:-0}" -lt 8 ] && return 0
+    sleep 1
+  done
+  echo "wait_vram: still ${used} GiB in use after 60 s" >&2
+}
 VB=$(bias_of); RB=$(bias_of --model r101)
 echo "planted background bias: vgg $VB r101 $RB"
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
@@ -39,6 +50,7 @@ if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
   python3 bench.py --kernel-table --steps 30 --no-cpu-baseline --no-secondary > /dev/null 2> $O/${TAG}_kernel_table.txt
   for cfg in "--trainer base" "--trainer base --res full --steps 40" "--res full --steps 40" "--batch 1 --steps 200" "--opts SFOD.ELIDE_DEAD_BRANCHES False" "--dtype f16x3"; do
     name=$(echo $cfg | tr -d ' -' | tr '.' '_')
+    wait_vram
     python3 bench.py $cfg --no-cpu-baseline --no-secondary > $O/${TAG}_bench_${name}.json 2> $O/${TAG}_bench_${name}.err
   done
   # config #5 with its labelled blocks (other parity mode fp32; reduced-precision bf16x3 / bf16) from child processes
