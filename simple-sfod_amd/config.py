@@ -402,6 +402,10 @@ def add_native_config(cfg):
     # roctx ranges around the stages of a step (teacher / student_forward / student_backward / exchange / update) for
     # rocprofv3 --marker-trace; also SFOD_ROCTX=1 (engine/trainer.py::stage)
     _C.SFOD.PROFILE_RANGES = False
+    # how many steps the host may have enqueued beyond the one the GPU has finished (0 = unbounded).  Bounds what torch's
+    # caching allocator reserves for tensors that crossed streams (engine/trainer.py::_throttle); free while the GPU is the
+    # slower side (host enqueue ~5 ms, GPU ~50 ms per step)
+    _C.SFOD.MAX_STEPS_IN_FLIGHT = 2
     # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass
     # that stores the activated output directly; sfod_conv_first_fused)
     _C.SFOD.FUSE_FIRST_LAYER = True

@@ -21,6 +21,7 @@ MI355X-first differences (documented in DESIGN.md):
   * zero-weighted dead branches (2nd ROI pass, BPC, domain classifier) are elided
     (``SFOD.ELIDE_DEAD_BRANCHES``).
 """
+import collections
 import contextlib
 import json
 import os
@@ -260,6 +261,45 @@ def _apply_process_knobs(cfg):
         _ROCTX[0] = True
 
 
+def _throttle(trainer):
+    """Keep the host at most ``SFOD.MAX_STEPS_IN_FLIGHT`` steps ahead of the GPU.  A step has no host synchronisation and
+    the host enqueues it ~10x faster than the GPU runs it, so an unbounded host runs as far ahead as the HIP queues let it;
+    every tensor that crossed streams (teacher stream, weight-gradient side stream, loader stream: ``record_stream``) stays
+    reserved until the GPU gets there, and torch's caching allocator grew to 137 GB for 14 GB of live tensors on the hot
+    yaml at B = 8 (246 of 288 GB on 1024 x 2048 tensors, where the next process then met a device still being emptied).
+    Waiting on the event recorded after step i - depth costs nothing while the GPU is the slower side."""
+    depth = _in_flight_depth(trainer)
+    if depth <= 0:
+        return
+    ev = trainer.__dict__.setdefault("_step_events", collections.deque())
+    while len(ev) >= depth:
+        ev.popleft().synchronize()
+
+
+def _in_flight_depth(trainer):
+    """``trainer._max_in_flight`` (settable: bench.py lifts the bound for its host-enqueue measurement), initialised from the
+    config the first time a step runs; 0 for anything that is not a trainer on a GPU (the tests' recorder stubs)."""
+    d = trainer.__dict__ if hasattr(trainer, "__dict__") else {}
+    if "_max_in_flight" not in d:
+        cfg, dev = d.get("cfg"), d.get("device")
+        on_gpu = dev is not None and torch.device(dev).type == "cuda"
+        depth = 0
+        if on_gpu and cfg is not None and "SFOD" in cfg:
+            depth = int(cfg.SFOD.MAX_STEPS_IN_FLIGHT) if "MAX_STEPS_IN_FLIGHT" in cfg.SFOD else 2
+        try:
+            trainer._max_in_flight = depth
+        except AttributeError:
+            return depth
+    return trainer._max_in_flight
+
+
+def _step_enqueued(trainer):
+    if _in_flight_depth(trainer) > 0:
+        e = torch.cuda.Event()
+        e.record()                      # main stream: the update at the end of a step has waited for every side stream
+        trainer.__dict__.setdefault("_step_events", collections.deque()).append(e)
+
+
 class BaseTrainer:
     """Source-only training (``TRAINER: "base"``)."""
 
@@ -373,6 +413,7 @@ class BaseTrainer:
     # ---- step ----------------------------------------------------------------------------------------
     def run_step(self):
         assert self.model.training, "[BaseTrainer] model was changed to eval mode!"
+        _throttle(self)
         start = time.perf_counter()
         data = next(self._data_loader_iter)
         data_time = time.perf_counter() - start
@@ -390,6 +431,7 @@ class BaseTrainer:
             self._reduce_gradients()
         with stage("update"):
             self.optimizer.step()
+        _step_enqueued(self)
 
     def _reduce_gradients(self):
         """The one exchange step: sum the flat gradient buffer over ranks (RCCL); the 1/world averaging
@@ -778,6 +820,7 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
     def run_step(self):
         cfg = self.cfg
         assert self.model.training, "[AdaptiveTeacherTrainer] model was changed to eval mode!"
+        _throttle(self)
         start = time.perf_counter()
         unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
         if not cfg.WEAK_STRONG_AUGMENT:
@@ -842,6 +885,7 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             self._reduce_gradients()
         with stage("update"):
             self.optimizer.step(ema=self.ema_enabled)  # EMA fused: _update_teacher_model (:583-603)
+        _step_enqueued(self)
 
     def _flush_metrics(self):
         self.model_teacher.proposal_generator.check_finite()
