@@ -78,8 +78,10 @@ Parity pin status
   same numbers directly, in all three arithmetic modes.
 * STILL UNPINNED: what no Detectron2 / torchvision test holds a literal vector for and those libraries (absent here) would
   have to be run for -- ``fast_rcnn_inference`` (test-time score threshold + per-class NMS + top-k), torchvision
-  ``batched_nms``'s two strategies beyond the single-class case the RPN vector exercises, the ResNet-101 forward,
-  ``Boxes.clip`` / ``nonempty`` corner cases, COCOeval, ColorJitter.  Those are restated from their published algorithms and
+  ``batched_nms``'s two strategies beyond the single-class case the RPN vector exercises, ``Boxes.clip`` / ``nonempty``
+  corner cases, COCOeval, ColorJitter's parameter sampling; the ResNet-50/101-C4 trunk has no Detectron2 vector but equals
+  an independent port -- HuggingFace ``transformers``' ResNet with the stride in the first 1x1 -- on the same weights in
+  eval and train mode (tests/test_oracle_r101.py).  Those are restated from their published algorithms and
   anchored on the reference's call sites plus hand-computed known-answer cases (tests/test_oracle_*.py); ``transformers``
   (installed) carries an independent port of torchvision's ``box_iou``: ``oracle.box_ops.pairwise_iou`` / ``box_area`` equal
   it bit for bit (tests/test_oracle_glue.py).  The generator for a full pin is committed (``python -m oracle.gen_golden

@@ -2,9 +2,12 @@
 (``build_resnet_backbone`` -- BasicStem + BottleneckBlock, STRIDE_IN_1X1, FREEZE_AT=2, NORM=BN), the
 backbone the reference selects in ``configs/r101_c4_cs_foggy_adaptive_teacher_source_free.yaml:1-28``.
 
-parity unpinned: Detectron2 is not vendored under /root/reference and is not installed here, so this
-restates its published structure over plain torch CPU ops; the
-state-dict keys are Detectron2's.  Only tests/ and __graft_entry__.smoke() may import this module.
+Detectron2 is not vendored under /root/reference and is not installed here, so this restates its published
+structure over plain torch CPU ops; the state-dict keys are Detectron2's.
+No Detectron2 vector pins it; a third-party cross-check does: HuggingFace ``transformers``' ResNet (installed)
+configured as the same MSRA-style C4 trunk gives the same output from the same weights in eval (FrozenBN) and
+train (batch statistics + running-statistics update) mode, depth 50 and 101
+(tests/test_oracle_r101.py::test_resnet_trunk_equals_the_transformers_port).  Only tests/ and __graft_entry__.smoke() may import this module.
 """
 import torch
 import torch.nn.functional as F

@@ -2,6 +2,7 @@
 oracle (oracle/model.py with Cfg.r101_c4(), oracle/resnet.py) is what tests/test_gpu_fullsize.py and
 tests/test_gpu_trajectory.py hold the device to on that config; this keeps it exercised without a GPU.  Parity unpinned
 (Detectron2 is not vendored): structure, shapes, gradient flow and the state side effects are what is checked here."""
+import pytest
 import torch
 
 from oracle import model as om
@@ -51,3 +52,77 @@ def test_r101_c4_oracle_teacher_student_step():
     assert live and all(s[k].grad is not None and torch.isfinite(s[k].grad).all() for k in live)
     assert all(getattr(s[k], "grad", None) is None for k in frozen)
     assert float(s["backbone.res3.0.conv1.weight"].grad.abs().sum()) > 0 and float(s["roi_heads.box_head.fc1.weight"].grad.abs().sum()) > 0
+
+
+def _hf_resnet_c4(depth):
+    """An independent port of the same architecture: HuggingFace ``transformers``' ResNet (installed here) configured as
+    Detectron2's MSRA-style C4 trunk -- bottleneck blocks, stride in the FIRST 1x1 (``downsample_in_bottleneck``), three
+    stages.  -> the model and a name map from Detectron2's state-dict keys to its parameters / buffers."""
+    from transformers import ResNetConfig, ResNetModel
+    from oracle import resnet as R
+    cfg = ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024], depths=R.BLOCKS[depth],
+                       layer_type="bottleneck", hidden_act="relu", downsample_in_first_stage=False,
+                       downsample_in_bottleneck=True)
+    m = ResNetModel(cfg)
+    names = {}
+
+    def conv_bn(d2, hf):            # a ResNetConvLayer (convolution + normalization) <- a Detectron2 Conv2d with .norm
+        names[d2 + ".weight"] = hf + ".convolution.weight"
+        for k in ("weight", "bias", "running_mean", "running_var"):
+            names[f"{d2}.norm.{k}"] = f"{hf}.normalization.{k}"
+
+    conv_bn("backbone.stem.conv1", "embedder.embedder")
+    for stage, bi, cin, cout, _, _ in R.block_specs(depth):
+        hf = f"encoder.stages.{int(stage[3]) - 2}.layers.{bi}"
+        if cin != cout:
+            conv_bn(f"backbone.{stage}.{bi}.shortcut", hf + ".shortcut")
+        for j in range(3):
+            conv_bn(f"backbone.{stage}.{bi}.conv{j + 1}", f"{hf}.layer.{j}")
+    return m, names
+
+
+@pytest.mark.parametrize("depth", [50, 101])
+def test_resnet_trunk_equals_the_transformers_port(depth):
+    """Third-party cross-check of ``oracle/resnet.py`` (Detectron2 absent): the same weights and statistics through
+    HuggingFace's ResNet.  Eval mode = FrozenBN everywhere (freeze_at 5 in the oracle); train mode = batch statistics in
+    every BatchNorm (freeze_at 0) incl. the running-statistics update with momentum 0.1 and the unbiased variance."""
+    from oracle import resnet as R
+    m, names = _hf_resnet_c4(depth)
+    g = torch.Generator().manual_seed(depth)
+    sd = R.init_state(depth, seed=3, freeze_at=0)
+    for k in list(sd):
+        if k.endswith("norm.weight"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+        elif k.endswith("norm.bias") or k.endswith("running_mean"):
+            sd[k] = torch.randn(sd[k].shape, generator=g) * 0.1
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(sd[k].shape, generator=g) + 0.5
+    hf = dict(m.named_parameters())
+    hf.update(dict(m.named_buffers()))
+    used = set()
+    with torch.no_grad():
+        for d2, name in names.items():
+            assert hf[name].shape == sd[d2].shape, (d2, name)
+            hf[name].copy_(sd[d2])
+            used.add(name)
+    assert {n for n in hf if not n.endswith("num_batches_tracked")} == used       # the two trunks have the same tensors
+    x = torch.randn(2, 3, 67, 93, generator=g)
+    # eval: every norm frozen
+    m.eval()
+    with torch.no_grad():
+        ref = m(x).last_hidden_state
+        got = R.forward({k: v.clone() for k, v in sd.items()}, x, depth=depth, training=False, freeze_at=5)
+    assert got.shape == ref.shape == (2, 1024, 5, 6)
+    assert ((got - ref).norm() / ref.norm()).item() < 2e-6
+    # train: batch statistics, running statistics refreshed
+    m.train()
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    with torch.no_grad():
+        ref = m(x).last_hidden_state
+        got = R.forward(sd2, x, depth=depth, training=True, freeze_at=0)
+    assert ((got - ref).norm() / ref.norm()).item() < 2e-5
+    hf2 = dict(m.named_buffers())
+    for d2, name in names.items():
+        if d2.endswith("running_mean") or d2.endswith("running_var"):
+            torch.testing.assert_close(sd2[d2], hf2[name], rtol=1e-4, atol=1e-6)
+    assert int(sd2["backbone.res4.0.conv1.norm.num_batches_tracked"]) == 1
