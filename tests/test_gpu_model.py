@@ -544,6 +544,32 @@ def test_eval_mode_inference_and_trainer_test_match_oracle(sfod, native, tmp_pat
     assert "bbox" in res2 and os.path.isfile(os.path.join(str(tmp_path), "adabn.pth"))
 
 
+@pytest.mark.parametrize("depth", [2, 0])
+def test_host_is_held_to_the_configured_number_of_steps_in_flight(sfod, native, depth):
+    """``SFOD.MAX_STEPS_IN_FLIGHT`` (engine/trainer.py::_throttle): after every ``run_step`` at most ``depth`` step-end events
+    are outstanding, and the one that was dropped has completed; 0 = unbounded: no events at all.  The results do not depend
+    on it (same seed: the same parameters after four steps)."""
+    def run(d):
+        cfg = make_cfg(sfod, opts=["SOLVER.IMS_PER_BATCH_TARGET", "2", "SFOD.SYNTHETIC.HEIGHT", "256",
+                                   "SFOD.SYNTHETIC.WIDTH", "512", "SFOD.SYNTHETIC.NUM_IMAGES", "4",
+                                   "INPUT.MIN_SIZE_TRAIN", "(192,)", "SOLVER.CHECKPOINT_PERIOD", "0",
+                                   "SFOD.MAX_STEPS_IN_FLIGHT", str(d), "SFOD.DETERMINISTIC", "True"])
+        torch.manual_seed(cfg.SEED)
+        tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+        for i in range(4):
+            tr.iter = i
+            tr.run_step()
+            ev = tr.__dict__.get("_step_events", [])
+            assert len(ev) <= max(d, 0)
+            if d == 0:
+                assert len(ev) == 0
+        torch.cuda.synchronize()
+        return tr.optimizer.flat.param.clone()
+    p = run(depth)
+    if depth:
+        assert torch.equal(p, run(0))
+
+
 @pytest.mark.parametrize("dtype", ["fp32", "bf16"])
 def test_trainer_steps_ema_and_lr(sfod, native, dtype):
     cfg = make_cfg(sfod, opts=["SFOD.COMPUTE_DTYPE", dtype, "SOLVER.IMS_PER_BATCH_TARGET", "2",
