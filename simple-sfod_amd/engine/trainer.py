@@ -821,6 +821,8 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         cfg = self.cfg
         assert self.model.training, "[AdaptiveTeacherTrainer] model was changed to eval mode!"
         _throttle(self)
+        if hasattr(self.model, "drop_prefetched"):
+            self.model.drop_prefetched()
         start = time.perf_counter()
         unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
         if not cfg.WEAK_STRONG_AUGMENT:

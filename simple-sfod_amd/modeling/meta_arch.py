@@ -23,6 +23,9 @@ from .batched import BatchedGT, gather_gt
 from .dann import DAInsHead, FCDiscriminator_img, dc_img_loss, dc_ins_loss
 
 
+_NO_PREFETCH_RPN = __import__("os").environ.get("SFOD_NO_PREFETCH_RPN", "0") == "1"
+
+
 def build_model(cfg):
     """d2 build_model: META_ARCH_REGISTRY.get(name)(cfg).to(cfg.MODEL.DEVICE)."""
     model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
@@ -77,13 +80,29 @@ class GeneralizedRCNN(nn.Module):
         """Run preprocessing + the backbone for ``batched_inputs`` NOW; the next ``forward`` on the same list
         object picks the result up instead of recomputing it.  Lets a trainer start the student's backbone
         before the pseudo-labels (which only the heads' losses need) exist."""
+        self.drop_prefetched()
         images = self.preprocess_image(batched_inputs)
-        self._prefetched = (batched_inputs, images, self._features(images))
+        features = self._features(images)
+        self._prefetched = (batched_inputs, images, features)
+        # ... and what else of the training pass needs no labels: the RPN's head convolutions and proposals (only the anchor
+        # matching and the losses wait for the pseudo labels) and the box head's weight packing (SFOD_NO_PREFETCH_RPN=1: A/B hook)
+        if self.training and not _NO_PREFETCH_RPN:
+            if hasattr(self.proposal_generator, "prefetch"):
+                self.proposal_generator.prefetch(images, features)
+            if hasattr(self.roi_heads, "prefetch_weights"):
+                self.roi_heads.prefetch_weights()
+
+    def drop_prefetched(self):
+        """forget whatever an earlier ``prefetch_features`` left behind (a step that raised before using it)"""
+        self.__dict__.pop("_prefetched", None)
+        self.proposal_generator.__dict__.pop("_prefetched", None)
+        self.roi_heads.__dict__.pop("_packed", None)
 
     def _images_and_features(self, batched_inputs):
         pf = self.__dict__.pop("_prefetched", None)
         if pf is not None and pf[0] is batched_inputs:
             return pf[1], pf[2]
+        self.proposal_generator.__dict__.pop("_prefetched", None)      # whatever was prefetched is not for this batch
         images = self.preprocess_image(batched_inputs)
         return images, self._features(images)
 

@@ -270,6 +270,27 @@ class StandardROIHeads(nn.Module):
         return [bh.fc1.weight, bh.fc1.bias, bh.fc2.weight, bh.fc2.bias, bp.cls_score.weight, bp.cls_score.bias,
                 bp.bbox_pred.weight, bp.bbox_pred.bias]
 
+    # ---- the training pass's weights, packed ahead of time ---------------------------------------------------------------
+    @torch.no_grad()
+    def prefetch_weights(self):
+        """Pack the box head's and predictor's weights in the forms the training pass multiplies with -- forward and
+        backward -- NOW; the next ``_box_forward`` takes them instead of packing (fc1 is 103 MB: four launches of 60-90 us
+        that otherwise sit between the pseudo labels and the losses).  The trainer calls it (``model.prefetch_features``)
+        while the teacher is still labelling; nothing changes the weights before this step's update, and what is not
+        taken by then is dropped at the start of the next step (``drop_prefetched``)."""
+        dt = native.dt_of_dtype(self.compute_dtype)
+        gdt = native.dt_of_dtype(native.grad_dtype_of(self.compute_dtype))
+        bh, bp, C = self.box_head, self.box_predictor, self.channels
+        wp = torch.cat([bp.cls_score.weight.detach(), bp.bbox_pred.weight.detach()])
+        self._packed = {
+            "w1": native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C),
+            "w2": native.pack_fc_weight(bh.fc2.weight.detach(), dt),
+            "wp": wp, "bpb": torch.cat([bp.cls_score.bias.detach(), bp.bbox_pred.bias.detach()]),
+            "wpp": native.pack_fc_weight(wp, dt),
+            "wpt": native.pack_fc_weight(wp, gdt, transpose=True, ld=self.pred_ld),
+            "w2t": native.pack_fc_weight(bh.fc2.weight.detach(), gdt, transpose=True),
+            "w1t": native.pack_fc_weight(bh.fc1.weight.detach(), gdt, chw_c=C, transpose=True)}
+
     # ---- box branch: ROIAlign -> fc1 -> fc2 -> fused (cls_score | bbox_pred) -------------------------
     def _box_forward(self, feat_nchw, rois):
         dtype = self.compute_dtype
@@ -277,18 +298,23 @@ class StandardROIHeads(nn.Module):
         feat = native.nhwc_operand(feat_nchw, dtype)
         bh, bp = self.box_head, self.box_predictor
         C, PP = self.channels, self.pooled * self.pooled
+        pk = self.__dict__.pop("_packed", None) or {}
         pooled = native.roi_align_fwd(feat, rois, self.pooled, self.box_pooler.scale)
         R = pooled.shape[0]
         x0 = pooled.view(R, PP * C)
-        w1 = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C)
+        w1 = pk["w1"] if pk else native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C)
         h1 = native.conv_fwd(x0, w1, bh.fc1.bias.detach(), bh.fc1.out_features, 1, act=1)
-        w2 = native.pack_fc_weight(bh.fc2.weight.detach(), dt)
+        w2 = pk["w2"] if pk else native.pack_fc_weight(bh.fc2.weight.detach(), dt)
         h2 = native.conv_fwd(h1, w2, bh.fc2.bias.detach(), bh.fc2.out_features, 1, act=1)
-        wp = torch.cat([bp.cls_score.weight.detach(), bp.bbox_pred.weight.detach()])
-        bpb = torch.cat([bp.cls_score.bias.detach(), bp.bbox_pred.bias.detach()])
-        wpp = native.pack_fc_weight(wp, dt)
+        wp = pk["wp"] if pk else torch.cat([bp.cls_score.weight.detach(), bp.bbox_pred.weight.detach()])
+        bpb = pk["bpb"] if pk else torch.cat([bp.cls_score.bias.detach(), bp.bbox_pred.bias.detach()])
+        wpp = pk["wpp"] if pk else native.pack_fc_weight(wp, dt)
         pred = native.conv_fwd(h2, wpp, bpb, wp.shape[0], 1, out_dtype=torch.float32, ldy=self.pred_ld)
-        return {"x0": x0, "h1": h1, "h2": h2, "pred": pred, "wp": wp, "feat_shape": tuple(feat.shape)}
+        st = {"x0": x0, "h1": h1, "h2": h2, "pred": pred, "wp": wp, "feat_shape": tuple(feat.shape)}
+        for k in ("wpt", "w2t", "w1t"):           # the backward's forms ride with the pass's state
+            if k in pk:
+                st[k] = pk[k]
+        return st
 
     def _box_backward(self, st, rois, d_pred, feat_shape_nchw):
         dtype = native.grad_dtype_of(self.compute_dtype)      # operands of the backward products ("f16x3": bf16 pairs)
@@ -300,7 +326,9 @@ class StandardROIHeads(nn.Module):
         # predictor
         dwp = native.conv_wgrad(st["h2"], d_pred_c, NP, 1, operand=dtype).view(NP, -1)
         dbp = native.bias_grad(d_pred, NP)
-        wpt = native.pack_fc_weight(st["wp"], dt, transpose=True, ld=self.pred_ld)
+        wpt = st.get("wpt")
+        if wpt is None:
+            wpt = native.pack_fc_weight(st["wp"], dt, transpose=True, ld=self.pred_ld)
         dh2 = native.conv_fwd(d_pred_c, wpt, None, bh.fc2.out_features, 1)
         dfeat, (dw1, db1, dw2, db2) = self._box_head_backward(st, rois, dh2)
         pgrads = [dw1, db1, dw2, db2, dwp[: K + 1].contiguous(), dbp[: K + 1].contiguous(),
@@ -318,7 +346,9 @@ class StandardROIHeads(nn.Module):
         # fc2
         dw2 = native.conv_wgrad(st["h1"], dh2, bh.fc2.out_features, 1, operand=dtype).view(bh.fc2.out_features, -1)
         db2 = native.bias_grad(dh2, bh.fc2.out_features)
-        w2t = native.pack_fc_weight(bh.fc2.weight.detach(), dt, transpose=True)
+        w2t = st.get("w2t")
+        if w2t is None:
+            w2t = native.pack_fc_weight(bh.fc2.weight.detach(), dt, transpose=True)
         dh1 = native.conv_fwd(dh2, w2t, None, bh.fc2.in_features, 1)
         native.act_bwd_(dh1, st["h1"], 1)
         # fc1 (K axis in (p, c) order inside the kernels, (c, p) in the state dict)
@@ -331,7 +361,9 @@ class StandardROIHeads(nn.Module):
             dw1 = torch.empty_like(bh.fc1.weight)
             native.unpack_fc_wgrad(dw1p, dw1, chw_c=C)
         db1 = native.bias_grad(dh1, bh.fc1.out_features)
-        w1t = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C, transpose=True)
+        w1t = st.get("w1t")
+        if w1t is None:
+            w1t = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C, transpose=True)
         dx0 = native.conv_fwd(dh1, w1t, None, bh.fc1.in_features, 1)
         B, H, W, _ = st["feat_shape"]
         dfeat = native.roi_align_bwd(dx0.view(-1, self.pooled * self.pooled, C), rois, (B, H, W, C), self.pooled,

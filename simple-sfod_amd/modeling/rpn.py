@@ -95,7 +95,9 @@ class _RPNLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rpn, feat_nchw, gt, keys, *params):
-        st = rpn._head_forward(feat_nchw, need_grad=True)
+        pf = rpn._take_prefetched(feat_nchw)        # the head's forward may have run already (``prefetch``): same state
+        st = pf[0] if pf is not None else rpn._head_forward(feat_nchw, need_grad=True)
+        rpn._prefetched_proposals = pf[1] if pf is not None else None
         loss, lab_state = rpn._loss_forward(st, gt, keys)
         ctx.rpn, ctx.st, ctx.lab_state, ctx.gt = rpn, st, lab_state, gt
         rpn._last_head_state = st
@@ -137,6 +139,25 @@ class RPN(nn.Module):
         self.ld = (5 * A + 7) // 8 * 8  # fused head output row stride (fp32), whole 16-byte chunks
         self._flags = None
         self._last_head_state = None
+
+    # ---- the label-free part of a training pass, ahead of time -----------------------------------------
+    @torch.no_grad()
+    def prefetch(self, images, features):
+        """Run what a training-mode ``forward`` does WITHOUT labels -- the head's convolutions and the proposals (decode,
+        sort, top-k, NMS) -- now; the next ``forward`` on the same feature tensor picks both up.  The trainer calls it (through
+        ``model.prefetch_features``) while the teacher is still producing the pseudo labels: only the anchor matching and
+        the losses wait for them.  Same kernels on the same inputs: the results are the ones ``forward`` would compute."""
+        feat = features[self.in_features[0]]
+        st = self._head_forward(feat, need_grad=True)
+        # ... and the weights in the forms the backward multiplies with (no weight changes before this step's update)
+        gdt = native.dt_of_dtype(native.grad_dtype_of(self.compute_dtype))
+        st["w1t"] = native.pack_fc_weight(st["w1"], gdt, transpose=True, ld=self.ld)
+        st["wr"] = native.pack_conv_weight(self.rpn_head.conv.weight.detach(), self.channels, gdt, rot180=True)
+        self._prefetched = (feat, st, self._proposals(st, images.image_sizes))
+
+    def _take_prefetched(self, feat):
+        pf = self.__dict__.pop("_prefetched", None)
+        return (pf[1], pf[2]) if pf is not None and pf[0] is feat else None
 
     # ---- head ----------------------------------------------------------------------------------------
     def _cell(self):
@@ -216,7 +237,9 @@ class RPN(nn.Module):
         # 1x1 heads: weight / bias gradients, then data gradient into the hidden map
         dw1 = native.conv_wgrad(t2, d_out_c, 5 * A, 1, operand=dtype).view(5 * A, C)
         db1 = native.bias_grad(d_out, 5 * A)
-        w1t = native.pack_fc_weight(st["w1"], dt, transpose=True, ld=self.ld)
+        w1t = st.get("w1t")
+        if w1t is None:
+            w1t = native.pack_fc_weight(st["w1"], dt, transpose=True, ld=self.ld)
         dt_ = native.conv_fwd(d_out_c, w1t, None, C, 1)
         native.act_bwd_(dt_, t2, 1)
         # 3x3 conv
@@ -224,7 +247,9 @@ class RPN(nn.Module):
         dt4 = dt_.view(B, Hf, Wf, C)
         dw0 = native.conv_weight_grad(st["feat_g"], dt4, h.conv.weight, operand=dtype)
         db0 = native.bias_grad(dt_, C)
-        wr = native.pack_conv_weight(h.conv.weight.detach(), C, dt, rot180=True)
+        wr = st.get("wr")
+        if wr is None:
+            wr = native.pack_conv_weight(h.conv.weight.detach(), C, dt, rot180=True)
         dfeat = native.conv_fwd(dt4, wr, None, C, 3)
         pgrads = [dw0, db0, dw1[:A].reshape(A, C, 1, 1), db1[:A], dw1[A:].reshape(4 * A, C, 1, 1), db1[A:]]
         return dfeat.permute(0, 3, 1, 2), pgrads
@@ -252,8 +277,10 @@ class RPN(nn.Module):
             with torch.no_grad():
                 st = self._head_forward(feat)
             losses = {}
-        with torch.no_grad():
-            proposals = self._proposals(st, images.image_sizes)
+        proposals = self.__dict__.pop("_prefetched_proposals", None) if want_loss else None
+        if proposals is None:
+            with torch.no_grad():
+                proposals = self._proposals(st, images.image_sizes)
         self._last_head_state = None
         return (proposals.to_instances() if as_instances else proposals), losses
 

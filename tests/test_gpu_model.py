@@ -544,6 +544,40 @@ def test_eval_mode_inference_and_trainer_test_match_oracle(sfod, native, tmp_pat
     assert "bbox" in res2 and os.path.isfile(os.path.join(str(tmp_path), "adabn.pth"))
 
 
+def test_rpn_head_and_proposals_ahead_of_the_pseudo_labels_change_nothing(sfod, native):
+    """``model.prefetch_features`` also runs the label-free part of the student's RPN pass (head convolutions, decode / sort
+    / top-k / NMS) while the teacher is still labelling (modeling/rpn.py::prefetch).  Same kernels on the same inputs: with
+    and without it, two steps from one seed end in bit-identical students and teachers (deterministic mode)."""
+    ma = sfod.modeling.meta_arch
+
+    def run(no_prefetch):
+        old = ma._NO_PREFETCH_RPN
+        ma._NO_PREFETCH_RPN = no_prefetch
+        try:
+            cfg = make_cfg(sfod, opts=["SOLVER.IMS_PER_BATCH_TARGET", "2", "SFOD.SYNTHETIC.HEIGHT", "256",
+                                       "SFOD.SYNTHETIC.WIDTH", "512", "SFOD.SYNTHETIC.NUM_IMAGES", "4",
+                                       "INPUT.MIN_SIZE_TRAIN", "(192,)", "SOLVER.CHECKPOINT_PERIOD", "0",
+                                       "SFOD.DETERMINISTIC", "True"])
+            torch.manual_seed(cfg.SEED)
+            tr = sfod.engine.SourceFreeAdaptiveTeacherTrainer(cfg)
+            used = []
+            pg = tr.model.proposal_generator
+            orig = pg._take_prefetched
+            pg._take_prefetched = lambda feat: (used.append(1), orig(feat))[1]
+            for i in range(2):
+                tr.iter = i
+                tr.run_step()
+            torch.cuda.synchronize()
+            hit = "_prefetched" not in pg.__dict__ and len(used) == 2
+            return tr.optimizer.flat.param.clone(), tr.teacher_flat.param.clone(), hit
+        finally:
+            ma._NO_PREFETCH_RPN = old
+    s1, t1, hit1 = run(False)
+    s0, t0, _ = run(True)
+    assert hit1
+    assert torch.equal(s1, s0) and torch.equal(t1, t0)
+
+
 @pytest.mark.parametrize("depth", [2, 0])
 def test_host_is_held_to_the_configured_number_of_steps_in_flight(sfod, native, depth):
     """``SFOD.MAX_STEPS_IN_FLIGHT`` (engine/trainer.py::_throttle): after every ``run_step`` at most ``depth`` step-end events
