@@ -291,12 +291,13 @@ CHECK_WINDOW = 120      # logged steps (warm-up + timed) the planted-workload ch
 
 
 def run_steps(trainer, first_iter, n):
-    for i in range(n):
-        trainer.iter = first_iter + i
-        trainer.run_step()
-        if STEP_LOG is not None:
-            STEP_LOG.after_step(trainer)
-        trainer.scheduler.step()
+    with trainer.step_stream():          # the trainers' own high-priority stream, as in Trainer.train()
+        for i in range(n):
+            trainer.iter = first_iter + i
+            trainer.run_step()
+            if STEP_LOG is not None:
+                STEP_LOG.after_step(trainer)
+            trainer.scheduler.step()
 
 
 def main():

@@ -406,6 +406,9 @@ def add_native_config(cfg):
     # caching allocator reserves for tensors that crossed streams (engine/trainer.py::_throttle); free while the GPU is the
     # slower side (host enqueue ~5 ms, GPU ~50 ms per step)
     _C.SFOD.MAX_STEPS_IN_FLIGHT = 2
+    # the stream a training step runs on: -1 = the trainer's own high-priority stream (the student's chain is the critical
+    # path; the weight gradients' side stream stays at normal priority), 0 = the caller's stream (engine/trainer.py::_on_step_stream)
+    _C.SFOD.STEP_STREAM_PRIORITY = -1
     # forward-only passes (the teacher): conv1_1 + BatchNorm + ReLU by recomputation (statistics pass, then a pass
     # that stores the activated output directly; sfod_conv_first_fused)
     _C.SFOD.FUSE_FIRST_LAYER = True
