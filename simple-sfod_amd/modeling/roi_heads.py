@@ -22,6 +22,9 @@ from ..structures import Boxes, Instances, ShapeSpec
 from .batched import BatchedDetections, BatchedGT, BatchedProposals
 
 
+_HEAD_WGRAD_STREAM = __import__("os").environ.get("SFOD_HEAD_WGRAD_STREAM", "1") != "0"
+
+
 class ROIPooler(nn.Module):
     """Single-level ROIAlignV2 pooler (aligned=True).  Attributes read from outside
     (source_free_adaptive_teacher_rcnn.py:190-194) are kept."""
@@ -351,16 +354,35 @@ class StandardROIHeads(nn.Module):
             w2t = native.pack_fc_weight(bh.fc2.weight.detach(), dt, transpose=True)
         dh1 = native.conv_fwd(dh2, w2t, None, bh.fc2.in_features, 1)
         native.act_bwd_(dh1, st["h1"], 1)
-        # fc1 (K axis in (p, c) order inside the kernels, (c, p) in the state dict)
-        dw1p = native.conv_wgrad(st["x0"], dh1, bh.fc1.out_features, 1, operand=dtype).view(bh.fc1.out_features, -1)
-        dw1 = native.grad_sink(bh.fc1.weight)
-        if dw1 is not None:     # 103 MB: accumulate straight into the flat gradient, nothing for autograd to add
-            native.unpack_fc_wgrad(dw1p, dw1, chw_c=C, accumulate=True)
-            dw1 = None
+        # fc1 (K axis in (p, c) order inside the kernels, (c, p) in the state dict).  Its weight gradient (the largest of the
+        # heads: 26-420 GFLOP + the 103-411 MB un-packing pass) does not feed the data-gradient path: it runs on a side
+        # stream beside dx0 and the ROIAlign backward -- a latency-bound gather that leaves most of the chip idle -- like the
+        # backbone's weight gradients beside its data-gradient chain (SFOD_HEAD_WGRAD_STREAM=0: one stream)
+        def fc1_param_grads():
+            dw1p = native.conv_wgrad(st["x0"], dh1, bh.fc1.out_features, 1, operand=dtype).view(bh.fc1.out_features, -1)
+            dw1_ = native.grad_sink(bh.fc1.weight)
+            if dw1_ is not None:     # 103 MB: accumulate straight into the flat gradient, nothing for autograd to add
+                native.unpack_fc_wgrad(dw1p, dw1_, chw_c=C, accumulate=True)
+                dw1_ = None
+            else:
+                dw1_ = torch.empty_like(bh.fc1.weight)
+                native.unpack_fc_wgrad(dw1p, dw1_, chw_c=C)
+            return dw1_, native.bias_grad(dh1, bh.fc1.out_features)
+
+        side = None
+        if _HEAD_WGRAD_STREAM and dh1.is_cuda:
+            side = self.__dict__.get("_wgrad_stream")
+            if side is None:
+                side = self.__dict__["_wgrad_stream"] = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record()                          # dh1 (after its ReLU mask) and x0 are complete on the main stream
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                dw1, db1 = fc1_param_grads()
+            for t_ in (st["x0"], dh1):           # main-pool memory read on the side stream
+                t_.record_stream(side)
         else:
-            dw1 = torch.empty_like(bh.fc1.weight)
-            native.unpack_fc_wgrad(dw1p, dw1, chw_c=C)
-        db1 = native.bias_grad(dh1, bh.fc1.out_features)
+            dw1, db1 = fc1_param_grads()
         w1t = st.get("w1t")
         if w1t is None:
             w1t = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C, transpose=True)
@@ -368,6 +390,12 @@ class StandardROIHeads(nn.Module):
         B, H, W, _ = st["feat_shape"]
         dfeat = native.roi_align_bwd(dx0.view(-1, self.pooled * self.pooled, C), rois, (B, H, W, C), self.pooled,
                                      self.box_pooler.scale)
+        if side is not None:                     # the heads' gradients are final before anyone (all-reduce, SGD, autograd) reads them
+            main = torch.cuda.current_stream()
+            main.wait_stream(side)
+            for t_ in (dw1, db1):
+                if t_ is not None:
+                    t_.record_stream(main)
         return dfeat.permute(0, 3, 1, 2), [dw1, db1, dw2, db2]
 
     # ---- label_and_sample_proposals (roi_heads.py:165-215) ----------------------------------------
