@@ -19,10 +19,8 @@ import torch.nn.functional as F
 from .. import native
 from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
 from ..structures import Boxes, Instances, ShapeSpec
+from .offchain import OffChain as _OffChain
 from .batched import BatchedDetections, BatchedGT, BatchedProposals
-
-
-_HEAD_WGRAD_STREAM = __import__("os").environ.get("SFOD_HEAD_WGRAD_STREAM", "1") != "0"
 
 
 class ROIPooler(nn.Module):
@@ -326,14 +324,16 @@ class StandardROIHeads(nn.Module):
         K = self.num_classes
         NP = 5 * K + 1
         d_pred_c = native.cast(d_pred, dtype)
-        # predictor
-        dwp = native.conv_wgrad(st["h2"], d_pred_c, NP, 1, operand=dtype).view(NP, -1)
-        dbp = native.bias_grad(d_pred, NP)
+        # predictor: its parameter gradients beside the data-gradient path (``_OffChain``), like fc2's and fc1's below
+        off = _OffChain(self, d_pred.is_cuda)
+        dwp, dbp = off.run(lambda: (native.conv_wgrad(st["h2"], d_pred_c, NP, 1, operand=dtype).view(NP, -1),
+                                    native.bias_grad(d_pred, NP)), st["h2"], d_pred_c, d_pred)
         wpt = st.get("wpt")
         if wpt is None:
             wpt = native.pack_fc_weight(st["wp"], dt, transpose=True, ld=self.pred_ld)
         dh2 = native.conv_fwd(d_pred_c, wpt, None, bh.fc2.out_features, 1)
-        dfeat, (dw1, db1, dw2, db2) = self._box_head_backward(st, rois, dh2)
+        dfeat, (dw1, db1, dw2, db2) = self._box_head_backward(st, rois, dh2)     # (joins the side stream)
+        off.join(dwp, dbp)
         pgrads = [dw1, db1, dw2, db2, dwp[: K + 1].contiguous(), dbp[: K + 1].contiguous(),
                   dwp[K + 1:].contiguous(), dbp[K + 1:].contiguous()]
         return dfeat, pgrads
@@ -347,8 +347,9 @@ class StandardROIHeads(nn.Module):
         C = self.channels
         native.act_bwd_(dh2, st["h2"], 1)
         # fc2
-        dw2 = native.conv_wgrad(st["h1"], dh2, bh.fc2.out_features, 1, operand=dtype).view(bh.fc2.out_features, -1)
-        db2 = native.bias_grad(dh2, bh.fc2.out_features)
+        off = _OffChain(self, dh2.is_cuda)
+        dw2, db2 = off.run(lambda: (native.conv_wgrad(st["h1"], dh2, bh.fc2.out_features, 1, operand=dtype).view(bh.fc2.out_features, -1),
+                                    native.bias_grad(dh2, bh.fc2.out_features)), st["h1"], dh2)
         w2t = st.get("w2t")
         if w2t is None:
             w2t = native.pack_fc_weight(bh.fc2.weight.detach(), dt, transpose=True)
@@ -369,20 +370,7 @@ class StandardROIHeads(nn.Module):
                 native.unpack_fc_wgrad(dw1p, dw1_, chw_c=C)
             return dw1_, native.bias_grad(dh1, bh.fc1.out_features)
 
-        side = None
-        if _HEAD_WGRAD_STREAM and dh1.is_cuda:
-            side = self.__dict__.get("_wgrad_stream")
-            if side is None:
-                side = self.__dict__["_wgrad_stream"] = torch.cuda.Stream()
-            ev = torch.cuda.Event()
-            ev.record()                          # dh1 (after its ReLU mask) and x0 are complete on the main stream
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                dw1, db1 = fc1_param_grads()
-            for t_ in (st["x0"], dh1):           # main-pool memory read on the side stream
-                t_.record_stream(side)
-        else:
-            dw1, db1 = fc1_param_grads()
+        dw1, db1 = off.run(fc1_param_grads, st["x0"], dh1)     # dh1 (after its ReLU mask) and x0 are complete on the main stream
         w1t = st.get("w1t")
         if w1t is None:
             w1t = native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C, transpose=True)
@@ -390,12 +378,7 @@ class StandardROIHeads(nn.Module):
         B, H, W, _ = st["feat_shape"]
         dfeat = native.roi_align_bwd(dx0.view(-1, self.pooled * self.pooled, C), rois, (B, H, W, C), self.pooled,
                                      self.box_pooler.scale)
-        if side is not None:                     # the heads' gradients are final before anyone (all-reduce, SGD, autograd) reads them
-            main = torch.cuda.current_stream()
-            main.wait_stream(side)
-            for t_ in (dw1, db1):
-                if t_ is not None:
-                    t_.record_stream(main)
+        off.join(dw1, db1, dw2, db2)     # the heads' gradients are final before anyone (all-reduce, SGD, autograd) reads them
         return dfeat.permute(0, 3, 1, 2), [dw1, db1, dw2, db2]
 
     # ---- label_and_sample_proposals (roi_heads.py:165-215) ----------------------------------------

@@ -17,6 +17,7 @@ import torch.nn as nn
 from .. import native
 from ..registry import PROPOSAL_GENERATOR_REGISTRY
 from .batched import BatchedGT, BatchedProposals
+from .offchain import OffChain
 
 
 class BufferList(nn.Module):
@@ -234,9 +235,10 @@ class RPN(nn.Module):
         M = B * Hf * Wf
         t2 = st["t"].view(M, C)
         d_out_c = native.cast(d_out, dtype)
-        # 1x1 heads: weight / bias gradients, then data gradient into the hidden map
-        dw1 = native.conv_wgrad(t2, d_out_c, 5 * A, 1, operand=dtype).view(5 * A, C)
-        db1 = native.bias_grad(d_out, 5 * A)
+        # 1x1 heads: weight / bias gradients (beside the data-gradient path: ``OffChain``), then data gradient into the hidden map
+        off = OffChain(self, d_out.is_cuda)
+        dw1, db1 = off.run(lambda: (native.conv_wgrad(t2, d_out_c, 5 * A, 1, operand=dtype).view(5 * A, C),
+                                    native.bias_grad(d_out, 5 * A)), st["t"], d_out_c, d_out)
         w1t = st.get("w1t")
         if w1t is None:
             w1t = native.pack_fc_weight(st["w1"], dt, transpose=True, ld=self.ld)
@@ -245,12 +247,13 @@ class RPN(nn.Module):
         # 3x3 conv
         h = self.rpn_head
         dt4 = dt_.view(B, Hf, Wf, C)
-        dw0 = native.conv_weight_grad(st["feat_g"], dt4, h.conv.weight, operand=dtype)
-        db0 = native.bias_grad(dt_, C)
+        dw0, db0 = off.run(lambda: (native.conv_weight_grad(st["feat_g"], dt4, h.conv.weight, operand=dtype),
+                                    native.bias_grad(dt_, C)), st["feat_g"], dt_)
         wr = st.get("wr")
         if wr is None:
             wr = native.pack_conv_weight(h.conv.weight.detach(), C, dt, rot180=True)
         dfeat = native.conv_fwd(dt4, wr, None, C, 3)
+        off.join(dw0, db0, dw1, db1)
         pgrads = [dw0, db0, dw1[:A].reshape(A, C, 1, 1), db1[:A], dw1[A:].reshape(4 * A, C, 1, 1), db1[A:]]
         return dfeat.permute(0, 3, 1, 2), pgrads
 
