@@ -632,6 +632,8 @@ class _WeightedLossSum(torch.autograd.Function):
     def backward(ctx, g_weighted, g_total):
         (w,) = ctx.saved_tensors
         g = w * g_total if g_weighted is None else w * (g_total + g_weighted)
+        from ..modeling.offchain import mark_loss_grads_ready
+        mark_loss_grads_ready(g)         # every loss gradient exists from here on (modeling/offchain.py)
         return (None,) + tuple(g[i] for i in range(ctx.n))
 
 

@@ -39,3 +39,29 @@ class OffChain:
         for t_ in outs:
             if t_ is not None:
                 t_.record_stream(main)
+
+
+# ---- a whole head's backward beside the other head's --------------------------------------------------------------------
+# The RPN's and the ROI heads' backward passes are independent until their feature-map gradients are added; autograd runs
+# them one after the other on one stream.  The trainer's weighted-loss node marks the point where every loss gradient
+# exists (``mark_loss_grads_ready``); a head that finds the mark runs its whole backward on its side stream from THERE --
+# not from wherever the main stream has got to -- and the main stream waits for it at the end.
+_loss_grads_ready = None
+
+
+def mark_loss_grads_ready(g):
+    """``g``: the tensor the loss gradients are slices of"""
+    global _loss_grads_ready
+    if _HEAD_WGRAD_STREAM and g.is_cuda:
+        ev = torch.cuda.Event()
+        ev.record()
+        _loss_grads_ready = (ev, g.untyped_storage().data_ptr())
+
+
+def take_loss_grads_ready(grad):
+    """the mark, if ``grad`` is one of the gradients it was made for (a stale mark of another backward is dropped)"""
+    global _loss_grads_ready
+    m, _loss_grads_ready = _loss_grads_ready, None
+    if m is None or not grad.is_cuda or grad.untyped_storage().data_ptr() != m[1]:
+        return None
+    return m[0]

@@ -17,7 +17,7 @@ import torch.nn as nn
 from .. import native
 from ..registry import PROPOSAL_GENERATOR_REGISTRY
 from .batched import BatchedGT, BatchedProposals
-from .offchain import OffChain
+from .offchain import OffChain, take_loss_grads_ready
 
 
 class BufferList(nn.Module):
@@ -95,22 +95,43 @@ class _RPNLossFn(torch.autograd.Function):
     """features -> (loss_rpn_cls, loss_rpn_loc); backward: loss grads -> 1x1 heads -> 3x3 conv."""
 
     @staticmethod
-    def forward(ctx, rpn, feat_nchw, gt, keys, *params):
+    def forward(ctx, rpn, feat_nchw, gt, keys, weights, *params):
+        """``weights``: the two loss weights (python floats) -- applied here, as fp32 scalar multiplications like the
+        ``loss * weight`` they replace, so that the node's incoming gradients are the trainer's loss gradients themselves"""
         pf = rpn._take_prefetched(feat_nchw)        # the head's forward may have run already (``prefetch``): same state
         st = pf[0] if pf is not None else rpn._head_forward(feat_nchw, need_grad=True)
         rpn._prefetched_proposals = pf[1] if pf is not None else None
         loss, lab_state = rpn._loss_forward(st, gt, keys)
-        ctx.rpn, ctx.st, ctx.lab_state, ctx.gt = rpn, st, lab_state, gt
+        ctx.rpn, ctx.st, ctx.lab_state, ctx.gt, ctx.weights = rpn, st, lab_state, gt, weights
         rpn._last_head_state = st
-        return loss[0].clone(), loss[1].clone()
+        return loss[0] * weights[0], loss[1] * weights[1]
 
     @staticmethod
     def backward(ctx, g_cls, g_loc):
         rpn, st = ctx.rpn, ctx.st
-        gs = torch.stack([g_cls.reshape(()), g_loc.reshape(())]).float().contiguous()
-        dfeat, pgrads = rpn._loss_backward(st, ctx.lab_state, ctx.gt, gs)
+
+        def run():
+            gs = torch.stack([(g_cls * ctx.weights[0]).reshape(()), (g_loc * ctx.weights[1]).reshape(())]).float().contiguous()
+            return rpn._loss_backward(st, ctx.lab_state, ctx.gt, gs)
+
+        # beside the ROI heads' backward when the trainer marked where the loss gradients became available (offchain.py)
+        ev = take_loss_grads_ready(g_cls)
+        side = OffChain(rpn, g_cls.is_cuda).side if ev is not None else None
+        if side is not None:
+            main = torch.cuda.current_stream()
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                dfeat, pgrads = run()
+            for t_ in (g_cls, g_loc):
+                t_.record_stream(side)
+            main.wait_stream(side)
+            for t_ in [dfeat] + list(pgrads):
+                if t_ is not None:
+                    t_.record_stream(main)
+        else:
+            dfeat, pgrads = run()
         ctx.st = ctx.lab_state = None
-        return (None, dfeat, None, None) + tuple(pgrads)
+        return (None, dfeat, None, None, None) + tuple(pgrads)
 
 
 @PROPOSAL_GENERATOR_REGISTRY.register()
@@ -270,12 +291,12 @@ class RPN(nn.Module):
             if keys is None:
                 keys = torch.randint(0, 2 ** 31 - 1, (B, Hf * Wf * self.num_anchors), dtype=torch.int32,
                                      device=feat.device)
-            l_cls, l_loc = _RPNLossFn.apply(self, feat, gt, keys, *self.rpn_head.params())
-            st = self._last_head_state
             # losses() applies loss_weight, PseudoLabRPN.forward applies it again (rpn.py:49)
             twice = isinstance(self, PseudoLabRPN)
-            losses = {"loss_rpn_cls": l_cls * self.loss_weight["loss_rpn_cls"] ** (2 if twice else 1),
-                      "loss_rpn_loc": l_loc * self.loss_weight["loss_rpn_loc"] ** (2 if twice else 1)}
+            wts = (self.loss_weight["loss_rpn_cls"] ** (2 if twice else 1), self.loss_weight["loss_rpn_loc"] ** (2 if twice else 1))
+            l_cls, l_loc = _RPNLossFn.apply(self, feat, gt, keys, wts, *self.rpn_head.params())
+            st = self._last_head_state
+            losses = {"loss_rpn_cls": l_cls, "loss_rpn_loc": l_loc}
         else:
             with torch.no_grad():
                 st = self._head_forward(feat)
