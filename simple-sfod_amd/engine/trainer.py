@@ -33,7 +33,6 @@ import torch.distributed as dist
 from .. import native
 from ..data.synthetic import TwoCropLoader
 from ..modeling import build_model
-from ..modeling import meta_arch as _meta_arch
 from ..modeling.batched import BatchedGT
 from ..structures import Boxes, Instances
 from .solver import FlatModelState, WarmupMultiStepLR, build_optimizer
@@ -862,7 +861,6 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         _throttle(self)
         if hasattr(self.model, "drop_prefetched"):
             self.model.drop_prefetched()
-            self.model_teacher.drop_prefetched()
         start = time.perf_counter()
         unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
         if not cfg.WEAK_STRONG_AUGMENT:
@@ -884,17 +882,6 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
             if side is None:
                 side = self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)
             side.wait_stream(main)       # EMA'd teacher weights, input frames, last step's readers of side buffers
-            # the teacher's chain is the longer one at the join (its heads run on every proposal): the packing of its box
-            # head's weights (fc1: 103-411 MB) leaves that chain -- a third stream packs them beside the two backbones, the
-            # teacher's box head waits for the event (SFOD_NO_PREFETCH_RPN=1 switches this off with the other prefetches)
-            th = self.model_teacher.roi_heads
-            if hasattr(th, "prefetch_weights") and not _meta_arch._NO_PREFETCH_RPN:
-                pk = self.__dict__.get("_pack_stream")
-                if pk is None:
-                    pk = self._pack_stream = torch.cuda.Stream(device=self.device)
-                pk.wait_stream(main)
-                with torch.cuda.stream(pk):
-                    th.prefetch_weights(forward_only=True, ready=torch.cuda.Event())
             with torch.cuda.stream(side), stage("teacher"):
                 pseudo = self._teacher_pass(unlabel_data_k)
             with self._student_pass_bn_updates(), stage("student_forward"):

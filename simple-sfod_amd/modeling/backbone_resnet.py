@@ -31,6 +31,7 @@ import torch
 import torch.nn as nn
 
 from .. import native
+from . import offchain as _offchain
 from ..registry import BACKBONE_REGISTRY
 from ..structures import ShapeSpec
 
@@ -493,7 +494,7 @@ class ResNet(nn.Module):
         if self.wgrad_stream and torch.cuda.is_available():
             st = self.__dict__.get("_side_stream")
             if st is None:
-                st = self.__dict__["_side_stream"] = torch.cuda.Stream()
+                st = self.__dict__["_side_stream"] = _offchain.shared_stream() if _offchain._SHARED else torch.cuda.Stream()
             self._side = st
         # only the last requested feature feeds the heads on the C4 path; earlier ones would add here
         live_names = [n for n in self.stage_names if n not in self.frozen]

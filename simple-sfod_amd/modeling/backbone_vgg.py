@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from .. import native
+from . import offchain as _offchain
 from ..registry import BACKBONE_REGISTRY
 from ..structures import ShapeSpec
 
@@ -326,7 +327,7 @@ class vgg_backbone(nn.Module):
         if self.wgrad_stream and dz_dev_is_cuda(out_grads):
             side = self.__dict__.get("_side_stream")
             if side is None:
-                side = self.__dict__["_side_stream"] = torch.cuda.Stream()
+                side = self.__dict__["_side_stream"] = _offchain.shared_stream() if _offchain._SHARED else torch.cuda.Stream()
         mid_hook = getattr(self, "_mid_backward", None)
         mid_layer = self._first_layer_of_stage(getattr(self, "_mid_stage", 2)) if mid_hook is not None else -1
         for li in range(len(self._plan) - 1, -1, -1):

@@ -3,7 +3,22 @@ import os
 
 import torch
 
+_SHARED = os.environ.get("SFOD_SHARED_SIDE_STREAM", "1") != "0"
 _HEAD_WGRAD_STREAM = os.environ.get("SFOD_HEAD_WGRAD_STREAM", "1") != "0"      # 0: everything on one stream (A/B hook)
+
+
+_shared = {}
+
+
+def shared_stream():
+    """ONE side stream per device for everything that runs beside a data-gradient path (the backbones' weight gradients, the
+    heads' parameter gradients, the RPN's backward): HIP multiplexes streams onto 4 hardware queues, and a stream per module
+    (six streams in a step) cost the 1024 x 2048 configuration 4.5 % (profiles/r5_prefetch_label_free_work.txt)."""
+    dev = torch.cuda.current_device()
+    st = _shared.get(dev)
+    if st is None:
+        st = _shared[dev] = torch.cuda.Stream()
+    return st
 
 
 class OffChain:
@@ -15,7 +30,7 @@ class OffChain:
     def __init__(self, owner, on):
         self.side = None
         if on and _HEAD_WGRAD_STREAM:
-            self.side = owner.__dict__.get("_wgrad_stream")
+            self.side = shared_stream() if _SHARED else owner.__dict__.get("_wgrad_stream")
             if self.side is None:
                 self.side = owner.__dict__["_wgrad_stream"] = torch.cuda.Stream()
 

@@ -273,14 +273,12 @@ class StandardROIHeads(nn.Module):
 
     # ---- the training pass's weights, packed ahead of time ---------------------------------------------------------------
     @torch.no_grad()
-    def prefetch_weights(self, forward_only=False, ready=None):
+    def prefetch_weights(self):
         """Pack the box head's and predictor's weights in the forms the training pass multiplies with -- forward and
         backward -- NOW; the next ``_box_forward`` takes them instead of packing (fc1 is 103 MB: four launches of 60-90 us
         that otherwise sit between the pseudo labels and the losses).  The trainer calls it (``model.prefetch_features``)
         while the teacher is still labelling; nothing changes the weights before this step's update, and what is not
-        taken by then is dropped at the start of the next step (``drop_prefetched``).  ``forward_only``: a pass without a
-        backward (the teacher's); ``ready``: the caller packs on another stream than the one that will run the pass and
-        records this event behind the packing -- ``_box_forward`` waits for it."""
+        taken by then is dropped at the start of the next step (``drop_prefetched``)."""
         dt = native.dt_of_dtype(self.compute_dtype)
         gdt = native.dt_of_dtype(native.grad_dtype_of(self.compute_dtype))
         bh, bp, C = self.box_head, self.box_predictor, self.channels
@@ -289,15 +287,10 @@ class StandardROIHeads(nn.Module):
             "w1": native.pack_fc_weight(bh.fc1.weight.detach(), dt, chw_c=C),
             "w2": native.pack_fc_weight(bh.fc2.weight.detach(), dt),
             "wp": wp, "bpb": torch.cat([bp.cls_score.bias.detach(), bp.bbox_pred.bias.detach()]),
-            "wpp": native.pack_fc_weight(wp, dt)}
-        if not forward_only:
-            self._packed.update({
-                "wpt": native.pack_fc_weight(wp, gdt, transpose=True, ld=self.pred_ld),
-                "w2t": native.pack_fc_weight(bh.fc2.weight.detach(), gdt, transpose=True),
-                "w1t": native.pack_fc_weight(bh.fc1.weight.detach(), gdt, chw_c=C, transpose=True)})
-        if ready is not None:
-            ready.record()
-            self._packed["ready"] = ready
+            "wpp": native.pack_fc_weight(wp, dt),
+            "wpt": native.pack_fc_weight(wp, gdt, transpose=True, ld=self.pred_ld),
+            "w2t": native.pack_fc_weight(bh.fc2.weight.detach(), gdt, transpose=True),
+            "w1t": native.pack_fc_weight(bh.fc1.weight.detach(), gdt, chw_c=C, transpose=True)}
 
     # ---- box branch: ROIAlign -> fc1 -> fc2 -> fused (cls_score | bbox_pred) -------------------------
     def _box_forward(self, feat_nchw, rois):
@@ -307,8 +300,6 @@ class StandardROIHeads(nn.Module):
         bh, bp = self.box_head, self.box_predictor
         C, PP = self.channels, self.pooled * self.pooled
         pk = self.__dict__.pop("_packed", None) or {}
-        if "ready" in pk:                 # packed on another stream (the teacher's weights: engine/trainer.py)
-            torch.cuda.current_stream().wait_event(pk["ready"])
         pooled = native.roi_align_fwd(feat, rois, self.pooled, self.box_pooler.scale)
         R = pooled.shape[0]
         x0 = pooled.view(R, PP * C)
