@@ -421,3 +421,18 @@ def test_teacher_pass_defers_batchnorm_only_where_it_pays(sfod, monkeypatch):
     monkeypatch.setattr(sfod.native, "conv_fwd_bnin_supported", lambda y, w, cout: False)
     bb.fuse_bn_input = True
     assert deferred(8) == []
+
+
+def test_offchain_helpers_are_plain_calls_without_a_gpu(sfod):
+    """modeling/offchain.py on CPU tensors: ``run`` is the call itself, ``join`` nothing, a loss-gradient mark is neither made
+    nor taken -- the heads' backward code paths are the single-stream ones (what the CPU-side oracle comparisons of the
+    modules' host logic rely on)."""
+    oc = sfod.modeling.offchain
+    off = oc.OffChain(object(), False)
+    assert off.side is None
+    seen = []
+    assert off.run(lambda: (seen.append(1), 7)[1], torch.zeros(2)) == 7 and seen == [1]
+    off.join(torch.zeros(1), None)
+    g = torch.arange(4.0)
+    oc.mark_loss_grads_ready(g)
+    assert oc.take_loss_grads_ready(g[1]) is None
