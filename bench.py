@@ -54,12 +54,11 @@ PARITY_DTYPE = {"vgg": "bf16x3", "r101": "f16x3"}
 OTHER_PARITY = {"vgg": {"bf16x3": ["f16x3", "fp32"], "f16x3": ["fp32"]}, "r101": {"f16x3": ["fp32"]}}
 # "planted-label" mode (BASELINE.md section 3 / SURVEY 8d: "teacher box-predictor bias is set so ~10-30 boxes/image pass"):
 # seeded random weights give no detection above 0.8, so the class logits are spread by a moderate scale on cls_score's
-# weights (PLANT) and the BACKGROUND bias is calibrated at start-up, by bisection over untimed teacher passes on the bench's
-# own frames, until the mean number of pseudo labels per image is PLANT_TARGET (plant_labels below).  The realised count
+# weights and the BACKGROUND bias is calibrated at start-up, by bisection over untimed teacher passes on the bench's
+# own frames, until the mean number of pseudo labels per image is the target.  The realised count
 # and the student's loss_cls_pseudo over warm-up + timed steps are asserted and reported in `config`.
-PLANT = {"vgg": 16.0, "r101": 4.0}      # gpurun_out/r5s1 (profiles/r5_planted_label_calibration.txt): smaller scales leave < 20 boxes at any bias
-PLANT_TARGET = 20.0
-PLANT_RANGE = (10.0, 30.0)
+# The head itself lives in the package (simple-sfod_amd/engine/planted.py: SCALE vgg x16 / r101 x4, TARGET 20, RANGE 10-30) so
+# that tests/test_gpu_fullsize.py and tests/test_gpu_pseudo_labels.py gate exactly the head this file times.
 # the committed PMC captures (profiles/pmc_hbm_traffic_latest.json: VGG16 bf16x3; pmc_hbm_traffic_r101_latest.json: R101 f16x3)
 # were taken on exactly these run configurations
 PMC_CAPTURE = {"trainer": "source_free", "res": "r600", "batch": 8,
@@ -223,43 +222,6 @@ def build_trainer(sfod, args, dtype, world, rank, local_rank):
     return cfg, trainer
 
 
-def plant_labels(trainer, scale, target=PLANT_TARGET, note=lambda m: None, bias=None):
-    """Planted-label mode: cls_score.weight *= scale (spreads the class logits of the random-weight head), then the
-    background bias is bisected over untimed teacher passes on the loader's frames until the mean pseudo-label count per
-    image is ``target``; student and teacher get the same values (teacher <- student copy, as at construction).
-    -> dict(scale, background_bias, pseudo labels per image on the calibration frames: mean / min / max)."""
-    import torch
-    bp = trainer.model.roi_heads.box_predictor
-    K = bp.cls_score.bias.numel() - 1
-    batches = [next(trainer._data_loader_iter)[1] for _ in range(2)]      # weak views of 2 batches
-
-    def counts(delta):
-        with torch.no_grad():
-            bp.cls_score.bias[K] = delta
-            trainer._copy_main_model()
-            c = [trainer._teacher_pass([dict(d) for d in b]).count.float() for b in batches]
-        trainer.storage._pending.clear()
-        return torch.cat(c)
-
-    with torch.no_grad():
-        bp.cls_score.weight.mul_(scale)
-    lo, hi = -40.0, 40.0          # more background bias -> fewer foreground detections: the count is monotone in it
-    if bias is not None:          # --plant-bias: a bias calibrated by an earlier run of the same configuration (profiling runs:
-        lo = hi = float(bias)     # the ~50 teacher passes of the bisection stay out of the kernel trace)
-    for _ in range(0 if bias is not None else 24):
-        mid = 0.5 * (lo + hi)
-        if counts(mid).mean().item() > target:
-            lo = mid
-        else:
-            hi = mid
-    c = counts(0.5 * (lo + hi))
-    out = {"cls_score_weight_scale": scale, "background_bias": round(0.5 * (lo + hi), 4),
-           "calibration_pseudo_labels_per_image": {"mean": round(c.mean().item(), 2), "min": int(c.min().item()),
-                                                   "max": int(c.max().item()), "images": int(c.numel())}}
-    note(f"planted labels: {out}")
-    return out
-
-
 class StepLog:
     """per-step device scalars of the run (no host sync until ``summary``): pseudo labels per image, loss_cls_pseudo"""
 
@@ -317,8 +279,10 @@ def main():
                          "training step of faster_rcnn_VGG_cityscapes_source_new.yaml (BASELINE config #2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the reduced-precision (bf16) secondary block")
+    ap.add_argument("--no-other-shapes", action="store_true",
+                    help="skip the RFULL / one-frame-per-GPU child runs of the default configuration")
     ap.add_argument("--no-planted", action="store_true")
-    ap.add_argument("--plant-scale", type=float, default=0.0, help="planted-label mode: scale on cls_score.weight (default: PLANT)")
+    ap.add_argument("--plant-scale", type=float, default=0.0, help="planted-label mode: scale on cls_score.weight (default: engine/planted.py SCALE)")
     ap.add_argument("--plant-bias", type=float, default=None,
                     help="planted-label mode: use this background bias instead of calibrating it (profiling runs; take it "
                          "from config.planted_labels.background_bias of an unprofiled run of the same configuration)")
@@ -374,8 +338,8 @@ def main():
     planted = None
     global STEP_LOG
     if args.trainer != "base" and not args.no_planted:
-        planted = plant_labels(trainer, args.plant_scale if args.plant_scale else PLANT[args.model], note=note,
-                               bias=args.plant_bias)
+        planted = sfod.engine.planted.plant_labels(trainer, args.plant_scale if args.plant_scale else
+                                                   sfod.engine.planted.SCALE[args.model], note=note, bias=args.plant_bias)
         if world > 1:       # every rank calibrated on its own shard: take rank 0's bias everywhere (one broadcast, untimed)
             bp = trainer.model.roi_heads.box_predictor
             with torch.no_grad():
@@ -586,6 +550,37 @@ def main():
         elif not secondary:
             secondary = None
     note("secondary block done")
+    # ---- the other shapes BASELINE.md section 3 names for this config (R600 AND RFULL, B = 1 AND B = 8 per GPU), measured by
+    # child processes of the default run like the other modes: 1024x2048 network tensors at B = 8, and the yaml's literal
+    # one frame per GPU (IMS_PER_BATCH_TARGET 1, reference yaml :33-46).  Same arithmetic mode, same planted head recipe.
+    other_shapes = None
+    if (not args.no_secondary and not args.no_other_shapes and world == 1 and args.res == "r600" and args.batch == 8
+            and args.trainer != "base" and not args.opts):
+        import subprocess
+        other_shapes = []
+        for label, extra in (("one frame per GPU (the yaml's IMS_PER_BATCH_TARGET 1), 600x1200 tensors",
+                              ["--batch", "1", "--res", "r600", "--steps", "120", "--warmup", "10"]),
+                             ("B = 8 per GPU, 1024x2048 network tensors (INPUT.MIN_SIZE_TRAIN (1024,), MAX 2048)",
+                              ["--batch", "8", "--res", "full", "--steps", "12", "--warmup", "3"]))[:2 if args.model == "vgg" else 1]:
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", args.dtype, "--model", args.model, "--trainer", args.trainer,
+                   "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"] + extra
+            cmd += (["--no-planted"] if args.no_planted else [])
+            cmd += ["--plant-scale", str(args.plant_scale)] if args.plant_scale else []
+            try:
+                r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+                d2 = json.loads(r.stdout.decode().strip().splitlines()[-1])
+                c2 = d2["config"]
+                other_shapes.append({"shape": label, "dtype": d2["dtype"], "value": d2["value"], "unit": "images/s",
+                                     "batch_per_gpu": c2["batch_per_gpu"], "steps": d2["steps"], "warmup": d2["warmup"],
+                                     "ms_per_step": d2["ms_per_step"], "step_tflops_per_gpu": d2["step_tflops_per_gpu"],
+                                     "peak_hbm_reserved_GB": c2["peak_hbm_reserved_GB"],
+                                     "peak_hbm_allocated_GB": c2["peak_hbm_allocated_GB"],
+                                     "pseudo_labels_per_image": c2.get("pseudo_labels_per_image", {}).get("mean"),
+                                     "note": "measured by a child process of this run (same mode, same planted-head recipe); "
+                                             "never `value`"})
+            except Exception as e:
+                other_shapes.append({"shape": label, "error": repr(e)[:200]})
+        note("other shapes done")
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -651,10 +646,10 @@ def main():
         # run in ``config`` beside the window's figures.
         win = step_log.summary(first=CHECK_WINDOW)
         pl, lc = win.get("pseudo_labels_per_image"), win.get("loss_cls_pseudo")
-        assert pl is not None and PLANT_RANGE[0] <= pl["mean"] <= PLANT_RANGE[1], f"pseudo labels per image {pl}"
+        assert pl is not None and sfod.engine.planted.RANGE[0] <= pl["mean"] <= sfod.engine.planted.RANGE[1], f"pseudo labels per image {pl}"
         assert lc is not None and 0.0 < lc["max"] < 5.0, f"loss_cls_pseudo {lc}"
         out["config"]["workload_check"] = {"window_steps": pl["steps"], "pseudo_labels_per_image": pl, "loss_cls_pseudo": lc,
-                                           "rule": f"mean count in {list(PLANT_RANGE)}, max loss < 5 over the first "
+                                           "rule": f"mean count in {list(sfod.engine.planted.RANGE)}, max loss < 5 over the first "
                                                    f"{CHECK_WINDOW} logged steps (the whole run's figures are beside it in "
                                                    "config: self-training on random weights loses its pseudo labels after "
                                                    "several hundred steps -- 1500 steps: mean 4.7, none at the end; the "
@@ -669,6 +664,8 @@ def main():
         out["reduced_precision_mode"] = secondary
     if other_modes:
         out["other_parity_modes"] = other_modes
+    if other_shapes:
+        out["other_shapes"] = other_shapes
     if timer is not None:
         summ = timer.summary()
         if args.kernel_table:

@@ -418,6 +418,9 @@ int sfod_frcnn_candidates(const float* pred, int ld, int B, int P, int K, const 
                           const int32_t* prop_count, const int32_t* image_sizes,
                           float score_thresh, float* cand_boxes, float* cand_scores,
                           int32_t* cand_count, void* stream);
+/* d2 FastRCNNOutputLayers.predict_probs (reached from daod/modeling/roi_heads/source_free_fast_rcnn.py:16-17): row
+ * softmax of scores [R, ld] (K+1 class scores per row) -> probs [R, K+1], in step 1's operation order. */
+int sfod_predict_probs(const float* scores, int ld, int R, int K, float* probs, void* stream);
 /* step 2 (after sorting scores): gather sorted candidates, classes, coordinate-offset boxes
  * and the torchvision strategy flag (mode[b]=1: coordinate trick, 0: per-class). */
 int sfod_frcnn_prepare_nms(const float* cand_boxes, const float* sorted_scores,

@@ -210,6 +210,8 @@ def get_cfg():
     _C.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT = 1.0
     _C.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS = (10.0, 10.0, 5.0, 5.0)
     _C.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA = 0.0
+    # d2's default.  The library's ROIAlign serves <= 16 forward and <= 8 backward: a TRAINING config has to set <= 8
+    # (the three named yamls set 7); StandardROIHeads raises at the first training forward otherwise.
     _C.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION = 14
     _C.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO = 0
     _C.MODEL.ROI_BOX_HEAD.POOLER_TYPE = "ROIAlignV2"

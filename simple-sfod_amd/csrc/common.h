@@ -79,6 +79,19 @@ __device__ __forceinline__ void split_load8(const split_t* p, float* out) {   //
     out[2 * i + 1] = __uint_as_float(hw[i] & 0xffff0000u) + __uint_as_float(lw[i] & 0xffff0000u);
   }
 }
+// 16-byte store, optionally non-temporal (`global_store_dwordx4 ... nt`): a write-once output stream that nobody re-reads
+// soon should not push re-used lines (a feature map gathered by many workgroups) out of L2
+typedef uint32_t sfod_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ void store16(void* p, uint4 v) {
+  if constexpr (NT) {
+    sfod_u32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<sfod_u32x4*>(p));
+  } else {
+    *reinterpret_cast<uint4*>(p) = v;
+  }
+}
+template <bool NT = false>
 __device__ __forceinline__ void split_store8(split_t* p, const float* in) {
   union { bf16_t h[8]; uint4 v; } hi, lo;
 #pragma unroll
@@ -86,8 +99,8 @@ __device__ __forceinline__ void split_store8(split_t* p, const float* in) {
     hi.h[i] = (bf16_t)in[i];
     lo.h[i] = (bf16_t)(in[i] - (float)hi.h[i]);
   }
-  reinterpret_cast<uint4*>(p)[0] = hi.v;
-  reinterpret_cast<uint4*>(p)[1] = lo.v;
+  store16<NT>(p, hi.v);
+  store16<NT>(reinterpret_cast<uint4*>(p) + 1, lo.v);
 }
 // ---- SFOD_F16X3 storage: the same layout with IEEE half pairs, hi = f16(v), lo = f16(v - hi) (include/sfod_hip.h).
 // |v| beyond the half range (infinities included) saturates at exactly +-65504, lo = 0 (NaN stays NaN).
@@ -118,12 +131,13 @@ __device__ __forceinline__ void split_load8(const splith_t* p, float* out) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) out[i] = (float)hi.h[i] + (float)lo.h[i];
 }
+template <bool NT = false>
 __device__ __forceinline__ void split_store8(splith_t* p, const float* in) {
   union { f16_t h[8]; uint4 v; } hi, lo;
 #pragma unroll
   for (int i = 0; i < 8; ++i) f16_pair(in[i], hi.h[i], lo.h[i]);
-  reinterpret_cast<uint4*>(p)[0] = hi.v;
-  reinterpret_cast<uint4*>(p)[1] = lo.v;
+  store16<NT>(p, hi.v);
+  store16<NT>(reinterpret_cast<uint4*>(p) + 1, lo.v);
 }
 
 // scalar access to logical element idx of a split tensor whose 8-groups start at `base`

@@ -1208,6 +1208,32 @@ extern "C" int sfod_frcnn_candidates(const float* pred, int ld, int B, int P, in
   return sfod_check_launch("frcnn_candidates");
 }
 
+// FastRCNNOutputLayers.predict_probs (d2; reached from source_free_fast_rcnn.py:16-17 convert_bbox_scores): the row
+// softmax over K + 1 class scores, in the operation order of k_frcnn_candidates above (max, exp(x - max), sum in class
+// order, one division per class) -- the probabilities the Instances-level API returns ARE the ones the fused teacher
+// post-processing thresholds.
+__global__ void __launch_bounds__(256)
+k_predict_probs(const float* __restrict__ scores, int ld, int R, int K, float* __restrict__ probs) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const float* row = scores + r * ld;
+  float prob[KMAX + 1];
+  float m = row[0];
+  for (int c = 1; c <= K; ++c) m = fmaxf(m, row[c]);
+  float ssum = 0.f;
+  for (int c = 0; c <= K; ++c) { prob[c] = expf(row[c] - m); ssum += prob[c]; }
+  for (int c = 0; c <= K; ++c) probs[r * (K + 1) + c] = prob[c] / ssum;
+}
+
+extern "C" int sfod_predict_probs(const float* scores, int ld, int R, int K, float* probs, void* stream) {
+  SFOD_REQUIRE_EXTENTS("predict_probs", ld, R, K);
+  SFOD_REQUIRE(K >= 1 && K <= KMAX && ld >= K + 1, "predict_probs K / ld");
+  if (R == 0) return 0;
+  SFOD_REQUIRE(scores != nullptr && probs != nullptr, "predict_probs: null argument");
+  hipLaunchKernelGGL(k_predict_probs, dim3(cdiv(R, 256)), dim3(256), 0, (hipStream_t)stream, scores, ld, R, K, probs);
+  return sfod_check_launch("predict_probs");
+}
+
 __global__ void __launch_bounds__(256)
 k_frcnn_gather(const float* __restrict__ cboxes, const int32_t* __restrict__ sidx,
                const int32_t* __restrict__ ccount, int n, int K, float* __restrict__ sboxes,

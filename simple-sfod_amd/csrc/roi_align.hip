@@ -63,6 +63,9 @@ template <> struct RVec<float> {
   static __device__ __forceinline__ void store(float* p, const float* o) {
     *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
   }
+  static __device__ __forceinline__ void store_nt(float* p, const float* o) {
+    store16<true>(p, make_uint4(__float_as_uint(o[0]), __float_as_uint(o[1]), __float_as_uint(o[2]), __float_as_uint(o[3])));
+  }
 };
 template <> struct RVec<bf16_t> {
   static constexpr int N = 8;
@@ -81,6 +84,12 @@ template <> struct RVec<bf16_t> {
     for (int i = 0; i < 8; ++i) u.h[i] = (bf16_t)o[i];
     *reinterpret_cast<uint4*>(p) = u.v;
   }
+  static __device__ __forceinline__ void store_nt(bf16_t* p, const float* o) {
+    union { bf16_t h[8]; uint4 v; } u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u.h[i] = (bf16_t)o[i];
+    store16<true>(p, u.v);
+  }
 };
 
 // SFOD_BF16X3 features / pooled outputs: 8 logical channels per lane (one 32-byte (8 hi | 8 lo) group)
@@ -88,11 +97,13 @@ template <> struct RVec<split_t> {
   static constexpr int N = 8;
   static __device__ __forceinline__ void load(const split_t* p, float* o) { split_load8(p, o); }
   static __device__ __forceinline__ void store(split_t* p, const float* o) { split_store8(p, o); }
+  static __device__ __forceinline__ void store_nt(split_t* p, const float* o) { split_store8<true>(p, o); }
 };
 template <> struct RVec<splith_t> {     // SFOD_F16X3: the same with half pairs
   static constexpr int N = 8;
   static __device__ __forceinline__ void load(const splith_t* p, float* o) { split_load8(p, o); }
   static __device__ __forceinline__ void store(splith_t* p, const float* o) { split_store8(p, o); }
+  static __device__ __forceinline__ void store_nt(splith_t* p, const float* o) { split_store8<true>(p, o); }
 };
 
 // Forward.  One workgroup per ROI; a lane owns one 16-byte channel vector (NHWC: a bilinear corner
@@ -182,7 +193,7 @@ template <> struct Pair<splith_t> {
   static __device__ __forceinline__ void store(splith_t* p, float, float) { *reinterpret_cast<uint2*>(p) = make_uint2(0u, 0u); }
 };
 
-template <typename T, int P>
+template <typename T, int P, bool NT>
 __global__ void __launch_bounds__(256)
 k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float* __restrict__ rois, float scale,
                     T* __restrict__ out, int R, int ncb) {
@@ -280,7 +291,8 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
       for (int pw = 0; pw < P; ++pw) {
 #pragma unroll
         for (int i = 0; i < V; ++i) o[pw][i] *= inv;
-        RVec<T>::store(orow + (int64_t)(ph * P + pw) * C + c * V, o[pw]);
+        if constexpr (NT) RVec<T>::store_nt(orow + (int64_t)(ph * P + pw) * C + c * V, o[pw]);
+        else RVec<T>::store(orow + (int64_t)(ph * P + pw) * C + c * V, o[pw]);
       }
     }
   }
@@ -296,6 +308,8 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
 // pixel and channel (a wavefront adds 256 contiguous bytes): ~5x fewer atomics than the scatter.
 #define ROI_MAXP 8
 #define ROI_MAXP_FWD 16
+#define ROI_CBLK_DEFAULT 256
+#define ROI_NT_DEFAULT 0
 
 template <typename T>
 __global__ void __launch_bounds__(256)
@@ -567,27 +581,30 @@ extern "C" int sfod_roi_align_fwd(const void* feat, int B, int H, int W, int C, 
   SFOD_REQUIRE(dt == SFOD_F32 || dt == SFOD_BF16 || sfod_is_pairs(dt), "roi_align: unknown dt");
   SFOD_REQUIRE(feat != nullptr && rois != nullptr && out != nullptr, "roi_align: null argument (feat, rois, out)");
   SFOD_REQUIRE(sfod_prod_fits({B, H, W, C}, 1LL << 40) && sfod_prod_fits({R, C, pooled, pooled}, 1LL << 40) &&
-               sfod_prod_fits({R, C / 256 + 1}), "roi_align: oversized problem");
+               sfod_prod_fits({R, C / 8 + 1}), "roi_align: oversized problem");
   SFOD_REQUIRE(C % ((dt == SFOD_F32) ? 4 : 8) == 0, "roi_align: C must be a multiple of the 16-byte vector");
   hipStream_t s = (hipStream_t)stream;
   const size_t lds = (size_t)pooled * (H + W) * 4 + 4 * pooled * 4;
   if (pooled == 7 && lds <= 48 * 1024) {       // the configs' POOLER_RESOLUTION: separable form
-    // channel blocks of 256 (one L2-resident slice of the feature map at a time): 1024 channels -> 4, 512 -> 2
-    static const int cblocks = []() { const char* e = getenv("SFOD_ROI_CBLOCKS"); return e ? atoi(e) : 1; }();    // 0: one workgroup per box (A/B)
-    const int ncb = (cblocks && C % 256 == 0 && C > 256) ? C / 256 : 1;
-    const dim3 grid((unsigned)R * ncb);
-    if (dt == SFOD_F32)
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<float, 7>), grid, dim3(256), lds, s, (const float*)feat, H, W, C,
-                         rois, scale, (float*)out, R, ncb);
-    else if (dt == SFOD_BF16X3)
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<split_t, 7>), grid, dim3(256), lds, s, (const split_t*)feat, H, W, C,
-                         rois, scale, (split_t*)out, R, ncb);
-    else if (dt == SFOD_F16X3)
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<splith_t, 7>), grid, dim3(256), lds, s, (const splith_t*)feat, H, W, C,
-                         rois, scale, (splith_t*)out, R, ncb);
-    else
-      hipLaunchKernelGGL((k_roi_align_fwd_sep<bf16_t, 7>), grid, dim3(256), lds, s, (const bf16_t*)feat, H, W, C,
-                         rois, scale, (bf16_t*)out, R, ncb);
+    // channel blocks (one L2-resident slice of the feature map at a time); SFOD_ROI_CBLK: logical channels per block
+    // (A/B; 0: one workgroup per box), SFOD_ROI_NT=1: non-temporal output stores
+    static const int cblk_env = []() { const char* e = getenv("SFOD_ROI_CBLK"); return e ? atoi(e) : ROI_CBLK_DEFAULT; }();
+    static const int nt = []() { const char* e = getenv("SFOD_ROI_NT"); return e ? atoi(e) : ROI_NT_DEFAULT; }();
+    const int V = (dt == SFOD_F32) ? 4 : 8;
+    int ncb = 1;
+    if (cblk_env > 0 && cblk_env % V == 0 && C % cblk_env == 0 && C > cblk_env) ncb = C / cblk_env;
+    const int cblk = C / ncb;
+    // threads: one lane per 16-byte (pairs: 32-byte) channel vector of the block x 8 bin-row groups (7 active)
+    int threads = (cblk / V) * 8;
+    threads = threads < 64 ? 64 : (threads > 256 ? 256 : threads);
+    const dim3 grid((unsigned)R * ncb), block((unsigned)threads);
+#define SFOD_ROI_SEP(T_, NT_) hipLaunchKernelGGL((k_roi_align_fwd_sep<T_, 7, NT_>), grid, block, lds, s, (const T_*)feat, H, W, C, \
+                                                 rois, scale, (T_*)out, R, ncb)
+    if (dt == SFOD_F32) { if (nt) SFOD_ROI_SEP(float, true); else SFOD_ROI_SEP(float, false); }
+    else if (dt == SFOD_BF16X3) { if (nt) SFOD_ROI_SEP(split_t, true); else SFOD_ROI_SEP(split_t, false); }
+    else if (dt == SFOD_F16X3) { if (nt) SFOD_ROI_SEP(splith_t, true); else SFOD_ROI_SEP(splith_t, false); }
+    else { if (nt) SFOD_ROI_SEP(bf16_t, true); else SFOD_ROI_SEP(bf16_t, false); }
+#undef SFOD_ROI_SEP
     return sfod_check_launch("roi_align_fwd_sep");
   }
   if (dt == SFOD_F32)

@@ -33,6 +33,7 @@ import torch.distributed as dist
 from .. import native
 from ..data.synthetic import TwoCropLoader
 from ..modeling import build_model
+from ..modeling import offchain
 from ..modeling.batched import BatchedGT
 from ..structures import Boxes, Instances
 from .solver import FlatModelState, WarmupMultiStepLR, build_optimizer
@@ -43,8 +44,12 @@ WRITER_PERIOD = 20  # hooks.PeriodicWriter(period=20), source_free_adaptive_teac
 # Stage markers for rocprofv3 --marker-trace (the reference has no profiler hooks; d2's would be
 # torch.profiler).  SFOD_ROCTX=1 (or SFOD.PROFILE_RANGES True): roctx ranges "sfod/teacher", "sfod/student_forward",
 # "sfod/student_backward", "sfod/exchange", "sfod/update" around the stages of run_step, so that a kernel trace can be cut
-# by stage (tools/stage_times.py).  Off: a no-op context manager, nothing is pushed.
-_ROCTX = [os.environ.get("SFOD_ROCTX", "0") == "1"]
+# by stage.  The ranges are HOST-side: pushed and popped when the stage is ENQUEUED, and the host runs up to
+# SFOD.MAX_STEPS_IN_FLIGHT steps ahead of the GPU, so their timestamps do not bracket the GPU work -- attribute kernels to a
+# stage through the correlation ids of the launches made inside a range (rocprofv3 --marker-trace --kernel-trace writes both;
+# tools/step_timeline.py reads the kernel trace per stream), not by time.  Off: a no-op context manager, nothing is pushed.
+_ROCTX_ENV = os.environ.get("SFOD_ROCTX", "0") == "1"
+_ROCTX = [_ROCTX_ENV]
 
 
 @contextlib.contextmanager
@@ -257,8 +262,9 @@ def _apply_process_knobs(cfg):
         # environment setting off.  Process-wide: the last trainer constructed decides.
         want = bool(cfg.SFOD.DETERMINISTIC) or os.environ.get("SFOD_DETERMINISTIC", "0") == "1"
         native.set_deterministic(want)
-    if "PROFILE_RANGES" in cfg.SFOD and cfg.SFOD.PROFILE_RANGES:
-        _ROCTX[0] = True
+    if "PROFILE_RANGES" in cfg.SFOD:
+        # like DETERMINISTIC: on when EITHER the config key or the environment asks; the last trainer constructed decides
+        _ROCTX[0] = bool(cfg.SFOD.PROFILE_RANGES) or _ROCTX_ENV
 
 
 def _throttle(trainer):
@@ -319,9 +325,14 @@ def _on_step_stream(trainer):
         yield
         return
     st.wait_stream(caller)
-    with torch.cuda.stream(st):
-        yield
-    caller.wait_stream(st)
+    try:
+        with torch.cuda.stream(st):
+            yield
+    finally:
+        # also when a step raised (check_finite's FloatingPointError is a designed path): a handler that checkpoints or
+        # evaluates on the caller's stream must not read parameters while the SGD + EMA update is still in flight here
+        caller.wait_stream(st)
+        torch.cuda.current_stream().wait_stream(st)
 
 
 def _step_enqueued(trainer):
@@ -461,7 +472,10 @@ class BaseTrainer:
         self._write_metrics(metrics_dict)
         self.optimizer.zero_grad()
         with stage("student_backward"):
-            losses.backward()
+            try:
+                losses.backward()
+            finally:
+                offchain.clear_loss_grads_mark()      # a mark no head consumed must not meet the next backward
         with stage("exchange"):
             self._reduce_gradients()
         with stage("update"):
@@ -920,7 +934,10 @@ class SourceFreeAdaptiveTeacherTrainer(BaseTrainer):
         self._write_metrics(metrics_dict, total=losses.detach())
         self.optimizer.zero_grad()
         with stage("student_backward"):
-            losses.backward()
+            try:
+                losses.backward()
+            finally:
+                offchain.clear_loss_grads_mark()      # a mark no head consumed must not meet the next backward
         with stage("exchange"):
             self._reduce_gradients()
         with stage("update"):

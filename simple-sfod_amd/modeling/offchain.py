@@ -65,18 +65,29 @@ _loss_grads_ready = None
 
 
 def mark_loss_grads_ready(g):
-    """``g``: the tensor the loss gradients are slices of"""
+    """``g``: the tensor the loss gradients are slices of.  The mark keeps ``g`` itself alive (so its storage cannot be
+    handed to another tensor while the mark exists) and is valid for ONE backward: ``clear_loss_grads_mark`` (the trainers
+    call it when ``backward()`` returns) or the first ``take`` drops it."""
     global _loss_grads_ready
     if _HEAD_WGRAD_STREAM and g.is_cuda:
         ev = torch.cuda.Event()
         ev.record()
-        _loss_grads_ready = (ev, g.untyped_storage().data_ptr())
+        _loss_grads_ready = (ev, g, g.device)
 
 
 def take_loss_grads_ready(grad):
-    """the mark, if ``grad`` is one of the gradients it was made for (a stale mark of another backward is dropped)"""
+    """the mark, if ``grad`` is a view of the very tensor it was made for (a mark of another backward or another device is
+    dropped): the marked tensor is held by reference, so equal storage addresses mean the same live storage"""
     global _loss_grads_ready
     m, _loss_grads_ready = _loss_grads_ready, None
-    if m is None or not grad.is_cuda or grad.untyped_storage().data_ptr() != m[1]:
+    if m is None or not grad.is_cuda or grad.device != m[2]:
+        return None
+    if grad.untyped_storage().data_ptr() != m[1].untyped_storage().data_ptr():
         return None
     return m[0]
+
+
+def clear_loss_grads_mark():
+    """after ``backward()``: a mark nobody consumed (a step without an RPN loss) must not survive into the next backward"""
+    global _loss_grads_ready
+    _loss_grads_ready = None

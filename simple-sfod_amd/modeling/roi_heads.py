@@ -14,7 +14,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import native
 from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
@@ -114,7 +113,8 @@ class _PredictorAPI:
 
     def predict_probs(self, predictions, proposals):
         scores, _ = predictions
-        return F.softmax(scores.float(), dim=-1).split([len(p) for p in proposals], dim=0)
+        # the library's row softmax (sfod_predict_probs: the fused teacher post-processing's own operation order)
+        return native.predict_probs(scores.float()).split([len(p) for p in proposals], dim=0)
 
     def predict_boxes_for_gt_classes(self, predictions, proposals):
         if not len(proposals):
@@ -294,6 +294,11 @@ class StandardROIHeads(nn.Module):
 
     # ---- box branch: ROIAlign -> fc1 -> fc2 -> fused (cls_score | bbox_pred) -------------------------
     def _box_forward(self, feat_nchw, rois):
+        if self.pooled > 8 and torch.is_grad_enabled():
+            # sfod_roi_align_bwd's register tiles stop at 8 (the forward serves <= 16: Detectron2's unit-test size); say so
+            # BEFORE the losses, not in the first backward.  config.py's default is d2's 14: the named yamls set 7.
+            raise ValueError(f"MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION {self.pooled}: the ROIAlign backward serves <= 8 "
+                             "(forward-only passes: <= 16)")
         dtype = self.compute_dtype
         dt = native.dt_of_dtype(dtype)
         feat = native.nhwc_operand(feat_nchw, dtype)

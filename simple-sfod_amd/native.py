@@ -1202,6 +1202,17 @@ def bpc_loss(pred, K, rois, roi_cls, sizes_dev, gt_boxes, gt_classes, gt_count, 
     return loss[0]
 
 
+def predict_probs(scores):
+    """Row softmax of the class scores [R, K+1] (any row stride) in the teacher post-processing kernel's operation order."""
+    assert scores.is_cuda, "native ops need device tensors"
+    assert scores.dim() == 2 and scores.dtype == torch.float32 and scores.stride(1) == 1
+    R, n = scores.shape
+    out = torch.empty(R, n, dtype=torch.float32, device=scores.device)
+    # (rows may be a strided view of the prediction matrix: the pointer goes in as is, the row stride as ld)
+    call("sfod_predict_probs", scores.data_ptr(), scores.stride(0) if R > 1 else n, R, n - 1, out)
+    return out
+
+
 def adaptive_pseudo_labels_(d, thr, reserve, row, class_acc, select):
     """In place on the detection dict of ``frcnn_inference``: updates ``reserve[row]`` / ``class_acc`` and, with
     ``select``, replaces ``gt_boxes`` / ``gt_classes`` / ``gt_count`` (adds ``gt_scores``) by the class-wise

@@ -711,21 +711,27 @@ def test_bpc_kernel_and_convert_bbox_scores_match_oracle(sfod, native):
     props = []
     for b in range(B):
         p = S.Instances(sizes[b])
-        p.proposal_boxes = S.Boxes(nb.split([len(i) for i in idx])[b])
-        p.gt_classes = roi_cls[idx[b]].long()
+        p.proposal_boxes = S.Boxes(nb.split([len(i) for i in idx])[b].to(DEV))
+        p.gt_classes = roi_cls[idx[b]].long().to(DEV)
         props.append(p)
-    res, kept = bp.convert_bbox_scores((sc, dl), props)
+    # on device tensors, as a model hands them over: predict_probs is the library's row softmax (sfod_predict_probs)
+    res, kept = bp.convert_bbox_scores((sc.to(DEV), dl.to(DEV)), props)
     for b in range(B):
-        torch.testing.assert_close(res[b].pred_boxes.tensor, inst[b]["boxes"], rtol=1e-6, atol=1e-5)
-        torch.testing.assert_close(res[b].scores, inst[b]["scores"], rtol=1e-6, atol=1e-7)
-        assert torch.equal(res[b].pred_classes, inst[b]["classes"]) and torch.equal(kept[b], inst[b]["roi_idx"])
+        torch.testing.assert_close(res[b].pred_boxes.tensor.cpu(), inst[b]["boxes"], rtol=1e-6, atol=1e-5)
+        torch.testing.assert_close(res[b].scores.cpu(), inst[b]["scores"], rtol=1e-6, atol=1e-7)
+        assert torch.equal(res[b].pred_classes.cpu(), inst[b]["classes"]) and torch.equal(kept[b].cpu(), inst[b]["roi_idx"])
     p0 = [S.Instances(sizes[b]) for b in range(B)]
     for b in range(B):
-        p0[b].proposal_boxes, p0[b].gt_classes = S.Boxes(rois[idx[b], 1:]), roi_cls[idx[b]].long()
-    nb2 = torch.cat(list(bp.predict_boxes_for_gt_classes((sc, dl), p0)))
+        p0[b].proposal_boxes, p0[b].gt_classes = S.Boxes(rois[idx[b], 1:].to(DEV)), roi_cls[idx[b]].long().to(DEV)
+    nb2 = torch.cat(list(bp.predict_boxes_for_gt_classes((sc.to(DEV), dl.to(DEV)), p0))).cpu()
     fin = torch.isfinite(nb).all(1)
     torch.testing.assert_close(nb2[fin], nb[fin], rtol=1e-6, atol=1e-5)
-    assert [tuple(t.shape) for t in bp.predict_probs((sc, dl), p0)] == [(per, K + 1)] * B
+    probs = bp.predict_probs((sc.to(DEV), dl.to(DEV)), p0)
+    assert [tuple(t.shape) for t in probs] == [(per, K + 1)] * B
+    finite_rows = torch.isfinite(sc).all(1)
+    torch.testing.assert_close(torch.cat(list(probs)).cpu()[finite_rows], torch.softmax(sc, -1)[finite_rows], rtol=2e-6, atol=1e-7)
+    with pytest.raises(AssertionError, match="device tensors"):      # no CPU fallback behind a reference-named method
+        bp.predict_probs((sc, dl), p0)
     # no image has a positive denominator -> 0 (bpc_loss.py:251-252)
     z = native.bpc_loss(pred.to(DEV), K, torch.full((R, 5), -1.0, device=DEV), roi_cls.to(DEV), sz, gtb.to(DEV),
                         gtc.to(DEV), gcnt.to(DEV))

@@ -17,4 +17,5 @@ for name, H, W, C, scale in (("vgg16", 19, 38, 512, 1 / 32), ("r101", 38, 75, 10
         e0.record(); out = native.roi_align_fwd(feat, rois, 7, scale); e1.record(); torch.cuda.synchronize()
         ts.append(e0.elapsed_time(e1))
     t = sorted(ts)[len(ts) // 2]
-    print(f"{name}: {R} boxes x 49 x {C} ch  {t:.3f} ms  ({4e-9 * R * 49 * C / t * 1e3:.2f} GB/s written)")
+    print(f"{name}: {R} boxes x 49 x {C} ch  {t:.3f} ms  ({4e-9 * R * 49 * C / t * 1e3:.2f} GB/s written)"
+          f"  [SFOD_ROI_CBLK={os.environ.get('SFOD_ROI_CBLK', 'default')} SFOD_ROI_NT={os.environ.get('SFOD_ROI_NT', 'default')}]")
