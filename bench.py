@@ -190,11 +190,16 @@ def pmc_matches(args):
             and not args.opts)
 
 
-def _launcher():
-    spec = importlib.util.spec_from_file_location("sfod_launch", os.path.join(ROOT, "simple-sfod_amd", "launch.py"))
+def _by_path(name, fname):
+    """a standard-library-only module of the package, loaded by path (before torch / the package are imported)"""
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "simple-sfod_amd", fname))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     return mod
+
+
+def _launcher():
+    return _by_path("sfod_launch", "launch.py")
 
 
 def build_trainer(sfod, args, dtype, world, rank, local_rank):
@@ -281,6 +286,7 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the reduced-precision (bf16) secondary block")
     ap.add_argument("--no-other-shapes", action="store_true",
                     help="skip the RFULL / one-frame-per-GPU child runs of the default configuration")
+    ap.add_argument("--no-smi", action="store_true", help="no rocm-smi clock / power samples beside the run")
     ap.add_argument("--no-planted", action="store_true")
     ap.add_argument("--plant-scale", type=float, default=0.0, help="planted-label mode: scale on cls_score.weight (default: engine/planted.py SCALE)")
     ap.add_argument("--plant-bias", type=float, default=None,
@@ -318,11 +324,18 @@ def main():
     if one_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    telemetry = _by_path("sfod_telemetry", "telemetry.py")
+    rccl_log = None
     if world > 1:
         if one_gpu:
             dist.init_process_group("gloo")
         else:
+            # RCCL's INFO lines (INIT / GRAPH / TUNING) of every rank go to a per-rank file: rank 0's is summarised in
+            # the line (algorithm / protocol per payload, channels, transports) so that a scaling run explains itself
+            rccl_log = telemetry.rccl_debug_setup(rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    # clocks and package power of every GPU of the node beside the run (rank 0: a host thread running rocm-smi)
+    smi = telemetry.SmiSampler().start() if rank == 0 and not args.no_smi else None
 
     note("torch imported")
     sfod = importlib.import_module("simple-sfod_amd")
@@ -436,10 +449,19 @@ def main():
         for b, w_ in zip(bbs, ws_saved):
             if w_ is not None:
                 b.wgrad_stream = w_
+    t_region = (t0, t0 + elapsed)
+    if smi is not None:
+        smi.stop()
+    per_rank = None
     if world > 1:
-        t = torch.tensor([elapsed], device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = t.item()
+        mine = torch.tensor([elapsed], device="cuda")
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        every = [e.item() for e in every]
+        elapsed = max(every)                                  # the contract's time: MAX over ranks
+        ms = [1000.0 * e / args.steps for e in every]
+        per_rank = {"ms_per_step": [round(m, 3) for m in ms], "ms_per_step_min": round(min(ms), 3),
+                    "ms_per_step_max": round(max(ms), 3), "slowest_rank": ms.index(max(ms))}
     rec = trainer.storage.flush()
     note(f"timed region done: {elapsed:.2f} s")
 
@@ -531,7 +553,7 @@ def main():
             n_dt = max(5, n2 // 3) if dt2 == "fp32" else n2
             cmd = [sys.executable, os.path.abspath(__file__), "--dtype", dt2, "--steps", str(n_dt), "--warmup", "3" if dt2 == "fp32" else "5",
                    "--batch", str(args.batch), "--res", args.res, "--model", args.model, "--trainer", args.trainer,
-                   "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"]
+                   "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer", "--no-smi"]
             cmd += (["--no-planted"] if args.no_planted else []) + (["--no-overlap"] if args.no_overlap else [])
             cmd += ["--plant-scale", str(args.plant_scale)] if args.plant_scale else []
             cmd += ["--plant-bias", str(args.plant_bias)] if args.plant_bias is not None else []
@@ -576,6 +598,7 @@ def main():
                                      "peak_hbm_reserved_GB": c2["peak_hbm_reserved_GB"],
                                      "peak_hbm_allocated_GB": c2["peak_hbm_allocated_GB"],
                                      "pseudo_labels_per_image": c2.get("pseudo_labels_per_image", {}).get("mean"),
+                                     "gpu_telemetry": d2.get("gpu_telemetry", {}).get("cards"),
                                      "note": "measured by a child process of this run (same mode, same planted-head recipe); "
                                              "never `value`"})
             except Exception as e:
@@ -657,7 +680,15 @@ def main():
     if gpu_fill is not None:
         out["gpu_fill"] = gpu_fill
     if comm is not None:
+        comm["rccl"] = telemetry.rccl_summary(rccl_log)       # None under the gloo test hook / when the log is elsewhere
         out["exchange"] = comm
+    if per_rank is not None:
+        out["per_rank"] = per_rank
+    if smi is not None:
+        tel = smi.summary(*t_region)
+        if tel is not None:
+            out["gpu_telemetry"] = {"during": "the timed region", "source": "rocm-smi --showpower --showclocks, sampled "
+                                    f"every {smi.interval} s by a host thread of rank 0", "cards": tel}
     if one_gpu:
         out["test_hook"] = "SFOD_BENCH_ONE_GPU: all ranks on cuda:0 over gloo -- exercises the N > 1 code path, not a measurement"
     if secondary is not None:

@@ -31,7 +31,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
-// (k_conv3x3_m16 has its own set for tools/experiments/m16_knockout.sh: M16_KO_{MFMA,WDMA,PDMA,BAR,EPI}, M16_V_LATEW.)
+// (k_conv3x3_m16 has its own set for tools/experiments/m16_knockout.sh: M16_KO_{MFMA,WDMA,PDMA,BAR,EPI}, M16_V_LATEW,
+// M16_V_NOCONF: fragment rows forced conflict-free -- what the LDS bank conflicts of ragged tile widths cost;
+// M16_V_EXTRAVALU=n: n more VALU instructions per stage -- the slope says what the loop's ~66 non-MFMA VALU instructions cost.)
 // Knock-out switches for tools/experiments/conv_knockout.sh (time floors of the bf16x3 loop; results are WRONG by
 // construction, the product build defines none): P3_KO_MFMA no MFMAs, P3_KO_READS no LDS fragment reads, P3_KO_PATCHDMA /
 // P3_KO_WDMA no patch / weight LDS-DMA inside the K loop, P3_KO_EPI no epilogue (stores, statistics).
@@ -906,6 +908,9 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
     const int p = wm * WPX + i * 16 + r16;
     const int ty = (int)fdiv((unsigned)p, (unsigned)a.TW, a.m_tw);
     rowA[i] = (p < npix) ? (ty * PW + (p - ty * a.TW)) : 0;
+#ifdef M16_V_NOCONF      // knock-out: the 16 pixels of a lane group on 16 consecutive patch rows (wrong pixels, no bank conflicts)
+    rowA[i] = p;
+#endif
     asm volatile("" : "+v"(rowA[i]));       // materialised here, not re-derived from spilled 64-bit products inside the K loop
   }
   // weight fragment of channel tile ic: + ic * 1024; lo = ^ 16   ((n >> 2) & 3 == (r16 >> 2) & 3 for n = 16 m + r16)
@@ -926,12 +931,18 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
     const int sa = (ua >= 9) ? 1 : 0, ta = ua - 9 * sa, sbb = (ub >= 9) ? 1 : 0, tb = ub - 9 * sbb;
     const int kya = (ta * 11) >> 5, kyb = (tb * 11) >> 5;            // t / 3 for t < 9
     const int dta = sa * PR + kya * PW + (ta - 3 * kya), dtb = sbb * PR + kyb * PW + (tb - 3 * kyb);
+#ifdef M16_V_NOCONF      // ... and both pairs of a stage 0 mod 16 rows apart
+    return pb ? (dtb & ~15) : (dta & ~15);
+#endif
     return pb ? dtb : dta;
   };
 
   {
   // ---- K loop: one rolled body per stage (j = stage inside the super-body sb; all stage constants are scalar values)
   int sb = 0, j = 0, par = 0, nprev = 0;      // nprev: patch pieces the previous stage issued behind its weights
+#ifdef M16_V_EXTRAVALU
+  int extra_valu = (int)threadIdx.x;
+#endif
 #ifdef M16_STAMP
   unsigned long long stamp_sum[4] = {0, 0, 0, 0};
 #endif
@@ -1018,6 +1029,10 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
 #endif
 #ifndef M16_KO_PDMA
       if (ip < PPS) { if (ip < np) issue_patch(pk + ip, pslice, pbuf); }
+#endif
+#ifdef M16_V_EXTRAVALU      // perturbation: M16_V_EXTRAVALU extra integer VALU instructions per stage (spread over the pixel tiles)
+#pragma unroll
+      for (int e = 0; e < (M16_V_EXTRAVALU + NIP - 1) / NIP; ++e) asm volatile("v_add_u32 %0, %0, %0" : "+v"(extra_valu));
 #endif
 #if defined(M16_V_LATEW) && !defined(M16_KO_WDMA)
       if (ip == 2) {

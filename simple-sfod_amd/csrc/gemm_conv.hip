@@ -16,6 +16,9 @@
 #include "conv_internal.h"
 #include <algorithm>
 #include <atomic>
+// Knock-out switches for tools/experiments/gemm_knockout.sh (time floors of k_conv_fwd's pair modes; results wrong by
+// construction, the product build defines none): GEMM_KO_MFMA no MFMAs, GEMM_KO_STORE no output stores (fp32 outputs),
+// GEMM_KO_STATS no BatchNorm partial statistics.
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -263,6 +266,13 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
           bh[j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + (((4 * t + 2 * h) ^ swzB[j]) << 4));
           bl[j] = *reinterpret_cast<const bf16x8*>(sB + offB[j] + (((4 * t + 2 * h + 1) ^ swzB[j]) << 4));
         }
+#ifdef GEMM_KO_MFMA
+#pragma unroll
+        for (int i = 0; i < WM; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+        for (int j = 0; j < WN; ++j) asm volatile("" ::"v"(bh[j]), "v"(bl[j]));
+        acc[0][0][0] += 1.0f;
+#else
 #pragma unroll
         for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -278,6 +288,7 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
 #pragma unroll
           for (int j = 0; j < WN; ++j)
             acc[i][j] = mfma_pairs<SPLIT>(ah[i], bh[j], acc[i][j]);
+#endif
       }
     } else if constexpr (sizeof(T) == 2) {
 #pragma unroll
@@ -393,7 +404,11 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
         if (STAGED) {
           *reinterpret_cast<OutT*>(smem + ml * CPITCH + nl * 2) = from_f32<OutT>(apply_act(v, a.act));
         } else {
+#ifdef GEMM_KO_STORE
+          if (v == 1.2345e-30f) y[(int64_t)m * a.ldy + n] = from_f32<OutT>(v);     // keeps v alive, stores nothing
+#else
           if (m < a.M && n < a.Cout) y[(int64_t)m * a.ldy + n] = from_f32<OutT>(apply_act(v, a.act));
+#endif
         }
       }
     }
@@ -415,6 +430,9 @@ k_conv_fwd(const T* __restrict__ x, const T* __restrict__ w, const float* __rest
     }
   }
 
+#ifdef GEMM_KO_STATS
+  stats = nullptr;
+#endif
   if (stats != nullptr) {
     // statistics are reported per 128-row half tile: wave rows (2*hf, 2*hf+1) form half hf
     __syncthreads();  // LDS reuse
@@ -637,6 +655,11 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
     if (forced == 4) return launch_one<T, OutT, 1, UT, 4, 3, SPLIT>(x, w, bias, y, stats, a, s);
     if constexpr (SPLIT && sizeof(OutT) == 4) {
       if (forced == 5) return launch_one<T, OutT, 4, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
+      // round 6: 64-byte K stages so that TWO workgroups share a CU (their prologues / epilogues / barrier stalls overlap):
+      // 6: 256 x 128, 3 stages (72 KiB); 7: 128 x 128, 3 stages (48 KiB: three per CU); 8: 256 x 128, 4 stages (96 KiB)
+      if (forced == 6) return launch_one<T, OutT, 2, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
+      if (forced == 7) return launch_one<T, OutT, 2, UT, 2, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
+      if (forced == 8) return launch_one<T, OutT, 2, UT, 4, 4, SPLIT, 64>(x, w, bias, y, stats, a, s);
     }
   }
   if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);

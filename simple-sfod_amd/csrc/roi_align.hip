@@ -8,6 +8,11 @@
 #include "conv_internal.h"
 #include <cstdlib>
 
+#define ROI_MAXP 8
+#define ROI_MAXP_FWD 16
+#define ROI_CBLK_DEFAULT 128
+#define ROI_NT_DEFAULT 1
+
 struct Sample {
   int y_low, x_low, y_high, x_high;
   float w1, w2, w3, w4;
@@ -199,10 +204,12 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
                     T* __restrict__ out, int R, int ncb) {
   extern __shared__ __attribute__((aligned(16))) float sw[];   // Ay [P][H], Ax [P][W], then int sup[2 * P][2]
   // grid = ncb channel blocks x R boxes, channel-block major: at any time the chip works on ONE slice of C / ncb channels of
-  // the feature map (38 x 75 x 256 channels x 4 B = 2.9 MB per image), which stays in an XCD's 4 MB L2 across the boxes
-  // that share it -- with all 1024 channels per workgroup the 16 000 boxes of a teacher pass re-read the 93 MB map ~80x
-  // past L2 (7.5 GB: profiles/r3_pmc_hbm_traffic_r101_f16x3.json).  Measured: 1.91 -> 1.84 ms at 1024 channels, nothing at
-  // 512 (tools/experiments/time_roi_align.py, SFOD_ROI_CBLOCKS=0 / 1): the re-reads were not what bounds the kernel.
+  // the feature map, which has to stay in an XCD's 4 MB L2 across the boxes that share it -- with all 1024 channels per
+  // workgroup the 16 000 boxes of a teacher pass re-read the 93 MB map ~80x past L2.  Round 6: the slice alone does not do
+  // it -- the [R,49,C] output STREAM (3.2 GB per teacher call) passes through the same L2 and evicts the slice between two
+  // touches of a line.  128-channel slices (1.45 MB per image) + non-temporal output stores (NT): HBM reads per launch
+  // 1596 -> 460 MB (mean of the two configs' teacher calls, PMC: profiles/r6_roi_align_fwd_ab.txt), 1.77 -> 1.68 ms at 1024
+  // channels.  The kernel is bound by neither its reads nor its gathers' latency (same file).
   const int r = blockIdx.x % R, cb = blockIdx.x / R;
   const float* roi = rois + (int64_t)r * 5;
   const int tid = threadIdx.x;
@@ -269,6 +276,9 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
       for (int pw = 0; pw < P; ++pw)
 #pragma unroll
         for (int i = 0; i < V; ++i) o[pw][i] = 0.f;
+      // (round 6: batching the rows of a footprint column into 2 / 4 loads in flight and requesting the next column ahead
+      // was built and measured -- 1.83 / 2.40 ms against this loop's 1.68 ms at 1024 channels, same box: the registers cost
+      // occupancy and the kernel is not waiting on its gathers.  profiles/r6_roi_align_fwd_ab.txt)
       for (int px = xlo; px <= xhi; ++px) {
         float col[V];
 #pragma unroll
@@ -306,10 +316,6 @@ k_roi_align_fwd_sep(const T* __restrict__ feat, int H, int W, int C, const float
 // (= one ROI) builds Ay [P][H] and Ax [P][W] in LDS, every thread keeps the P x P upstream values of
 // its channels in registers, contracts them with Ax and Ay and issues ONE atomic add per footprint
 // pixel and channel (a wavefront adds 256 contiguous bytes): ~5x fewer atomics than the scatter.
-#define ROI_MAXP 8
-#define ROI_MAXP_FWD 16
-#define ROI_CBLK_DEFAULT 256
-#define ROI_NT_DEFAULT 0
 
 template <typename T>
 __global__ void __launch_bounds__(256)

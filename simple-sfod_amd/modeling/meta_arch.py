@@ -232,3 +232,38 @@ class SourceFreeAdaptiveTeacherGeneralizedRCNN(GeneralizedRCNN):
                 losses["loss_DC_ins_" + tag] = dc_ins_loss(rh, self.DC_ins, features[rh.in_features[0]], rois, label,
                                                            training=self.training)
         return losses, [], []
+
+
+@META_ARCH_REGISTRY.register()
+class AdaptiveTeacherGeneralizedRCNN(SourceFreeAdaptiveTeacherGeneralizedRCNN):
+    """The with-source meta-architecture (``daod/modeling/meta_arch/adaptive_teacher_rcnn.py:24-350``, reached by
+    ``TRAINER: "adaptive_teacher"``).  Same sub-modules as the source-free class; what differs per branch:
+
+      ``supervised``         :210-257  the image-level discriminator sees the source features through the gradient-reversal
+                                       layer (label 0) and ``loss_DC_img_s * 0.001`` joins the losses;
+      ``supervised_target``  :259-288  RPN + ROI losses only: no second (loss-free) ROI pass, no BPC; three values;
+      ``unsup_data_weak`` / ``domain_classifier``: the source-free class's (three values).
+    """
+
+    def forward(self, batched_inputs, branch="supervised", given_proposals=None, val_mode=False, batched=False):
+        if (not self.training) and (not val_mode):
+            return self.inference(batched_inputs)
+        if branch in ("domain_classifier", "unsup_data_weak"):
+            return super().forward(batched_inputs, branch=branch, given_proposals=given_proposals, val_mode=val_mode,
+                                   batched=batched)
+        if branch not in ("supervised", "supervised_target"):
+            raise ValueError(f"unknown branch {branch}")
+        images, features = self._images_and_features(batched_inputs)
+        gt = gather_gt(batched_inputs, self.device)
+        losses = {}
+        loss_dc = None
+        if branch == "supervised":          # :211-213, before the proposal generator like the reference
+            loss_dc = dc_img_loss(self.DC_img, features[self.dis_type], 0)
+        proposals_rpn, proposal_losses = self.proposal_generator(images, features, gt, as_instances=False)
+        _, detector_losses, _, _ = self.roi_heads(images, features, proposals_rpn, compute_loss=True, targets=gt,
+                                                  branch=branch)
+        losses.update(detector_losses)
+        losses.update(proposal_losses)
+        if loss_dc is not None:
+            losses["loss_DC_img_s"] = loss_dc * 0.001      # :256
+        return losses, [], []
