@@ -925,6 +925,211 @@ def gen_glue():
           "buckets b2:", out["bucket_weak_ids_b2"].shape, "cfg keys:", sorted(node.keys()))
 
 
+def gen_adaptive_teacher():
+    """The with-source path (``TRAINER: "adaptive_teacher"``), the reference's own code objects on recorder stubs ->
+    ``tests/golden/adaptive_teacher_ref.npz``:
+
+      at*  ``AdaptiveTeacherTrainer.run_step`` (daod/engine/trainers/adaptive_teacher.py:191-336) at five iterations around
+           BURN_UP_STEP = 5 with TEACHER_UPDATE_ITER = 2: which branches run on which lists (tags), when
+           ``_update_teacher_model`` is called and with which keep_rate, the labels the teacher / student see, the scalars,
+           the weight of every loss key (gradients ``losses.backward()`` leaves on the loss leaves), which value of the
+           doubly-defined ``loss_DC_img_s`` survives, what reaches ``_write_metrics`` (unweighted);
+      atm* ``AdaptiveTeacherGeneralizedRCNN.forward`` (daod/modeling/meta_arch/adaptive_teacher_rcnn.py:102-292): per branch the
+           sub-module calls with their flags, tuple arity, loss keys / values (``loss_DC_img_s * 0.001`` of ``supervised``);
+      at4* ``AspectRatioGroupedSemiSupDatasetTwoCrop.__iter__`` (daod/data/common.py:119-160): the four lists of every batch
+           for streams of mixed aspect ratios, incl. the elements it drops while one side waits for the other."""
+    import contextlib
+    import io
+    m = _ref_modules()
+    from detectron2.structures import Boxes, Instances
+    at = _load_by_path("ref_at", os.path.join(REF, "daod/engine/trainers/adaptive_teacher.py"))
+    T = at.AdaptiveTeacherTrainer
+    g = torch.Generator().manual_seed(77)
+    out = {"torch_version": np.array(torch.__version__)}
+    K = 8
+
+    def detections(n):
+        p = Instances((600, 1200))
+        p.pred_boxes = Boxes(torch.rand(n, 4, generator=g) * 500)
+        p.scores = torch.rand(n, generator=g).sort(descending=True).values
+        p.pred_classes = torch.randint(0, K, (n,), generator=g)
+        return p
+
+    def rpn_props(n):
+        p = Instances((600, 1200))
+        p.proposal_boxes = Boxes(torch.rand(n, 4, generator=g) * 500)
+        p.objectness_logits = torch.randn(n, generator=g) * 2
+        return p
+    dets, props = [detections(30)], [rpn_props(50)]
+    sup_keys = ["loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc", "loss_DC_img_s"]
+    tgt_keys = ["loss_cls", "loss_box_reg", "loss_rpn_cls", "loss_rpn_loc"]
+    dc_keys = ["loss_DC_img_s", "loss_DC_img_t", "loss_DC_ins_s", "loss_DC_ins_t"]
+    ns = types.SimpleNamespace
+    cfg = ns(SEMISUPNET=ns(BURN_UP_STEP=5, TEACHER_UPDATE_ITER=2, EMA_KEEP_RATE=0.75, BBOX_THRESHOLD=0.8, UNSUP_LOSS_WEIGHT=3.0,
+                           DIS_LOSS_WEIGHT=0.25))
+    iters = [2, 5, 6, 7, 9]
+    out["at_iters"], out["at_burn_up"], out["at_update_iter"] = np.array(iters), np.int64(5), np.int64(2)
+    out["at_weights_cfg"] = np.array([3.0, 0.25, 0.75])           # UNSUP_LOSS_WEIGHT, DIS_LOSS_WEIGHT, EMA_KEEP_RATE
+    for it in iters:
+        calls, scalars, written, ema_calls, leaves = [], {}, {}, [], {}
+
+        def teacher(data, branch=""):
+            calls.append("teacher:%s:%s:inst=%s" % (branch, ",".join(d["tag"] for d in data), ",".join(str(int("instances" in d)) for d in data)))
+            return {}, props, dets
+
+        class Student:
+            training = True
+
+            def __call__(self, data, branch=""):
+                if branch == "domain_classifier":
+                    calls.append("student:%s:%s:unl=%s" % (branch, ",".join(d["tag"] for d in data),
+                                                          ",".join(str(d.get("tag_unlabeled")) for d in data)))
+                    keys, suffix = dc_keys, "@dc"
+                else:
+                    lab = ",".join(("n%d" % len(d["instances"])) if isinstance(d["instances"], Instances) else str(d["instances"])
+                                   for d in data)
+                    calls.append("student:%s:%s:labels=%s" % (branch, ",".join(d["tag"] for d in data), lab))
+                    keys, suffix = (sup_keys, "@sup") if branch == "supervised" else (tgt_keys, "@tgt")
+                rec = {}
+                for k in keys:
+                    leaves[k + suffix] = torch.tensor(float(len(leaves) + 1), requires_grad=True)
+                    rec[k] = leaves[k + suffix]
+                return rec, [], []
+        lq = [{"image": 0, "instances": "gt_lq0", "tag": "lq0"}]
+        lk = [{"image": 0, "instances": "gt_lk0", "tag": "lk0"}]
+        uq = [{"image": 0, "instances": "gt_uq0", "tag": "uq0"}]
+        uk = [{"image": 0, "instances": "gt_uk0", "tag": "uk0"}]
+        opt = ns(n_zero=0, n_step=0)
+        opt.zero_grad = lambda: setattr(opt, "n_zero", opt.n_zero + 1)
+        opt.step = lambda: setattr(opt, "n_step", opt.n_step + 1)
+        stub = object.__new__(T)
+        stub.__dict__.update(dict(
+            iter=it, cfg=cfg, model=Student(), model_teacher=teacher, optimizer=opt,
+            _trainer=ns(iter=None, _data_loader_iter=iter([(lq, lk, uq, uk)])),
+            _update_teacher_model=lambda keep_rate=0.9996: ema_calls.append(float(keep_rate)) or calls.append("ema:%g" % keep_rate),
+            storage=ns(put_scalar=lambda n, v: scalars.__setitem__(n, float(v))),
+            _write_metrics=lambda d: written.update({kk: (float(v) if not isinstance(v, float) else v) for kk, v in d.items()})))
+        T.run_step(stub)
+        pre = f"at{it}_"
+        out[pre + "calls"] = np.array(calls)
+        out[pre + "ema_calls"] = np.array(ema_calls)
+        out[pre + "leaf_keys"] = np.array(list(leaves))
+        out[pre + "leaf_vals"] = np.array([float(v) for v in leaves.values()])
+        out[pre + "leaf_grads"] = np.array([float(v.grad) if v.grad is not None else np.nan for v in leaves.values()])
+        out[pre + "scalar_keys"] = np.array(sorted(scalars))
+        out[pre + "scalar_vals"] = np.array([scalars[kk] for kk in sorted(scalars)])
+        out[pre + "metrics_keys"] = np.array(sorted(written))
+        out[pre + "metrics_vals"] = np.array([written[kk] if kk != "data_time" else -1.0 for kk in sorted(written)])
+        out[pre + "opt_calls"] = np.array([opt.n_zero, opt.n_step])
+    out["at_det_scores"], out["at_rpn_logits"] = dets[0].scores.numpy(), props[0].objectness_logits.numpy()
+
+    # ---- _update_teacher_model: keep_rate 0 is a copy, 0.75 the EMA (conv + BatchNorm model, int64 counter included)
+    def net():
+        return torch.nn.Sequential(torch.nn.Conv2d(3, 4, 3), torch.nn.BatchNorm2d(4))
+    torch.manual_seed(5)
+    student, teacher_m = net(), net()
+    with torch.no_grad():
+        student[1].num_batches_tracked.fill_(7)
+        teacher_m[1].num_batches_tracked.fill_(3)
+        student[1].running_mean.uniform_(-1, 1)
+    for keep in (0.0, 0.75):
+        t2 = net()
+        t2.load_state_dict(teacher_m.state_dict())
+        stub = object.__new__(T)
+        stub.__dict__.update(dict(model=student, model_teacher=t2))
+        T._update_teacher_model(stub, keep_rate=keep)
+        for k, v in t2.state_dict().items():
+            out["atema%g/%s" % (keep, k)] = v.numpy().copy()
+    for k, v in student.state_dict().items():
+        out["atema_student/" + k] = v.numpy().copy()
+    for k, v in teacher_m.state_dict().items():
+        out["atema_teacher/" + k] = v.numpy().copy()
+
+    # ---- meta-architecture ----------------------------------------------------------------------------------------
+    import importlib
+    importlib.import_module("daod.modeling.meta_arch")
+    mod = _load_by_path("daod.modeling.meta_arch.ref_at_rcnn", os.path.join(REF, "daod/modeling/meta_arch/adaptive_teacher_rcnn.py"))
+    dann = _load_by_path("ref_dann_for_at_rcnn", os.path.join(REF, "daod/modeling/dann/dann.py"))
+    mod.gradient_scalar = dann.gradient_scalar
+    mod.assign_boxes_to_levels = lambda boxes, *a: "levels"
+    cls = mod.AdaptiveTeacherGeneralizedRCNN
+    trace = []
+    feat = torch.randn(2, 4, 3, 5, generator=g)
+    logits_by_call = []
+
+    def dc_img(x):
+        y = (x * torch.linspace(-1, 1, x.numel()).view_as(x)).sum(1, keepdim=True)
+        logits_by_call.append(y.detach().clone())
+        trace.append("DC_img")
+        return y
+
+    def rpn(images, features, gt=None, compute_loss=True, compute_val_loss=False):
+        trace.append("rpn(images=%s,gt=%d,compute_loss=%d)" % (images.tag, gt is not None, compute_loss))
+        return "proposals_rpn", {"loss_rpn_cls": torch.tensor(1.0), "loss_rpn_loc": torch.tensor(2.0)}
+
+    def roi(images, features, proposals, targets=None, compute_loss=True, branch="", compute_val_loss=False):
+        trace.append("roi(images=%s,targets=%d,compute_loss=%d,branch=%s)" % (images.tag, targets is not None, compute_loss, branch))
+        if compute_loss:
+            return [ns(proposal_boxes="b")], {"loss_cls": torch.tensor(3.0), "loss_box_reg": torch.tensor(4.0)}, "box_features"
+        return "pred_instances", "predictions"
+    roi.box_pooler = ns(min_level=4, max_level=4, canonical_box_size=224, canonical_level=4)
+
+    def make(ins_dc):
+        stub = object.__new__(cls)
+        stub.__dict__.update(dict(
+            training=True, device=torch.device("cpu"), vis_period=0, dis_type="vgg4", ins_dc=ins_dc,
+            preprocess_image=lambda b: ns(tensor="x", tag="k"),
+            preprocess_image_train=lambda b: (ns(tensor="xs", tag="s"), ns(tensor="xt", tag="t")),
+            backbone=lambda t: trace.append("backbone(%s)" % t) or {"vgg4": feat},
+            proposal_generator=rpn, roi_heads=roi, DC_img=dc_img,
+            instance_dc_loss=lambda bf, lv, label: trace.append("instance_dc_loss(%s,%s,label=%d)" % (bf, lv, label)) or torch.tensor(0.5 + label)))
+        return stub
+    inst = ns(to=lambda dev: "gt")
+    with_gt = [{"image": 0, "instances": inst, "instances_unlabeled": inst, "image_unlabeled": 0}]
+    without = [{"image": 0, "image_unlabeled": 0}]
+    cases = [("supervised", with_gt, False), ("supervised_target", with_gt, False), ("unsup_data_weak", without, False),
+             ("domain_classifier", with_gt, False)]
+    names = []
+    for ci, (branch, data, ins_dc) in enumerate(cases):
+        del trace[:]
+        del logits_by_call[:]
+        with contextlib.redirect_stdout(io.StringIO()):
+            r = cls.forward(make(ins_dc), data, branch=branch)
+        pre = f"atm{ci}_"
+        names.append(branch)
+        out[pre + "trace"] = np.array(list(trace))
+        out[pre + "arity"] = np.int64(len(r))
+        out[pre + "loss_keys"] = np.array(sorted(r[0].keys()))
+        out[pre + "loss_vals"] = np.array([float(r[0][k]) for k in sorted(r[0].keys())])
+        out[pre + "rest"] = np.array([repr(x) for x in r[1:]])
+        for j, lg in enumerate(logits_by_call):
+            out[pre + f"dc_logits_{j}"] = lg.numpy()
+    out["atm_cases"] = np.array(names)
+
+    # ---- four-way batches -----------------------------------------------------------------------------------------
+    gen = torch.Generator().manual_seed(3)
+
+    def stream(prefix, n, p_wide):
+        for i in range(n):
+            wide = bool(torch.rand(1, generator=gen).item() < p_wide)
+            w, h = (1200, 600) if wide else (600, 1200)
+            yield ({"width": w, "height": h, "id": f"{prefix}{i}s"}, {"width": w, "height": h, "id": f"{prefix}{i}w"})
+    for ci, (bl, bu, pl, pu) in enumerate(((1, 1, 0.7, 0.4), (2, 2, 0.6, 0.5), (2, 3, 0.5, 0.8))):
+        lab, unl = list(stream("L", 60, pl)), list(stream("U", 60, pu))
+        ds = m.common.AspectRatioGroupedSemiSupDatasetTwoCrop((iter(lab), iter(unl)), (bl, bu))
+        batches = list(ds)
+        pre = f"at4_{ci}_"
+        out[pre + "sizes"] = np.array([bl, bu])
+        out[pre + "label_wide"] = np.array([d[0]["width"] > d[0]["height"] for d in lab])
+        out[pre + "unlabel_wide"] = np.array([d[0]["width"] > d[0]["height"] for d in unl])
+        out[pre + "n_batches"] = np.int64(len(batches))
+        for j, part in enumerate(("ls", "lw", "us", "uw")):
+            out[pre + part] = np.array([[d["id"] for d in b[j]] for b in batches])
+    m.hook.uninstall()
+    np.savez_compressed(os.path.join(OUT, "adaptive_teacher_ref.npz"), **out)
+    print("adaptive_teacher_ref.npz:", {it: list(out[f"at{it}_calls"]) for it in iters})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     if len(sys.argv) > 1 and sys.argv[1] == "--upstream":
@@ -947,6 +1152,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "glue":
         gen_glue()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "adaptive_teacher":
+        gen_adaptive_teacher()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "vgg":
         gen_vgg()

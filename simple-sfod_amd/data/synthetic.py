@@ -279,3 +279,63 @@ class TwoCropLoader:
             ev = torch.cuda.Event()
             ev.record(st)
         return batch, ev
+
+
+class FourWayLoader:
+    """``build_detection_semisup_train_loader_two_crops`` (daod/data/build.py:145-213) behind
+    ``AdaptiveTeacherTrainer.build_train_loader`` (daod/engine/trainers/adaptive_teacher.py:78-81): yields
+    ``(label_strong, label_weak, unlabel_strong, unlabel_weak)`` -- labelled source frames from ``DATASETS.TRAIN``
+    (``SOLVER.IMS_PER_BATCH`` per step) beside unlabelled target frames from ``DATASETS.TRAIN_TARGET``
+    (``SOLVER.IMS_PER_BATCH_TARGET``), each as the two crops of ``DatasetMapperTwoCropSeparate``.
+
+    Batch formation is ``AspectRatioGroupedSemiSupDatasetTwoCrop.__iter__`` (daod/data/common.py:119-160) statement for
+    statement, including what it does when one side's batch is complete and the other's is not: BOTH streams advance every
+    iteration, and the element drawn for the side whose current bucket is already full is dropped."""
+
+    def __init__(self, cfg, device, rank=0, world=1, label_dataset=None, unlabel_dataset=None):
+        nl, nu = cfg.SOLVER.IMS_PER_BATCH, cfg.SOLVER.IMS_PER_BATCH_TARGET
+        # build.py:229-239 (the second message reports the LABEL batch size: the reference's own slip, kept)
+        assert nl > 0 and nl % world == 0, \
+            "Total label batch size ({}) must be divisible by the number of gpus ({}).".format(nl, world)
+        assert nu > 0 and nu % world == 0, \
+            "Total unlabel batch size ({}) must be divisible by the number of gpus ({}).".format(nl, world)
+        self.lab = TwoCropLoader(cfg, device, rank, world, labeled=True, dataset=label_dataset)
+        self.unl = TwoCropLoader(cfg, device, rank, world, labeled=False, dataset=unlabel_dataset)
+        self.batch_size_label, self.batch_size_unlabel = nl // world, nu // world
+        # the labelled frames' strong crop (two_crop_augmentation_mapper.py:141-146: both datasets go through the same mapper)
+        self.strong_aug = None
+        if torch.device(device).type == "cuda" and cfg.SFOD.SYNTHETIC.STRONG_AUGMENT:
+            from .augment import StrongAugmentation
+            self.strong_aug = StrongAugmentation(torch.Generator().manual_seed(max(cfg.SEED, 0) + 104729 * (rank + 1)))
+        self._label_buckets, self._label_buckets_key = [[], []], [[], []]
+        self._unlabel_buckets, self._unlabel_buckets_key = [[], []], [[], []]
+        self._label_bucket, self._unlabel_bucket = [], []          # common.py:120: the buckets last appended to
+        self._label_key, self._unlabel_key = [], []
+
+    def _two_crops(self, src):
+        weak = src._map(src.dataset.items[next(src.sampler)])
+        strong = dict(weak)
+        if self.strong_aug is not None:
+            strong["image"] = self.strong_aug(weak["image"])
+        return strong, weak                                        # d[0] strong, d[1] weak (common.py:123-124)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        while True:
+            d_label, d_unlabel = self._two_crops(self.lab), self._two_crops(self.unl)
+            if len(self._label_bucket) != self.batch_size_label:
+                i = 0 if d_label[0]["width"] > d_label[0]["height"] else 1
+                self._label_bucket, self._label_key = self._label_buckets[i], self._label_buckets_key[i]
+                self._label_bucket.append(d_label[0])
+                self._label_key.append(d_label[1])
+            if len(self._unlabel_bucket) != self.batch_size_unlabel:
+                i = 0 if d_unlabel[0]["width"] > d_unlabel[0]["height"] else 1
+                self._unlabel_bucket, self._unlabel_key = self._unlabel_buckets[i], self._unlabel_buckets_key[i]
+                self._unlabel_bucket.append(d_unlabel[0])
+                self._unlabel_key.append(d_unlabel[1])
+            if len(self._label_bucket) == self.batch_size_label and len(self._unlabel_bucket) == self.batch_size_unlabel:
+                out = (self._label_bucket[:], self._label_key[:], self._unlabel_bucket[:], self._unlabel_key[:])
+                del self._label_bucket[:], self._label_key[:], self._unlabel_bucket[:], self._unlabel_key[:]
+                return out

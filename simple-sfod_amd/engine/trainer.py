@@ -971,6 +971,127 @@ class SourceFreeAdaptiveTeacherSingleTrainer(SourceFreeAdaptiveTeacherTrainer):
             self.model_teacher = teacher
 
 
+class AdaptiveTeacherTrainer(SourceFreeAdaptiveTeacherTrainer):
+    """``TRAINER: "adaptive_teacher"`` (daod/engine/trainers/adaptive_teacher.py:31-420): the with-source teacher-student
+    loop the source-free trainer was derived from.  Differences that matter here:
+
+      * four lists per step -- labelled source frames (strong, weak) and unlabelled target frames (strong, weak), :195-199;
+      * burn-in (:202-213): until ``SEMISUPNET.BURN_UP_STEP`` only ``branch="supervised"`` on the 2 x IMS_PER_BATCH
+        labelled crops, every loss x 1;
+      * the teacher is updated at the START of a step on its own schedule (:215-223): a copy of the student
+        (``keep_rate = 0``) at ``iter == BURN_UP_STEP``, afterwards the EMA every ``TEACHER_UPDATE_ITER`` steps -- not
+        fused into the optimizer step (the update of step i therefore sees the student as step i - 1 left it, and a
+        checkpoint / evaluation between two steps sees the teacher the reference's hooks see);
+      * after burn-in (:225-329): teacher on the weak target crops -> pseudo labels -> student on ALL labelled crops
+        (``supervised``), on the strong target crops (``supervised_target``) and on (weak source, weak target) pairs
+        (``domain_classifier``, always: no DOMAIN_CLASSIFIER switch on this path); the domain pass's ``loss_DC_img_s``
+        REPLACES the ``supervised`` branch's (same dict key, :314); weights :316-327 -- pseudo box regression 0, other
+        ``*_pseudo`` UNSUP_LOSS_WEIGHT, ``loss_DC_img_{s,t}`` DIS_LOSS_WEIGHT, everything else (incl. the instance-level
+        discriminator) 1; the UNWEIGHTED record goes to ``_write_metrics`` (:331-333).
+    Pinned by running the reference's ``run_step`` on recorder stubs (tests/golden/adaptive_teacher_ref.npz)."""
+
+    def __init__(self, cfg, data_loader=None):
+        super().__init__(cfg, data_loader)
+        self.ema_enabled = False                 # never fused: see above
+        self.elide = False
+        self._elided_bn_updates = 1              # every pass of the reference runs
+        self.burn_up_step = int(cfg.SEMISUPNET.BURN_UP_STEP)
+        self.teacher_update_iter = int(cfg.SEMISUPNET.TEACHER_UPDATE_ITER)
+        self.ema_keep_rate = float(cfg.SEMISUPNET.EMA_KEEP_RATE)
+
+    @staticmethod
+    def _frozen(cfg):
+        return ()                                # the discriminators train on this path
+
+    def _attach_reducer(self):
+        self._reducer = None                     # several backbone passes per backward: one blocking exchange afterwards
+
+    def build_train_loader(self, cfg):
+        from ..data.synthetic import FourWayLoader
+        return FourWayLoader(cfg, self.device, get_rank(), get_world_size())
+
+    @torch.no_grad()
+    def _update_teacher_model(self, keep_rate=0.9996):
+        """:338-357 -- teacher <- student * (1 - keep_rate) + teacher * keep_rate over parameters AND buffers (the int64
+        counters in float32, truncated: SURVEY A.17 iv); keep_rate 0 is the burn-in hand-over."""
+        s, t = self.optimizer.flat, self.teacher_flat
+        native.ema_(t.param, s.param, keep_rate)
+        native.ema_(t.fbuf, s.fbuf, keep_rate)
+        native.ema_i64_(t.ibuf, s.ibuf, keep_rate)
+        t.values_rewritten()
+
+    @staticmethod
+    def loss_weight(key, cfg):
+        """:316-327, the same branch order"""
+        if key == "loss_rpn_loc_pseudo" or key == "loss_box_reg_pseudo":
+            return 0.0
+        if key[-6:] == "pseudo":
+            return float(cfg.SEMISUPNET.UNSUP_LOSS_WEIGHT)
+        if key == "loss_DC_img_s" or key == "loss_DC_img_t":
+            return float(cfg.SEMISUPNET.DIS_LOSS_WEIGHT)
+        return 1.0
+
+    def run_step(self):
+        cfg = self.cfg
+        assert self.model.training, "[AdaptiveTeacherTrainer] model was changed to eval mode!"
+        _throttle(self)
+        if hasattr(self.model, "drop_prefetched"):
+            self.model.drop_prefetched()
+        start = time.perf_counter()
+        label_data_q, label_data_k, unlabel_data_q, unlabel_data_k = next(self._data_loader_iter)
+        data_time = time.perf_counter() - start
+        if self.iter < self.burn_up_step:
+            label_data_q = list(label_data_q)
+            label_data_q.extend(label_data_k)
+            with stage("student_forward"):
+                record_dict, _, _ = self.model(label_data_q, branch="supervised")
+            keys = [k for k in record_dict if k[:4] == "loss" and k[-3:] != "val"]
+            weights = [1.0] * len(keys)
+        else:
+            if self.iter == self.burn_up_step:
+                self._update_teacher_model(keep_rate=0.00)
+            elif (self.iter - self.burn_up_step) % self.teacher_update_iter == 0:
+                self._update_teacher_model(keep_rate=self.ema_keep_rate)
+            record_dict = {}
+            unlabel_data_q = self.remove_label(unlabel_data_q)
+            unlabel_data_k = self.remove_label(unlabel_data_k)
+            with stage("teacher"):
+                pseudo = self._teacher_pass(unlabel_data_k)
+            self.storage._pending.pop("roi_head/mean_confidence", None)      # (the source-free trainer's scalar, not logged here)
+            unlabel_data_q = self.add_label(unlabel_data_q, pseudo)
+            unlabel_data_k = self.add_label(unlabel_data_k, pseudo)
+            all_label_data = list(label_data_q) + list(label_data_k)
+            with stage("student_forward"):
+                record_all_label_data, _, _ = self.model(all_label_data, branch="supervised")
+                record_dict.update(record_all_label_data)
+                record_all_unlabel_data, _, _ = self.model(unlabel_data_q, branch="supervised_target", batched=True)
+                for key, v in record_all_unlabel_data.items():
+                    record_dict[key + "_pseudo"] = v
+                for i in range(len(unlabel_data_k)):
+                    for k, v in unlabel_data_k[i].items():
+                        label_data_k[i][k + "_unlabeled"] = v
+                record_all_domain_data, _, _ = self.model(label_data_k, branch="domain_classifier")
+                record_dict.update(record_all_domain_data)       # its loss_DC_img_s replaces the supervised branch's
+            keys = [k for k in record_dict if k.startswith("loss") and k[-3:] != "val"]
+            weights = [self.loss_weight(k, cfg) for k in keys]
+        wdev = native.dev_const(tuple(weights), torch.float32, self.device)
+        _, losses = weighted_loss_sum(wdev, [record_dict[k] for k in keys])
+        metrics_dict = dict(record_dict)
+        metrics_dict["data_time"] = data_time
+        self._write_metrics(metrics_dict)
+        self.optimizer.zero_grad()
+        with stage("student_backward"):
+            try:
+                losses.backward()
+            finally:
+                offchain.clear_loss_grads_mark()
+        with stage("exchange"):
+            self._reduce_gradients()
+        with stage("update"):
+            self.optimizer.step(ema=False)
+        _step_enqueued(self)
+
+
 # ---- AdaBN refinement (base.py:270-337) -----------------------------------------------------------
 def reset_bn_stats(model):
     """reset every BatchNorm2d running_mean / running_var to 0 / 1 (:318-328)."""
@@ -1013,6 +1134,7 @@ TRAINERS = {
     "base": BaseTrainer,
     "source_free_adaptive_teacher": SourceFreeAdaptiveTeacherTrainer,
     "source_free_adaptive_teacher_single": SourceFreeAdaptiveTeacherSingleTrainer,
+    "adaptive_teacher": AdaptiveTeacherTrainer,
 }
 
 
