@@ -258,12 +258,14 @@ class FusedSGD:
         return loaded
 
 
-def build_optimizer(cfg, model):
-    """d2 build_optimizer for SOLVER.{BASE_LR,MOMENTUM,WEIGHT_DECAY,WEIGHT_DECAY_NORM}."""
-    frozen = ()
-    if "DOMAIN_CLASSIFIER" in cfg and not cfg.DOMAIN_CLASSIFIER.ENABLED:
-        # the domain branch never runs: the reference leaves these grads None and SGD skips them
-        frozen = ("DC_img.", "DC_ins.")
+def build_optimizer(cfg, model, frozen=None):
+    """d2 build_optimizer for SOLVER.{BASE_LR,MOMENTUM,WEIGHT_DECAY,WEIGHT_DECAY_NORM}.  ``frozen``: parameter prefixes that
+    never receive a gradient in this trainer (default: the discriminators when DOMAIN_CLASSIFIER is off)."""
+    if frozen is None:
+        frozen = ()
+        if "DOMAIN_CLASSIFIER" in cfg and not cfg.DOMAIN_CLASSIFIER.ENABLED:
+            # the domain branch never runs: the reference leaves these grads None and SGD skips them
+            frozen = ("DC_img.", "DC_ins.")
     flat = FlatModelState(model, frozen_prefixes=frozen)
     assert cfg.SOLVER.BIAS_LR_FACTOR == 1.0 and cfg.SOLVER.WEIGHT_DECAY_BIAS in (None, cfg.SOLVER.WEIGHT_DECAY)
     assert not cfg.SOLVER.CLIP_GRADIENTS.ENABLED and not cfg.SOLVER.NESTEROV

@@ -1003,6 +1003,10 @@ class AdaptiveTeacherTrainer(SourceFreeAdaptiveTeacherTrainer):
     def _frozen(cfg):
         return ()                                # the discriminators train on this path
 
+    @classmethod
+    def build_optimizer(cls, cfg, model):
+        return build_optimizer(cfg, model, frozen=cls._frozen(cfg))
+
     def _attach_reducer(self):
         self._reducer = None                     # several backbone passes per backward: one blocking exchange afterwards
 
