@@ -129,7 +129,7 @@ def _trajectory_case(sfod, native, model, dtype, elide):
                 return 8e-2
             return 6e-2 if x3 else 4e-2
         if name.startswith("roi_heads"):
-            if resnet:      # the heads read res4 features that already carry the network's 1e-4 forward noise (section 1a
+            if resnet:      # the heads read res4 features that already carry the network's 1e-4 forward noise (DESIGN section 2
                 return 8e-3  # of DESIGN.md): more ReLU flips in fc1 / fc2 than behind VGG16 (seen: 2.2e-3)
             return 4e-3 if x3 else 2e-3
         if ".rpn_head." in name:        # few hidden units under sparse gradients: ONE flipped ReLU shows as 1e-3 .. 2e-2
