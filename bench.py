@@ -335,7 +335,7 @@ def main():
             rccl_log = telemetry.rccl_debug_setup(rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     # clocks and package power of every GPU of the node beside the run (rank 0: a host thread running rocm-smi)
-    smi = telemetry.SmiSampler().start() if rank == 0 and not args.no_smi else None
+    smi = telemetry.SmiSampler().start() if rank == 0 and not args.no_smi and not telemetry.under_profiler() else None
 
     note("torch imported")
     sfod = importlib.import_module("simple-sfod_amd")

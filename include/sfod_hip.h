@@ -137,8 +137,9 @@ int sfod_conv_fwd_bnin(const float* x_pre, const float* in_mean, const float* in
 /* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
  * 4 = 512 x 64 (applied where the channel counts allow it), 5 = 256 x 128 on v_mfma_f32_16x16x32 (operand pairs with
  * Cin % 32 == 0; otherwise as 2: 8 waves x (64 px x 64 ch), four waves per SIMD), 6 = the same with 4 waves x (128 px x
- * 64 ch), two per SIMD (leaves registers for a co-resident kernel; tools/experiments/corun_conv_bn.py).  For A/B runs and
- * parity tests. */
+ * 64 ch), two per SIMD (leaves registers for a co-resident kernel; tools/experiments/corun_conv_bn.py), 7 / 8 = shapes 3 / 4
+ * on v_mfma_f32_16x16x32 (operand pairs with Cin % 32 == 0: 4 waves x (64 px x 64 ch) / 8 waves of them; otherwise as 3 / 4).
+ * For A/B runs and parity tests. */
 int sfod_set_conv3x3_variant(int variant);
 /* Deterministic gradients (default 0; environment SFOD_DETERMINISTIC, config SFOD.DETERMINISTIC): the generic weight-gradient
  * kernels (1x1 / linear / first layer / fp32) store every pixel split's partial tile into a slab of the workspace

@@ -714,16 +714,22 @@ __device__ __forceinline__ void wait_vm_dyn(int n) {
   }
 }
 
-template <int NW, int NIP> struct M16Lay {
-  static constexpr int PIX = (NW / 2) * NIP * 16;           // pixels per workgroup: 256 | 512
+// NWN = waves along the channel axis: 2 -> 128 output channels per workgroup (the shapes above), 1 -> 64 (round 6: the
+// 64-channel tile shapes of the plan -- Cout <= 64 layers, conv5 / RPN at 600x1200 -- on the same loop instead of the
+// 32x32x16 kernel's 32 x 64 wave tiles: <4, 4, 1> = 4 waves x (64 px x 64 ch) = 256 px x 64 ch, 64 KiB, two workgroups per CU;
+// <8, 4, 1> = 512 px x 64 ch, 96 KiB)
+template <int NW, int NIP, int NWN = 2> struct M16Lay {
+  static constexpr int PIX = (NW / NWN) * NIP * 16;         // pixels per workgroup: 256 | 512
   static constexpr int PR = (PIX == 256) ? 384 : 640;       // patch rows (pixels incl. halo) per buffer
   static constexpr int NPW = PR / 16 / NW;                  // 1 KiB patch pieces per wave and slice
   static constexpr int PPS = (NPW + 2) / 3;                 // ... issued per stage (stages 0-2 / 5-7)
-  static constexpr int WPW = 16 / NW;                       // 1 KiB weight pieces per wave and stage: 4 | 2
+  static constexpr int PPP = 4 * NWN;                       // 1 KiB weight pieces per (tap, slice) pair: 64 * NWN rows x 64 B
+  static constexpr int WPW = 2 * PPP / NW;                  // 1 KiB weight pieces per wave and stage: 4 | 2 | 1
   static constexpr int PATCH_BYTES = PR * 64;
   static constexpr int WR_OFF = 2 * PATCH_BYTES;
-  static constexpr int WSLOT = 16384;
-  static constexpr int LDS = WR_OFF + 2 * WSLOT;            // 81920 (256 pixels) | 114688
+  static constexpr int WSLOT = 2 * PPP * 1024;              // 16384 | 8192
+  static constexpr int LDS = WR_OFF + 2 * WSLOT;            // 81920 (256 pixels) | 114688; NWN = 1: 65536 | 98304
+  static_assert(WPW >= 1 && PPP % WPW == 0 && PPS <= 3, "a wave's weight pieces of a stage lie inside one pair");
 };
 
 #ifdef M16_STAMP
@@ -734,22 +740,25 @@ __device__ unsigned long long g_m16_stamps[8];
 
 typedef float __attribute__((address_space(4))) cfloat_k;      // a float in the constant address space
 
-template <int NW, int NIP, int FMT, bool RED, bool XF = false>
-__global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::LDS)) / 4) k_conv3x3_m16(P3Args a) {
-  using L = M16Lay<NW, NIP>;
+template <int NW, int NIP, int FMT, bool RED, bool XF = false, int NWN = 2>
+__global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP, NWN>::LDS)) / 4 > 0 ? (NW * (160 * 1024 / M16Lay<NW, NIP, NWN>::LDS)) / 4 : 1)
+k_conv3x3_m16(P3Args a) {
+  using L = M16Lay<NW, NIP, NWN>;
+  static_assert(!XF || NWN == 2, "the in-LDS BatchNorm transform lives in the 128-channel shape");
   static_assert(!XF || (NW == 4 && NIP == 8 && FMT == 1 && !RED), "the in-LDS BatchNorm transform lives in the 4-wave bf16-pair forward kernel");
 #ifdef M16_STAMP
   const unsigned long long stamp_t0 = __builtin_amdgcn_s_memtime();
 #endif
   constexpr int PR = L::PR, NPW = L::NPW, WPW = L::WPW, PATCH_BYTES = L::PATCH_BYTES, WR_OFF = L::WR_OFF, WSLOT = L::WSLOT;
-  constexpr int NWM = NW / 2;            // waves along the pixel axis
+  constexpr int NWM = NW / NWN;          // waves along the pixel axis
+  constexpr int PPP = L::PPP;
   constexpr int WPX = NIP * 16;          // pixels per wave (NIP 16-pixel tiles)
   constexpr int XB = (NIP >= 8) ? 2 : 1; // pixel fragment register sets: the 128-register shape has room for one only
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int q = lane >> 4, r16 = lane & 15;
   const int pb = q & 1, chh = q >> 1;        // which pair of the stage / which 8-channel half this lane group feeds
 
@@ -766,7 +775,7 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
   const int b = (int)fdiv((unsigned)t2, (unsigned)a.tiles_y, a.m_ty);
   const int tyi = t2 - b * a.tiles_y;
   const int mtile = (b * a.tiles_y + tyi) * a.tiles_x + txi;
-  const int x0 = txi * a.TW, y0 = tyi * a.TH, n0 = tn * 128;
+  const int x0 = txi * a.TW, y0 = tyi * a.TH, n0 = tn * (64 * NWN);
   const int PW = a.PW;
   const int npix = a.TH * a.TW;
   const bf16_t* ximg = a.x + (int64_t)b * a.H * a.W * a.Cin;
@@ -785,15 +794,15 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
     const bool ok = (py < a.TH + 2) && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
     return ok ? (unsigned)(((iy * a.W + ix) * a.Cin + lc * 8) * 2) : OOB_OFF;
   };
-  // weight pieces of a stage: 16 x 1 KiB = (pair a: 128 rows, pair b: 128 rows); wave w issues pieces w*WPW .. +WPW-1
+  // weight pieces of a stage: 2 PPP x 1 KiB = (pair a: 64 NWN rows, pair b: 64 NWN rows); wave w issues pieces w*WPW .. +WPW-1
   unsigned boff[WPW];
 #pragma unroll
   for (int k = 0; k < WPW; ++k) {
-    const int n = ((wave * WPW + k) & 7) * 16 + (lane >> 2);
+    const int n = ((wave * WPW + k) & (PPP - 1)) * 16 + (lane >> 2);
     const int lc = (lane & 3) ^ ((n >> 2) & 3);
     boff[k] = (n0 + n < a.Cout) ? (unsigned)(((n0 + n) * Ktot + lc * 8) * 2) : OOB_OFF;
   }
-  const int wpair = (wave * WPW) >> 3;       // which pair of a stage this wave's weight pieces belong to
+  const int wpair = (wave * WPW) / PPP;      // which pair of a stage this wave's weight pieces belong to
   auto issue_patch = [&](int k, int slice, int buf) {
     bufload16(xres, patch_off(k), (unsigned)__builtin_amdgcn_readfirstlane(slice * 64),
               smem + buf * PATCH_BYTES + (wave * NPW + k) * 1024);
@@ -914,7 +923,7 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
     asm volatile("" : "+v"(rowA[i]));       // materialised here, not re-derived from spilled 64-bit products inside the K loop
   }
   // weight fragment of channel tile ic: + ic * 1024; lo = ^ 16   ((n >> 2) & 3 == (r16 >> 2) & 3 for n = 16 m + r16)
-  const int offW = pb * 8192 + (wn * 64 + r16) * 64 + (((2 * chh) ^ ((r16 >> 2) & 3)) << 4);
+  const int offW = pb * (PPP * 1024) + (wn * 64 + r16) * 64 + (((2 * chh) ^ ((r16 >> 2) & 3)) << 4);
 
   f32x4_t acc[4][NIP];     // [channel tile][pixel tile]: channel = wn*64 + ic*16 + q*4 + r, pixel = wm*128 + ip*16 + r16
 #pragma unroll
@@ -1193,13 +1202,13 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
       }
     }
     __syncthreads();
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < 64 * NWN) {
       const int col = threadIdx.x, cwn = col >> 6, cl = col & 63;
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int k = 0; k < NWM; ++k) {
-        s1 += sred[((k * 2 + cwn) * 64 + cl) * 2 + 0];
-        s2 += sred[((k * 2 + cwn) * 64 + cl) * 2 + 1];
+        s1 += sred[((k * NWN + cwn) * 64 + cl) * 2 + 0];
+        s2 += sred[((k * NWN + cwn) * 64 + cl) * 2 + 1];
       }
       const int n = n0 + col;
       if (n < a.Cout) {
@@ -1241,12 +1250,12 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
       }
     if (lane == 0) scnt[wave] = (float)cnt;
     __syncthreads();
-    if (threadIdx.x < 128) {
+    if (threadIdx.x < 64 * NWN) {
       const int col = threadIdx.x, cwn = col >> 6, cl = col & 63;
       double n_tot = 0.0, s_tot = 0.0;
 #pragma unroll
       for (int k = 0; k < NWM; ++k) {
-        const int wv = k * 2 + cwn;
+        const int wv = k * NWN + cwn;
         n_tot += (double)scnt[wv];
         s_tot += (double)sred[(wv * 64 + cl) * 2 + 0];
       }
@@ -1254,7 +1263,7 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
       double m2 = 0.0;
 #pragma unroll
       for (int k = 0; k < NWM; ++k) {
-        const int wv = k * 2 + cwn;
+        const int wv = k * NWN + cwn;
         const double nk = (double)scnt[wv];
         if (nk > 0.0) {
           const double d = (double)sred[(wv * 64 + cl) * 2 + 0] / nk - mu;
@@ -1282,6 +1291,10 @@ __global__ void __launch_bounds__(NW * 64, (NW * (160 * 1024 / M16Lay<NW, NIP>::
 //      with Cin % 32 == 0 only, everything else runs as 2).  The automatic choice takes it wherever it picks shape 2
 //      (SFOD_P3_M16=0 / sfod_set_conv3x3_m16(0): the 32x32x16 kernel everywhere, for A/B runs)
 //   6  the same on 4 waves per workgroup (k_conv3x3_m16<4, 8>, wave tile 128 x 64)
+//   7  shape 3 on v_mfma_f32_16x16x32 (round 6: k_conv3x3_m16<4, 4, NWN = 1>: 4 waves x (64 px x 64 ch), 64 KiB, two workgroups
+//      per CU; operand pairs with Cin % 32 == 0).  The automatic choice takes it wherever it picks shape 3 (SFOD_P3_M16_N64=0:
+//      the 32x32x16 kernel there, for A/B runs)
+//   8  shape 4 on it (k_conv3x3_m16<8, 4, NWN = 1>: 512 px x 64 ch, 96 KiB, one workgroup per CU)
 // Measured per layer (tools/bench_conv.py, interleaved A/B; profiles/r1q_conv_variants.txt): two resident
 // workgroups overlap each other's prologue / epilogue / barrier stalls, which beats the larger tiles' lower
 // L2 -> LDS traffic on every VGG shape; between the two small shapes the 64 x 64 wave tile needs one LDS
@@ -1298,6 +1311,10 @@ extern "C" int sfod_set_conv3x3_m16(int on) {
   g_p3_m16.store((on >= 0 && on <= 2) ? on : 1, std::memory_order_relaxed);
   return 0;
 }
+static int p3_m16_n64_enabled() {
+  static const int on = []() { const char* e = getenv("SFOD_P3_M16_N64"); return e ? atoi(e) : 1; }();
+  return on;
+}
 static int p3_m16_enabled() {       // 0 off, 1 the 8-wave form (default), 2 the 4-wave form (SFOD_P3_M16=2: co-residency experiments)
   int v = g_p3_m16.load(std::memory_order_relaxed);
   if (v < 0) {
@@ -1311,7 +1328,7 @@ static int p3_m16_enabled() {       // 0 off, 1 the 8-wave form (default), 2 the
 }
 
 extern "C" int sfod_set_conv3x3_variant(int variant) {
-  g_p3_variant.store((variant >= 1 && variant <= 6) ? variant : 0, std::memory_order_relaxed);
+  g_p3_variant.store((variant >= 1 && variant <= 8) ? variant : 0, std::memory_order_relaxed);
   return 0;
 }
 
@@ -1351,8 +1368,10 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout, int pairs) {
     g_p3_variant.compare_exchange_strong(expect, variant, std::memory_order_relaxed);   // a concurrent setter wins
     variant = g_p3_variant.load(std::memory_order_relaxed);
   }
-  p.m16 = (variant == 5) ? 1 : (variant == 6 ? 2 : ((variant < 1 || variant > 6) ? p3_m16_enabled() : 0));
+  p.m16 = (variant == 5 || variant == 7 || variant == 8) ? 1 : (variant == 6 ? 2 : ((variant < 1 || variant > 8) ? p3_m16_enabled() : 0));
   if (variant == 5 || variant == 6) variant = 2;
+  if (variant == 7) variant = 3;        // the 64-channel tile shapes on the 16x16x32 loop (k_conv3x3_m16<.., NWN = 1>)
+  if (variant == 8) variant = 4;
   if (variant < 1 || variant > 4) {
     const int64_t mt = ((int64_t)B * H * W + 255) / 256;          // 256-pixel tiles (lower bound)
     const int64_t wg128 = mt * ((Cout + 127) / 128);
@@ -1394,10 +1413,10 @@ extern "C" int sfod_debug_m16_stamps(unsigned long long* out8, int reset) {
 }
 #endif
 
-template <int NW, int NIP, int FMT, bool RED, bool XF = false>
+template <int NW, int NIP, int FMT, bool RED, bool XF = false, int NWN = 2>
 static int p3_launch_m16(P3Args a, hipStream_t s) {
-  auto kern = k_conv3x3_m16<NW, NIP, FMT, RED, XF>;
-  constexpr int LDS = M16Lay<NW, NIP>::LDS;
+  auto kern = k_conv3x3_m16<NW, NIP, FMT, RED, XF, NWN>;
+  constexpr int LDS = M16Lay<NW, NIP, NWN>::LDS;
   static const hipError_t attr_rc =
       hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
   if (attr_rc != hipSuccess) { sfod_set_error("hipFuncSetAttribute(m16): %s", hipGetErrorString(attr_rc)); return -(int)attr_rc; }
@@ -1463,6 +1482,16 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
       }
       if (red != nullptr) return p3_launch_m16<8, 4, 1, true>(a, s);
       return split == 2 ? p3_launch_m16<8, 4, 2, false>(a, s) : p3_launch_m16<8, 4, 1, false>(a, s);
+    }
+    // round 6: the 64-channel tile shapes on the same loop (shape 3: 256 px x 64 ch -> <4, 4, NWN = 1>; shape 4: 512 px x 64 ch
+    // -> <8, 4, NWN = 1>); SFOD_P3_M16_N64=0 keeps them on the 32x32x16 kernel (A/B)
+    if (p.m16 && p.G == 2 && Cin % 64 == 0 && (red == nullptr || split == 1) && p3_m16_n64_enabled()) {
+      if (p.FM == 1) {
+        if (red != nullptr) return p3_launch_m16<4, 4, 1, true, false, 1>(a, s);
+        return split == 2 ? p3_launch_m16<4, 4, 2, false, false, 1>(a, s) : p3_launch_m16<4, 4, 1, false, false, 1>(a, s);
+      }
+      if (red != nullptr) return p3_launch_m16<8, 4, 1, true, false, 1>(a, s);
+      return split == 2 ? p3_launch_m16<8, 4, 2, false, false, 1>(a, s) : p3_launch_m16<8, 4, 1, false, false, 1>(a, s);
     }
     if (red != nullptr) {
       if (split != 1) { sfod_set_error("conv3x3_patch: the BatchNorm-backward epilogue runs on bf16x3 operands"); return SFOD_EBADARG; }

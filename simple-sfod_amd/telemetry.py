@@ -35,11 +35,36 @@ def parse_smi(text):
     return out
 
 
+def under_profiler():
+    """rocprofv3 preloads its tool library into the process (and, through the environment, into every child): a child that
+    hops through ``#!/usr/bin/env`` then counts as a GPU-initialised process replacing itself, which this pool refuses.  No
+    sampling beside a profiled run."""
+    pre = os.environ.get("LD_PRELOAD", "") + os.environ.get("ROCP_TOOL_LIBRARIES", "")
+    return "rocprof" in pre.lower() or "ROCPROFILER_LIBRARY_CTOR" in os.environ
+
+
+def smi_command(args=("--showpower", "--showclocks", "--json")):
+    """``rocm-smi`` is a Python script behind ``#!/usr/bin/env python3``: run it with THIS interpreter directly -- one exec
+    in the child, no ``env`` hop in between"""
+    import shutil
+    import sys
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    real = os.path.realpath(exe)
+    try:
+        with open(real, "rb") as fh:
+            head = fh.read(64)
+    except OSError:
+        return [exe] + list(args)
+    if head.startswith(b"#!") and b"python" in head.split(b"\n")[0]:
+        return [sys.executable, real] + list(args)
+    return [exe] + list(args)
+
+
 class SmiSampler:
     """Samples every GPU of the node every ``interval`` seconds from a daemon thread (a child ``rocm-smi`` per sample)."""
 
-    def __init__(self, interval=0.4, cmd=("rocm-smi", "--showpower", "--showclocks", "--json")):
-        self.interval, self.cmd = interval, list(cmd)
+    def __init__(self, interval=0.4, cmd=None):
+        self.interval, self.cmd = interval, list(cmd) if cmd is not None else smi_command()
         self.samples = []            # (perf_counter time, {card: (W, MHz)})
         self._stop = threading.Event()
         self._thread = None

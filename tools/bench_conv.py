@@ -39,7 +39,7 @@ def main():
         ("conv3_1", H0 // 4, W0 // 4, 128, 256), ("conv3_2", H0 // 4, W0 // 4, 256, 256),
         ("conv4_1", H0 // 8, W0 // 8, 256, 512), ("conv4_2", H0 // 8, W0 // 8, 512, 512),
         ("conv5_1", H0 // 16, W0 // 16, 512, 512), ("rpn", H0 // 32, W0 // 32, 512, 512),
-        ("dgrad2_1", H0 // 2, W0 // 2, 128, 64), ("dgrad3_1", H0 // 4, W0 // 4, 256, 128),
+        ("dgrad2_1", H0 // 2, W0 // 2, 128, 64), ("dgrad3_1", H0 // 4, W0 // 4, 256, 128), ("dgrad1_2", H0, W0, 64, 64),
     ]
     if args.layers:
         keep = set(args.layers.split(","))
@@ -86,7 +86,7 @@ def main():
             continue
         if args.variants:
             native.set_conv_algo(2)
-            vt = {v: [] for v in (0, 1, 2, 3, 4, 5, 6)}
+            vt = {v: [] for v in (0, 1, 2, 3, 4, 5, 6, 7, 8)}
             for r in range(args.rounds + 1):
                 for v in vt:
                     native.set_conv3x3_variant(v)
@@ -99,7 +99,8 @@ def main():
                         vt[v].append(e0.elapsed_time(e1))
             native.set_conv3x3_variant(0)
             native.set_conv_algo(0)
-            names = {0: "auto", 1: "512x128", 2: "256x128", 3: "256x64", 4: "512x64", 5: "256x128 m16", 6: "256x128 m16 4w"}
+            names = {0: "auto", 1: "512x128", 2: "256x128", 3: "256x64", 4: "512x64", 5: "256x128 m16", 6: "256x128 m16 4w",
+                     7: "256x64 m16", 8: "512x64 m16"}
             line = f"{name:9s} {B}x{H}x{W} {Cin:4d}->{Cout:4d} {flops / 1e9:8.1f} GF"
             for v in vt:
                 t = sorted(vt[v])[len(vt[v]) // 2]

@@ -25,7 +25,7 @@ VB=$(bias_of); RB=$(bias_of --model r101)
 echo "planted background bias: vgg $VB r101 $RB"
 if [ "$WHAT" = pmc ] || [ "$WHAT" = all ]; then
   rm -rf $O/prof_kt
-  rocprofv3 --kernel-trace --stats -d $O/prof_kt -o kt -- python3 bench.py --plant-bias $VB --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --steps 20 --warmup 5 > /dev/null 2> $O/${TAG}_kt.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_kt -o kt -- python3 bench.py --plant-bias $VB --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --no-smi --steps 20 --warmup 5 > /dev/null 2> $O/${TAG}_kt.err
   DB=$(find $O/prof_kt -name "*.db" | head -1)
   python3 tools/rocpd_stats.py $DB 25 > $O/${TAG}_bf16x3_B8_r600_single_stream_kernel_stats.csv
   rm -rf $O/prof_kt
@@ -60,7 +60,7 @@ if [ "$WHAT" = r101 ] || [ "$WHAT" = all ]; then
   # config #5 in its parity mode (f16x3): kernel trace of single-stream steps, GPU busy fraction (union of kernel intervals
   # over the span of the timed steps, and the un-profiled step time of the bench line beside the profiled kernel-time sum)
   rm -rf $O/prof_r101
-  rocprofv3 --kernel-trace --stats -d $O/prof_r101 -o r101 -- python3 bench.py --model r101 --plant-bias $RB --no-overlap --steps 12 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timer > $O/${TAG}_r101_f16x3_profiled_bench.json 2> $O/${TAG}_r101_prof.err
+  rocprofv3 --kernel-trace --stats -d $O/prof_r101 -o r101 -- python3 bench.py --model r101 --plant-bias $RB --no-overlap --steps 12 --warmup 3 --no-cpu-baseline --no-secondary --no-kernel-timer --no-smi > $O/${TAG}_r101_f16x3_profiled_bench.json 2> $O/${TAG}_r101_prof.err
   DB=$(find $O/prof_r101 -name "*.db" | head -1)
   python3 tools/rocpd_stats.py $DB 15 > $O/${TAG}_r101_f16x3_kernel_stats.csv
   python3 tools/busy_fraction.py $DB 0.3 > $O/${TAG}_r101_f16x3_busy_fraction.txt

@@ -3,7 +3,7 @@
 # usage (GPU box): bash tools/pmc_hbm_run.sh <out.json> [bench.py args]
 export TMPDIR=/tmp
 OUT=$1; shift
-B="python3 bench.py --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --steps 3 --warmup 2 $@"
+B="python3 bench.py --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --no-smi --steps 3 --warmup 2 $@"
 rm -rf gpurun_out/pmc_hbm; mkdir -p gpurun_out/pmc_hbm
 rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_hbm/f -o f --output-format csv -- $B > /dev/null 2> gpurun_out/pmc_hbm/f.err
 rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_hbm/w -o w --output-format csv -- $B > /dev/null 2> gpurun_out/pmc_hbm/w.err
