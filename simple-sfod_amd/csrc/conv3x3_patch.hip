@@ -1292,8 +1292,8 @@ k_conv3x3_m16(P3Args a) {
 //      (SFOD_P3_M16=0 / sfod_set_conv3x3_m16(0): the 32x32x16 kernel everywhere, for A/B runs)
 //   6  the same on 4 waves per workgroup (k_conv3x3_m16<4, 8>, wave tile 128 x 64)
 //   7  shape 3 on v_mfma_f32_16x16x32 (round 6: k_conv3x3_m16<4, 4, NWN = 1>: 4 waves x (64 px x 64 ch), 64 KiB, two workgroups
-//      per CU; operand pairs with Cin % 32 == 0).  The automatic choice takes it wherever it picks shape 3 (SFOD_P3_M16_N64=0:
-//      the 32x32x16 kernel there, for A/B runs)
+//      per CU; operand pairs with Cin % 32 == 0).  Slower than shape 3 on every layer measured (see sfod_p3_launch): never the
+//      automatic choice unless SFOD_P3_M16_N64=1
 //   8  shape 4 on it (k_conv3x3_m16<8, 4, NWN = 1>: 512 px x 64 ch, 96 KiB, one workgroup per CU)
 // Measured per layer (tools/bench_conv.py, interleaved A/B; profiles/r1q_conv_variants.txt): two resident
 // workgroups overlap each other's prologue / epilogue / barrier stalls, which beats the larger tiles' lower
@@ -1312,7 +1312,7 @@ extern "C" int sfod_set_conv3x3_m16(int on) {
   return 0;
 }
 static int p3_m16_n64_enabled() {
-  static const int on = []() { const char* e = getenv("SFOD_P3_M16_N64"); return e ? atoi(e) : 1; }();
+  static const int on = []() { const char* e = getenv("SFOD_P3_M16_N64"); return e ? atoi(e) : 0; }();
   return on;
 }
 static int p3_m16_enabled() {       // 0 off, 1 the 8-wave form (default), 2 the 4-wave form (SFOD_P3_M16=2: co-residency experiments)
@@ -1368,7 +1368,7 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout, int pairs) {
     g_p3_variant.compare_exchange_strong(expect, variant, std::memory_order_relaxed);   // a concurrent setter wins
     variant = g_p3_variant.load(std::memory_order_relaxed);
   }
-  p.m16 = (variant == 5 || variant == 7 || variant == 8) ? 1 : (variant == 6 ? 2 : ((variant < 1 || variant > 8) ? p3_m16_enabled() : 0));
+  p.m16 = (variant == 5) ? 1 : ((variant == 7 || variant == 8) ? 3 : (variant == 6 ? 2 : ((variant < 1 || variant > 8) ? p3_m16_enabled() : 0)));
   if (variant == 5 || variant == 6) variant = 2;
   if (variant == 7) variant = 3;        // the 64-channel tile shapes on the 16x16x32 loop (k_conv3x3_m16<.., NWN = 1>)
   if (variant == 8) variant = 4;
@@ -1484,8 +1484,11 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
       return split == 2 ? p3_launch_m16<8, 4, 2, false>(a, s) : p3_launch_m16<8, 4, 1, false>(a, s);
     }
     // round 6: the 64-channel tile shapes on the same loop (shape 3: 256 px x 64 ch -> <4, 4, NWN = 1>; shape 4: 512 px x 64 ch
-    // -> <8, 4, NWN = 1>); SFOD_P3_M16_N64=0 keeps them on the 32x32x16 kernel (A/B)
-    if (p.m16 && p.G == 2 && Cin % 64 == 0 && (red == nullptr || split == 1) && p3_m16_n64_enabled()) {
+    // -> <8, 4, NWN = 1>).  Built, bit-checked (variants 7 / 8 in the kernel tests) and measured SLOWER than the 32x32x16 kernel's
+    // 8-wave 256 x 64 shape on every layer that takes these tiles (conv1_2 1.35 vs 1.15 ms, dgrad2_1 0.62 vs 0.55, conv5_1 0.31
+    // vs 0.28, RPN 0.14 vs 0.10: profiles/r6_m16_n64_variants.txt) -- half the resident waves (8 per CU) cost more on these
+    // short-K, store-heavy shapes than the 4.5x fewer fragment reads return.  Forced variants 7 / 8 and SFOD_P3_M16_N64=1 only.
+    if (p.m16 && p.G == 2 && Cin % 64 == 0 && (red == nullptr || split == 1) && (p.m16 == 3 || p3_m16_n64_enabled())) {
       if (p.FM == 1) {
         if (red != nullptr) return p3_launch_m16<4, 4, 1, true, false, 1>(a, s);
         return split == 2 ? p3_launch_m16<4, 4, 2, false, false, 1>(a, s) : p3_launch_m16<4, 4, 1, false, false, 1>(a, s);

@@ -359,7 +359,7 @@ def test_conv_first_layer_kernel_split(native, hw):
     assert rel_err(zf, native.cast(z2, torch.float32).cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("wg", [2, 5, 6, 7, 8])
+@pytest.mark.parametrize("wg", [2, 5, 6, 7])      # (7: the 64-channel tiles on 16x16x32; 256-pixel tiles like 2: same statistics blocks)
 def test_conv3x3_pairs_under_load_is_deterministic(native, wg):
     """Full-chip launch on operand pairs (two workgroups per CU): the 32x32x16 kernel (2) and the 16x16x32 kernel (5) must
     each be run-to-run bit-identical -- guards the counted-wait DMA pipelines, whose hazards (a fragment read still queued
