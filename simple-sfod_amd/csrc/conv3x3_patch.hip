@@ -1295,6 +1295,7 @@ k_conv3x3_m16(P3Args a) {
 //      per CU; operand pairs with Cin % 32 == 0).  Slower than shape 3 on every layer measured (see sfod_p3_launch): never the
 //      automatic choice unless SFOD_P3_M16_N64=1
 //   8  shape 4 on it (k_conv3x3_m16<8, 4, NWN = 1>: 512 px x 64 ch, 96 KiB, one workgroup per CU)
+//   9  shape 3 on it with 8 waves x (32 px x 64 ch) (k_conv3x3_m16<8, 2, NWN = 1>: 64 KiB, two workgroups = 16 waves per CU)
 // Measured per layer (tools/bench_conv.py, interleaved A/B; profiles/r1q_conv_variants.txt): two resident
 // workgroups overlap each other's prologue / epilogue / barrier stalls, which beats the larger tiles' lower
 // L2 -> LDS traffic on every VGG shape; between the two small shapes the 64 x 64 wave tile needs one LDS
@@ -1328,7 +1329,7 @@ static int p3_m16_enabled() {       // 0 off, 1 the 8-wave form (default), 2 the
 }
 
 extern "C" int sfod_set_conv3x3_variant(int variant) {
-  g_p3_variant.store((variant >= 1 && variant <= 8) ? variant : 0, std::memory_order_relaxed);
+  g_p3_variant.store((variant >= 1 && variant <= 9) ? variant : 0, std::memory_order_relaxed);
   return 0;
 }
 
@@ -1368,9 +1369,9 @@ P3Plan sfod_p3_plan(int B, int H, int W, int Cin, int Cout, int pairs) {
     g_p3_variant.compare_exchange_strong(expect, variant, std::memory_order_relaxed);   // a concurrent setter wins
     variant = g_p3_variant.load(std::memory_order_relaxed);
   }
-  p.m16 = (variant == 5) ? 1 : ((variant == 7 || variant == 8) ? 3 : (variant == 6 ? 2 : ((variant < 1 || variant > 8) ? p3_m16_enabled() : 0)));
+  p.m16 = (variant == 5) ? 1 : ((variant == 7 || variant == 8) ? 3 : (variant == 9 ? 4 : (variant == 6 ? 2 : ((variant < 1 || variant > 9) ? p3_m16_enabled() : 0))));
   if (variant == 5 || variant == 6) variant = 2;
-  if (variant == 7) variant = 3;        // the 64-channel tile shapes on the 16x16x32 loop (k_conv3x3_m16<.., NWN = 1>)
+  if (variant == 7 || variant == 9) variant = 3;        // the 64-channel tile shapes on the 16x16x32 loop (k_conv3x3_m16<.., NWN = 1>)
   if (variant == 8) variant = 4;
   if (variant < 1 || variant > 4) {
     const int64_t mt = ((int64_t)B * H * W + 255) / 256;          // 256-pixel tiles (lower bound)
@@ -1488,7 +1489,11 @@ int sfod_p3_launch(const P3Plan& p, const void* x, const void* w, const float* b
     // 8-wave 256 x 64 shape on every layer that takes these tiles (conv1_2 1.35 vs 1.15 ms, dgrad2_1 0.62 vs 0.55, conv5_1 0.31
     // vs 0.28, RPN 0.14 vs 0.10: profiles/r6_m16_n64_variants.txt) -- half the resident waves (8 per CU) cost more on these
     // short-K, store-heavy shapes than the 4.5x fewer fragment reads return.  Forced variants 7 / 8 and SFOD_P3_M16_N64=1 only.
-    if (p.m16 && p.G == 2 && Cin % 64 == 0 && (red == nullptr || split == 1) && (p.m16 == 3 || p3_m16_n64_enabled())) {
+    if (p.m16 && p.G == 2 && Cin % 64 == 0 && (red == nullptr || split == 1) && (p.m16 >= 3 || p3_m16_n64_enabled())) {
+      if (p.FM == 1 && (p.m16 == 4 || p3_m16_n64_enabled() == 2)) {      // variant 9: 8 waves x (32 px x 64 ch), 16 waves per CU
+        if (red != nullptr) return p3_launch_m16<8, 2, 1, true, false, 1>(a, s);
+        return split == 2 ? p3_launch_m16<8, 2, 2, false, false, 1>(a, s) : p3_launch_m16<8, 2, 1, false, false, 1>(a, s);
+      }
       if (p.FM == 1) {
         if (red != nullptr) return p3_launch_m16<4, 4, 1, true, false, 1>(a, s);
         return split == 2 ? p3_launch_m16<4, 4, 2, false, false, 1>(a, s) : p3_launch_m16<4, 4, 1, false, false, 1>(a, s);

@@ -45,8 +45,8 @@ import re
 
 SWEEP_PATTERNS = [re.compile(p) for p in (
     # forced workgroup shapes of the halo-patch convolution: keep auto (0) and the 16x16x32 defaults (5: 128-channel, 7: 64-channel tiles)
-    r"test_conv3x3_patch_kernel\[(1|2|3|4|6|8)-",
-    r"test_gpu_bf16x3\.py::test_dgrad_with_fused_batchnorm_backward_reduction\[(1|2|4|5|6|8)-",
+    r"test_conv3x3_patch_kernel\[(1|2|3|4|6|8|9)-",
+    r"test_gpu_bf16x3\.py::test_dgrad_with_fused_batchnorm_backward_reduction\[(1|2|4|5|6|8|9)-",
     r"test_gpu_bf16x3\.py::test_conv_dgrad_and_wgrad\[(1|4)-",                  # forced algorithms; 0 = the planner
     r"test_gpu_bf16x3\.py::test_conv3x3_patch_wgrad\[(1|0)-",                   # the non-default loops of the weight gradient
     r"test_gpu_bf16x3\.py::test_conv3x3_with_batchnorm_folded_into_its_input\[(2|6)",

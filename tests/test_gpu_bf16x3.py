@@ -110,7 +110,7 @@ def test_conv_fwd_generic_kernel(native, shape, act):
     (3, 5, 6, 256, 256),
 ])
 @pytest.mark.parametrize("variant", ["plain", "relu_stats", "ldy"])
-@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4, 5, 6, 7, 8])   # 7 / 8: the 64-channel tile shapes on 16x16x32 (round 6)
+@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])   # 7 / 8 / 9: the 64-channel tile shapes on 16x16x32 (round 6)
 def test_conv3x3_patch_kernel(native, shape, variant, wg):
     B, H, W, Cin, Cout = shape
     g = torch.Generator().manual_seed(sum(shape))
@@ -359,7 +359,7 @@ def test_conv_first_layer_kernel_split(native, hw):
     assert rel_err(zf, native.cast(z2, torch.float32).cpu()) < 1e-6
 
 
-@pytest.mark.parametrize("wg", [2, 5, 6, 7])      # (7: the 64-channel tiles on 16x16x32; 256-pixel tiles like 2: same statistics blocks)
+@pytest.mark.parametrize("wg", [2, 5, 6, 7, 9])      # (7, 9: the 64-channel tiles on 16x16x32; 256-pixel tiles like 2: same statistics blocks)
 def test_conv3x3_pairs_under_load_is_deterministic(native, wg):
     """Full-chip launch on operand pairs (two workgroups per CU): the 32x32x16 kernel (2) and the 16x16x32 kernel (5) must
     each be run-to-run bit-identical -- guards the counted-wait DMA pipelines, whose hazards (a fragment read still queued
@@ -388,7 +388,7 @@ def test_conv3x3_pairs_under_load_is_deterministic(native, wg):
 
 
 @pytest.mark.parametrize("shape", [(2, 37, 75, 64, 128), (1, 40, 64, 128, 64), (2, 18, 25, 256, 256), (1, 33, 31, 64, 64)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize("variant", [0, 1, 2, 4, 5, 6, 7, 8, 9])
 def test_dgrad_with_fused_batchnorm_backward_reduction(native, shape, variant):
     """sfod_conv_dgrad_bnred: the data-gradient kernel's epilogue also makes the (dbeta, dgamma) partial sums of the layer
     below.  dz must be bit-identical to the plain kernel's, and BatchNorm backward fed with the pre-reduced workspace must

@@ -159,7 +159,7 @@ def test_linear_kernels_wide_and_tall(native, shape):
     (3, 5, 6, 256, 256),
 ])
 @pytest.mark.parametrize("variant", ["plain", "relu_stats", "ldy"])
-@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4, 5, 6, 7, 8])   # 7 / 8: the 64-channel tile shapes on 16x16x32 (round 6)
+@pytest.mark.parametrize("wg", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9])   # 7 / 8 / 9: the 64-channel tile shapes on 16x16x32 (round 6)
 def test_conv3x3_patch_kernel(native, shape, variant, wg):
     B, H, W, Cin, Cout = shape
     g = torch.Generator().manual_seed(sum(shape))

@@ -86,7 +86,7 @@ def main():
             continue
         if args.variants:
             native.set_conv_algo(2)
-            vt = {v: [] for v in (0, 1, 2, 3, 4, 5, 6, 7, 8)}
+            vt = {v: [] for v in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9)}
             for r in range(args.rounds + 1):
                 for v in vt:
                     native.set_conv3x3_variant(v)
@@ -100,7 +100,7 @@ def main():
             native.set_conv3x3_variant(0)
             native.set_conv_algo(0)
             names = {0: "auto", 1: "512x128", 2: "256x128", 3: "256x64", 4: "512x64", 5: "256x128 m16", 6: "256x128 m16 4w",
-                     7: "256x64 m16", 8: "512x64 m16"}
+                     7: "256x64 m16 4w", 8: "512x64 m16", 9: "256x64 m16 8w"}
             line = f"{name:9s} {B}x{H}x{W} {Cin:4d}->{Cout:4d} {flops / 1e9:8.1f} GF"
             for v in vt:
                 t = sorted(vt[v])[len(vt[v]) // 2]
