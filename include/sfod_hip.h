@@ -134,6 +134,12 @@ int sfod_conv_fwd_bnin_supported(int B, int H, int W, int Cin, int Cout, int dt)
 int sfod_conv_fwd_bnin(const float* x_pre, const float* in_mean, const float* in_invstd, const float* in_gamma,
                        const float* in_beta, const void* w, const float* bias, float* y, int B, int H, int W, int Cin,
                        int Cout, int ldy, int act, float* stats, int dt, void* stream);
+/* Tile shape of the generic implicit-GEMM kernel behind sfod_conv_fwd (1x1 / linear / first layer): 0 = the planner's choice
+ * (environment SFOD_GEMM_TILE), 1 = 128 x 64, 2 = 128 x 128, 3 = 256 x 128, 4 = 256 x 64, 5 = 256 x 256 (pairs, fp32 out),
+ * 6 / 7 / 8 = 256 x 128 / 128 x 128 / 256 x 128 (four stages) with 64-byte K stages (pairs, fp32 out: two or three
+ * workgroups per CU); shapes a layer cannot take fall back to the planner's.  Every shape computes the same values.  For
+ * A/B runs and parity tests. */
+int sfod_set_gemm_tile(int tile);
 /* workgroup shape of the halo-patch kernel: 0 auto, 1 = 512 px x 128 ch, 2 = 256 x 128, 3 = 256 x 64,
  * 4 = 512 x 64 (applied where the channel counts allow it), 5 = 256 x 128 on v_mfma_f32_16x16x32 (operand pairs with
  * Cin % 32 == 0; otherwise as 2: 8 waves x (64 px x 64 ch), four waves per SIMD), 6 = the same with 4 waves x (128 px x

@@ -643,11 +643,29 @@ static bool use_wide_gemm(int M, int Cout, int ks) {
   return wide == 2 || (t256 >= 200 && r256 * 0.80 <= r128);
 }
 
+// forced tile shape of the generic kernel (A/B runs, tests): -1 not initialised (SFOD_GEMM_TILE or 0 = the planner's choice)
+static std::atomic<int> g_gemm_tile{-1};
+extern "C" int sfod_set_gemm_tile(int tile) {
+  g_gemm_tile.store((tile >= 0 && tile <= 8) ? tile : 0, std::memory_order_relaxed);
+  return 0;
+}
+static int gemm_tile_forced() {
+  int v = g_gemm_tile.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("SFOD_GEMM_TILE");
+    int want = e ? atoi(e) : 0, expect = -1;
+    if (want < 0 || want > 8) want = 0;
+    g_gemm_tile.compare_exchange_strong(expect, want, std::memory_order_relaxed);
+    v = g_gemm_tile.load(std::memory_order_relaxed);
+  }
+  return v;
+}
+
 template <typename T, typename OutT, bool UT, int SPLIT = 0>
 static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, void* y, float* stats,
                               const ConvArgs& a, hipStream_t s) {
   // SFOD_GEMM_TILE = 1..5: force a tile shape where it exists (A/B runs: 1 128x64, 2 128x128, 3 256x128, 4 256x64, 5 256x256)
-  static const int forced = []() { const char* e = getenv("SFOD_GEMM_TILE"); return e ? atoi(e) : 0; }();
+  const int forced = gemm_tile_forced();
   if constexpr (UT) {
     if (forced == 1) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
     if (forced == 2) return launch_one<T, OutT, 2, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);
@@ -660,6 +678,10 @@ static int launch_conv_fwd_ut(const void* x, const void* w, const float* bias, v
       if (forced == 6) return launch_one<T, OutT, 2, UT, 4, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
       if (forced == 7) return launch_one<T, OutT, 2, UT, 2, 3, SPLIT, 64>(x, w, bias, y, stats, a, s);
       if (forced == 8) return launch_one<T, OutT, 2, UT, 4, 4, SPLIT, 64>(x, w, bias, y, stats, a, s);
+      // (9 / 10, round 6: a PERSISTENT form of this tile -- one workgroup walking several tiles, its DMA pipeline running across
+      // tile boundaries, statistics scratch behind the stages, epilogue barriers that leave vmcnt alone -- was built, was
+      // bit-identical to 3 / 6 on 20 cases, and ran 15 % / 35 % SLOWER on every ResNet-101-C4 1x1 shape: the cold pipeline
+      // per tile is not what these launches wait for.  Removed; profiles/r6_r101_gemm_floor.txt has the table.)
     }
   }
   if (a.Cout <= 64) return launch_one<T, OutT, 1, UT, 2, 2, SPLIT>(x, w, bias, y, stats, a, s);

@@ -285,6 +285,11 @@ def set_wgrad3x3_pipe(on):
     load().sfod_set_wgrad3x3_pipe(int(on))
 
 
+def set_gemm_tile(tile):
+    """Tile shape of the generic implicit-GEMM kernel: 0 the planner's choice, 1..10 see include/sfod_hip.h (A/B runs, tests)."""
+    load().sfod_set_gemm_tile(int(tile))
+
+
 def set_conv3x3_variant(variant):
     """Workgroup shape of the halo-patch kernel: 0 auto, 1..5 see include/sfod_hip.h (A/B runs, tests)."""
     load().sfod_set_conv3x3_variant(int(variant))

@@ -590,3 +590,38 @@ def test_conv3x3_batchnorm_input_under_load_is_deterministic(native):
     torch.cuda.synchronize()
     for y, st in outs:
         assert torch.equal(y, ref) and torch.equal(st, ref_stats)
+
+
+
+@pytest.mark.parametrize("fmt", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("shape", [(22800, 256, 1024), (5000, 96, 200), (700, 1024, 256)])
+@pytest.mark.parametrize("tile", [6, 7, 8])
+def test_gemm_tiles_with_64_byte_stages_equal_the_planners_choice(native, shape, fmt, tile):
+    """The round-6 tile shapes of the generic kernel (64-byte K stages: two / three workgroups per CU; sfod_set_gemm_tile 6 / 7 / 8)
+    against the planner's own choice on the same operands: the same products in another summation order (fp32 rounding), the same
+    BatchNorm statistics to their tolerance, and within the mode's tolerance of fp64.  Ragged M / N / K tails included."""
+    M, K, N = shape
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, generator=g)
+    if fmt == "bf16x3":
+        xd, wp = to_split(native, x.to(DEV)), native.pack_fc_weight(w.to(DEV), native.BF16X3)
+    else:
+        xd, wp = native.cast(x.to(DEV), native.SPLITH_DTYPE), native.pack_fc_weight(w.to(DEV), native.F16X3)
+    xd = xd.view(M, 1, 1, -1)
+    try:
+        native.set_gemm_tile(0)
+        y0, st0 = native.conv_fwd(xd, wp, bias.to(DEV), N, 1, act=1, want_stats=True)
+        native.set_gemm_tile(tile)
+        y1, st1 = native.conv_fwd(xd, wp, bias.to(DEV), N, 1, act=1, want_stats=True)
+        torch.cuda.synchronize()
+    finally:
+        native.set_gemm_tile(0)
+    ref = x.double() @ w.double().t() + bias.double()
+    assert rel_err(y1.view(M, N).cpu(), F.relu(ref)) < TOL and rel_err(y1, y0) < 2e-6
+    rm, rv = torch.zeros(N, device=DEV), torch.ones(N, device=DEV)
+    m0, i0 = native.bn_finalize(st0, M, N, rm.clone(), rv.clone(), 0.1, 1e-5)
+    m1, i1 = native.bn_finalize(st1, M, N, rm.clone(), rv.clone(), 0.1, 1e-5)
+    torch.testing.assert_close(m1, m0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(i1, i0, rtol=1e-5, atol=1e-9)
