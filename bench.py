@@ -733,6 +733,11 @@ def main():
                          if key.endswith("patch3x3") else
                          pmc_traffic(args.model, "k_conv_fwd<", {"bf16x3": (", 1, 64>", ", 1, 128>"), "f16x3": (", 2, 64>", ", 2, 128>")}.get(args.dtype, "-")))
                         if pmc_matches(args) else None),
+            # what the traffic figure says, in words (DESIGN.md section 6 / profiles/HISTORY.md round 3): writes = algorithmic; the
+            # halo-patch kernel READS ~2x its algorithmic bytes -- the two 64-byte halves of a 128-byte line are fetched a K-body
+            # apart and the line leaves L2 in between (real double fetching, sized at ~8 W; not fixed)
+            "traffic_note": ("reads ~2x algorithmic (both halves of a line fetched a K-body apart); writes = algorithmic"
+                             if key.endswith("patch3x3") else "see DESIGN.md section 6"),
             "launches_per_step": k["launches"] // max(rl_steps, 1),
             "avg_launch_ms": round(k["ms"] / max(k["launches"], 1), 4),
             "algorithmic_gflop_per_launch": round(k["flops"] / max(k["launches"], 1) / 1e9, 3),

@@ -51,8 +51,16 @@ Parity pin status
                        daod/data/build.py:312-367 (per-rank batch for world 1/2/4, the           a13, e
                          divisibility assertion's text, the ASPECT_RATIO_GROUPING error)
     config_ref.json    daod/config.py:8-142 (add_config on a recording node)                    b
+    adaptive_teacher_ref.npz   (round 6, the with-source path: SURVEY 8f rank 4's last entry)
+                       daod/engine/trainers/adaptive_teacher.py:191-336 (run_step at five        f4 (with-source trainer)
+                         iterations around BURN_UP_STEP: branches, lists, EMA schedule, weights,
+                         the doubly defined loss_DC_img_s, unweighted metrics)
+                       ... :338-357 (_update_teacher_model: keep_rate 0 = copy, EMA, int64)
+                       daod/modeling/meta_arch/adaptive_teacher_rcnn.py:102-292 (forward on
+                         recorder sub-modules: DC_img before the RPN, x 0.001, three-tuples)
+                       daod/data/common.py:119-160 (four-way batch iterator incl. dropped elements)
 
-  ``tests/test_oracle_golden.py`` / ``tests/test_oracle_glue.py`` hold the restatements in this directory to those vectors
+  ``tests/test_oracle_golden.py`` / ``tests/test_oracle_glue.py`` / ``tests/test_oracle_adaptive_teacher.py`` hold the restatements in this directory to those vectors
   (bit-exact for everything discrete and for the EMA; 1e-4 for the VGG trunk), ``tests/test_gpu_glue.py`` /
   ``tests/test_gpu_model.py`` hold the HIP path to the same vectors directly.
 * PINNED against Detectron2's own unit tests (round 5) -- the half that lives in Detectron2: three of its unit tests are

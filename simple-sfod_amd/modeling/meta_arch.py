@@ -95,14 +95,18 @@ class GeneralizedRCNN(nn.Module):
     def drop_prefetched(self):
         """forget whatever an earlier ``prefetch_features`` left behind (a step that raised before using it)"""
         self.__dict__.pop("_prefetched", None)
-        self.proposal_generator.__dict__.pop("_prefetched", None)
-        self.roi_heads.__dict__.pop("_packed", None)
+        # (a GeneralizedRCNN may be built without a proposal generator or ROI heads: d2 allows precomputed proposals)
+        if self.proposal_generator is not None:
+            self.proposal_generator.__dict__.pop("_prefetched", None)
+        if self.roi_heads is not None:
+            self.roi_heads.__dict__.pop("_packed", None)
 
     def _images_and_features(self, batched_inputs):
         pf = self.__dict__.pop("_prefetched", None)
         if pf is not None and pf[0] is batched_inputs:
             return pf[1], pf[2]
-        self.proposal_generator.__dict__.pop("_prefetched", None)      # whatever was prefetched is not for this batch
+        if self.proposal_generator is not None:
+            self.proposal_generator.__dict__.pop("_prefetched", None)  # whatever was prefetched is not for this batch
         images = self.preprocess_image(batched_inputs)
         return images, self._features(images)
 

@@ -298,6 +298,10 @@ class RPN(nn.Module):
             st = self._last_head_state
             losses = {"loss_rpn_cls": l_cls, "loss_rpn_loc": l_loc}
         else:
+            # a head state prefetched for a LOSS pass is not consumed here (it was made under the training pass's settings):
+            # dropped, so that it neither lives to the next step nor gets mistaken for this pass's
+            self.__dict__.pop("_prefetched", None)
+            self.__dict__.pop("_prefetched_proposals", None)
             with torch.no_grad():
                 st = self._head_forward(feat)
             losses = {}
