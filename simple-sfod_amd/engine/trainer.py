@@ -88,6 +88,8 @@ class EventStorage:
         self.history = []
 
     def put_scalar(self, name, value, rank_mean=False):
+        if isinstance(value, torch.Tensor) and value.requires_grad:
+            value = value.detach()          # a logged scalar must not keep its autograd graph (and everything it saved) alive
         self._pending[name] = value
         (self._rank_mean.add if rank_mean else self._rank_mean.discard)(name)
 

@@ -35,7 +35,10 @@ class OffChain:
                 self.side = owner.__dict__["_wgrad_stream"] = torch.cuda.Stream()
 
     def run(self, fn, *reads):
-        if self.side is None:
+        # already ON the side stream (the RPN's whole backward runs there, and its own parameter gradients come through here):
+        # plain calls -- an event recorded on a stream and awaited by the same stream is a no-op eagerly (and a self-dependency
+        # inside a graph capture: what made hipStreamEndCapture crash in round 6's graph experiment)
+        if self.side is None or torch.cuda.current_stream() == self.side:
             return fn()
         ev = torch.cuda.Event()
         ev.record()
@@ -50,6 +53,8 @@ class OffChain:
         if self.side is None:
             return
         main = torch.cuda.current_stream()
+        if main == self.side:
+            return
         main.wait_stream(self.side)
         for t_ in outs:
             if t_ is not None:
