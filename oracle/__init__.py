@@ -84,10 +84,18 @@ Parity pin status
 
   ``tests/test_gpu_d2_golden.py`` runs the PRODUCT's ``RPN`` / ``StandardROIHeads`` modules on the HIP kernels against the
   same numbers directly, in all three arithmetic modes.
+* PINNED against an independent implementation that IS in this image (round 6): greedy NMS and class-wise ``batched_nms`` --
+  HuggingFace ``transformers``' OwlViT post-processing carries its own greedy NMS (argsort by score, fp32 inter / union,
+  strict '>': transformers/models/owlvit/image_processing_pil_owlvit.py); ``tests/helpers/hf_nms.py`` CALLS it, and
+  ``oracle.box_ops.nms`` returns its keep list (order included) on 64 .. 600 random boxes at three thresholds and on an exact
+  IoU == threshold case; ``batched_nms`` -- both the coordinate-offset form and the per-class form above torchvision's 20 000-
+  element switch -- returns what that NMS gives when run once per class (tests/test_oracle_hf_nms.py); the HIP kernels do the
+  same on 600 / 2000 boxes (tests/test_gpu_ops.py::test_nms_kernel_equals_the_independent_huggingface_implementation).
 * STILL UNPINNED: what no Detectron2 / torchvision test holds a literal vector for and those libraries (absent here) would
-  have to be run for -- ``fast_rcnn_inference`` (test-time score threshold + per-class NMS + top-k), torchvision
-  ``batched_nms``'s two strategies beyond the single-class case the RPN vector exercises, ``Boxes.clip`` / ``nonempty``
-  corner cases, COCOeval, ColorJitter's parameter sampling; the ResNet-50/101-C4 trunk has no Detectron2 vector but equals
+  have to be run for -- the COMPOSITION of ``fast_rcnn_inference`` (softmax -> per-class decode -> clip -> score > 0.05 ->
+  class-wise NMS -> top-k: every stage of it is pinned on its own -- softmax is torch's, the box transform by test_rpn /
+  test_fast_rcnn, the NMS stage as above -- the glue between them is restated from the published function), ``Boxes.clip`` /
+  ``nonempty`` corner cases, COCOeval, ColorJitter's parameter sampling; the ResNet-50/101-C4 trunk has no Detectron2 vector but equals
   an independent port -- HuggingFace ``transformers``' ResNet with the stride in the first 1x1 -- on the same weights in
   eval and train mode (tests/test_oracle_r101.py).  Those are restated from their published algorithms and
   anchored on the reference's call sites plus hand-computed known-answer cases (tests/test_oracle_*.py); ``transformers``

@@ -3,8 +3,10 @@
 CPU restatement in fp32 torch/numpy of the Detectron2 / torchvision semantics the
 reference reaches through ``daod/modeling/proposal_generator/rpn.py:25,45,54`` and
 ``daod/modeling/roi_heads/source_free_adaptive_teacher_roi_heads.py:165-215``
-(SURVEY.md Appendix A.3, A.5-A.9).  PARITY UNPINNED: Detectron2/torchvision are not
-installed; these follow their published algorithms.
+(SURVEY.md Appendix A.3, A.5-A.9).  Detectron2 / torchvision are not installed: these follow their published
+algorithms and are pinned by Detectron2's / torchvision's own unit-test vectors (anchors, Matcher, pairwise_iou, box
+transform: tests/test_oracle_ops.py, tests/test_oracle_d2_golden.py) and, for ``nms`` / ``batched_nms``, by the independent
+greedy NMS inside HuggingFace ``transformers`` (tests/test_oracle_hf_nms.py); oracle/__init__.py lists what is still unpinned.
 """
 import math
 

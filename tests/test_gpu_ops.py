@@ -1051,3 +1051,25 @@ def test_linear_split_k_for_few_rows(native, dtype, shape):
     assert err_split <= max(1.5 * err_ref, 2e-6), (err_split, err_ref)
     # (true-fp32 products over K = 25088 carry ~3e-6 of summation-order noise themselves)
     assert ((outs[0] - ref).double().norm() / ref.double().norm()).item() < max(2e-6, 3 * err_ref)
+
+
+@pytest.mark.parametrize("n,thr,span", [(600, 0.7, 300.0), (2000, 0.5, 500.0)])
+def test_nms_kernel_equals_the_independent_huggingface_implementation(native, n, thr, span):
+    """The ballot / readlane NMS kernels against an NMS nobody here wrote: HuggingFace transformers' OwlViT post-processing
+    (tests/helpers/hf_nms.py; greedy, fp32 inter / union, strict '>').  Same corner boxes, same scores -> the same keep list."""
+    from helpers import hf_nms as H
+    g = torch.Generator().manual_seed(n)
+    B = 2
+    keep_ref, sorted_boxes, orders = [], [], []
+    for b in range(B):
+        centers, scores = H.random_centers(n, g, span=span), H.distinct_scores(n, g)
+        corners = H.hf_corners(centers)
+        order = torch.argsort(scores, descending=True)
+        keep_ref.append(H.hf_greedy_nms(centers, scores, thr))
+        sorted_boxes.append(corners[order])
+        orders.append(order)
+    keep_idx, keep_cnt = native.nms(torch.stack(sorted_boxes).to(DEV), thr, n)
+    for b in range(B):
+        c = keep_cnt[b].item()
+        got = orders[b][keep_idx[b, :c].cpu().long()]
+        assert 0 < len(keep_ref[b]) < n and got.tolist() == keep_ref[b].tolist()
