@@ -250,3 +250,57 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, model):
     assert 0.85 * ex["payload_MB"] < sum(ex["exposed_ms_per_phase"]["slices_MB"]) <= ex["payload_MB"] + 0.5
     pl = d["config"]["pseudo_labels_per_image"]
     assert 10 <= pl["mean"] <= 30
+
+
+def test_with_source_trainer_two_ranks(tmp_path):
+    """``TRAINER: "adaptive_teacher"`` at world_size 2 (daod/engine/trainers/adaptive_teacher.py:31-76: DDP with
+    ``broadcast_buffers=False``; daod/data/build.py:229-239: both batch sizes divided by the world size): three steps around
+    BURN_UP_STEP = 1 on two ranks sharing cuda:0 over gloo.  The trainer exchanges the flat gradient in ONE blocking all-reduce
+    after the backward (several backbone passes per backward: no in-backward phases), so after every step the students are
+    bit-identical across ranks; the teachers' parameters are too (copy at the hand-over, EMA afterwards -- per rank, no
+    collective), their BatchNorm statistics are not (per-rank frames); the loader shards are disjoint; the logged losses are
+    the mean over ranks."""
+    port = _free_port()
+    worker = os.path.join(ROOT, "tests", "helpers", "two_rank_at_worker.py")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("MASTER_ADDR", None)
+        log = open(os.path.join(tmp_path, f"rank{r}.log"), "w")
+        procs.append((subprocess.Popen([sys.executable, worker, "--out", str(tmp_path), "--port", str(port)], env=env, stdout=log,
+                                       stderr=subprocess.STDOUT), log))
+    codes = []
+    try:
+        for p, log in procs:
+            codes.append(p.wait(timeout=600))
+    finally:
+        for p, log in procs:
+            if p.poll() is None:
+                p.kill()
+            log.close()
+    if any(codes):
+        tails = "\n".join(open(os.path.join(tmp_path, f"rank{r}.log")).read()[-3000:] for r in range(2))
+        pytest.fail(f"worker exit codes {codes}\n{tails}")
+    r0, r1 = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(2)]
+    assert r0["reducer"] is None and r0["label_batch"] == r0["unlabel_batch"] == 1
+    for it in range(3):
+        # rank-strided shards of one shared-seed stream, for the labelled and the unlabelled loader alike
+        assert set(r0["ids"][it][0]).isdisjoint(r1["ids"][it][0]) and set(r0["ids"][it][1]).isdisjoint(r1["ids"][it][1])
+        s0, s1, t0, t1 = r0["students"][it], r1["students"][it], r0["teachers"][it], r1["teachers"][it]
+        for k in s0:
+            if "running" in k or "num_batches" in k:
+                continue
+            assert torch.equal(s0[k], s1[k]), ("student", it, k)
+        for k in t0:
+            if "running" in k or "num_batches" in k:
+                continue
+            assert torch.equal(t0[k], t1[k]), ("teacher", it, k)
+        if it >= 1:      # the teacher ran on different frames per rank
+            assert any(not torch.equal(t0[k], t1[k]) for k in t0 if "running_mean" in k)
+        for k in r0["recs"][it]:
+            if k.startswith("loss"):
+                assert r0["recs"][it][k] == r1["recs"][it][k], (it, k)        # the flush is the rank mean on every rank
+    # burn-in left the teacher where the constructor put it; the hand-over made it the (rank-identical) student of step 0
+    assert all(torch.equal(r0["teachers"][1][k], r0["students"][0][k]) for k in r0["students"][0]
+               if "running" not in k and "num_batches" not in k)
+    assert sorted(k for k in r0["recs"][2] if k.startswith("loss_DC")) == ["loss_DC_img_s", "loss_DC_img_t"]
