@@ -294,11 +294,6 @@ class StandardROIHeads(nn.Module):
 
     # ---- box branch: ROIAlign -> fc1 -> fc2 -> fused (cls_score | bbox_pred) -------------------------
     def _box_forward(self, feat_nchw, rois):
-        if self.pooled > 8 and torch.is_grad_enabled():
-            # sfod_roi_align_bwd's register tiles stop at 8 (the forward serves <= 16: Detectron2's unit-test size); say so
-            # BEFORE the losses, not in the first backward.  config.py's default is d2's 14: the named yamls set 7.
-            raise ValueError(f"MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION {self.pooled}: the ROIAlign backward serves <= 8 "
-                             "(forward-only passes: <= 16)")
         dtype = self.compute_dtype
         dt = native.dt_of_dtype(dtype)
         feat = native.nhwc_operand(feat_nchw, dtype)
@@ -429,6 +424,12 @@ class StandardROIHeads(nn.Module):
             proposals = _proposals_from_instances(proposals, feat.device)
         if (self.training and compute_loss) or compute_val_loss:
             assert targets is not None
+            if self.pooled > 8 and torch.is_grad_enabled():
+                # sfod_roi_align_bwd's register tiles stop at 8 (the forward serves <= 16: Detectron2's unit-test size); say so
+                # BEFORE the losses, not in the first backward.  config.py's default is d2's 14: the named yamls set 7.
+                # (Checked here, not in _box_forward: inside an autograd.Function's forward grad mode is always off.)
+                raise ValueError(f"MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION {self.pooled}: the ROIAlign backward serves <= 8 "
+                                 "(forward-only passes: <= 16)")
             if not isinstance(targets, BatchedGT):
                 targets = BatchedGT.from_instances(targets, feat.device)
             append = self.proposal_append_gt

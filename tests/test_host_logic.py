@@ -436,3 +436,21 @@ def test_offchain_helpers_are_plain_calls_without_a_gpu(sfod):
     g = torch.arange(4.0)
     oc.mark_loss_grads_ready(g)
     assert oc.take_loss_grads_ready(g[1]) is None
+
+
+def test_pooler_resolution_beyond_the_backward_kernel_is_refused_before_the_losses(sfod):
+    """config.py's POOLER_RESOLUTION default is Detectron2's 14; the ROIAlign backward serves <= 8.  A TRAINING forward with
+    gradients enabled says so at once (advisor, round 5: it used to surface as EBADARG in the first backward); forward-only
+    passes (no_grad: the teacher, evaluation, Detectron2's own 14 x 14 unit-test size) are not affected."""
+    import types
+    import pytest
+    import torch
+    RH = sfod.modeling.roi_heads.StandardROIHeads
+    stub = types.SimpleNamespace(in_features=["vgg4"], training=True, pooled=14)
+    feats = {"vgg4": torch.zeros(1, 8, 4, 4)}
+    props = sfod.modeling.batched.BatchedProposals(torch.zeros(1, 1, 4), torch.zeros(1, 1), torch.ones(1, dtype=torch.int32), [(64, 64)])
+    with pytest.raises(ValueError, match="POOLER_RESOLUTION 14"):
+        RH.forward(stub, None, feats, props, targets=object(), compute_loss=True)
+    stub.pooled = 7          # the named yamls' value passes this point (and then needs real targets)
+    with pytest.raises((AttributeError, TypeError, AssertionError)):
+        RH.forward(stub, None, feats, props, targets=object(), compute_loss=True)
