@@ -28,7 +28,8 @@ def hf_greedy_nms(centers, scores, thr):
     out = types.SimpleNamespace(logits=logits.view(1, -1, 1).clone(), target_pred_boxes=centers.view(1, -1, 4).clone())
     res = proc.post_process_image_guided_detection(out, threshold=0.0, nms_threshold=float(thr), target_sizes=None)
     kept_boxes = res[0]["boxes"]
-    corners = hf_corners(centers)
+    import transformers.models.owlvit.image_processing_pil_owlvit as _mod
+    corners = _mod.center_to_corners_format(centers)          # (the identity while hf_greedy_nms_corners has it bypassed)
     # rows are distinct: exact match gives the index
     idx = []
     for kb in kept_boxes:
@@ -49,3 +50,22 @@ def random_centers(n, g, span=600.0, size=160.0):
 def distinct_scores(n, g):
     s = 0.5 + 0.49 * (torch.randperm(n, generator=g).float() + torch.rand(n, generator=g) * 0.5) / n
     return s
+
+
+def hf_greedy_nms_corners(corners, scores, thr):
+    """The same independent NMS on CORNER boxes with arbitrary distinct scores: the method's centre -> corner conversion is
+    bypassed for the call (its module-level ``center_to_corners_format`` replaced by the identity), and the scores are replaced
+    by their ranks mapped into [0.5, 1) -- greedy NMS depends on the score ORDER only.  -> kept indices, best first."""
+    import transformers.models.owlvit.image_processing_pil_owlvit as mod
+    n = len(scores)
+    if n == 0:
+        return torch.zeros(0, dtype=torch.int64)
+    order = torch.argsort(scores, descending=True, stable=True)
+    ranked = torch.empty(n)
+    ranked[order] = 0.5 + 0.49 * (n - torch.arange(n, dtype=torch.float32)) / (n + 1)
+    saved = mod.center_to_corners_format
+    mod.center_to_corners_format = lambda x: x
+    try:
+        return hf_greedy_nms(corners, ranked, thr)
+    finally:
+        mod.center_to_corners_format = saved

@@ -55,3 +55,44 @@ def test_class_wise_batched_nms_equals_independent_nms_run_per_class(n, K, thr):
     vanilla = OB.batched_nms(corners, scores, idxs, thr, numel_limit=0)           # per-class loop
     assert 0 < len(ref) < n
     assert trick.tolist() == ref.tolist() and vanilla.tolist() == ref.tolist()
+
+
+def test_fast_rcnn_inference_equals_a_composition_around_the_independent_nms():
+    """``fast_rcnn_inference`` (Detectron2, reached from source_free_adaptive_teacher_roi_heads.py:161) end to end: the
+    oracle's function against a composition whose NMS stage is the independent one -- softmax (torch), per-class decode
+    (``apply_deltas``: pinned by Detectron2's test_rpn / test_fast_rcnn vectors), clip to the image, ``score > 0.05``, the
+    HuggingFace greedy NMS run once per class at 0.5, then the best 100 by score.  Same detections, same order."""
+    from oracle import model as om
+    cfg = om.Cfg()
+    K = cfg.num_classes
+    g = torch.Generator().manual_seed(4)
+    sizes = [(300, 500), (260, 420)]
+    props, n_per = [], [180, 140]
+    for (h, w), n in zip(sizes, n_per):
+        xy = torch.rand(n, 2, generator=g) * torch.tensor([w * 0.8, h * 0.8])
+        wh = torch.rand(n, 2, generator=g) * torch.tensor([w * 0.3, h * 0.3]) + 8
+        props.append(torch.cat([xy, xy + wh], 1))
+    R = sum(n_per)
+    scores = torch.randn(R, K + 1, generator=g) * 2.5
+    scores[:, K] += 1.0
+    deltas = torch.randn(R, 4 * K, generator=g) * 0.6
+    got = om.fast_rcnn_inference(scores, deltas, props, sizes, cfg)
+    probs = torch.softmax(scores, -1)
+    start = 0
+    for i, ((h, w), n) in enumerate(zip(sizes, n_per)):
+        p, d, pb = probs[start:start + n, :K], deltas[start:start + n], props[i]
+        start += n
+        boxes = OB.apply_deltas(d, pb, cfg.roi_bbox_weights).view(n, K, 4)
+        boxes = torch.stack([boxes[..., 0].clamp(0, w), boxes[..., 1].clamp(0, h), boxes[..., 2].clamp(0, w), boxes[..., 3].clamp(0, h)], -1)
+        det_b, det_s, det_c = [], [], []
+        for c in range(K):
+            m = (p[:, c] > 0.05).nonzero().flatten()
+            if len(m) == 0:
+                continue
+            keep = m[H.hf_greedy_nms_corners(boxes[m, c], p[m, c], 0.5)]
+            det_b.append(boxes[keep, c]); det_s.append(p[keep, c]); det_c.append(torch.full((len(keep),), c))
+        det_b, det_s, det_c = torch.cat(det_b), torch.cat(det_s), torch.cat(det_c)
+        order = torch.argsort(det_s, descending=True, stable=True)[:100]
+        assert len(got[i]["scores"]) == len(order) == 100
+        assert torch.equal(got[i]["classes"], det_c[order]) and torch.equal(got[i]["scores"], det_s[order])
+        assert torch.equal(got[i]["boxes"], det_b[order])
