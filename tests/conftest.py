@@ -52,11 +52,12 @@ SWEEP_PATTERNS = [re.compile(p) for p in (
     r"test_gpu_bf16x3\.py::test_conv3x3_with_batchnorm_folded_into_its_input\[(2|6)",
     # long oracle comparisons: the default keeps the mode bench.py reports for the config (+ one fp32 / non-elided case)
     r"test_three_steps_match_the_oracle_trajectory\[(vgg-fp32-True|r101-fp32-True|vgg-f16x3-True|vgg-f16x3-False)\]",
-    # (two-rank steps: all three cases are in the default selection since round 6 -- config #4 in the mode bench.py
-    # reports AND in fp32, config #5 in its reported mode)
+    # two-rank steps: config #4 and #5 each in the mode bench.py reports for it; config #4 in fp32 is the sweep's
+    r"test_two_ranks_on_one_gpu_take_the_oracles_mean_gradient_step\[vgg-fp32\]",
     r"test_bench_two_ranks_on_one_gpu\[r101\]",
     r"test_hot_yaml_teacher_and_student_at_600x1200\[(f16x3-2|bf16x3-2)\]",
-    r"test_r101_yaml_teacher_and_student_at_600x1200\[(fp32|bf16x3)\]",
+    # (R101 at full size: the default keeps the case on the head bench.py times; the (60, 20) head's cases are the sweep's)
+    r"test_r101_yaml_teacher_and_student_at_600x1200\[(fp32|bf16x3|f16x3)\]",
     r"test_r101_yaml_on_the_benchmarked_head_at_600x1200\[fp32\]",
     r"test_r101_yaml_on_a_well_conditioned_weight_set_at_600x1200\[(fp32|f16x3)\]",   # default: the yaml's own weights, f16x3
 )]
