@@ -91,10 +91,13 @@ Parity pin status
   IoU == threshold case; ``batched_nms`` -- both the coordinate-offset form and the per-class form above torchvision's 20 000-
   element switch -- returns what that NMS gives when run once per class (tests/test_oracle_hf_nms.py); the HIP kernels do the
   same on 600 / 2000 boxes (tests/test_gpu_ops.py::test_nms_kernel_equals_the_independent_huggingface_implementation).
+  ``model.fast_rcnn_inference`` END TO END equals a composition written around that NMS (softmax -> per-class decode -> clip ->
+  score > 0.05 -> the HuggingFace NMS once per class -> best 100): boxes, scores, classes and order
+  (tests/test_oracle_hf_nms.py::test_fast_rcnn_inference_equals_a_composition_around_the_independent_nms).
 * STILL UNPINNED: what no Detectron2 / torchvision test holds a literal vector for and those libraries (absent here) would
-  have to be run for -- the COMPOSITION of ``fast_rcnn_inference`` (softmax -> per-class decode -> clip -> score > 0.05 ->
-  class-wise NMS -> top-k: every stage of it is pinned on its own -- softmax is torch's, the box transform by test_rpn /
-  test_fast_rcnn, the NMS stage as above -- the glue between them is restated from the published function), ``Boxes.clip`` /
+  have to be run for -- the glue of ``fast_rcnn_inference`` against a RUN of Detectron2's function (softmax -> per-class
+  decode -> clip -> score > 0.05 -> class-wise NMS -> top-k: every stage is pinned on its own and the whole equals the
+  composition above, whose stage order is this repo's reading of the published function), ``Boxes.clip`` /
   ``nonempty`` corner cases, COCOeval, ColorJitter's parameter sampling; the ResNet-50/101-C4 trunk has no Detectron2 vector but equals
   an independent port -- HuggingFace ``transformers``' ResNet with the stride in the first 1x1 -- on the same weights in
   eval and train mode (tests/test_oracle_r101.py).  Those are restated from their published algorithms and
