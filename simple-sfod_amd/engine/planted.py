@@ -9,7 +9,7 @@ definition, here, so that the two cannot drift apart.
 """
 import torch
 
-# smaller scales leave fewer than 20 boxes above 0.8 at ANY bias (profiles/r5_planted_label_calibration.txt)
+# smaller scales leave fewer than 20 boxes above 0.8 at ANY bias (profiles/round5/r5_planted_label_calibration.txt)
 SCALE = {"vgg": 16.0, "r101": 4.0}
 TARGET = 20.0
 RANGE = (10.0, 30.0)

@@ -308,7 +308,7 @@ def _on_step_stream(trainer):
     path; the weight gradients it feeds run on a normal-priority side stream, and as workgroup slots free up the dispatcher
     hands them to the chain first (+1.0 % on the hot yaml at B = 8, +0.65 % on the R101 yaml).  Around the whole loop, not
     around each step: switching streams per step -- a wait on the caller's (null) stream at every step boundary -- cost
-    4-7 % on the R101 yaml / at one frame per GPU (profiles/r5_step_stream_priority.txt).  Ordered after everything the
+    4-7 % on the R101 yaml / at one frame per GPU (profiles/round5/r5_step_stream_priority.txt).  Ordered after everything the
     caller's stream holds at entry; the caller's stream waits for the loop at exit.  ``run_step`` called on its own (tests)
     runs on the caller's stream as before."""
     d = trainer.__dict__ if hasattr(trainer, "__dict__") else {}

@@ -234,7 +234,7 @@ class vgg_backbone(nn.Module):
             return False
         # the in-LDS transform costs the convolution 12-15 % (it is not hidden behind the MFMAs); the apply pass it removes
         # costs its HBM bytes, and a tensor that fits the 256 MB Infinity Cache is cheap to re-read: the fold pays for
-        # conv2_2 / conv3_2 / conv3_3 of a teacher batch at 600 x 1200 and loses on conv4_x (profiles/r4_bnin_layers.txt)
+        # conv2_2 / conv3_2 / conv3_3 of a teacher batch at 600 x 1200 and loses on conv4_x (profiles/round4/r4_bnin_layers.txt)
         if y.numel() * 4 < self.fuse_bn_input_min_bytes:
             return False
         nxt = self._plan[li + 1][0]

@@ -13,7 +13,7 @@ _shared = {}
 def shared_stream():
     """ONE side stream per device for everything that runs beside a data-gradient path (the backbones' weight gradients, the
     heads' parameter gradients, the RPN's backward): HIP multiplexes streams onto 4 hardware queues, and a stream per module
-    (six streams in a step) cost the 1024 x 2048 configuration 4.5 % (profiles/r5_prefetch_label_free_work.txt)."""
+    (six streams in a step) cost the 1024 x 2048 configuration 4.5 % (profiles/round5/r5_prefetch_label_free_work.txt)."""
     dev = torch.cuda.current_device()
     st = _shared.get(dev)
     if st is None:

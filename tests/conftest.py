@@ -40,7 +40,7 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 # selection: every parity gate at BASELINE sizes in the mode bench.py reports for that config, every golden-fixture test, the
 # two-rank run of config #4, and ONE case per kernel family and variant axis (the planner's own choice); the exhaustive
 # axes -- forced workgroup shapes, forced algorithms, the other arithmetic modes of the long oracle comparisons -- run
-# with -m "gpu and sweep".  Durations that decided the cut: gpurun_out / profiles/r5_gpu_suite_durations.txt.
+# with -m "gpu and sweep".  Durations that decided the cut: gpurun_out / profiles/round5/r5a_gpu_suite_durations.txt.
 import re
 
 SWEEP_PATTERNS = [re.compile(p) for p in (

@@ -61,7 +61,7 @@ R101_YAML = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "r101_c4_cs_f
 #   decoded detection boxes     the same over all R x K x 4 coordinates
 #   intermediates               RPN logits / deltas, box-head scores / deltas: relative L2 < GATE_INTERMEDIATE[dtype], or
 #                               3 x the reference arithmetic's OWN error on this network when that is larger (below)
-# bf16x3 carries 16 significand bits per operand (4.4e-6 rms per dot product, profiles/r2_mfma_split_precision.txt);
+# bf16x3 carries 16 significand bits per operand (4.4e-6 rms per dot product, profiles/round2/r2_mfma_split_precision.txt);
 # over 14 VGG convolutions the intermediates reach ~1e-4 relative L2, which is why they get 2e-4 and NOT the 1e-4 of the
 # north-star quantities (bench.py's dtype_note says the same).
 #
