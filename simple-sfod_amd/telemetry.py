@@ -111,17 +111,26 @@ class SmiSampler:
 # ---- what RCCL chose ----------------------------------------------------------------------------------------------------
 def rccl_debug_setup(rank, directory="/tmp"):
     """Before ``init_process_group``: have RCCL write its INFO lines of the INIT / GRAPH / TUNING subsystems to a per-rank
-    file (the user's own NCCL_DEBUG* settings win).  -> the file this rank writes, or None when the user redirected it."""
-    if "NCCL_DEBUG" in os.environ or "NCCL_DEBUG_FILE" in os.environ:
-        return os.environ.get("NCCL_DEBUG_FILE")
+    file.  -> the file this rank writes.
+
+    What the environment already says is kept where it says MORE: a ``NCCL_DEBUG_FILE`` of the user's is used as it is (with
+    their level), ``NCCL_DEBUG=INFO`` / ``TRACE`` keeps its own subsystem list.  A quieter level is raised -- the GPU boxes of
+    this pool export ``NCCL_DEBUG=VERSION``, with which RCCL prints a five-line banner on STDOUT, where ``bench.py``'s one JSON
+    line goes: the per-rank file takes the banner too."""
+    if "NCCL_DEBUG_FILE" in os.environ:
+        return os.environ["NCCL_DEBUG_FILE"]
     path = os.path.join(directory, f"sfod_rccl_{os.getpid()}_rank{rank}.log")
-    os.environ["NCCL_DEBUG"] = "INFO"
-    os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
     os.environ["NCCL_DEBUG_FILE"] = path
+    if os.environ.get("NCCL_DEBUG", "").upper() not in ("INFO", "TRACE"):
+        os.environ["NCCL_DEBUG"] = "INFO"
+        os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING"
     return path
 
 
-_TUNING = re.compile(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+) time ([0-9.eE+-]+)")
+# the TUNING line of a collective: RCCL 2.26 (this image) prints NAMES and the channel range --
+#   "AllReduce: 466747392 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..63}"
+# -- older builds printed the enum values and a predicted time ("... -> Algo 1 proto 2 time 2345.6"); both are read
+_TUNING = re.compile(r"(\w+): (\d+) Bytes -> Algo (\w+) proto (\w+)(?: channel\{Lo\.\.Hi\}=\{(\d+)\.\.(\d+)\})?")
 
 
 def parse_rccl_log(text):
@@ -131,10 +140,13 @@ def parse_rccl_log(text):
     for line in text.splitlines():
         m = _TUNING.search(line)
         if m:
-            key = (m.group(1), int(m.group(2)), int(m.group(3)), int(m.group(4)))
+            algo = ALGO.get(int(m.group(3)), m.group(3)) if m.group(3).isdigit() else m.group(3).upper()
+            proto = PROTO.get(int(m.group(4)), m.group(4)) if m.group(4).isdigit() else m.group(4).upper()
+            nch = int(m.group(6)) - int(m.group(5)) + 1 if m.group(5) is not None else None
+            key = (m.group(1), int(m.group(2)), algo, proto, nch)
             seen[key] = seen.get(key, 0) + 1
             continue
-        m = re.search(r"(RCCL|NCCL) version ([^\s]+)", line)
+        m = re.search(r"(RCCL|NCCL) version\s*:?\s*([^\s:]\S*)", line)
         if m and out["version"] is None:
             out["version"] = f"{m.group(1)} {m.group(2)}"
         m = re.search(r"(\d+) coll channels", line)
@@ -143,9 +155,11 @@ def parse_rccl_log(text):
         m = re.search(r" via ([A-Za-z0-9_/]+)", line)
         if m and "Channel" in line:
             out["transports"][m.group(1)] = out["transports"].get(m.group(1), 0) + 1
-    for (coll, nbytes, algo, proto), n in sorted(seen.items(), key=lambda kv: -kv[0][1]):
-        out["collectives"].append({"coll": coll, "bytes": nbytes, "algo": ALGO.get(algo, str(algo)),
-                                   "proto": PROTO.get(proto, str(proto)), "calls": n})
+    for (coll, nbytes, algo, proto, nch), n in sorted(seen.items(), key=lambda kv: -kv[0][1]):
+        row = {"coll": coll, "bytes": nbytes, "algo": algo, "proto": proto, "calls": n}
+        if nch is not None:
+            row["channels"] = nch
+        out["collectives"].append(row)
     out["collectives"] = out["collectives"][:8]
     return out
 

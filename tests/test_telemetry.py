@@ -53,6 +53,33 @@ def test_rccl_info_lines():
     assert tel.rccl_summary(None) is None and tel.rccl_summary("/nonexistent/file.log") is None
 
 
+def test_rccl_2_26_formats_of_this_image():
+    """What the RCCL inside this image's torch really writes: ``tests/golden/rccl_2_26_one_rank_info.log`` is the INFO log of a
+    one-rank communicator on an MI355X box (tools/experiments/probe_rccl_one_rank.py; repeated per-channel lines thinned), the
+    multi-rank lines below are its format strings (``strings librccl.so``) filled in: names instead of enum values in the TUNING
+    line, a channel range instead of a predicted time, ``version :`` with a colon."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    s = tel.rccl_summary(os.path.join(here, "golden", "rccl_2_26_one_rank_info.log"))
+    assert s["version"] == "RCCL 2.26.6-HEAD:64f48b6" and s["channels"] == 128 and s["collectives"] == [] and s["transports"] == {}
+    multi = """
+runc:376:446 [0] NCCL INFO RCCL version : 2.26.6-HEAD:64f48b6
+runc:376:446 [0] NCCL INFO Channel 00/0 : 0[75000] -> 1[85000] via P2P/IPC comm 0x55 nRanks 08
+runc:376:446 [0] NCCL INFO Channel 01/0 : 0[75000] -> 1[85000] via P2P/IPC comm 0x55 nRanks 08
+runc:376:446 [0] NCCL INFO Channel 00/0 : 7[f5000] -> 0[75000] via P2P/direct pointer comm 0x55 nRanks 08
+runc:376:446 [0] NCCL INFO 64 coll channels, 64 collnet channels, 0 nvls channels, 64 p2p channels, 8 p2p channels per peer
+runc:376:446 [0] NCCL INFO AllReduce: 466747392 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..63}
+runc:376:446 [0] NCCL INFO AllReduce: 466747392 Bytes -> Algo RING proto SIMPLE channel{Lo..Hi}={0..63}
+runc:376:446 [0] NCCL INFO AllReduce: 4280320 Bytes -> Algo TREE proto LL128 channel{Lo..Hi}={0..15}
+runc:376:446 [0] NCCL INFO Broadcast: 36 Bytes -> Algo RING proto LL channel{Lo..Hi}={0..0}
+"""
+    s = tel.parse_rccl_log(multi)
+    assert s["version"] == "RCCL 2.26.6-HEAD:64f48b6" and s["channels"] == 64 and s["transports"] == {"P2P/IPC": 2, "P2P/direct": 1}
+    assert s["collectives"][0] == {"coll": "AllReduce", "bytes": 466747392, "algo": "RING", "proto": "SIMPLE", "calls": 2, "channels": 64}
+    assert {"coll": "AllReduce", "bytes": 4280320, "algo": "TREE", "proto": "LL128", "calls": 1, "channels": 16} in s["collectives"]
+    assert {"coll": "Broadcast", "bytes": 36, "algo": "RING", "proto": "LL", "calls": 1, "channels": 1} in s["collectives"]
+
+
 def test_debug_setup_respects_the_users_settings(monkeypatch, tmp_path):
     for k in ("NCCL_DEBUG", "NCCL_DEBUG_FILE", "NCCL_DEBUG_SUBSYS"):
         monkeypatch.delenv(k, raising=False)
@@ -62,5 +89,16 @@ def test_debug_setup_respects_the_users_settings(monkeypatch, tmp_path):
     monkeypatch.setenv("NCCL_DEBUG", "WARN")
     monkeypatch.setenv("NCCL_DEBUG_FILE", "/elsewhere.log")
     assert tel.rccl_debug_setup(0) == "/elsewhere.log" and os.environ["NCCL_DEBUG"] == "WARN"
+    # the GPU boxes of this pool export NCCL_DEBUG=VERSION (RCCL then prints a banner on stdout, beside bench.py's JSON line):
+    # a quieter level without a file is raised to INFO and redirected; INFO with the user's own subsystem list is kept
+    monkeypatch.delenv("NCCL_DEBUG_FILE")
+    monkeypatch.setenv("NCCL_DEBUG", "VERSION")
+    p = tel.rccl_debug_setup(1, directory=str(tmp_path))
+    assert os.environ["NCCL_DEBUG"] == "INFO" and os.environ["NCCL_DEBUG_FILE"] == p and "TUNING" in os.environ["NCCL_DEBUG_SUBSYS"]
+    monkeypatch.delenv("NCCL_DEBUG_FILE")
+    monkeypatch.setenv("NCCL_DEBUG", "INFO")
+    monkeypatch.setenv("NCCL_DEBUG_SUBSYS", "COLL")
+    p = tel.rccl_debug_setup(2, directory=str(tmp_path))
+    assert os.environ["NCCL_DEBUG_SUBSYS"] == "COLL" and os.environ["NCCL_DEBUG_FILE"] == p
     for k in ("NCCL_DEBUG", "NCCL_DEBUG_FILE", "NCCL_DEBUG_SUBSYS"):
         monkeypatch.delenv(k, raising=False)
