@@ -217,6 +217,8 @@ def build_trainer(sfod, args, dtype, world, rank, local_rank):
         os.environ["SFOD_VGG_WGRAD_STREAM"] = "0"
     if args.res == "full":
         opts += ["INPUT.MIN_SIZE_TRAIN", "(1024,)", "INPUT.MAX_SIZE_TRAIN", "2048"]
+    if args.host_frames:
+        opts += ["SFOD.SYNTHETIC.HOST_FRAMES", "True"]
     yaml = YAML["vgg_base"] if args.trainer == "base" else YAML[args.model]
     cfg = sfod.config.setup_cfg(os.path.join(ROOT, "configs", yaml), opts + list(args.opts))
     torch.manual_seed(cfg.SEED + rank)
@@ -287,6 +289,9 @@ def main():
     ap.add_argument("--no-other-shapes", action="store_true",
                     help="skip the RFULL / one-frame-per-GPU child runs of the default configuration")
     ap.add_argument("--no-smi", action="store_true", help="no rocm-smi clock / power samples beside the run")
+    ap.add_argument("--host-frames", action="store_true",
+                    help="frames in pinned host memory, uploaded every step on the loader's stream (SFOD.SYNTHETIC.HOST_FRAMES): the "
+                         "PCIe-inclusive rate of DESIGN.md section 6 -- never the headline `value`")
     ap.add_argument("--no-planted", action="store_true")
     ap.add_argument("--plant-scale", type=float, default=0.0, help="planted-label mode: scale on cls_score.weight (default: engine/planted.py SCALE)")
     ap.add_argument("--plant-bias", type=float, default=None,
@@ -644,7 +649,10 @@ def main():
                         f"frames -> {h}x{w} network tensors ({'INPUT.MIN_SIZE_TRAIN=600 of the config' if args.res == 'r600' else 'MIN_SIZE_TRAIN overridden to 1024'})",
             "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
             "ema": bool(cfg.SFOD.EMA.ENABLED) and args.trainer != "base", "teacher_on_second_stream": overlapped,
-            "input_pipeline": ("uint8 1024x2048 frames resident in HBM; ResizeShortestEdge (Pillow-exact bilinear) + "
+            "input_pipeline": (("uint8 1024x2048 frames in PINNED HOST memory, each uploaded over PCIe on the loader's stream every "
+                                "step (--host-frames: the PCIe-inclusive rate, not the headline)"
+                                if args.host_frames and args.res == "r600" else "uint8 1024x2048 frames resident in HBM") +
+                               "; ResizeShortestEdge (Pillow-exact bilinear) + "
                                "RandomFlip on the device every step, prefetched one batch ahead on a loader stream"
                                if bool(cfg.SFOD.SYNTHETIC.DEVICE_RESIZE) else
                                "frames resized once at start-up (Pillow), RandomFlip on the device every step"), "elide_zero_weight_branches": bool(cfg.SFOD.ELIDE_DEAD_BRANCHES),

@@ -439,6 +439,10 @@ def add_native_config(cfg):
     # with WEAK_STRONG_AUGMENT: the mapper's strong augmentation (colour jitter, grayscale, blur, erasing) on the
     # device (sfod_aug_*); False: the strong list repeats the weak frames
     _C.SFOD.SYNTHETIC.STRONG_AUGMENT = True
+    # keep the frames in PINNED HOST memory (what the reference's loader hands over: CPU uint8 tensors, moved by
+    # ``preprocess_image``'s ``.to(device)``) and upload each one on the loader's stream every iteration, one batch ahead of
+    # its step; False (bench.py's `value`): frames resident in HBM.  DESIGN.md section 6 has the PCIe-inclusive rate.
+    _C.SFOD.SYNTHETIC.HOST_FRAMES = False
 
 
 def setup_cfg(config_file=None, opts=()):

@@ -87,7 +87,8 @@ class SyntheticTargetDataset:
                 if not self.device_resize:
                     img = _resize_u8(img, newh, neww)
                 boxes = boxes * torch.tensor([neww / s.WIDTH, newh / s.HEIGHT] * 2)
-            self.items.append({"image": img.to(device), "boxes": boxes.to(device), "classes": classes.to(device),
+            host = bool(s.get("HOST_FRAMES", False)) and self.device_resize and train      # (the training mapper uploads; section 6)
+            self.items.append({"image": img.pin_memory() if host else img.to(device), "boxes": boxes.to(device), "classes": classes.to(device),
                                "height": s.HEIGHT, "width": s.WIDTH, "image_id": i,
                                "file_name": f"synthetic/{i:06d}.png"})
         self.size = (newh, neww)
@@ -219,6 +220,8 @@ class TwoCropLoader:
         do_flip = bool(self.flip and torch.rand(1, generator=self.gen).item() < 0.5)
         newh, neww = item.get("size", self.dataset.size)
         if getattr(self.dataset, "device_resize", False) and (newh, neww) != tuple(img.shape[1:]):
+            if not img.is_cuda:        # SFOD.SYNTHETIC.HOST_FRAMES: the frame comes from pinned host memory, on the loader's stream
+                img = img.to(boxes.device, non_blocking=True)
             img = native.resize_bilinear_u8(img, newh, neww, flip=do_flip)     # resize (+ flip) in one launch
         elif do_flip:
             img = native.hflip_u8(img) if img.is_cuda else torch.flip(img, dims=[2])

@@ -1137,3 +1137,24 @@ def test_two_phase_gradient_reducer_on_rccl_single_rank_group(sfod, native, mode
         T.get_world_size = orig
         if created:
             dist.destroy_process_group()
+
+
+def test_frames_from_pinned_host_memory_give_the_same_batches(sfod, native):
+    """``SFOD.SYNTHETIC.HOST_FRAMES``: the training mapper takes its frames from pinned host memory (what the reference's loader
+    hands over: CPU uint8 tensors) and uploads them on the loader's stream -- the batches are the device-resident frames' batches,
+    bit for bit (``bench.py --host-frames`` = the PCIe-inclusive rate of DESIGN.md section 6)."""
+    yaml = os.path.join(os.path.dirname(GOLDEN), "..", "configs", "faster_rcnn_VGG_cityscapes_foggy_adaptive_teacher_source_free.yaml")
+    base = ["OUTPUT_DIR", "", "SFOD.SYNTHETIC.HEIGHT", "256", "SFOD.SYNTHETIC.WIDTH", "512", "SFOD.SYNTHETIC.NUM_IMAGES", "6",
+            "INPUT.MIN_SIZE_TRAIN", "(192,)", "SOLVER.IMS_PER_BATCH_TARGET", "2"]
+    out = []
+    for host in ("False", "True"):
+        cfg = sfod.config.setup_cfg(yaml, base + ["SFOD.SYNTHETIC.HOST_FRAMES", host])
+        loader = sfod.data.synthetic.TwoCropLoader(cfg, torch.device("cuda"), dataset=sfod.data.synthetic.SyntheticTargetDataset(cfg, "cuda"))
+        assert loader.dataset.items[0]["image"].is_cuda == (host == "False")
+        assert host == "False" or loader.dataset.items[0]["image"].is_pinned()
+        batches = [next(loader) for _ in range(4)]
+        torch.cuda.synchronize()
+        out.append([[(d["image"].clone(), d["instances"].gt_boxes.tensor.clone(), d["image_id"]) for d in weak] for _, weak in batches])
+    for ba, bb in zip(*out):
+        for (ia, xa, ida), (ib, xb, idb) in zip(ba, bb):
+            assert ida == idb and ia.is_cuda and ib.is_cuda and torch.equal(ia, ib) and torch.equal(xa, xb)
