@@ -588,7 +588,12 @@ def main():
         for label, extra in (("one frame per GPU (the yaml's IMS_PER_BATCH_TARGET 1), 600x1200 tensors",
                               ["--batch", "1", "--res", "r600", "--steps", "120", "--warmup", "10"]),
                              ("B = 8 per GPU, 1024x2048 network tensors (INPUT.MIN_SIZE_TRAIN (1024,), MAX 2048)",
-                              ["--batch", "8", "--res", "full", "--steps", "12", "--warmup", "3"]))[:2 if args.model == "vgg" else 1]:
+                              ["--batch", "8", "--res", "full", "--steps", "12", "--warmup", "3"]),
+                             # the PCIe-inclusive rate of the headline configuration
+                             ("this line's configuration with the frames in pinned HOST memory, each uploaded over PCIe every step "
+                              "(the reference's hand-over: CPU uint8 tensors)",
+                              ["--batch", "8", "--res", "r600", "--steps", str(args.steps), "--warmup", "5", "--host-frames"]),
+                             )[:3 if args.model == "vgg" else 1]:
             cmd = [sys.executable, os.path.abspath(__file__), "--dtype", args.dtype, "--model", args.model, "--trainer", args.trainer,
                    "--no-cpu-baseline", "--no-secondary", "--no-kernel-timer"] + extra
             cmd += (["--no-planted"] if args.no_planted else [])
