@@ -98,7 +98,8 @@ Parity pin status
   have to be run for -- the glue of ``fast_rcnn_inference`` against a RUN of Detectron2's function (softmax -> per-class
   decode -> clip -> score > 0.05 -> class-wise NMS -> top-k: every stage is pinned on its own and the whole equals the
   composition above, whose stage order is this repo's reading of the published function), ``Boxes.clip`` /
-  ``nonempty`` corner cases, COCOeval, ColorJitter's parameter sampling; the ResNet-50/101-C4 trunk has no Detectron2 vector but equals
+  ``nonempty`` corner cases, COCOeval's matching rule (simple-sfod_amd/evaluation.py: its AP interpolation equals an independent
+  computation through scikit-learn's precision_recall_curve, tests/test_evaluation.py), ColorJitter's parameter sampling; the ResNet-50/101-C4 trunk has no Detectron2 vector but equals
   an independent port -- HuggingFace ``transformers``' ResNet with the stride in the first 1x1 -- on the same weights in
   eval and train mode (tests/test_oracle_r101.py).  Those are restated from their published algorithms and
   anchored on the reference's call sites plus hand-computed known-answer cases (tests/test_oracle_*.py); ``transformers``

@@ -167,3 +167,65 @@ def test_trainer_test_with_a_stand_in_model(sfod):
                                        "128", "SFOD.SYNTHETIC.NUM_TEST_IMAGES", "2", "INPUT.MIN_SIZE_TEST", "32",
                                        "DATASETS.TEST", "('synthetic_cityscapes_foggy_val',)"])
     assert "bbox" in sfod.engine.BaseTrainer.test(cfg1, model)
+
+
+def test_ap50_equals_an_independent_computation_from_scikit_learns_pr_curve(sfod):
+    """A second route to the same number on a randomised scene whose matching is unambiguous (every detection overlaps at most one
+    ground truth, with IoU ~0.8 or 0): precision / recall points from scikit-learn's ``precision_recall_curve`` (its own sort and
+    cumulative sums; recall rescaled to COCO's denominator = ALL ground truths of the class), then COCOeval's published rule --
+    precision made non-increasing from the right, sampled at recall 0:0.01:1 at the first point with recall >= r, 0 beyond the last
+    -- written here in numpy.  Per class and overall AP50 of ``COCOevalBBox`` must equal it."""
+    from sklearn.metrics import precision_recall_curve
+    rng = np.random.default_rng(5)
+    K, n_img = 3, 6
+    gts, dts, truth = [], [], {k: ([], []) for k in range(K)}            # class -> (is_tp flags, scores)
+    npig = {k: 0 for k in range(K)}
+    used_scores = set()
+
+    def score():
+        while True:
+            s = round(float(rng.uniform(0.05, 0.99)), 4)
+            if s not in used_scores:
+                used_scores.add(s)
+                return s
+    for img in range(1, n_img + 1):
+        cell = 0
+        for k in range(K):
+            for _ in range(int(rng.integers(2, 5))):
+                x, y = 120.0 * (cell % 8), 120.0 * (cell // 8)            # one 120 x 120 cell per object: nothing else overlaps it
+                cell += 1
+                w, h = float(rng.uniform(40, 90)), float(rng.uniform(40, 90))
+                gts.append(_gt(img, k, (x, y, w, h)))
+                npig[k] += 1
+                r = rng.uniform()
+                if r < 0.7:                                              # found: same box shrunk by 10 % in w (IoU 0.9)
+                    s = score()
+                    dts.append(_dt(img, k, (x, y, 0.9 * w, h), s))
+                    truth[k][0].append(1), truth[k][1].append(s)
+                    if rng.uniform() < 0.3:                              # ... and a lower-scored duplicate: a false positive
+                        s2 = round(s * 0.5, 5)
+                        dts.append(_dt(img, k, (x, y, 0.9 * w, h), s2))
+                        truth[k][0].append(0), truth[k][1].append(s2)
+                # else: missed
+            for _ in range(int(rng.integers(0, 3))):                      # false positives in empty cells
+                x, y = 120.0 * (cell % 8), 120.0 * (cell // 8)
+                cell += 1
+                s = score()
+                dts.append(_dt(img, k, (x, y, 50.0, 50.0), s))
+                truth[k][0].append(0), truth[k][1].append(s)
+    ev = _run(sfod, gts, dts, list(range(K)), list(range(1, n_img + 1)))
+    rec_thrs = np.linspace(0.0, 1.0, 101)
+    aps = []
+    for k in range(K):
+        y, s = np.array(truth[k][0]), np.array(truth[k][1])
+        assert y.sum() > 0 and (1 - y).sum() > 0 and len(set(s.tolist())) == len(s)
+        prec, rec, _ = precision_recall_curve(y, s)            # decreasing recall, last point (recall 0, precision 1) appended
+        prec, rec = prec[:-1][::-1], rec[:-1][::-1]            # by descending score threshold = COCO's cumulative order
+        rec = rec * y.sum() / npig[k]                          # COCO divides by every ground truth, found or not
+        env = np.maximum.accumulate(prec[::-1])[::-1]          # non-increasing from the right
+        idx = np.searchsorted(rec, rec_thrs, side="left")
+        q = np.where(idx < len(env), env[np.minimum(idx, len(env) - 1)], 0.0)
+        aps.append(q.mean())
+        got = ev.eval["precision"][0, :, k, 0, 2]              # IoU 0.50, all areas, maxDets 100
+        np.testing.assert_allclose(got, q, rtol=0, atol=1e-12)
+    assert abs(ev.stats[1] - float(np.mean(aps))) < 1e-12
