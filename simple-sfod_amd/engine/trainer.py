@@ -519,7 +519,9 @@ class BaseTrainer:
         the storage is written with this iteration's number."""
         self.scheduler.step()
         nxt = self.iter + 1
-        self.storage.iter = nxt
+        # d2 stamps a scalar with the iteration it was put in (TrainerBase.before_step: ``storage.iter = self.iter``; JSONWriter
+        # writes that number): the last record of a 4-iteration run says ``"iteration": 3``
+        self.storage.iter = self.iter
         # PeriodicCheckpointer: every CHECKPOINT_PERIOD iterations, and ``model_final`` after the last one (what
         # the reference's eval / AdaBN configs point MODEL.WEIGHTS at)
         p = self.cfg.SOLVER.CHECKPOINT_PERIOD
