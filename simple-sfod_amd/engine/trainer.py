@@ -81,24 +81,50 @@ class EventStorage:
     the ValLossHook's ``*_val`` keys, evaluation results) is rank-local there -- each rank has its own storage and only
     the main process writes -- so the record carries this rank's value and rank 0's is what reaches ``metrics.json``."""
 
+    SMOOTH_WINDOW = 20       # d2 JSONWriter(window_size=20) / EventStorage.latest_with_smoothing_hint
+
     def __init__(self, start_iter=0):
         self.iter = start_iter
         self._pending = {}
         self._rank_mean = set()
+        self._window = {}        # name -> the last SMOOTH_WINDOW values put with a smoothing hint (d2 HistoryBuffer)
         self.history = []
 
-    def put_scalar(self, name, value, rank_mean=False):
+    def put_scalar(self, name, value, rank_mean=False, smoothing_hint=True):
+        """d2 ``EventStorage.put_scalar``: ``smoothing_hint`` (default True, as there) says the writers may report the
+        median of the last values instead of the last one -- the reference puts every loss / statistic with the default,
+        d2's EvalHook and LR hook put theirs with ``False``."""
         if isinstance(value, torch.Tensor) and value.requires_grad:
             value = value.detach()          # a logged scalar must not keep its autograd graph (and everything it saved) alive
         self._pending[name] = value
         (self._rank_mean.add if rank_mean else self._rank_mean.discard)(name)
+        if smoothing_hint:
+            w = self._window.get(name)
+            if w is None:
+                w = self._window[name] = collections.deque(maxlen=self.SMOOTH_WINDOW)
+            w.append(value)
+        else:
+            self._window.pop(name, None)
 
-    def put_scalars(self, _rank_mean=False, **kw):
+    def put_scalars(self, _rank_mean=False, smoothing_hint=True, **kw):
         """``_rank_mean`` is positional / underscored so that a metric may itself be called ``rank_mean``."""
         for k, v in kw.items():
-            self.put_scalar(k, v, rank_mean=_rank_mean)
+            self.put_scalar(k, v, rank_mean=_rank_mean, smoothing_hint=smoothing_hint)
 
-    def flush(self, reduce_over_ranks=False):
+    def _smoothed(self, name):
+        """median of the window (numpy's: the mean of the two middle values for an even count), on the device for device
+        scalars -- no host synchronisation here"""
+        w = self._window.get(name)
+        if w is None or len(w) < 2:
+            return self._pending[name]
+        n = len(w)
+        if all(isinstance(v, torch.Tensor) for v in w):
+            srt = torch.sort(torch.stack([v.detach().float().reshape(()) for v in w])).values
+            return (srt[(n - 1) // 2] + srt[n // 2]) * 0.5
+        srt = sorted(float(v) for v in w)
+        return 0.5 * (srt[(n - 1) // 2] + srt[n // 2])
+
+    def flush(self, reduce_over_ranks=False, smooth=False):
         """-> the record of this writer period.  ``reduce_over_ranks``: the ``rank_mean`` keys of the period are stacked
         and averaged with ONE small all-reduce (+ one MAX all-reduce for ``data_time``); every rank must call it with
         the same ``rank_mean`` keys (they follow from the config, not from the data).  If the ranks disagree on their
@@ -106,6 +132,10 @@ class EventStorage:
         says so once on stderr."""
         if not self._pending:
             return {}
+        if smooth:      # the periodic writer (d2 JSONWriter): hinted scalars as the median of their last 20 values.  With
+            # N > 1 ranks this is the rank mean of per-rank medians, where d2 takes the median of per-step rank means
+            # (its _write_metrics gathers every step; here nothing is exchanged between writer periods): equal at N = 1
+            self._pending = {n_: self._smoothed(n_) for n_ in self._pending}
         names = list(self._pending)
         vals = [v.detach().float().reshape(()) if isinstance(v, torch.Tensor) else None for v in self._pending.values()]
         world = get_world_size() if reduce_over_ranks else 1
@@ -595,7 +625,7 @@ class BaseTrainer:
                         else:
                             flat[prefix + k] = float(v)
                 walk("", {k + suffix: v for k, v in results.items()} if suffix else results)
-                self.storage.put_scalars(**flat)
+                self.storage.put_scalars(smoothing_hint=False, **flat)       # d2 EvalHook: smoothing_hint=False
 
     def _flush_metrics(self):
         rpn = getattr(self.model, "proposal_generator", None)
@@ -603,7 +633,7 @@ class BaseTrainer:
             rpn.check_finite()
         if str(self.cfg.SFOD.COMPUTE_DTYPE).lower() == "f16x3":     # half pairs: clamped values are reported, not silent
             native.check_f16x3_range(torch.device(self.device))
-        rec = self.storage.flush(reduce_over_ranks=True)
+        rec = self.storage.flush(reduce_over_ranks=True, smooth=True)
         rec["lr"] = self.optimizer.param_groups[0]["lr"]
         if get_rank() == 0 and self.cfg.OUTPUT_DIR:
             os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)

@@ -165,7 +165,8 @@ def _trajectory_case(sfod, native, model, dtype, elide):
         tr.iter = it
         tr.run_step()
         tr.after_step()
-        rec = tr._flush_metrics()
+        rec = tr.storage.flush()          # THIS step's values (the periodic writer reports d2's median over the last 20 steps)
+        tr._flush_metrics()               # ... and the writer's own path: finiteness checks, nothing pending
         torch.cuda.synchronize()
         # ---- the same step on the oracle ---------------------------------------------------------------------------
         images = cap["images"]

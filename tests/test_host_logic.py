@@ -454,3 +454,31 @@ def test_pooler_resolution_beyond_the_backward_kernel_is_refused_before_the_loss
     stub.pooled = 7          # the named yamls' value passes this point (and then needs real targets)
     with pytest.raises((AttributeError, TypeError, AssertionError)):
         RH.forward(stub, None, feats, props, targets=object(), compute_loss=True)
+
+
+def test_periodic_writer_reports_the_median_of_the_last_twenty_values_like_d2s_json_writer(sfod):
+    """d2 ``JSONWriter`` writes ``storage.latest_with_smoothing_hint(20)``: a scalar put with the (default) smoothing hint is
+    reported as numpy's median of its last 20 values, one put with ``smoothing_hint=False`` (d2's EvalHook / LR hook) as its
+    last value; records are stamped with the iteration the scalars were put in.  ``flush()`` without ``smooth`` (bench.py,
+    the per-step readers of the tests) stays the last value."""
+    import numpy as np
+    st = sfod.engine.trainer.EventStorage()
+    vals = [3.0, 9.0, 1.0, 7.0, 5.0, 11.0]
+    for i, v in enumerate(vals):
+        st.iter = i
+        st.put_scalar("loss_a", torch.tensor(v))                  # device-style scalar
+        st.put_scalar("host_b", v * 2)                             # plain float
+        st.put_scalars(smoothing_hint=False, **{"bbox/AP50": v})
+    rec = st.flush(smooth=True)
+    assert rec["iteration"] == 5
+    assert rec["loss_a"] == float(np.median(vals)) == 6.0 and rec["host_b"] == 12.0 and rec["bbox/AP50"] == 11.0
+    # the window outlives a flush (d2's HistoryBuffer does) and holds the last 20 values only
+    more = [float(x) for x in range(100, 125)]
+    for v in more:
+        st.put_scalar("loss_a", torch.tensor(v))
+    assert st.flush(smooth=True)["loss_a"] == float(np.median(more[-20:]))
+    st.put_scalar("loss_a", torch.tensor(-1.0))
+    assert st.flush()["loss_a"] == -1.0                            # unsmoothed reader: the last value
+    # a key switched to "no hint" forgets its window
+    st.put_scalar("loss_a", 4.0, smoothing_hint=False)
+    assert st.flush(smooth=True)["loss_a"] == 4.0
