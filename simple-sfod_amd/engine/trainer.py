@@ -635,6 +635,13 @@ class BaseTrainer:
             native.check_f16x3_range(torch.device(self.device))
         rec = self.storage.flush(reduce_over_ranks=True, smooth=True)
         rec["lr"] = self.optimizer.param_groups[0]["lr"]
+        # d2 hooks.IterationTimer puts ``time`` (seconds per iteration) every step; a step here has no host synchronisation, so
+        # the figure is the wall time of the writer period over its iterations (the flush above is the period's one host sync)
+        now, it_now = time.perf_counter(), int(getattr(self, "iter", 0))
+        last = self.__dict__.get("_writer_mark")
+        if last is not None and it_now > last[1] and rec:
+            rec["time"] = (now - last[0]) / (it_now - last[1])
+        self._writer_mark = (now, it_now)
         if get_rank() == 0 and self.cfg.OUTPUT_DIR:
             os.makedirs(self.cfg.OUTPUT_DIR, exist_ok=True)
             with open(os.path.join(self.cfg.OUTPUT_DIR, "metrics.json"), "a") as f:
