@@ -55,7 +55,9 @@ SWEEP_PATTERNS = [re.compile(p) for p in (
     # two-rank steps: config #4 and #5 each in the mode bench.py reports for it; config #4 in fp32 is the sweep's
     r"test_two_ranks_on_one_gpu_take_the_oracles_mean_gradient_step\[vgg-fp32\]",
     r"test_bench_two_ranks_on_one_gpu\[r101\]",
-    r"test_hot_yaml_teacher_and_student_at_600x1200\[(f16x3-2|bf16x3-2)\]",
+    # (the hot yaml at full size: the default keeps the cases on the head bench.py times, bf16x3 at B = 8 and fp32; the (60, 20)
+    # head's cases -- same sizes, same gates, another score distribution -- run in the sweep)
+    r"test_hot_yaml_teacher_and_student_at_600x1200\[(f16x3-2|bf16x3-2|bf16x3-8|fp32-2)\]",
     # (R101 at full size: the default keeps the case on the head bench.py times; the (60, 20) head's cases are the sweep's)
     r"test_r101_yaml_teacher_and_student_at_600x1200\[(fp32|bf16x3|f16x3)\]",
     r"test_r101_yaml_on_the_benchmarked_head_at_600x1200\[fp32\]",
