@@ -252,6 +252,10 @@ int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
  * statistics (k forward passes over the same batch between two optimiser steps -- the reference's student runs its
  * backbone three times per step when its zero-weighted domain branch is on, source_free_adaptive_teacher.py:527-537).
  * num_batches_tracked: the BatchNorm buffer of that name (device int64 scalar), incremented by k; may be NULL. */
+/* Layers whose statistics fit one slice (nblocks <= 64) are finalised by ONE launch instead of two (default 1; environment
+ * SFOD_BN_FINALIZE_FUSED): the same sums in the same order, bit-identical outputs.  0 keeps the two launches (A/B runs, the
+ * parity test). */
+int sfod_set_bn_finalize_fused(int on);
 /* size (in floats, 8-byte aligned) of the `ws` scratch of sfod_bn_finalize */
 int sfod_bn_finalize_ws_floats(int C);
 /* z = relu(gamma*(y-mean)*invstd+beta); `pool` is a flag word: bit 0 additionally 2x2/2 max-pools z

@@ -5,6 +5,8 @@
 // (4 x fp32 or 8 x bf16) so a wavefront covers 1 KiB of contiguous channels per instruction.
 #include "conv_internal.h"
 #include <type_traits>
+#include <atomic>
+#include <stdlib.h>
 
 template <typename T> struct VecT;
 template <> struct VecT<float> {
@@ -447,6 +449,79 @@ k_bn_final(const double* __restrict__ part, int nsplit, int M, int C, float* __r
   }
 }
 
+// <= 64 statistics blocks (one slice: every layer of a one-frame-per-GPU step below the first stages, every live BatchNorm of
+// ResNet-101-C4 at that size) in ONE launch: slice 0's sums in k_bn_partial's order (16 waves stride the blocks, combined
+// w = 0 .. 15), then k_bn_final's arithmetic for nsplit = 1 -- bit-identical to the two launches
+// (sfod_set_bn_finalize_fused(0) keeps them, for the A/B and the test), one 5 us launch less per BatchNorm.
+__global__ void __launch_bounds__(1024)
+k_bn_finalize_one(const float* __restrict__ stats, int nblocks, int M, int C, float* __restrict__ mean,
+                  float* __restrict__ invstd, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                  float eps, int update_running, long long* __restrict__ nbt) {
+  __shared__ double red[16][3][64];
+  if (nbt != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *nbt += update_running;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const float* counts = stats + (int64_t)nblocks * 2 * C;
+  double a = 0.0, q = 0.0, m2 = 0.0;
+  if (c < C)
+    for (int blk = wave; blk < nblocks; blk += 16) {
+      const double nb = (double)counts[blk];
+      const double sb = (double)stats[((int64_t)blk * 2) * C + c];
+      const double mb = (double)stats[((int64_t)blk * 2 + 1) * C + c];
+      if (nb > 0.0) {
+        a += sb;
+        q += sb * sb / nb;
+        m2 += mb;
+      }
+    }
+  red[wave][0][lane] = a; red[wave][1][lane] = q; red[wave][2][lane] = m2;
+  __syncthreads();
+  if (wave != 0 || c >= C) return;
+  double p[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) v += red[w][k][lane];
+    p[k] = v;                       // = part[(0 * 3 + k) * C + c] of the two-launch form
+  }
+  // k_bn_final, nsplit = 1: wave 0 adds part[0] to 0.0, waves 1 .. 3 hold 0.0, summed ((w0 + w1) + w2) + w3
+  a = (0.0 + p[0]) + 0.0 + 0.0 + 0.0;
+  q = (0.0 + p[1]) + 0.0 + 0.0 + 0.0;
+  m2 = (0.0 + p[2]) + 0.0 + 0.0 + 0.0;
+  const double mu = a / (double)M;
+  double tot = m2 + q - a * a / (double)M;
+  if (tot < 0.0) tot = 0.0;
+  const double var = tot / (double)M;
+  mean[c] = (float)mu;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (update_running) {
+    const double unbiased = (M > 1) ? tot / (double)(M - 1) : var;
+    float rm = rmean[c], rv = rvar[c];
+    for (int k = 0; k < update_running; ++k) {
+      rm = (float)((1.0 - (double)momentum) * (double)rm + (double)momentum * mu);
+      rv = (float)((1.0 - (double)momentum) * (double)rv + (double)momentum * unbiased);
+    }
+    rmean[c] = rm;
+    rvar[c] = rv;
+  }
+}
+
+static std::atomic<int> g_bn_finalize_fused{-1};      // -1: not initialised (environment SFOD_BN_FINALIZE_FUSED, default on)
+extern "C" int sfod_set_bn_finalize_fused(int on) {
+  g_bn_finalize_fused.store(on ? 1 : 0);
+  return 0;
+}
+static bool bn_finalize_fused() {
+  int v = g_bn_finalize_fused.load();
+  if (v < 0) {
+    const char* e = getenv("SFOD_BN_FINALIZE_FUSED");
+    v = (e != nullptr && e[0] == '0') ? 0 : 1;
+    g_bn_finalize_fused.store(v);
+  }
+  return v != 0;
+}
+
 extern "C" int sfod_bn_finalize_ws_floats(int C) {
   if (!sfod_prod_fits({BNF_SPLITS * 6, C})) return 0;
   return BNF_SPLITS * 3 * C * 2;
@@ -462,6 +537,12 @@ extern "C" int sfod_bn_finalize(const float* stats, int nblocks, int M, int C,
   int nsplit = (nblocks + 63) / 64;   // >= 64 blocks (4 per wave) per slice
   if (nsplit > BNF_SPLITS) nsplit = BNF_SPLITS;
   if (nsplit < 1) nsplit = 1;
+  if (nsplit == 1 && bn_finalize_fused()) {
+    hipLaunchKernelGGL(k_bn_finalize_one, dim3(cdiv(C, 64)), dim3(1024), 0, s, stats, nblocks, M, C, mean, invstd,
+                       running_mean, running_var, momentum, eps, update_running,
+                       update_running ? (long long*)num_batches_tracked : (long long*)nullptr);
+    return sfod_check_launch("bn_finalize");
+  }
   double* part = reinterpret_cast<double*>(ws);
   hipLaunchKernelGGL(k_bn_partial, dim3(cdiv(C, 64), nsplit), dim3(1024), 0, s, stats, nblocks, C, part);
   hipLaunchKernelGGL(k_bn_final, dim3(cdiv(C, 64)), dim3(256), 0, s, part, nsplit, M, C, mean, invstd,

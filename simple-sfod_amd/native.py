@@ -303,6 +303,11 @@ def set_deterministic(on):
     return prev
 
 
+def set_bn_finalize_fused(on):
+    """One-launch BatchNorm finalize for layers of <= 64 statistics blocks (default on; include/sfod_hip.h)."""
+    load().sfod_set_bn_finalize_fused(int(bool(on)))
+
+
 def set_conv3x3_m16(on):
     """Automatic shape choice: run the 256 x 128 shape on 16x16x32 MFMAs (default on; include/sfod_hip.h)."""
     load().sfod_set_conv3x3_m16(int(on))       # 0 off, 1 the 8-wave form, 2 the 4-wave form

@@ -324,6 +324,33 @@ def test_bn_fused_accumulators(native):
     assert torch.allclose(ga, dgam + 2.0, rtol=0, atol=1e-5) and torch.allclose(ba, dbet - 1.0, rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 38, 75, 256), (2, 19, 37, 1024), (1, 75, 150, 128), (1, 9, 11, 64), (1, 120, 128, 72)])
+def test_one_launch_batchnorm_finalize_is_the_two_launch_one_bit_for_bit(native, shape):
+    """Layers of <= 64 statistics blocks are finalised in one launch (k_bn_finalize_one): mean, invstd, the running statistics
+    after k momentum updates and the batch counter equal the two-launch form's bit for bit (the last shape has > 64 blocks:
+    both settings take the two launches there)."""
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(C + H)
+    x = (torch.randn(B, H, W, 64, generator=g) * 3.0 + 0.7).to(DEV)
+    wp = native.pack_conv_weight(torch.randn(C, 64, 1, 1, generator=g).to(DEV) * 0.2, 64, native.F32)
+    _, stats = native.conv_fwd(x, wp, None, C, 1, want_stats=True)
+    outs = []
+    try:
+        for fused in (True, False):
+            native.set_bn_finalize_fused(fused)
+            rm, rv = torch.linspace(-1, 1, C).to(DEV), (torch.linspace(0.5, 2, C)).to(DEV)
+            nbt = torch.tensor(7, dtype=torch.int64, device=DEV)
+            mean, invstd = native.bn_finalize(stats, B * H * W, C, rm, rv, 0.1, 1e-5, 3, num_batches_tracked=nbt)
+            outs.append((mean, invstd, rm, rv, int(nbt)))
+    finally:
+        native.set_bn_finalize_fused(True)
+    (m1, i1, rm1, rv1, n1), (m0, i0, rm0, rv0, n0) = outs
+    assert torch.equal(m1, m0) and torch.equal(i1, i0) and torch.equal(rm1, rm0) and torch.equal(rv1, rv0) and n1 == n0 == 10
+    assert torch.isfinite(m1).all() and (i1 > 0).all()
+    if shape in ((1, 38, 75, 256), (2, 19, 37, 1024), (1, 9, 11, 64)):          # these are one-launch shapes; the others have > 64 blocks
+        assert stats.nblk <= 64, stats.nblk
+
+
 # -------------------------------------------------------------------------------------------------
 # BatchNorm + ReLU + pool
 # -------------------------------------------------------------------------------------------------
