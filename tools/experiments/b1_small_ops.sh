@@ -1,9 +1,10 @@
 # What runs outside libsfod_hip.so in a one-frame-per-GPU step?  rocprofv3 kernel trace of bench.py --batch 1 (single stream), then
-# the kernels that are NOT the library's, per step.   bash tools/experiments/b1_small_ops.sh <out.txt>
+# the kernels that are NOT the library's, per step.
+#   bash tools/experiments/b1_small_ops.sh <out.txt>
 export TMPDIR=/tmp
-OUT=$1; D=gpurun_out/b1_trace; rm -rf $D; mkdir -p $D
-B=$(python3 bench.py --batch 1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timer 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['config']['planted_labels']['background_bias'])")
-rocprofv3 --kernel-trace --stats -d $D -o kt -- python3 bench.py --batch 1 --plant-bias $B --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --no-smi --steps 40 --warmup 10 > /dev/null 2> $D/err.txt
+OUT=$1; shift; EXTRA="$@"; D=gpurun_out/b1_trace; rm -rf $D; mkdir -p $D
+B=$(python3 bench.py $EXTRA --batch 1 --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-kernel-timer 2>/dev/null | python3 -c "import json,sys; print(json.loads(sys.stdin.read().strip().splitlines()[-1])['config']['planted_labels']['background_bias'])")
+rocprofv3 --kernel-trace --stats -d $D -o kt -- python3 bench.py $EXTRA --batch 1 --plant-bias $B --no-overlap --no-cpu-baseline --no-secondary --no-kernel-timer --no-smi --steps 40 --warmup 10 > /dev/null 2> $D/err.txt
 DB=$(find $D -name "*.db" | head -1)
 python3 tools/rocpd_stats.py $DB 50 > $D/stats.csv
 python3 - $D/stats.csv > $OUT <<'PY'
